@@ -1,0 +1,243 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE (build container only).
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py [kge|sampler|pgpr|all]
+
+The reference (/root/reference, tail-unica/hopwise v0.9.1.post1) is imported through
+``_refimport.install()``; this script only *calls* reference classes on seeded inputs and
+stores inputs + outputs as .npz / .json.  No reference source text is copied.  The GPU box
+never runs this file (it has no /root/reference); it only reads the committed fixtures.
+
+What is pinned
+  kge_<Model>_d<dim>.npz   tables, RSKG batch, predict / predict_kg scores, calculate_loss value,
+                           dense table grads, full_sort_predict(_kg) matrices, masked top-10
+  kge_train_<Model>.npz    3 Adam steps through the reference model (losses + final tables) -- A18 protocol
+  sampler_*.npz            KGSampler / Sampler draws under a fixed numpy seed (stream-exact for the oracle)
+  pgpr_*.npz / .json       PGPR on the reference's own tests/test_data fixture: actions, states, MLP outputs,
+                           beam-search paths/probs (dropout patched to identity), collect_scores matrix
+"""
+
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+
+_refimport.install()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(1)
+
+FIELDS = dict(
+    USER_ID_FIELD="user_id",
+    ITEM_ID_FIELD="item_id",
+    NEG_PREFIX="neg_",
+    ENTITY_ID_FIELD="entity_id",
+    RELATION_ID_FIELD="relation_id",
+    HEAD_ENTITY_ID_FIELD="head_id",
+    TAIL_ENTITY_ID_FIELD="tail_id",
+)
+
+
+class FakeDataset:
+    """The four things a KGE model constructor reads from a dataset (transe.py:34-53, rotate.py:36-59)."""
+
+    ui_relation = "[UI-Relation]"
+
+    def __init__(self, n_users, n_items, n_entities, n_relations):
+        self._num = dict(user_id=n_users, item_id=n_items, entity_id=n_entities, relation_id=n_relations)
+        self.field2token_id = {"relation_id": {self.ui_relation: n_relations - 1}}
+
+    def num(self, field):
+        return self._num[field]
+
+
+def make_batch(rng, n_users, n_items, n_entities, n_relations, b_rec, b_kg):
+    inter = dict(
+        user_id=rng.integers(1, n_users, b_rec),
+        item_id=rng.integers(1, n_items, b_rec),
+        neg_item_id=rng.integers(1, n_items, b_rec),
+        head_id=rng.integers(1, n_entities, b_kg),
+        relation_id=rng.integers(1, n_relations - 1, b_kg),
+        tail_id=rng.integers(1, n_entities, b_kg),
+        neg_tail_id=rng.integers(1, n_entities, b_kg),
+    )
+    # PAD row 0 and repeated indices must be exercised (scatter-add of grads into the same row)
+    inter["user_id"][:3] = [0, 5, 5]
+    inter["item_id"][:3] = [0, 7, 7]
+    inter["neg_item_id"][1:3] = 9
+    inter["head_id"][:4] = [0, 11, 11, 11]
+    inter["tail_id"][:4] = [0, 13, 13, 11]
+    inter["neg_tail_id"][:2] = [0, 13]
+    inter["relation_id"][:3] = [0, n_relations - 1, 2]
+    return {k: v.astype(np.int64) for k, v in inter.items()}
+
+
+def gen_kge(out_dir):
+    from hopwise.model.knowledge_graph_embedding_recommender.complex import ComplEx
+    from hopwise.model.knowledge_graph_embedding_recommender.distmult import DistMult
+    from hopwise.model.knowledge_graph_embedding_recommender.rotate import RotatE
+    from hopwise.model.knowledge_graph_embedding_recommender.transe import TransE
+
+    nU, nI, nE, nR = 20, 16, 48, 5
+    classes = dict(TransE=TransE, RotatE=RotatE, ComplEx=ComplEx, DistMult=DistMult)
+    for name, cls in classes.items():
+        for d in (8, 64, 200):
+            torch.manual_seed(2024 + d)
+            config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"))
+            model = cls(config, FakeDataset(nU, nI, nE, nR))
+            rng = np.random.default_rng(7 + d)
+            inter_np = make_batch(rng, nU, nI, nE, nR, 24, 32)
+            inter = {k: torch.from_numpy(v) for k, v in inter_np.items()}
+
+            out = {f"table.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
+            out.update({f"inter.{k}": v for k, v in inter_np.items()})
+            with torch.no_grad():
+                out["predict"] = model.predict(inter).numpy()
+                out["predict_kg"] = model.predict_kg(inter).numpy()
+            model.zero_grad()
+            loss = model.calculate_loss(inter)
+            loss.backward()
+            out["loss"] = loss.detach().numpy()
+            for k, p in model.named_parameters():
+                out[f"grad.{k}"] = p.grad.numpy().copy()
+            with torch.no_grad():
+                users = torch.tensor([1, 5, 0, 19, 5])
+                fs = model.full_sort_predict({"user_id": users}).view(len(users), nI)
+                heads = torch.tensor([3, 0, 47, 11])
+                rels = torch.tensor([1, 4, 0, 2])
+                fskg = model.full_sort_predict_kg({"head_id": heads, "relation_id": rels}).view(len(heads), nE)
+            out["fs.users"] = users.numpy()
+            out["fs.scores"] = fs.numpy()
+            out["fskg.heads"] = heads.numpy()
+            out["fskg.rels"] = rels.numpy()
+            out["fskg.scores"] = fskg.numpy()
+            # evaluation protocol (trainer.py:731-734, collector.py:173-183)
+            hist_rows = rng.integers(0, len(users), 12)
+            hist_cols = rng.integers(1, nI, 12)
+            masked = fs.clone()
+            masked[:, 0] = -np.inf
+            masked[torch.from_numpy(hist_rows), torch.from_numpy(hist_cols)] = -np.inf
+            tv, ti = torch.topk(masked, 10, dim=-1)
+            out["eval.history_rows"] = hist_rows.astype(np.int64)
+            out["eval.history_cols"] = hist_cols.astype(np.int64)
+            out["eval.masked"] = masked.numpy()
+            out["eval.topk_values"] = tv.numpy()
+            out["eval.topk_idx"] = ti.numpy()
+            out["margin"] = np.float32(1.0)
+            np.savez_compressed(os.path.join(out_dir, f"kge_{name}_d{d}.npz"), **out)
+            print("kge", name, d, float(loss))
+
+        # A18: three optimizer steps the way Trainer._train_epoch drives the model (trainer.py:208-268):
+        # zero_grad -> calculate_loss -> backward -> Adam(lr=1e-3).step, dense grads.
+        torch.manual_seed(99)
+        d = 16
+        config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"))
+        model = cls(config, FakeDataset(nU, nI, nE, nR))
+        out = {f"init.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
+        rng = np.random.default_rng(123)
+        losses = []
+        model.train()
+        for step in range(3):
+            inter_np = make_batch(rng, nU, nI, nE, nR, 16, 16)
+            for k, v in inter_np.items():
+                out[f"step{step}.{k}"] = v
+            inter = {k: torch.from_numpy(v) for k, v in inter_np.items()}
+            opt.zero_grad()
+            loss = model.calculate_loss(inter)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        out["losses"] = np.array(losses, np.float32)
+        out.update({f"final.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()})
+        np.savez_compressed(os.path.join(out_dir, f"kge_train_{name}.npz"), **out)
+        print("kge_train", name, losses)
+
+
+# ---------------------------------------------------------------------------------------------
+# sampler (sampler.py:140-183, :186-291, :294-357)
+# ---------------------------------------------------------------------------------------------
+class _FakeKG:
+    head_entity_field = "head_id"
+    tail_entity_field = "tail_id"
+
+    def __init__(self, heads, tails, entity_num):
+        self.head_entities = heads
+        self.tail_entities = tails
+        self.entity_num = entity_num
+
+
+class _FakeInter:
+    uid_field = "user_id"
+    iid_field = "item_id"
+
+    def __init__(self, users, items, user_num, item_num):
+        self.inter_feat = {"user_id": torch.from_numpy(users), "item_id": torch.from_numpy(items)}
+        self.user_num = user_num
+        self.item_num = item_num
+
+
+def gen_sampler(out_dir):
+    from hopwise.sampler import KGSampler, Sampler
+
+    rng = np.random.default_rng(5)
+    nE = 60
+    heads = rng.integers(1, nE, 400).astype(np.int64)
+    tails = rng.integers(1, nE, 400).astype(np.int64)
+    # one dense head: almost every tail used -> many rejection rounds
+    heads[:50] = 7
+    tails[:50] = np.arange(2, 52)
+    out = dict(heads=heads, tails=tails, entity_num=np.int64(nE))
+    for dist in ("uniform", "popularity"):
+        s = KGSampler(_FakeKG(heads, tails, nE), distribution=dist, alpha=0.75)
+        keys = heads[rng.integers(0, 400, 33)]
+        keys[:4] = 7
+        np.random.seed(2024)
+        v1 = s.sample_by_entity_ids(keys, 1).numpy()
+        v3 = s.sample_by_entity_ids(keys, 3).numpy()
+        same = np.full(9, 7, np.int64)  # all-keys-equal fast path (sampler.py:157-165)
+        vs = s.sample_by_entity_ids(same, 4).numpy()
+        out[f"kg.{dist}.keys"] = keys
+        out[f"kg.{dist}.num1"] = v1
+        out[f"kg.{dist}.num3"] = v3
+        out[f"kg.{dist}.same_keys"] = same
+        out[f"kg.{dist}.same_num4"] = vs
+
+    nU, nI = 25, 30
+    phases = ["train", "valid", "test"]
+    dsets = []
+    for p in range(3):
+        users = rng.integers(1, nU, 80).astype(np.int64)
+        items = rng.integers(1, nI, 80).astype(np.int64)
+        dsets.append(_FakeInter(users, items, nU, nI))
+        out[f"rec.{phases[p]}.users"] = users
+        out[f"rec.{phases[p]}.items"] = items
+    out["rec.user_num"] = np.int64(nU)
+    out["rec.item_num"] = np.int64(nI)
+    for dist in ("uniform", "popularity"):
+        s = Sampler(phases, dsets, distribution=dist, alpha=1.0)
+        for ph in phases:
+            sp = s.set_phase(ph)
+            keys = rng.integers(1, nU, 8).astype(np.int64)
+            np.random.seed(11)
+            v = sp.sample_by_user_ids(keys, None, 5).numpy()
+            out[f"rec.{dist}.{ph}.keys"] = keys
+            out[f"rec.{dist}.{ph}.num5"] = v
+    np.savez_compressed(os.path.join(out_dir, "sampler.npz"), **out)
+    print("sampler ok")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("kge", "all"):
+        gen_kge(HERE)
+    if what in ("sampler", "all"):
+        gen_sampler(HERE)
+    if what in ("pgpr", "all"):
+        from make_golden_pgpr import gen_pgpr
+
+        gen_pgpr(HERE)
