@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""Headline benchmark: KGE triples scored / s on BASELINE.json configs[1]
+(RotatE dim=200, 256 negatives per positive, ml-1m-small-shaped synthetic KG), per GPU and whole job.
+
+One *step* = one pass of the scoring hot path over one batch, inputs resident in HBM:
+    1. device negative sampling: 256 negatives for each of 2048 (user, positive item) pairs, rejecting
+       the user's interacted items (hw_neg_sample, writes straight into the grouped index buffer);
+    2. grouped RotatE scorer over 2048 x (1 + 256) = 526 336 (h, r, t) triples (hw_kge_score_grouped);
+    3. self-adversarial negative-weighting loss over the [2048, 257] scores (hw_loss_self_adversarial).
+value = triples scored per second over the whole job (all ranks).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); the 22 MB of tables are replicated
+and every rank scores its own batches -- the path shards by independent (h, r) groups, there is no
+data-path collective, so scaling is weak.  The row-sharded all-to-all lookup for tables
+that are worth sharding is exercised by tests/test_dist_gloo.py, not by this default run.
+
+The JSON line also carries `roofline` for the dominant kernel (the grouped scorer, HBM-bound) and
+`cpu_baseline` (oracle/kge_ref.c, the C restatement, on the host cores).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+DIM, K_NEG, B_POS = 200, 256, 2048
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_triple(dim=DIM, k=K_NEG):
+    """tail rows 2*d*4 + tail id 8 + score 4 + shared (h_re, h_im, theta rows + 2 ids)/(K+1)."""
+    return 2 * dim * 4 + 8 + 4 + (3 * dim * 4 + 16) / (k + 1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--entities", type=int, default=0, help="override n_entities (HBM-resident variant, e.g. 2600000)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from hopwise_amd import ops
+    from hopwise_amd.data import synthetic
+
+    kg = synthetic.make("ml-1m-small", seed=2024)
+    nE = args.entities if args.entities > 0 else kg.n_entities
+    g = torch.Generator(device="cpu").manual_seed(2024)
+
+    def xavier(rows):
+        return (torch.randn(rows, DIM, generator=g) * (2.0 / (rows + DIM)) ** 0.5).to(dev)
+
+    user_re, user_im = xavier(kg.n_users), xavier(kg.n_users)
+    ent_re, ent_im = xavier(nE), xavier(nE)
+    theta = (torch.rand(kg.n_relations, DIM, generator=g) * (2 * np.pi)).to(dev)
+    head, rel, tail = (user_re, user_im), (theta,), (ent_re, ent_im)
+    desc = ops.make_desc("RotatE", head, rel, tail, margin=1.0)
+
+    # batches differ per rank; sampler "used" sets = the user's interacted items
+    rng = np.random.default_rng(2024 + rank)
+    pick = rng.integers(0, len(kg.inter_users), B_POS)
+    users = torch.from_numpy(kg.inter_users[pick]).to(dev)
+    pos = torch.from_numpy(kg.inter_items[pick]).to(dev)
+    uptr, uidx = synthetic.used_csr(kg.inter_users, kg.inter_items, kg.n_users)
+    uptr, uidx = torch.from_numpy(uptr).to(dev), torch.from_numpy(uidx).to(dev)
+    n_items = kg.n_items if args.entities == 0 else nE  # HBM variant draws negatives over the whole big table
+    idx = torch.empty((1 + K_NEG, B_POS), dtype=torch.int64, device=dev)  # j-major: row 0 positives
+    idx[0] = pos
+    neg_flat = idx[1:].view(-1)
+    t_idx = idx.t()  # [B, 1+K] view, strides (1, B)
+    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    loss_box = [None]
+
+    def step(i, timed=False):
+        ops.neg_sample(uptr, uidx, users, K_NEG, n_items, seed=2024 + rank, offset=i, out=neg_flat)
+        if timed:
+            ev_a[i].record()
+        scores = ops.kge_score_grouped_raw(desc, users, None, kg.ui_relation, t_idx)
+        if timed:
+            ev_b[i].record()
+        loss_box[0] = ops.self_adversarial_mean(scores, 1.0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, timed=True)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(loss_box[0]).item()
+    assert ops.oob_count(dev) == 0
+
+    triples_per_step = B_POS * (1 + K_NEG)
+    value = world * triples_per_step * args.steps / dt
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev_a, ev_b)]))
+    abytes = algorithmic_bytes_per_triple() * triples_per_step
+    achieved = abytes / (kern_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("kge_score_grouped_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "KGE triples scored per second (RotatE d=200, 256 negatives; sampler + scorer + self-adversarial loss)",
+        "value": value,
+        "unit": "triples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "configs[1]: RotatE dim=200, 256 negatives, ml-1m-small-shaped KG, grouped scorer B=2048 x 257",
+            "n_users": kg.n_users, "n_items": kg.n_items, "n_entities": nE, "n_relations": kg.n_relations,
+            "triples_per_step": triples_per_step, "parallelism": f"replicas x{world}",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "kge_score_grouped_kernel<RotatE>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,
+            "scorer_only_triples_per_s": triples_per_step / (kern_ms * 1e-3),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cref
+
+        tabs = [t.cpu().numpy() for t in (user_re, user_im, theta, ent_re, ent_im)]
+        h_np, t_np = users.cpu().numpy(), np.ascontiguousarray(t_idx.cpu().numpy())
+        outb = np.empty(t_np.shape, np.float32)
+        cref.score_grouped("RotatE", tabs[0:2], tabs[2:3], tabs[3:5], h_np, None, kg.ui_relation, t_np, 1.0, 0.0, outb)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < args.cpu_seconds:
+            cref.score_grouped("RotatE", tabs[0:2], tabs[2:3], tabs[3:5], h_np, None, kg.ui_relation, t_np, 1.0, 0.0, outb)
+            reps += 1
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {
+            "value": reps * triples_per_step / cdt, "unit": "triples/s", "cores": cref.threads(), "kind": "port",
+            "sample": f"{reps} passes of the same 2048 x 257 grouped RotatE scoring batch (scorer only) through "
+                      f"oracle/kge_ref.c (OpenMP) in {cdt:.1f} s; host has {os.cpu_count()} logical CPUs",
+        }
+        gpu_scores = ops.kge_score_grouped_raw(desc, users, None, kg.ui_relation, t_idx).cpu().numpy()
+        np.testing.assert_allclose(gpu_scores, outb, rtol=1e-4, atol=1e-5)  # same inputs, same answers
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""ctypes binding of libhopwise_amd.so -- the C ABI declared in include/hopwise_amd.h.
+
+There is NO fallback: if the library is missing or a symbol is absent the import raises, and every
+compute wrapper in :mod:`hopwise_amd.ops` refuses CPU tensors.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libhopwise_amd.so")
+
+HW_TRANSE, HW_ROTATE, HW_COMPLEX, HW_DISTMULT = 0, 1, 2, 3
+MODEL_IDS = {"TransE": HW_TRANSE, "RotatE": HW_ROTATE, "ComplEx": HW_COMPLEX, "DistMult": HW_DISTMULT}
+
+STATUS = {0: "HW_OK", -1: "HW_ERR_INVALID_ARG", -2: "HW_ERR_UNSUPPORTED", -3: "HW_ERR_LAUNCH", -4: "HW_ERR_WORKSPACE"}
+
+c_f32p = C.c_void_p  # device pointers travel as integers
+c_i64p = C.c_void_p
+c_i32p = C.c_void_p
+
+
+class KgeDesc(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32),
+        ("dim", C.c_int32),
+        ("head", C.c_void_p * 2),
+        ("rel", C.c_void_p * 2),
+        ("tail", C.c_void_p * 2),
+        ("n_head", C.c_int64),
+        ("n_rel", C.c_int64),
+        ("n_tail", C.c_int64),
+        ("margin", C.c_float),
+        ("eps", C.c_float),
+    ]
+
+
+class KgeGrads(C.Structure):
+    _fields_ = [("head", C.c_void_p * 2), ("rel", C.c_void_p * 2), ("tail", C.c_void_p * 2)]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check that every symbol declared in
+# include/hopwise_amd.h is exported.
+SIGNATURES = {
+    "hw_kge_score_grouped": (
+        C.c_int,
+        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+         c_f32p, C.c_int64, C.c_int64, c_i32p, C.c_void_p],
+    ),
+    "hw_kge_full_sort": (
+        C.c_int,
+        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64,
+         c_i32p, C.c_void_p],
+    ),
+    "hw_kge_grad_grouped": (
+        C.c_int,
+        [C.POINTER(KgeDesc), C.POINTER(KgeGrads), c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int64,
+         C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_void_p],
+    ),
+    "hw_loss_workspace_floats": (C.c_int64, []),
+    "hw_loss_bce_logits": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "hw_loss_margin_ranking": (
+        C.c_int,
+        [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],
+    ),
+    "hw_loss_self_adversarial": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, C.c_void_p],
+    ),
+    "hw_mask_scores": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_void_p]),
+    "hw_topk_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_f32p, c_i64p, C.c_void_p]),
+    "hw_neg_sample": (
+        C.c_int,
+        [c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int32, C.c_int64, c_f32p, c_i64p, c_i64p, C.c_int64,
+         C.c_uint64, C.c_uint64, c_i64p, c_i32p, C.c_void_p],
+    ),
+    "hw_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class HopwiseAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and attach the argtypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HopwiseAmdError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m hopwise_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HopwiseAmdError(f"{what} failed: {STATUS.get(rc, rc)}")

@@ -1,0 +1,176 @@
+// Backward of the grouped scorer: row-gradient scatter into dense grad tables with f32 atomics.
+//
+// The kernel recomputes the forward pieces from the gathered rows (cheaper than storing [B, G, d]
+// intermediates: it re-reads rows that are L2/MALL resident) and emits
+//   * one atomic row per tail table per (b, j)                       -- unavoidable traffic,
+//   * one atomic row per head / relation table per WAVE TASK          -- the K+1 contributions of a
+//     group are summed in registers first (Guideline 12: sum on chip what shares a destination).
+// Rows use the dword-per-lane mapping (lane l owns columns l, l+64, ...) so that every atomic
+// wave-instruction covers 256 contiguous bytes of one row, the shape global_atomic_add_f32 runs at
+// full rate for (MI355X_MICROARCH.md 'Global float atomics').
+//
+// Gradient formulas (g = dL/dscore of one (b, j); u = residual / norm, 0 where norm == 0, which is
+// torch's sub-gradient for vector_norm / norm at 0):
+//   TransE   d = (Q - t) + eps, n = |d|          gQ = -g d/n      gt = +g d/n      gh = gr = gQ
+//   DistMult                                      gQ =  g t        gt =  g Q        gh = gQ r, gr = gQ h
+//   RotatE   a = Q0 - t_re, b = Q1 - t_im        gQ0 = -g a/n, gQ1 = -g b/n, gt_re = g a/n, gt_im = g b/n
+//            gh_re = gQ0 c + gQ1 s, gh_im = -gQ0 s + gQ1 c, gtheta = gQ0 (-s h_re - c h_im) + gQ1 (-s h_im + c h_re)
+//   ComplEx  gQ0 = g t_re, gQ1 = g t_im, gt_re = g Q0, gt_im = g Q1
+//            gh_re = gQ0 r_re + gQ1 r_im, gh_im = gQ1 (r_re - r_im), gr_re = gQ0 h_re + gQ1 h_im, gr_im = gQ1 (h_re - h_im)
+#include "kge_model.h"
+
+namespace hw {
+
+template <int MODEL, int NE>
+__global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
+    hw_kge_desc d, hw_kge_grads gr, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx,
+    int64_t r_fixed, const int64_t* __restrict__ t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
+    const float* __restrict__ g, int64_t gsb, int64_t gsj) {
+    constexpr int G = 64;
+    using SC = Scorer<MODEL, G, NE, false>;
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, false>;
+
+    const int gl = threadIdx.x & (HW_WAVE - 1);
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + (threadIdx.x / HW_WAVE);
+    if (task >= n_groups * S) return;
+    const int64_t b = task / S;
+    const int s = (int)(task % S);
+
+    const int h = clamp_row(h_idx[b], d.n_head, nullptr);
+    const int r = clamp_row(r_idx ? r_idx[b] : r_fixed, d.n_rel, nullptr);
+    SC sc;
+    R hraw[2], rraw[2];
+    sc.template build<true>(d, h, r, gl, hraw, rraw);
+
+    float GQ[MT::NQ][NE];
+#pragma unroll
+    for (int k = 0; k < MT::NQ; ++k)
+#pragma unroll
+        for (int i = 0; i < NE; ++i) GQ[k][i] = 0.f;
+
+    const int64_t* __restrict__ tb = t_idx + b * tsb;
+    const float* __restrict__ gb = g + b * gsb;
+
+    for (int j = s; j < ntail; j += S) {
+        const float gs = gb[(int64_t)j * gsj];
+        if (gs == 0.f) continue;  // wave-uniform (one address per wave): inactive margin pairs add nothing
+        const int tj = clamp_row(tb[(int64_t)j * tsj], d.n_tail, nullptr);
+        R t[MT::NT];
+#pragma unroll
+        for (int k = 0; k < MT::NT; ++k) t[k].load(d.tail[k] + (size_t)tj * d.dim, d.dim, gl);
+        float scale = gs;
+        if constexpr (MODEL == HW_TRANSE || MODEL == HW_ROTATE) {
+            float p = group_sum<G>(sc.partial(t, d.eps, d.dim, gl));
+            const float n = sqrtf(p);
+            scale = n > 0.f ? gs / n : 0.f;
+        }
+        const size_t to = (size_t)tj * d.dim;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int c = R::col(i, d.dim, gl);
+            if (c < 0) continue;
+            if constexpr (MODEL == HW_TRANSE) {
+                const float u = ((sc.q[0].v[i] - t[0].v[i]) + d.eps) * scale;
+                GQ[0][i] -= u;
+                if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, u);
+            } else if constexpr (MODEL == HW_DISTMULT) {
+                GQ[0][i] = fmaf(scale, t[0].v[i], GQ[0][i]);
+                if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, scale * sc.q[0].v[i]);
+            } else if constexpr (MODEL == HW_ROTATE) {
+                const float ua = (sc.q[0].v[i] - t[0].v[i]) * scale;
+                const float ub = (sc.q[1].v[i] - t[1].v[i]) * scale;
+                GQ[0][i] -= ua;
+                GQ[1][i] -= ub;
+                if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, ua);
+                if (gr.tail[1]) atomicAdd(gr.tail[1] + to + c, ub);
+            } else {
+                GQ[0][i] = fmaf(scale, t[0].v[i], GQ[0][i]);
+                GQ[1][i] = fmaf(scale, t[1].v[i], GQ[1][i]);
+                if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, scale * sc.q[0].v[i]);
+                if (gr.tail[1]) atomicAdd(gr.tail[1] + to + c, scale * sc.q[1].v[i]);
+            }
+        }
+    }
+
+    const size_t ho = (size_t)h * d.dim, ro = (size_t)r * d.dim;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = R::col(i, d.dim, gl);
+        if (c < 0) continue;
+        if constexpr (MODEL == HW_TRANSE) {
+            if (GQ[0][i] != 0.f) {
+                if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, GQ[0][i]);
+                if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, GQ[0][i]);
+            }
+        } else if constexpr (MODEL == HW_DISTMULT) {
+            if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, GQ[0][i] * rraw[0].v[i]);
+            if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, GQ[0][i] * hraw[0].v[i]);
+        } else if constexpr (MODEL == HW_ROTATE) {
+            const float cs = rraw[0].v[i], sn = rraw[1].v[i];
+            const float hr = hraw[0].v[i], hi = hraw[1].v[i];
+            const float g0 = GQ[0][i], g1 = GQ[1][i];
+            if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, g0 * cs + g1 * sn);
+            if (gr.head[1]) atomicAdd(gr.head[1] + ho + c, g1 * cs - g0 * sn);
+            if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, g0 * (-sn * hr - cs * hi) + g1 * (cs * hr - sn * hi));
+        } else {
+            const float rr = rraw[0].v[i], ri = rraw[1].v[i];
+            const float hr = hraw[0].v[i], hi = hraw[1].v[i];
+            const float g0 = GQ[0][i], g1 = GQ[1][i];
+            if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, g0 * rr + g1 * ri);
+            if (gr.head[1]) atomicAdd(gr.head[1] + ho + c, g1 * (rr - ri));
+            if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, g0 * hr + g1 * hi);
+            if (gr.rel[1]) atomicAdd(gr.rel[1] + ro + c, g1 * (hr - hi));
+        }
+    }
+}
+
+}  // namespace hw
+
+using namespace hw;
+
+extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* grads, const int64_t* h_idx,
+                                   const int64_t* r_idx, int64_t r_fixed, const int64_t* t_idx, int64_t t_stride_b,
+                                   int64_t t_stride_j, int64_t n_groups, int64_t n_tail_per_group, const float* g,
+                                   int64_t g_stride_b, int64_t g_stride_j, void* stream) {
+    if (!desc || !grads || !h_idx || !t_idx || !g) return HW_ERR_INVALID_ARG;
+    if (desc->dim < 1 || desc->dim > HW_MAX_DIM || n_groups < 0 || n_tail_per_group < 0) return HW_ERR_INVALID_ARG;
+    if (desc->n_head < 1 || desc->n_rel < 1 || desc->n_tail < 1) return HW_ERR_INVALID_ARG;
+    if (n_tail_per_group > INT32_MAX / 2) return HW_ERR_INVALID_ARG;
+    if (n_groups == 0 || n_tail_per_group == 0) return HW_OK;
+    const int ntail = (int)n_tail_per_group;
+    // splits: the head/relation rows are flushed once per wave task, so prefer few, long tasks; split
+    // only as far as needed to put ~8k waves on the chip.
+    int S = 1;
+    {
+        const int s_max = (ntail + 7) / 8;
+        const int64_t want = (8192 + n_groups - 1) / n_groups;
+        S = (int)(want < 1 ? 1 : (want > s_max ? s_max : want));
+        if (S < 1) S = 1;
+    }
+    const int64_t n_tasks = n_groups * S;
+    const int64_t n_blocks = (n_tasks + 3) / 4;
+    if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    const int NE = desc->dim <= 64 ? 1 : (desc->dim <= 256 ? 4 : 16);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(MODEL, NE_)                                                                                           \
+    hipLaunchKernelGGL((kge_grad_grouped_kernel<MODEL, NE_>), dim3((unsigned)n_blocks), dim3(256), 0, st, *desc,     \
+                       *grads, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, g,          \
+                       g_stride_b, g_stride_j)
+#define BYNE(MODEL)                        \
+    do {                                   \
+        if (NE == 1) CALL(MODEL, 1);       \
+        else if (NE == 4) CALL(MODEL, 4);  \
+        else CALL(MODEL, 16);              \
+    } while (0)
+    switch (desc->model) {
+        case HW_TRANSE: BYNE(HW_TRANSE); break;
+        case HW_ROTATE: BYNE(HW_ROTATE); break;
+        case HW_COMPLEX: BYNE(HW_COMPLEX); break;
+        case HW_DISTMULT: BYNE(HW_DISTMULT); break;
+        default: return HW_ERR_UNSUPPORTED;
+    }
+#undef BYNE
+#undef CALL
+    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+}

@@ -1,0 +1,254 @@
+// Loss reductions over score vectors + the evaluation mask / top-k.
+//
+// Reductions are two-stage and deterministic (fixed partition, fixed order): stage 1 writes one
+// partial per block into the caller's workspace, stage 2 (one block) adds them in index order.
+#include "hw_common.h"
+
+namespace hw {
+
+constexpr int LOSS_BLOCKS = 256;
+constexpr int LOSS_THREADS = 256;
+
+__device__ __forceinline__ float block_sum_256(float v) {
+    __shared__ float red[LOSS_THREADS / HW_WAVE];
+    v = group_sum<64>(v);
+    const int w = threadIdx.x / HW_WAVE;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < LOSS_THREADS / HW_WAVE; ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void finish_mean_kernel(const float* __restrict__ partial, int n_partial,
+                                                                   float inv_n, float* __restrict__ loss_out) {
+    // single block; every thread takes a fixed subset, then an ordered tree
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n_partial; i += LOSS_THREADS) v += partial[i];
+    v = block_sum_256(v);
+    if (threadIdx.x == 0) loss_out[0] = v * inv_n;
+}
+
+// BCEWithLogits: l = max(x,0) - x*y + log1p(exp(-|x|)); dl/dx = sigmoid(x) - y
+__global__ __launch_bounds__(LOSS_THREADS) void bce_logits_kernel(const float* __restrict__ x, int64_t n, int64_t n_pos,
+                                                                  float inv_n, float* __restrict__ gx,
+                                                                  float* __restrict__ partial) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * LOSS_THREADS) {
+        const float xi = x[i];
+        const float y = i < n_pos ? 1.f : 0.f;
+        const float e = expf(-fabsf(xi));
+        acc += fmaxf(xi, 0.f) - xi * y + log1pf(e);
+        if (gx) {
+            const float sg = xi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            gx[i] = (sg - y) * inv_n;
+        }
+    }
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void margin_ranking_kernel(const float* __restrict__ pos,
+                                                                      const float* __restrict__ neg, int64_t n,
+                                                                      float margin, float inv_n, float* __restrict__ gpos,
+                                                                      float* __restrict__ gneg,
+                                                                      float* __restrict__ partial) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * LOSS_THREADS) {
+        const float l = -(pos[i] - neg[i]) + margin;
+        const bool act = l > 0.f;
+        acc += act ? l : 0.f;
+        if (gpos) gpos[i] = act ? -inv_n : 0.f;
+        if (gneg) gneg[i] = act ? inv_n : 0.f;
+    }
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__device__ __forceinline__ float log_sigmoid(float x) {  // -(max(-x,0) + log1p(exp(-|x|)))
+    return -(fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))));
+}
+__device__ __forceinline__ float sigmoidf(float x) {
+    const float e = expf(-fabsf(x));
+    return x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+
+// one wave per group row [1 + K]
+__global__ __launch_bounds__(256) void self_adv_kernel(const float* __restrict__ sc, int64_t n_groups, int n_cols,
+                                                       float alpha, float inv_b, float* __restrict__ gsc,
+                                                       float* __restrict__ group_loss) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_groups) return;
+    const float* __restrict__ row = sc + b * n_cols;
+    float mx = -INFINITY;
+    for (int j = 1 + lane; j < n_cols; j += 64) mx = fmaxf(mx, alpha * row[j]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    float z = 0.f;
+    for (int j = 1 + lane; j < n_cols; j += 64) z += expf(alpha * row[j] - mx);
+    z = group_sum<64>(z);
+    const float inv_z = z > 0.f ? 1.f / z : 0.f;
+    float acc = 0.f;
+    for (int j = 1 + lane; j < n_cols; j += 64) {
+        const float s = row[j];
+        const float p = expf(alpha * s - mx) * inv_z;
+        acc -= p * log_sigmoid(-s);
+        if (gsc) gsc[b * n_cols + j] = p * sigmoidf(s) * inv_b;
+    }
+    acc = group_sum<64>(acc);
+    if (lane == 0) {
+        const float sp = row[0];
+        group_loss[b] = acc - log_sigmoid(sp);
+        if (gsc) gsc[b * n_cols] = -(1.f - sigmoidf(sp)) * inv_b;
+    }
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void sum_partial_kernel(const float* __restrict__ v, int64_t n,
+                                                                   float* __restrict__ partial) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * LOSS_THREADS)
+        acc += v[i];
+    acc = block_sum_256(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+// ---- evaluation mask (trainer.py:731-734) ----
+__global__ void mask_scores_kernel(float* __restrict__ s, int64_t n_rows, int64_t n_cols,
+                                   const int64_t* __restrict__ hr, const int64_t* __restrict__ hc, int64_t n_hist) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_rows) s[i * n_cols] = -INFINITY;
+    if (i < n_hist) {
+        const int64_t r = hr[i], c = hc[i];
+        if (r >= 0 && r < n_rows && c >= 0 && c < n_cols) s[r * n_cols + c] = -INFINITY;
+    }
+}
+
+// ---- row-wise top-k, ordered (value desc, index asc) ----
+// key = (orderable(value) << 32) | ~index : unique per column, so "next best" is simply the largest
+// key strictly below the previous winner -- no marking pass.  One block per row, k rounds.
+__device__ __forceinline__ uint64_t topk_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)(~idx);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void topk_rows_kernel(const float* __restrict__ s, int64_t n_cols, int64_t ld,
+                                                            int k, float* __restrict__ out_val,
+                                                            int64_t* __restrict__ out_idx) {
+    __shared__ uint64_t red[THREADS / HW_WAVE];
+    __shared__ uint64_t winner;
+    const float* __restrict__ row = s + (int64_t)blockIdx.x * ld;
+    uint64_t bound = ~0ull;  // exclusive upper bound
+    for (int round = 0; round < k; ++round) {
+        uint64_t best = 0;
+        for (int64_t c = threadIdx.x; c < n_cols; c += THREADS) {
+            const uint64_t key = topk_key(row[c], (uint32_t)c);
+            if (key < bound && key > best) best = key;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t o = __shfl_xor(best, m, 64);
+            best = o > best ? o : best;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x / HW_WAVE] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t w = red[0];
+#pragma unroll
+            for (int i = 1; i < THREADS / HW_WAVE; ++i) w = red[i] > w ? red[i] : w;
+            winner = w;
+            const int64_t o = (int64_t)blockIdx.x * k + round;
+            if (w == 0) {  // fewer than k columns
+                out_val[o] = -INFINITY;
+                out_idx[o] = -1;
+            } else {
+                const uint32_t idx = ~(uint32_t)(w & 0xffffffffu);
+                out_val[o] = row[idx];
+                out_idx[o] = idx;
+            }
+        }
+        __syncthreads();
+        bound = winner;
+        if (bound == 0) bound = 0;  // stays exhausted
+    }
+}
+
+}  // namespace hw
+
+using namespace hw;
+
+extern "C" int64_t hw_loss_workspace_floats(void) { return LOSS_BLOCKS; }
+
+static int loss_grid(int64_t n) {
+    int64_t b = (n + LOSS_THREADS - 1) / LOSS_THREADS;
+    return (int)(b < 1 ? 1 : (b > LOSS_BLOCKS ? LOSS_BLOCKS : b));
+}
+
+extern "C" int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, float* loss_out, float* gx,
+                                  float* workspace, void* stream) {
+    if (!x || !loss_out || !workspace || n <= 0 || n_pos < 0) return HW_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = loss_grid(n);
+    const float inv_n = 1.0f / (float)n;
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, x, n, n_pos, inv_n, gx, workspace);
+    hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_n, loss_out);
+    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+}
+
+extern "C" int hw_loss_margin_ranking(const float* pos, const float* neg, int64_t n, float margin, float* loss_out,
+                                      float* gpos, float* gneg, float* workspace, void* stream) {
+    if (!pos || !neg || !loss_out || !workspace || n <= 0) return HW_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = loss_grid(n);
+    const float inv_n = 1.0f / (float)n;
+    hipLaunchKernelGGL(margin_ranking_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, pos, neg, n, margin, inv_n, gpos,
+                       gneg, workspace);
+    hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_n, loss_out);
+    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+}
+
+extern "C" int hw_loss_self_adversarial(const float* scores, int64_t n_groups, int64_t n_cols, float alpha,
+                                        float* loss_out, float* gscores, float* workspace, void* stream) {
+    // workspace: LOSS_BLOCKS partials followed by n_groups per-group losses
+    if (!scores || !loss_out || !workspace || n_groups <= 0 || n_cols < 2 || n_cols > INT32_MAX) return HW_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* group_loss = workspace + LOSS_BLOCKS;
+    const float inv_b = 1.0f / (float)n_groups;
+    hipLaunchKernelGGL(self_adv_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, st, scores, n_groups,
+                       (int)n_cols, alpha, inv_b, gscores, group_loss);
+    const int grid = loss_grid(n_groups);
+    hipLaunchKernelGGL(sum_partial_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, group_loss, n_groups, workspace);
+    hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_b, loss_out);
+    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+}
+
+extern "C" int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols, const int64_t* hist_rows,
+                              const int64_t* hist_cols, int64_t n_hist, void* stream) {
+    if (!scores || n_rows < 0 || n_cols < 1 || n_hist < 0 || (n_hist > 0 && (!hist_rows || !hist_cols)))
+        return HW_ERR_INVALID_ARG;
+    const int64_t n = n_rows > n_hist ? n_rows : n_hist;
+    if (n == 0) return HW_OK;
+    hipLaunchKernelGGL(mask_scores_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores,
+                       n_rows, n_cols, hist_rows, hist_cols, n_hist);
+    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+}
+
+extern "C" int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k, float* out_val,
+                            int64_t* out_idx, void* stream) {
+    if (!scores || !out_val || !out_idx || n_rows < 0 || n_cols < 1 || ld < n_cols || k < 1 || k > 1024)
+        return HW_ERR_INVALID_ARG;
+    if (n_cols > 0xffffffffll || n_rows > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (n_rows == 0) return HW_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_cols <= 1024)
+        hipLaunchKernelGGL((topk_rows_kernel<64>), dim3((unsigned)n_rows), dim3(64), 0, st, scores, n_cols, ld, k,
+                           out_val, out_idx);
+    else
+        hipLaunchKernelGGL((topk_rows_kernel<256>), dim3((unsigned)n_rows), dim3(256), 0, st, scores, n_cols, ld, k,
+                           out_val, out_idx);
+    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+}

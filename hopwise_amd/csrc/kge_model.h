@@ -1,0 +1,119 @@
+// Per-model arithmetic of the four gather-bound scorers, written once and shared by the grouped
+// scorer, the full-sort scorer and the gradient kernel.
+//
+// Every model factors as   score(h, r, t) = finalize( sum_d  f(Q(h, r)_d, t_d) )
+// where the "query" Q depends only on the (head, relation) pair, so a group of tails that share
+// (h, r) -- one positive + K negatives, or all N candidates of a full sort -- pays for the head /
+// relation rows (and RotatE's sincos) once.
+//
+//   TransE   Q0 = h + r                      f = ((Q0 - t) + eps)^2                 -sqrt(s)      transe.py:55-57
+//   DistMult Q0 = h * r                      f = Q0 * t                             s             distmult.py:50-51
+//   RotatE   Q0 = cos(th) h_re - sin(th) h_im
+//            Q1 = cos(th) h_im + sin(th) h_re f = (Q0 - t_re)^2 + (Q1 - t_im)^2     margin-sqrt(s) rotate.py:61-69
+//   ComplEx  Q0 = h_re r_re
+//            Q1 = h_im r_re + h_re r_im - h_im r_im   f = Q0 t_re + Q1 t_im         s             complex.py:53-62
+//            (the 4th term multiplies t_im, exactly as the reference does -- not the paper's t_re)
+#pragma once
+#include "hw_common.h"
+
+namespace hw {
+
+template <int MODEL>
+struct ModelTraits;
+template <>
+struct ModelTraits<HW_TRANSE> {
+    static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
+};
+template <>
+struct ModelTraits<HW_DISTMULT> {
+    static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
+};
+template <>
+struct ModelTraits<HW_ROTATE> {
+    static constexpr int NH = 2, NR = 1, NT = 2, NQ = 2;
+};
+template <>
+struct ModelTraits<HW_COMPLEX> {
+    static constexpr int NH = 2, NR = 2, NT = 2, NQ = 2;
+};
+
+template <int MODEL, int G, int NE, bool VEC>
+struct Scorer {
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, VEC>;
+
+    R q[MT::NQ];
+
+    // Load the head / relation rows of one (h, r) pair and fold them into the query.
+    // KEEP = true additionally returns the raw rows (the gradient kernel needs them).
+    template <bool KEEP>
+    __device__ __forceinline__ void build(const hw_kge_desc& d, int h, int r, int gl, R* hraw, R* rraw) {
+        R hh[MT::NH], rr[MT::NR];
+        const size_t ho = (size_t)h * d.dim, ro = (size_t)r * d.dim;
+#pragma unroll
+        for (int k = 0; k < MT::NH; ++k) hh[k].load(d.head[k] + ho, d.dim, gl);
+#pragma unroll
+        for (int k = 0; k < MT::NR; ++k) rr[k].load(d.rel[k] + ro, d.dim, gl);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if constexpr (MODEL == HW_TRANSE) {
+                q[0].v[i] = hh[0].v[i] + rr[0].v[i];
+            } else if constexpr (MODEL == HW_DISTMULT) {
+                q[0].v[i] = hh[0].v[i] * rr[0].v[i];
+            } else if constexpr (MODEL == HW_ROTATE) {
+                float sn, cs;
+                sincosf(rr[0].v[i], &sn, &cs);
+                q[0].v[i] = cs * hh[0].v[i] - sn * hh[1].v[i];
+                q[1].v[i] = cs * hh[1].v[i] + sn * hh[0].v[i];
+                if constexpr (KEEP) {  // hand back (cos, sin) instead of theta: what the backward consumes
+                    rraw[0].v[i] = cs;
+                    rraw[1].v[i] = sn;
+                }
+            } else {  // ComplEx
+                q[0].v[i] = hh[0].v[i] * rr[0].v[i];
+                q[1].v[i] = hh[1].v[i] * rr[0].v[i] + hh[0].v[i] * rr[1].v[i] - hh[1].v[i] * rr[1].v[i];
+            }
+        }
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int k = 0; k < MT::NH; ++k) hraw[k] = hh[k];
+            if constexpr (MODEL != HW_ROTATE) {
+#pragma unroll
+                for (int k = 0; k < MT::NR; ++k) rraw[k] = rr[k];
+            }
+        }
+    }
+
+    // This lane's share of sum_d f(Q_d, t_d).  Padding slots contribute 0 for every model except
+    // TransE with eps != 0, which is why `dim`/`gl` are needed there.
+    __device__ __forceinline__ float partial(const R* t, float eps, int dim, int gl) const {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if constexpr (MODEL == HW_TRANSE) {
+                float df = (q[0].v[i] - t[0].v[i]) + eps;
+                if (eps != 0.f && R::col(i, dim, gl) < 0) df = 0.f;
+                s = fmaf(df, df, s);
+            } else if constexpr (MODEL == HW_DISTMULT) {
+                s = fmaf(q[0].v[i], t[0].v[i], s);
+            } else if constexpr (MODEL == HW_ROTATE) {
+                const float a = q[0].v[i] - t[0].v[i];
+                const float b = q[1].v[i] - t[1].v[i];
+                s = fmaf(a, a, s);
+                s = fmaf(b, b, s);
+            } else {
+                s = fmaf(q[0].v[i], t[0].v[i], s);
+                s = fmaf(q[1].v[i], t[1].v[i], s);
+            }
+        }
+        return s;
+    }
+
+    __device__ __forceinline__ static float finalize(float s, float margin) {
+        if constexpr (MODEL == HW_TRANSE) return -sqrtf(s);
+        if constexpr (MODEL == HW_ROTATE) return margin - sqrtf(s);
+        return s;
+    }
+};
+
+}  // namespace hw

@@ -1,0 +1,232 @@
+"""TransE / RotatE / ComplEx / DistMult with the reference's constructor, methods, config keys and
+``state_dict`` names, computing on the gfx950 kernels.
+
+Reference classes (paths under /root/reference/hopwise/model/knowledge_graph_embedding_recommender):
+  TransE transe.py:21-154, RotatE rotate.py:24-220, ComplEx complex.py:21-219, DistMult distmult.py:21-146.
+
+What is kept identical: ``Model(config, dataset)``; parameter names (checkpoint compatible);
+xavier-normal init (+ U(0, 2pi) phases for RotatE, rotate.py:58-59); ``calculate_loss`` semantics per
+model (TripletMarginLoss over cat(rec, kg) for TransE; BCEWithLogits on rec and kg separately, summed,
+for RotatE/ComplEx; MarginRankingLoss over cat(rec, kg) for DistMult); ``predict``, ``predict_kg``,
+``full_sort_predict``, ``full_sort_predict_kg``; which relation row the rec side uses
+(``relation_embedding.weight[-1]`` vs the ``ui_relation`` token id, per method, as in the reference).
+
+What differs by design: no [B, d] gathered temporaries and no [B, N, d] broadcast temporaries exist;
+rows are gathered inside the scoring kernel, gradients are scattered straight into dense grad tables.
+
+Extension (NOT in the reference, default off -- SURVEY.md §8 A9): ``self_adversarial: True`` with
+``adversarial_temperature`` switches the rec-side loss of RotatE/ComplEx to self-adversarial negative
+weighting over the ``train_neg_sample_args.sample_num`` negatives of each positive.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..utils import InputType
+from .abstract_recommender import KnowledgeRecommender
+
+
+def xavier_normal_initialization(module):
+    """model/init.py:13-29 of the reference."""
+    if isinstance(module, nn.Embedding):
+        nn.init.xavier_normal_(module.weight.data)
+    elif isinstance(module, nn.Linear):
+        nn.init.xavier_normal_(module.weight.data)
+        if module.bias is not None:
+            nn.init.constant_(module.bias.data, 0)
+
+
+def _cfg(config, key, default):
+    try:
+        v = config[key]
+    except (KeyError, IndexError):
+        return default
+    return default if v is None else v
+
+
+class _GatherKGE(KnowledgeRecommender):
+    """Shared driver of the four gather-bound scorers."""
+
+    input_type = InputType.PAIRWISE
+    MODEL = None  # "TransE" | "RotatE" | "ComplEx" | "DistMult"
+    USER_TABLES = ()  # attribute names, slot order
+    ENTITY_TABLES = ()
+    RELATION_TABLES = ()
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.embedding_size = config["embedding_size"]
+        self.margin = float(_cfg(config, "margin", 0.0))
+        self.ui_relation = dataset.field2token_id["relation_id"][dataset.ui_relation]
+        for n in self.USER_TABLES:
+            setattr(self, n, nn.Embedding(self.n_users, self.embedding_size))
+        for n in self.ENTITY_TABLES:
+            setattr(self, n, nn.Embedding(self.n_entities, self.embedding_size))
+        for n in self.RELATION_TABLES:
+            setattr(self, n, nn.Embedding(self.n_relations, self.embedding_size))
+        # extension knobs (absent from reference configs -> reference behaviour)
+        self.self_adversarial = bool(_cfg(config, "self_adversarial", False))
+        self.adversarial_temperature = float(_cfg(config, "adversarial_temperature", 1.0))
+        self.sample_num = int(_cfg(_cfg(config, "train_neg_sample_args", {}) or {}, "sample_num", 1))
+        self.apply(xavier_normal_initialization)
+
+    # -- table tuples in slot order ---------------------------------------------------------------
+    def _w(self, names):
+        return tuple(getattr(self, n).weight for n in names)
+
+    def _tables(self, side):
+        head = self._w(self.USER_TABLES if side == "rec" else self.ENTITY_TABLES)
+        return head, self._w(self.RELATION_TABLES), self._w(self.ENTITY_TABLES)
+
+    # which relation row the rec side reads, per method (mirrors each reference method)
+    def _rec_rel_loss(self):
+        return self.ui_relation
+
+    def _rec_rel_full_sort(self):
+        return self.ui_relation
+
+    def _score(self, side, h_idx, r_idx, r_fixed, t_idx, eps=0.0, j_major_out=False):
+        head, rel, tail = self._tables(side)
+        return ops.kge_score_grouped(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, self.margin, eps,
+                                     j_major_out)
+
+    @staticmethod
+    def _pair(pos, neg):
+        """[B, 2] index view (column 0 positive) over one [2, B] buffer."""
+        return torch.stack([pos, neg], dim=0).t()
+
+    def _pair_scores(self, interaction, eps=0.0):
+        """([2, B_rec], [2, B_kg]) score matrices: row 0 positives, row 1 negatives."""
+        user = interaction[self.USER_ID]
+        rec = self._score("rec", user, None, self._rec_rel_loss(),
+                          self._pair(interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]), eps, True)
+        kg = self._score("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
+                         self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]), eps, True)
+        return rec.t(), kg.t()
+
+    # -- reference API ------------------------------------------------------------------------------
+    def forward(self, *rows):
+        raise NotImplementedError(
+            "hopwise_amd scorers gather inside the kernel; use predict / predict_kg / calculate_loss"
+        )
+
+    def predict(self, interaction):
+        user = interaction[self.USER_ID]
+        item = interaction[self.ITEM_ID]
+        return self._score("rec", user, None, self._rec_rel_loss(), item.view(-1, 1)).view(-1)
+
+    def predict_kg(self, interaction):
+        head = interaction[self.HEAD_ENTITY_ID]
+        return self._score("kg", head, interaction[self.RELATION_ID], 0,
+                           interaction[self.TAIL_ENTITY_ID].view(-1, 1)).view(-1)
+
+    def full_sort_predict(self, interaction):
+        user = interaction[self.USER_ID]
+        head, rel, tail = self._tables("rec")
+        return ops.kge_full_sort(self.MODEL, head, rel, tail, user, None, self._rec_rel_full_sort(), 0, self.n_items,
+                                 self.margin)
+
+    def full_sort_predict_kg(self, interaction):
+        head, rel, tail = self._tables("kg")
+        return ops.kge_full_sort(self.MODEL, head, rel, tail, interaction[self.HEAD_ENTITY_ID],
+                                 interaction[self.RELATION_ID], 0, 0, self.n_entities, self.margin)
+
+    # -- extension: grouped negatives ---------------------------------------------------------------
+    def score_grouped(self, side, h_idx, r_idx, t_idx):
+        """scores [B, 1+K] of B (h, r) groups against t_idx [B, 1+K] (column 0 = positive)."""
+        r_fixed = self._rec_rel_loss() if r_idx is None else 0
+        return self._score(side, h_idx, r_idx, r_fixed, t_idx)
+
+    def _rec_grouped_from_tiled(self, interaction):
+        """Undo the reference's tile layout (abstract_dataloader.py:192-198): the batch holds P positives
+        tiled K times, row j*P + i = j-th negative of positive i.  Returns (users [P], tails [P, 1+K])."""
+        K = self.sample_num
+        user = interaction[self.USER_ID]
+        P = user.shape[0] // K
+        pos = interaction[self.ITEM_ID][:P]
+        neg = interaction[self.NEG_ITEM_ID].view(K, P).t()
+        return user[:P], torch.cat([pos.view(P, 1), neg], dim=1)
+
+
+class TransE(_GatherKGE):
+    MODEL = "TransE"
+    USER_TABLES = ("user_embedding",)
+    ENTITY_TABLES = ("entity_embedding",)
+    RELATION_TABLES = ("relation_embedding",)
+
+    def _rec_rel_loss(self):  # relation_embedding.weight[-1]  (transe.py:63,108,117)
+        return self.n_relations - 1
+
+    _rec_rel_full_sort = _rec_rel_loss
+
+    def calculate_loss(self, interaction):
+        # TripletMarginLoss(margin, p=2) on (h + r, t+, t-) over cat(rec, kg) (transe.py:86-96); its
+        # distance is ||a - b + 1e-6||, so the loss path scores with eps = 1e-6.
+        rec, kg = self._pair_scores(interaction, eps=ops.PAIRWISE_EPS)
+        pos = torch.cat([rec[0], kg[0]])
+        neg = torch.cat([rec[1], kg[1]])
+        return ops.margin_ranking_mean(pos, neg, self.margin)
+
+
+class DistMult(_GatherKGE):
+    MODEL = "DistMult"
+    USER_TABLES = ("user_embedding",)
+    ENTITY_TABLES = ("entity_embedding",)
+    RELATION_TABLES = ("relation_embedding",)
+
+    def _rec_rel_loss(self):  # relation_embedding.weight[-1]  (distmult.py:57,103,123)
+        return self.n_relations - 1
+
+    _rec_rel_full_sort = _rec_rel_loss
+
+    def calculate_loss(self, interaction):  # distmult.py:69-95
+        rec, kg = self._pair_scores(interaction)
+        pos = torch.cat([rec[0], kg[0]])
+        neg = torch.cat([rec[1], kg[1]])
+        return ops.margin_ranking_mean(pos, neg, self.margin)
+
+
+class _BceKGE(_GatherKGE):
+    def calculate_loss(self, interaction):
+        # BCEWithLogitsLoss on cat(pos, neg) with labels (1, 0), rec and kg separately, summed
+        # (rotate.py:118-131, complex.py:115-128).
+        if self.self_adversarial and self.sample_num > 1:
+            users, tails = self._rec_grouped_from_tiled(interaction)
+            rec_scores = self.score_grouped("rec", users, None, tails)
+            rec_loss = ops.self_adversarial_mean(rec_scores, self.adversarial_temperature)
+            kg = self._score("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
+                             self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]),
+                             0.0, True).t()
+            return rec_loss + ops.bce_logits_mean(kg, kg.shape[1])
+        rec, kg = self._pair_scores(interaction)
+        return ops.bce_logits_mean(rec, rec.shape[1]) + ops.bce_logits_mean(kg, kg.shape[1])
+
+
+class RotatE(_BceKGE):
+    MODEL = "RotatE"
+    USER_TABLES = ("user_embedding", "user_embedding_im")
+    ENTITY_TABLES = ("entity_embedding", "entity_embedding_im")
+    RELATION_TABLES = ("relation_embedding",)
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        nn.init.uniform_(self.relation_embedding.weight, 0, 2 * math.pi)  # rotate.py:59
+
+
+class ComplEx(_BceKGE):
+    MODEL = "ComplEx"
+    USER_TABLES = ("user_re_embedding", "user_im_embedding")
+    ENTITY_TABLES = ("entity_re_embedding", "entity_im_embedding")
+    RELATION_TABLES = ("relation_re_embedding", "relation_im_embedding")
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.margin = 0.0  # ComplEx has no margin (complex.py:30-50)
+
+    def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (complex.py:167-168)
+        return self.n_relations - 1

@@ -1,0 +1,352 @@
+"""torch-tensor wrappers over the C ABI (device pointers + current HIP stream) and their autograd glue.
+
+PyTorch only provides device memory, the stream and autograd bookkeeping here; all arithmetic on
+the path runs in the hand-written gfx950 kernels of ``csrc/``.  CPU tensors are rejected -- there
+is deliberately no fallback implementation.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import MODEL_IDS, KgeDesc, KgeGrads, check
+
+PAIRWISE_EPS = 1e-6  # torch pairwise_distance eps used by TripletMarginLoss (TransE loss path)
+
+_N_SLOT = {"TransE": (1, 1, 1), "DistMult": (1, 1, 1), "RotatE": (2, 1, 2), "ComplEx": (2, 2, 2)}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype, what: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.HopwiseAmdError(f"{what}: expected a CUDA(HIP) tensor; hopwise_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0) -> KgeDesc:
+    """Describe one scorer call.  ``head``/``rel``/``tail`` are tuples of [rows, dim] fp32 tables."""
+    nh, nr, nt = _N_SLOT[model]
+    if (len(head), len(rel), len(tail)) != (nh, nr, nt):
+        raise ValueError(f"{model} takes {nh}/{nr}/{nt} head/rel/tail tables")
+    d = KgeDesc()
+    d.model = MODEL_IDS[model]
+    dim = head[0].shape[1]
+    for slot, tabs in (("head", head), ("rel", rel), ("tail", tail)):
+        arr = getattr(d, slot)
+        for k in range(2):
+            arr[k] = None
+        rows = tabs[0].shape[0]
+        for k, t in enumerate(tabs):
+            _dev(t, torch.float32, f"{slot} table")
+            if t.dim() != 2 or t.shape[1] != dim or t.shape[0] != rows or not t.is_contiguous():
+                raise ValueError(f"{slot} table {k}: need contiguous [rows, {dim}]")
+            arr[k] = t.data_ptr()
+    d.dim = dim
+    d.n_head, d.n_rel, d.n_tail = head[0].shape[0], rel[0].shape[0], tail[0].shape[0]
+    d.margin = float(margin)
+    d.eps = float(eps)
+    return d
+
+
+def _idx(t, what):
+    t = _dev(t, torch.int64, what)
+    return t
+
+
+class _OobCounter:
+    """Per-device int32 counter the kernels bump when an id falls outside its table."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, device):
+        key = (device.type, device.index)
+        if key not in cls._cache:
+            cls._cache[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return cls._cache[key]
+
+
+def oob_count(device=None) -> int:
+    """Number of out-of-range ids seen so far on ``device`` (synchronises)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return int(_OobCounter.get(device).item())
+
+
+def kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, t_idx, j_major_out=False):
+    """scores[b, j] for t_idx[b, j] (any strides).  Returns a [B, G] tensor; with ``j_major_out`` its
+    memory is [G, B] contiguous (positives-first layout used by the BCE label convention)."""
+    lib = _lib.load()
+    h_idx = _idx(h_idx, "h_idx").contiguous()
+    t_idx = _idx(t_idx, "t_idx")
+    if t_idx.dim() != 2 or t_idx.shape[0] != h_idx.shape[0]:
+        raise ValueError("t_idx must be [n_groups, n_tail_per_group]")
+    if r_idx is not None:
+        r_idx = _idx(r_idx, "r_idx").contiguous()
+        if r_idx.shape != h_idx.shape:
+            raise ValueError("r_idx must match h_idx")
+    B, G = t_idx.shape
+    if j_major_out:
+        out = torch.empty((G, B), dtype=torch.float32, device=h_idx.device).t()
+    else:
+        out = torch.empty((B, G), dtype=torch.float32, device=h_idx.device)
+    rc = lib.hw_kge_score_grouped(
+        C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), _ptr(t_idx), t_idx.stride(0), t_idx.stride(1), B, G,
+        _ptr(out), out.stride(0), out.stride(1), _ptr(_OobCounter.get(h_idx.device)), _stream(),
+    )
+    check(rc, "hw_kge_score_grouped")
+    return out
+
+
+def kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi):
+    lib = _lib.load()
+    h_idx = _idx(h_idx, "h_idx").contiguous()
+    if r_idx is not None:
+        r_idx = _idx(r_idx, "r_idx").contiguous()
+    B = h_idx.shape[0]
+    out = torch.empty((B, hi - lo), dtype=torch.float32, device=h_idx.device)
+    rc = lib.hw_kge_full_sort(
+        C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, int(lo), int(hi), _ptr(out), hi - lo,
+        _ptr(_OobCounter.get(h_idx.device)), _stream(),
+    )
+    check(rc, "hw_kge_full_sort")
+    return out
+
+
+class KgeScoreGrouped(torch.autograd.Function):
+    """Differentiable grouped scorer.  Inputs after the fixed arguments are the head, relation and
+    tail tables in slot order; the same Parameter may appear in several slots (kg side: entity tables
+    are both head and tail) -- its gradient buffer is then shared and returned once."""
+
+    @staticmethod
+    def forward(ctx, model, margin, eps, h_idx, r_idx, r_fixed, t_idx, j_major_out, *tables):
+        nh, nr, nt = _N_SLOT[model]
+        head, rel, tail = tables[:nh], tables[nh : nh + nr], tables[nh + nr :]
+        desc = make_desc(model, head, rel, tail, margin, eps)
+        out = kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, t_idx, j_major_out)
+        ctx.model, ctx.margin, ctx.eps, ctx.r_fixed = model, margin, eps, r_fixed
+        ctx.has_r = r_idx is not None
+        ctx.save_for_backward(h_idx, t_idx, *([r_idx] if r_idx is not None else []), *tables)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        h_idx, t_idx = saved[0], saved[1]
+        off = 2
+        r_idx = None
+        if ctx.has_r:
+            r_idx = saved[2].contiguous()
+            off = 3
+        tables = saved[off:]
+        model = ctx.model
+        nh, nr, nt = _N_SLOT[model]
+        head, rel, tail = tables[:nh], tables[nh : nh + nr], tables[nh + nr :]
+        desc = make_desc(model, head, rel, tail, ctx.margin, ctx.eps)
+        g = g.contiguous()  # [B, G] row-major
+        bufs = {}
+        grads_out = []
+        gs = KgeGrads()
+        slots = [("head", nh), ("rel", nr), ("tail", nt)]
+        k = 0
+        for slot, n in slots:
+            arr = getattr(gs, slot)
+            for i in range(2):
+                arr[i] = None
+            for i in range(n):
+                t = tables[k]
+                need = ctx.needs_input_grad[8 + k]
+                if need:
+                    key = t.data_ptr()
+                    if key in bufs:
+                        grads_out.append(None)  # shared buffer already returned for an earlier slot
+                    else:
+                        bufs[key] = torch.zeros_like(t)
+                        grads_out.append(bufs[key])
+                    arr[i] = bufs[key].data_ptr()
+                else:
+                    grads_out.append(None)
+                k += 1
+        h_idx = h_idx.contiguous()
+        B, G = t_idx.shape
+        rc = lib.hw_kge_grad_grouped(
+            C.byref(desc), C.byref(gs), _ptr(h_idx), _ptr(r_idx), int(ctx.r_fixed), _ptr(t_idx), t_idx.stride(0),
+            t_idx.stride(1), B, G, _ptr(g), g.stride(0), g.stride(1), _stream(),
+        )
+        check(rc, "hw_kge_grad_grouped")
+        return (None,) * 8 + tuple(grads_out)
+
+
+def kge_score_grouped(model, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, margin=0.0, eps=0.0, j_major_out=False):
+    return KgeScoreGrouped.apply(model, float(margin), float(eps), h_idx, r_idx, int(r_fixed), t_idx, j_major_out,
+                                 *head, *rel, *tail)
+
+
+def kge_full_sort(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin=0.0):
+    desc = make_desc(model, head, rel, tail, margin, 0.0)
+    return kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi)
+
+
+# ------------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------------
+def _workspace(device, extra=0):
+    n = int(_lib.load().hw_loss_workspace_floats()) + int(extra)
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+class BceLogitsMean(torch.autograd.Function):
+    """BCEWithLogitsLoss(mean) over a flat score vector whose first ``n_pos`` entries are positives."""
+
+    @staticmethod
+    def forward(ctx, x, n_pos):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "scores").contiguous().view(-1)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        gx = torch.empty_like(x) if x.requires_grad or ctx.needs_input_grad[0] else None
+        ws = _workspace(x.device)
+        check(lib.hw_loss_bce_logits(_ptr(x), x.numel(), int(n_pos), _ptr(loss), _ptr(gx), _ptr(ws), _stream()),
+              "hw_loss_bce_logits")
+        ctx.save_for_backward(gx)
+        ctx.shape = x.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (gx,) = ctx.saved_tensors
+        return gx * g, None
+
+
+class MarginRankingMean(torch.autograd.Function):
+    """mean(max(0, -(pos - neg) + margin)); also TransE's triplet loss on scores = -distance."""
+
+    @staticmethod
+    def forward(ctx, pos, neg, margin):
+        lib = _lib.load()
+        pos = _dev(pos, torch.float32, "pos").contiguous().view(-1)
+        neg = _dev(neg, torch.float32, "neg").contiguous().view(-1)
+        loss = torch.empty(1, dtype=torch.float32, device=pos.device)
+        gp, gn = torch.empty_like(pos), torch.empty_like(neg)
+        ws = _workspace(pos.device)
+        check(
+            lib.hw_loss_margin_ranking(_ptr(pos), _ptr(neg), pos.numel(), float(margin), _ptr(loss), _ptr(gp),
+                                       _ptr(gn), _ptr(ws), _stream()),
+            "hw_loss_margin_ranking",
+        )
+        ctx.save_for_backward(gp, gn)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        gp, gn = ctx.saved_tensors
+        return gp * g, gn * g, None
+
+
+class SelfAdversarialMean(torch.autograd.Function):
+    """Self-adversarial negative-sampling loss on grouped scores [B, 1+K] (column 0 = positive)."""
+
+    @staticmethod
+    def forward(ctx, scores, alpha):
+        lib = _lib.load()
+        s = _dev(scores, torch.float32, "scores").contiguous()
+        B, Gc = s.shape
+        loss = torch.empty(1, dtype=torch.float32, device=s.device)
+        gs = torch.empty_like(s)
+        ws = _workspace(s.device, extra=B)
+        check(lib.hw_loss_self_adversarial(_ptr(s), B, Gc, float(alpha), _ptr(loss), _ptr(gs), _ptr(ws), _stream()),
+              "hw_loss_self_adversarial")
+        ctx.save_for_backward(gs)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (gs,) = ctx.saved_tensors
+        return gs * g, None
+
+
+def bce_logits_mean(x, n_pos):
+    return BceLogitsMean.apply(x, n_pos)
+
+
+def margin_ranking_mean(pos, neg, margin):
+    return MarginRankingMean.apply(pos, neg, margin)
+
+
+def self_adversarial_mean(scores, alpha):
+    return SelfAdversarialMean.apply(scores, alpha)
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation
+# ------------------------------------------------------------------------------------------------
+def mask_scores_(scores, history_index=None):
+    """In place: scores[:, 0] = -inf; scores[history_index] = -inf (trainer.py:731-734)."""
+    lib = _lib.load()
+    s = _dev(scores, torch.float32, "scores")
+    if s.dim() != 2 or not s.is_contiguous():
+        raise ValueError("scores must be contiguous [rows, cols]")
+    hr = hc = None
+    n = 0
+    if history_index is not None:
+        hr = _idx(history_index[0], "history rows").contiguous()
+        hc = _idx(history_index[1], "history cols").contiguous()
+        n = hr.numel()
+    check(lib.hw_mask_scores(_ptr(s), s.shape[0], s.shape[1], _ptr(hr), _ptr(hc), n, _stream()), "hw_mask_scores")
+    return scores
+
+
+def topk_rows(scores, k):
+    """Row-wise top-k ordered (value desc, index asc): (values [R, k] fp32, indices [R, k] int64)."""
+    lib = _lib.load()
+    s = _dev(scores, torch.float32, "scores")
+    if s.dim() != 2 or s.stride(1) != 1:
+        raise ValueError("scores must be [rows, cols] with unit column stride")
+    R, N = s.shape
+    val = torch.empty((R, k), dtype=torch.float32, device=s.device)
+    idx = torch.empty((R, k), dtype=torch.int64, device=s.device)
+    check(lib.hw_topk_rows(_ptr(s), R, N, s.stride(0), int(k), _ptr(val), _ptr(idx), _stream()), "hw_topk_rows")
+    return val, idx
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler
+# ------------------------------------------------------------------------------------------------
+def neg_sample(used_ptr, used_idx, keys, num, value_num, seed, offset, alias=None, out=None):
+    """out[j*len(keys)+i]: j-th negative of keys[i], never in used(keys[i]) (sampler.py:140-183).
+    ``out`` (optional, contiguous int64 [num*len(keys)]) lets the draw land directly in a grouped index buffer."""
+    lib = _lib.load()
+    used_ptr = _idx(used_ptr, "used_ptr").contiguous()
+    used_idx = _idx(used_idx, "used_idx").contiguous()
+    keys = _idx(keys, "keys").contiguous()
+    if out is None:
+        out = torch.empty(keys.numel() * int(num), dtype=torch.int64, device=keys.device)
+    else:
+        out = _idx(out, "out")
+        if not out.is_contiguous() or out.numel() != keys.numel() * int(num):
+            raise ValueError("out must be contiguous with num*len(keys) elements")
+    ap = ak = aa = None
+    na = 0
+    if alias is not None:
+        ap, ak, aa = alias
+        ap = _dev(ap, torch.float32, "alias prob").contiguous()
+        ak, aa = _idx(ak, "alias keys").contiguous(), _idx(aa, "alias alias").contiguous()
+        na = ap.numel()
+    check(
+        lib.hw_neg_sample(_ptr(used_ptr), _ptr(used_idx), used_ptr.numel() - 1, _ptr(keys), keys.numel(), int(num),
+                          int(value_num), _ptr(ap), _ptr(ak), _ptr(aa), na, C.c_uint64(seed & (2**64 - 1)),
+                          C.c_uint64(offset & (2**64 - 1)), _ptr(out), _ptr(_OobCounter.get(keys.device)), _stream()),
+        "hw_neg_sample",
+    )
+    return out

@@ -1,0 +1,147 @@
+/* hopwise_amd.h -- C ABI of the MI355X-native KGE-scoring / negative-sampling / PGPR beam-search engine.
+ *
+ * The shared library (hopwise_amd/csrc/libhopwise_amd.so, built by hipcc for gfx950) is the drop-in
+ * boundary.  Every entry point
+ *   - takes plain device pointers + sizes (caller owns every buffer; nothing is allocated or freed),
+ *   - launches asynchronously on the given hipStream_t (passed as void*; NULL = the null stream),
+ *   - returns HW_OK (0) or a negative hw_status code, never throws, never synchronises,
+ *   - is safe to capture into a hipGraph.
+ * All tables are row-major contiguous float32 [rows, dim]; all ids are int64 (what the reference's
+ * Interaction carries, /root/reference/hopwise/data/interaction.py:44-118).  Out-of-range ids are
+ * clamped into the table (never fault) and counted in the optional `oob_counter`.
+ *
+ * Each function names the reference interface it replaces (paths relative to /root/reference/hopwise).
+ */
+#ifndef HOPWISE_AMD_H
+#define HOPWISE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    HW_OK = 0,
+    HW_ERR_INVALID_ARG = -1,  /* null pointer, negative size, unsupported dim */
+    HW_ERR_UNSUPPORTED = -2,  /* model / option combination not built */
+    HW_ERR_LAUNCH = -3,       /* hipGetLastError() != hipSuccess after the launch */
+    HW_ERR_WORKSPACE = -4     /* caller workspace too small */
+} hw_status;
+
+typedef enum {
+    HW_TRANSE = 0,   /* model/knowledge_graph_embedding_recommender/transe.py:55-57   */
+    HW_ROTATE = 1,   /* .../rotate.py:61-69   */
+    HW_COMPLEX = 2,  /* .../complex.py:53-62  */
+    HW_DISTMULT = 3  /* .../distmult.py:50-51 */
+} hw_kge_model;
+
+/* Table set of one scorer call.  Slots with a single table leave [1] NULL.
+ *   TransE/DistMult: head[0], rel[0], tail[0]
+ *   RotatE:          head = {re, im}, rel = {theta}, tail = {re, im}
+ *   ComplEx:         head = {re, im}, rel = {re, im}, tail = {re, im}
+ * "head" is the user table(s) on the rec side and the entity table(s) on the kg side. */
+typedef struct {
+    int32_t model;        /* hw_kge_model */
+    int32_t dim;          /* embedding_size, 1..1024 */
+    const float* head[2];
+    const float* rel[2];
+    const float* tail[2];
+    int64_t n_head;       /* rows of head[*] */
+    int64_t n_rel;
+    int64_t n_tail;
+    float margin;         /* RotatE: score = margin - ||.|| (rotate.py:69) */
+    float eps;            /* TransE only: distance of (h + r - t + eps); 0 for scoring, 1e-6 inside the
+                             TripletMarginLoss path (torch pairwise_distance) */
+} hw_kge_desc;
+
+/* Gradient destination tables, same slot layout as hw_kge_desc (dense [rows, dim] float32,
+ * accumulated into with atomic adds; the caller zeroes them).  NULL = that slot gets no gradient. */
+typedef struct {
+    float* head[2];
+    float* rel[2];
+    float* tail[2];
+} hw_kge_grads;
+
+/* ---- KGE scoring ---------------------------------------------------------------------------------
+ * score[b, j] of group b = (h_idx[b], r) against tail t_idx[b*t_stride_b + j*t_stride_j], j in [0, n_tail_per_group).
+ * r = r_idx[b] or, when r_idx == NULL, the fixed relation row r_fixed (the [UI-Relation] row used by the
+ * rec side: transe.py:63, rotate.py:76-77).  out[b*o_stride_b + j*o_stride_j].
+ * Replaces <Model>.forward on gathered rows as used by calculate_loss / predict / predict_kg
+ * (rotate.py:98-159 and the same methods of transe.py / complex.py / distmult.py); with
+ * n_tail_per_group = 1 + K it scores one positive and K negatives per (h, r) group in one pass. */
+int hw_kge_score_grouped(const hw_kge_desc* desc,
+                         const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                         const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
+                         int64_t n_groups, int64_t n_tail_per_group,
+                         float* out, int64_t o_stride_b, int64_t o_stride_j,
+                         int32_t* oob_counter, void* stream);
+
+/* Full sort: out[b, n - tail_lo] = score(h_idx[b], r, n) for every tail row n in [tail_lo, tail_hi).
+ * Replaces full_sort_predict / full_sort_predict_kg (rotate.py:161-220, transe.py:112-154,
+ * complex.py:162-219, distmult.py:119-146) without the [B, N, d] temporaries. */
+int hw_kge_full_sort(const hw_kge_desc* desc,
+                     const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                     int64_t n_heads, int64_t tail_lo, int64_t tail_hi,
+                     float* out, int64_t out_ld,
+                     int32_t* oob_counter, void* stream);
+
+/* Backward of hw_kge_score_grouped: given g[b, j] = dLoss/dscore[b, j] (same strides as `out`),
+ * atomically accumulates the row gradients into `grads`.  Replaces autograd through
+ * nn.Embedding + <Model>.forward (dense embedding_dense_backward in the reference). */
+int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* grads,
+                        const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                        const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
+                        int64_t n_groups, int64_t n_tail_per_group,
+                        const float* g, int64_t g_stride_b, int64_t g_stride_j,
+                        void* stream);
+
+/* ---- losses on score vectors (deterministic two-stage reductions) ---------------------------------
+ * `workspace` must hold at least hw_loss_workspace_floats() floats. */
+int64_t hw_loss_workspace_floats(void);
+
+/* torch.nn.BCEWithLogitsLoss(mean) over x[0..n): label 1 for i < n_pos, else 0 (rotate.py:118-131,
+ * complex.py:115-128).  loss_out[0] = loss * loss_scale...; gx (nullable) receives dLoss/dx. */
+int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, float* loss_out, float* gx,
+                       float* workspace, void* stream);
+
+/* mean(max(0, -(pos - neg) + margin)): torch MarginRankingLoss(target=+1) (distmult.py:86-93) and,
+ * on scores = -distance, TripletMarginLoss (transe.py:48,96).  gpos/gneg nullable. */
+int hw_loss_margin_ranking(const float* pos, const float* neg, int64_t n, float margin,
+                           float* loss_out, float* gpos, float* gneg, float* workspace, void* stream);
+
+/* Self-adversarial negative weighting (RotatE paper; NOT in the reference -- SURVEY.md §8 A9, opt-in):
+ * scores [n_groups, 1+K] row-major, column 0 positive.  loss = mean_b( -logsig(s_pos)
+ * - sum_i softmax(alpha*s_neg)_i * logsig(-s_neg_i) ), weights detached.  gscores nullable. */
+int hw_loss_self_adversarial(const float* scores, int64_t n_groups, int64_t n_cols, float alpha,
+                             float* loss_out, float* gscores, float* workspace, void* stream);
+
+/* ---- evaluation: mask + top-k ---------------------------------------------------------------------
+ * In-place masking of a [n_rows, n_cols] score matrix the way KGTrainer._full_sort_batch_eval does
+ * (trainer/trainer.py:731-734): column 0 and every (hist_rows[i], hist_cols[i]) := -inf. */
+int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols,
+                   const int64_t* hist_rows, const int64_t* hist_cols, int64_t n_hist, void* stream);
+
+/* Row-wise top-k ordered (value desc, index asc) -- replaces torch.topk in
+ * evaluator/collector.py:173-183 and pgpr.py:454.  k <= 1024. */
+int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
+                 float* out_val, int64_t* out_idx, void* stream);
+
+/* ---- negative sampling ----------------------------------------------------------------------------
+ * Device restatement of AbstractSampler.sample_by_key_ids (sampler/sampler.py:140-183) for
+ * KGSampler (:294-357) and Sampler (:186-291): for key i and draw j, out[j*n_keys + i] is uniform over
+ * [1, value_num) minus used(keys[i]), by rejection.  used sets are a CSR (used_ptr[n_key_space+1],
+ * used_idx sorted ascending inside each row).  Philox4x32-10 counter RNG keyed by (seed, offset).
+ * alias_prob/alias_keys/alias_alias (nullable) switch to the popularity distribution (:68-116). */
+int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, int64_t n_key_space,
+                  const int64_t* keys, int64_t n_keys, int32_t num, int64_t value_num,
+                  const float* alias_prob, const int64_t* alias_keys, const int64_t* alias_alias,
+                  int64_t n_alias, uint64_t seed, uint64_t offset,
+                  int64_t* out, int32_t* oob_counter, void* stream);
+
+const char* hw_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOPWISE_AMD_H */

@@ -1,0 +1,51 @@
+"""CPU checks of the boundary: the library loads and exports every symbol include/hopwise_amd.h declares."""
+
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hopwise_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hw_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from hopwise_amd import _lib
+
+    lib = _lib.load()
+    syms = declared_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    for s in _lib.SIGNATURES:
+        assert s in syms, f"{s} bound in _lib.py but not declared in the header"
+    assert b"gfx950" in lib.hw_version()
+    assert lib.hw_loss_workspace_floats() >= 1
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    import ctypes as C
+
+    from hopwise_amd import _lib
+
+    lib = _lib.load()
+    d = _lib.KgeDesc()
+    d.model, d.dim = 1, 0
+    assert lib.hw_kge_score_grouped(C.byref(d), None, None, 0, None, 0, 0, 1, 1, None, 0, 0, None, None) == -1
+    assert lib.hw_topk_rows(None, 1, 1, 1, 1, None, None, None) == -1
+    assert lib.hw_loss_bce_logits(None, 1, 1, None, None, None, None) == -1
+    assert lib.hw_neg_sample(None, None, 1, None, 0, 1, 2, None, None, None, 0, 0, 0, None, None, None) == -1
+
+
+def test_no_cpu_fallback_in_product():
+    """The product package must not import the oracle."""
+    import pathlib
+
+    for p in pathlib.Path(ROOT, "hopwise_amd").rglob("*.py"):
+        src = p.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, p

@@ -1,0 +1,284 @@
+"""HIP scorers / losses / gradients against (1) vectors produced by the reference and (2) the numpy oracle.
+
+Tolerances: scores 1e-4 relative (north star) with 1e-5 absolute floor; gradients 2e-4 relative with an
+absolute floor scaled to the gradient magnitude (atomics reorder float adds); ranked indices exact where
+the oracle's adjacent score gap exceeds the score tolerance.
+"""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import kge as okge
+from tests.helpers import FakeDataset, load_tables, make_config, random_tables
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+KGE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "kge_[A-Z]*_d*.npz")))
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def get_cls(name):
+    import hopwise_amd.model as M
+
+    return getattr(M, name)
+
+
+def golden_case(path):
+    z = np.load(path)
+    tables = {k[len("table.") : -len(".weight")]: z[k] for k in z.files if k.startswith("table.")}
+    inter = {k[len("inter.") :]: z[k] for k in z.files if k.startswith("inter.")}
+    model = os.path.basename(path).split("_")[1]
+    return z, model, tables, inter
+
+
+def build(model, tables, d, nU, nI, nE, nR, **extra):
+    m = get_cls(model)(make_config(dev(), d, 1.0, **extra), FakeDataset(nU, nI, nE, nR)).to(dev())
+    return load_tables(m, tables, dev())
+
+
+def to_dev(inter):
+    return {k: torch.from_numpy(v).to(dev()) for k, v in inter.items()}
+
+
+@pytest.mark.parametrize("path", KGE_FILES, ids=[os.path.basename(p)[4:-4] for p in KGE_FILES])
+def test_against_reference_golden(path):
+    z, model, tables, inter = golden_case(path)
+    d = next(iter(tables.values())).shape[1]
+    nI = z["fs.scores"].shape[1]
+    m = build(model, tables, d, 20, nI, 48, 5)
+    it = to_dev(inter)
+    with torch.no_grad():
+        np.testing.assert_allclose(m.predict(it).cpu().numpy(), z["predict"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(m.predict_kg(it).cpu().numpy(), z["predict_kg"], rtol=RTOL, atol=ATOL)
+    m.zero_grad()
+    loss = m.calculate_loss(it)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["loss"], rtol=1e-5)
+    for k, p in m.named_parameters():
+        ref = z[f"grad.{k}"]
+        scale = np.abs(ref).max() + 1e-12
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
+    with torch.no_grad():
+        fs = m.full_sort_predict({"user_id": torch.from_numpy(z["fs.users"]).to(dev())})
+        assert tuple(fs.shape) == z["fs.scores"].shape
+        np.testing.assert_allclose(fs.cpu().numpy(), z["fs.scores"], rtol=RTOL, atol=ATOL)
+        fskg = m.full_sort_predict_kg(
+            {"head_id": torch.from_numpy(z["fskg.heads"]).to(dev()), "relation_id": torch.from_numpy(z["fskg.rels"]).to(dev())}
+        )
+        np.testing.assert_allclose(fskg.cpu().numpy(), z["fskg.scores"], rtol=RTOL, atol=ATOL)
+    # evaluation protocol on device: mask + top-10; indices must equal the reference's wherever the
+    # reference's neighbouring scores are further apart than the score tolerance
+    from hopwise_amd import ops
+
+    masked = ops.mask_scores_(fs.clone(), (torch.from_numpy(z["eval.history_rows"]).to(dev()),
+                                           torch.from_numpy(z["eval.history_cols"]).to(dev())))
+    assert np.array_equal(np.isneginf(masked.cpu().numpy()), np.isneginf(z["eval.masked"]))
+    tv, ti = ops.topk_rows(masked, 10)
+    tv, ti = tv.cpu().numpy(), ti.cpu().numpy()
+    ref_v, ref_i = z["eval.topk_values"], z["eval.topk_idx"]
+    full_sorted = -np.sort(-z["eval.masked"], axis=1)
+    for r in range(ref_v.shape[0]):
+        for c in range(10):
+            if not np.isfinite(ref_v[r, c]):
+                continue
+            gap_prev = np.inf if c == 0 else full_sorted[r, c - 1] - full_sorted[r, c]
+            gap_next = full_sorted[r, c] - full_sorted[r, c + 1] if c + 1 < full_sorted.shape[1] else np.inf
+            tol = ATOL + RTOL * abs(ref_v[r, c])
+            if min(gap_prev, gap_next) > 4 * tol:
+                assert ti[r, c] == ref_i[r, c], (r, c)
+            np.testing.assert_allclose(tv[r, c], ref_v[r, c], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("model", okge.MODELS)
+@pytest.mark.parametrize("dim", [4, 7, 50, 100, 130, 200, 256, 500, 1024])
+def test_grouped_scorer_vs_oracle(model, dim):
+    nU, nE, nR, B, K = 300, 2000, 9, 37, 19
+    tables = random_tables(model, nU, nE, nR, dim, seed=dim)
+    rng = np.random.default_rng(dim + 1)
+    m = build(model, tables, dim, nU, 100, nE, nR)
+    from hopwise_amd import ops
+
+    for side, n_head in (("rec", nU), ("kg", nE)):
+        h = rng.integers(0, n_head, B)
+        r = rng.integers(0, nR, B)
+        t = rng.integers(0, nE, (B, 1 + K))
+        ref = okge.score_grouped(model, tables, side, h, r, t, margin=m.margin)
+        head, rel, tail = m._tables(side)
+        got = ops.kge_score_grouped(model, head, rel, tail, torch.from_numpy(h).to(dev()), torch.from_numpy(r).to(dev()),
+                                    0, torch.from_numpy(t).to(dev()), m.margin)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+        # j-major output layout + strided (transposed) index input give the same numbers
+        tt = torch.from_numpy(np.ascontiguousarray(t.T)).to(dev()).t()
+        got2 = ops.kge_score_grouped(model, head, rel, tail, torch.from_numpy(h).to(dev()),
+                                     torch.from_numpy(r).to(dev()), 0, tt, m.margin, 0.0, True)
+        assert got2.stride() == (1, B)
+        np.testing.assert_array_equal(got2.detach().cpu().numpy(), got.detach().cpu().numpy())
+    assert ops.oob_count(dev()) == 0
+
+
+@pytest.mark.parametrize("model", okge.MODELS)
+def test_full_sort_vs_oracle_ragged(model):
+    # sizes chosen so that chunks, head blocks and sub-wave groups all have ragged tails
+    for dim, nE, B in ((64, 1003, 1), (200, 777, 5), (100, 130, 9), (24, 67, 2)):
+        nU, nR, nI = 50, 6, min(nE, 61)
+        tables = random_tables(model, nU, nE, nR, dim, seed=dim + B)
+        m = build(model, tables, dim, nU, nI, nE, nR)
+        rng = np.random.default_rng(3)
+        users = rng.integers(0, nU, B)
+        heads = rng.integers(0, nE, B)
+        rels = rng.integers(0, nR, B)
+        with torch.no_grad():
+            fs = m.full_sort_predict({"user_id": torch.from_numpy(users).to(dev())}).cpu().numpy()
+            fk = m.full_sort_predict_kg({"head_id": torch.from_numpy(heads).to(dev()),
+                                         "relation_id": torch.from_numpy(rels).to(dev())}).cpu().numpy()
+        ui = nR - 1
+        np.testing.assert_allclose(fs, okge.full_sort_predict(model, tables, users, nI, m.margin, ui), rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(fk, okge.full_sort_predict_kg(model, tables, heads, rels, m.margin), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("model", okge.MODELS)
+@pytest.mark.parametrize("dim", [16, 200, 300])
+def test_loss_and_grads_vs_oracle(model, dim):
+    nU, nI, nE, nR, Br, Bk = 40, 30, 90, 7, 64, 96
+    tables = random_tables(model, nU, nE, nR, dim, seed=11)
+    rng = np.random.default_rng(5)
+    inter = dict(
+        user_id=rng.integers(0, nU, Br), item_id=rng.integers(0, nI, Br), neg_item_id=rng.integers(0, nI, Br),
+        head_id=rng.integers(0, nE, Bk), relation_id=rng.integers(0, nR, Bk), tail_id=rng.integers(0, nE, Bk),
+        neg_tail_id=rng.integers(0, nE, Bk),
+    )
+    m = build(model, tables, dim, nU, nI, nE, nR)
+    loss_ref, grads_ref = okge.calculate_loss(model, tables, inter, m.margin if model != "ComplEx" else 1.0,
+                                              ui_relation=nR - 1, with_grad=True)
+    m.zero_grad()
+    loss = m.calculate_loss(to_dev(inter))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), loss_ref, rtol=1e-5)
+    for k, p in m.named_parameters():
+        ref = grads_ref[k[: -len(".weight")]]
+        scale = np.abs(ref).max() + 1e-12
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("model", okge.MODELS)
+def test_three_adam_steps_match_reference(model):
+    """A18: zero_grad -> calculate_loss -> backward -> Adam.step, compared with the reference run."""
+    z = np.load(os.path.join(GOLDEN, f"kge_train_{model}.npz"))
+    tables = {k[len("init.") : -len(".weight")]: z[k] for k in z.files if k.startswith("init.")}
+    m = build(model, tables, 16, 20, 16, 48, 5)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=0.0)
+    m.train()
+    losses = []
+    for step in range(3):
+        inter = {k[len(f"step{step}.") :]: z[k] for k in z.files if k.startswith(f"step{step}.")}
+        opt.zero_grad()
+        loss = m.calculate_loss(to_dev(inter))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    np.testing.assert_allclose(losses, z["losses"], rtol=2e-5)
+    for k, v in m.state_dict().items():
+        # Adam normalises the step, so a 1e-7 gradient difference can move a weight by up to lr; the
+        # bound below is 3 steps * lr * 2% plus float noise.
+        np.testing.assert_allclose(v.cpu().numpy(), z[f"final.{k}"], rtol=0, atol=6e-5, err_msg=k)
+
+
+def test_losses_vs_oracle():
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 300, 70001):
+        x = (rng.standard_normal(n) * 4).astype(np.float32)
+        npos = n // 3
+        y = (np.arange(n) < npos).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev()).requires_grad_(True)
+        l = ops.bce_logits_mean(xt, npos)
+        l.backward()
+        np.testing.assert_allclose(l.item(), okge.bce_with_logits_mean(x, y), rtol=2e-6)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), okge.bce_with_logits_grad(x, y), rtol=1e-5, atol=1e-9)
+        p = rng.standard_normal(n).astype(np.float32)
+        q = rng.standard_normal(n).astype(np.float32)
+        pt = torch.from_numpy(p).to(dev()).requires_grad_(True)
+        qt = torch.from_numpy(q).to(dev()).requires_grad_(True)
+        l = ops.margin_ranking_mean(pt, qt, 0.7)
+        l.backward()
+        np.testing.assert_allclose(l.item(), okge.margin_ranking_mean(p, q, 0.7), rtol=2e-6)
+        act = ((-(p.astype(np.float64) - q) + 0.7) > 0) / n
+        np.testing.assert_allclose(pt.grad.cpu().numpy(), -act, rtol=1e-6)
+        np.testing.assert_allclose(qt.grad.cpu().numpy(), act, rtol=1e-6)
+    for B, K in ((1, 1), (5, 3), (300, 256), (2048, 70)):
+        s = (rng.standard_normal((B, 1 + K)) * 3).astype(np.float32)
+        st = torch.from_numpy(s).to(dev()).requires_grad_(True)
+        l = ops.self_adversarial_mean(st, 0.5)
+        l.backward()
+        np.testing.assert_allclose(l.item(), okge.self_adversarial_loss(s, 0.5), rtol=1e-5)
+        np.testing.assert_allclose(st.grad.cpu().numpy(), okge.self_adversarial_grad(s, 0.5), rtol=1e-4, atol=1e-9)
+
+
+def test_self_adversarial_known_answer():
+    """Closed form (A9 is unpinned by the reference): with equal negative scores the weights are uniform."""
+    from hopwise_amd import ops
+
+    s = torch.tensor([[0.0, 1.0, 1.0, 1.0, 1.0]], device=dev())
+    want = np.log(2.0) + np.log1p(np.e)  # -logsig(0) + 4 * (1/4) * -logsig(-1)
+    assert abs(ops.self_adversarial_mean(s, 2.0).item() - want) < 1e-6
+
+
+def test_topk_ties_and_short_rows():
+    from hopwise_amd import ops
+
+    s = torch.tensor([[1.0, 3.0, 3.0, -np.inf, 2.0], [0.0, 0.0, 0.0, 0.0, 0.0]], device=dev())
+    v, i = ops.topk_rows(s, 4)
+    assert i.cpu().tolist() == [[1, 2, 4, 0], [0, 1, 2, 3]]
+    v, i = ops.topk_rows(s[:, :3], 5)  # k > columns, strided rows
+    assert i.cpu().tolist()[0] == [1, 2, 0, -1, -1]
+    rng = np.random.default_rng(1)
+    big = rng.standard_normal((3, 13805)).astype(np.float32)
+    v, i = ops.topk_rows(torch.from_numpy(big).to(dev()), 10)
+    rv, ri = okge.topk_desc(big, 10)
+    np.testing.assert_array_equal(i.cpu().numpy(), ri)
+    np.testing.assert_array_equal(v.cpu().numpy(), rv)
+
+
+def test_cpu_tensors_are_rejected():
+    from hopwise_amd import _lib, ops
+
+    with pytest.raises(_lib.HopwiseAmdError):
+        ops.topk_rows(torch.zeros(2, 3), 1)
+
+
+def test_self_adversarial_model_path():
+    """RotatE with self_adversarial=True on a tiled (P positives x K negatives) batch vs the oracle."""
+    model, dim, nU, nI, nE, nR, P, K, Bk = "RotatE", 32, 30, 25, 60, 5, 6, 8, 16
+    tables = random_tables(model, nU, nE, nR, dim, seed=2)
+    rng = np.random.default_rng(9)
+    users, pos = rng.integers(1, nU, P), rng.integers(1, nI, P)
+    neg = rng.integers(1, nI, (K, P))
+    inter = dict(user_id=np.tile(users, K), item_id=np.tile(pos, K), neg_item_id=neg.reshape(-1),
+                 head_id=rng.integers(1, nE, Bk), relation_id=rng.integers(1, nR, Bk), tail_id=rng.integers(1, nE, Bk),
+                 neg_tail_id=rng.integers(1, nE, Bk))
+    m = build(model, tables, dim, nU, nI, nE, nR, self_adversarial=True, adversarial_temperature=0.7,
+              train_neg_sample_args={"sample_num": K})
+    loss = m.calculate_loss(to_dev(inter))
+    tails = np.concatenate([pos[:, None], neg.T], axis=1)
+    s = okge.score_grouped(model, tables, "rec", users, np.full(P, nR - 1), tails, margin=1.0)
+    kgp = okge.score_rows(model, (tables["entity_embedding"][inter["head_id"]], tables["entity_embedding_im"][inter["head_id"]]),
+                          (tables["relation_embedding"][inter["relation_id"]],),
+                          (tables["entity_embedding"][inter["tail_id"]], tables["entity_embedding_im"][inter["tail_id"]]), 1.0)
+    kgn = okge.score_rows(model, (tables["entity_embedding"][inter["head_id"]], tables["entity_embedding_im"][inter["head_id"]]),
+                          (tables["relation_embedding"][inter["relation_id"]],),
+                          (tables["entity_embedding"][inter["neg_tail_id"]], tables["entity_embedding_im"][inter["neg_tail_id"]]), 1.0)
+    want = okge.self_adversarial_loss(s, 0.7) + okge.bce_with_logits_mean(
+        np.concatenate([kgp, kgn]), np.concatenate([np.ones(Bk), np.zeros(Bk)]))
+    np.testing.assert_allclose(loss.item(), want, rtol=1e-5)
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
