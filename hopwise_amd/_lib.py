@@ -91,6 +91,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; import it first so that this library's DT_NEEDED entry resolves
+    # to the SAME runtime instance (streams / device pointers are only valid inside one runtime).
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise HopwiseAmdError(
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m hopwise_amd.build` "

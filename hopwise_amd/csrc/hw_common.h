@@ -8,6 +8,11 @@
 #define HW_WAVE 64
 #define HW_MAX_DIM 1024
 
+// hipGetLastError() reports the last error of ANY earlier runtime call on this thread (torch leaves benign
+// ones behind), so every launcher clears it first and reads it back right after its own launches.
+#define HW_CLEAR_ERR() ((void)hipGetLastError())
+#define HW_LAUNCH_RC() (hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH)
+
 namespace hw {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

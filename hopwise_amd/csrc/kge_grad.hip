@@ -152,6 +152,7 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     const int64_t n_blocks = (n_tasks + 3) / 4;
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
     const int NE = desc->dim <= 64 ? 1 : (desc->dim <= 256 ? 4 : 16);
+    HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
 #define CALL(MODEL, NE_)                                                                                           \
     hipLaunchKernelGGL((kge_grad_grouped_kernel<MODEL, NE_>), dim3((unsigned)n_blocks), dim3(256), 0, st, *desc,     \
@@ -172,5 +173,5 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     }
 #undef BYNE
 #undef CALL
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }

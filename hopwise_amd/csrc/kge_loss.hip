@@ -191,30 +191,33 @@ static int loss_grid(int64_t n) {
 extern "C" int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, float* loss_out, float* gx,
                                   float* workspace, void* stream) {
     if (!x || !loss_out || !workspace || n <= 0 || n_pos < 0) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int grid = loss_grid(n);
     const float inv_n = 1.0f / (float)n;
     hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, x, n, n_pos, inv_n, gx, workspace);
     hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_n, loss_out);
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }
 
 extern "C" int hw_loss_margin_ranking(const float* pos, const float* neg, int64_t n, float margin, float* loss_out,
                                       float* gpos, float* gneg, float* workspace, void* stream) {
     if (!pos || !neg || !loss_out || !workspace || n <= 0) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int grid = loss_grid(n);
     const float inv_n = 1.0f / (float)n;
     hipLaunchKernelGGL(margin_ranking_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, pos, neg, n, margin, inv_n, gpos,
                        gneg, workspace);
     hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_n, loss_out);
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }
 
 extern "C" int hw_loss_self_adversarial(const float* scores, int64_t n_groups, int64_t n_cols, float alpha,
                                         float* loss_out, float* gscores, float* workspace, void* stream) {
     // workspace: LOSS_BLOCKS partials followed by n_groups per-group losses
     if (!scores || !loss_out || !workspace || n_groups <= 0 || n_cols < 2 || n_cols > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     float* group_loss = workspace + LOSS_BLOCKS;
     const float inv_b = 1.0f / (float)n_groups;
@@ -223,7 +226,7 @@ extern "C" int hw_loss_self_adversarial(const float* scores, int64_t n_groups, i
     const int grid = loss_grid(n_groups);
     hipLaunchKernelGGL(sum_partial_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, group_loss, n_groups, workspace);
     hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_b, loss_out);
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }
 
 extern "C" int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols, const int64_t* hist_rows,
@@ -232,9 +235,10 @@ extern "C" int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols, con
         return HW_ERR_INVALID_ARG;
     const int64_t n = n_rows > n_hist ? n_rows : n_hist;
     if (n == 0) return HW_OK;
+    HW_CLEAR_ERR();
     hipLaunchKernelGGL(mask_scores_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores,
                        n_rows, n_cols, hist_rows, hist_cols, n_hist);
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }
 
 extern "C" int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k, float* out_val,
@@ -243,6 +247,7 @@ extern "C" int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols,
         return HW_ERR_INVALID_ARG;
     if (n_cols > 0xffffffffll || n_rows > INT32_MAX) return HW_ERR_INVALID_ARG;
     if (n_rows == 0) return HW_OK;
+    HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     if (n_cols <= 1024)
         hipLaunchKernelGGL((topk_rows_kernel<64>), dim3((unsigned)n_rows), dim3(64), 0, st, scores, n_cols, ld, k,
@@ -250,5 +255,5 @@ extern "C" int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols,
     else
         hipLaunchKernelGGL((topk_rows_kernel<256>), dim3((unsigned)n_rows), dim3(256), 0, st, scores, n_cols, ld, k,
                            out_val, out_idx);
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }

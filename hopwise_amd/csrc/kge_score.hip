@@ -213,6 +213,7 @@ extern "C" int hw_kge_score_grouped(const hw_kge_desc* desc, const int64_t* h_id
     const int64_t n_tasks = n_groups * S;
     const int64_t n_blocks = (n_tasks + 3) / 4;
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
 #define CALL(MODEL, G_, NE_, VEC_)                                                                              \
     hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U>), dim3((unsigned)n_blocks), dim3(256), 0, \
@@ -220,7 +221,7 @@ extern "C" int hw_kge_score_grouped(const hw_kge_desc* desc, const int64_t* h_id
                        o_stride_b, o_stride_j, oob_counter)
     HW_DISPATCH_MODEL(desc->model, shape, CALL);
 #undef CALL
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }
 
 extern "C" int hw_kge_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
@@ -252,6 +253,7 @@ extern "C" int hw_kge_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, c
     const int64_t n_tasks = n_chunks * n_hb;
     const int64_t n_blocks = (n_tasks + 3) / 4;
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int nh = (int)n_heads;
 #define CALL(MODEL, G_, NE_, VEC_)                                                                                  \
@@ -267,5 +269,5 @@ extern "C" int hw_kge_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, c
     } while (0)
     HW_DISPATCH_MODEL(desc->model, shape, CALL);
 #undef CALL
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }

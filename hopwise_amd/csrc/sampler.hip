@@ -104,10 +104,11 @@ extern "C" int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, i
     const int64_t total = n_keys * (int64_t)num;
     if (total == 0) return HW_OK;
     if ((total + 255) / 256 > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
     hipLaunchKernelGGL(neg_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        used_ptr, used_idx, n_key_space, keys, n_keys, total, value_num, alias_prob, alias_keys,
                        alias_alias, n_alias, seed, offset, out, oob_counter);
-    return hipGetLastError() == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+    return HW_LAUNCH_RC();
 }
 
 extern "C" const char* hw_version(void) { return "hopwise_amd 0.1.0 (gfx950)"; }

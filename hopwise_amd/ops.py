@@ -213,6 +213,7 @@ class BceLogitsMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_pos):
         lib = _lib.load()
+        ctx.in_shape = x.shape
         x = _dev(x, torch.float32, "scores").contiguous().view(-1)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         gx = torch.empty_like(x) if x.requires_grad or ctx.needs_input_grad[0] else None
@@ -220,13 +221,12 @@ class BceLogitsMean(torch.autograd.Function):
         check(lib.hw_loss_bce_logits(_ptr(x), x.numel(), int(n_pos), _ptr(loss), _ptr(gx), _ptr(ws), _stream()),
               "hw_loss_bce_logits")
         ctx.save_for_backward(gx)
-        ctx.shape = x.shape
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
         (gx,) = ctx.saved_tensors
-        return gx * g, None
+        return (gx * g).view(ctx.in_shape), None
 
 
 class MarginRankingMean(torch.autograd.Function):
@@ -235,6 +235,7 @@ class MarginRankingMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pos, neg, margin):
         lib = _lib.load()
+        ctx.shapes = (pos.shape, neg.shape)
         pos = _dev(pos, torch.float32, "pos").contiguous().view(-1)
         neg = _dev(neg, torch.float32, "neg").contiguous().view(-1)
         loss = torch.empty(1, dtype=torch.float32, device=pos.device)
@@ -251,7 +252,7 @@ class MarginRankingMean(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         gp, gn = ctx.saved_tensors
-        return gp * g, gn * g, None
+        return (gp * g).view(ctx.shapes[0]), (gn * g).view(ctx.shapes[1]), None
 
 
 class SelfAdversarialMean(torch.autograd.Function):

@@ -49,3 +49,14 @@ def test_no_cpu_fallback_in_product():
     for p in pathlib.Path(ROOT, "hopwise_amd").rglob("*.py"):
         src = p.read_text()
         assert "import oracle" not in src and "from oracle" not in src, p
+
+
+def test_single_hip_runtime_mapped():
+    """torch bundles its own libamdhip64; the C-ABI library must bind to that same instance."""
+    import re
+
+    from hopwise_amd import _lib
+
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert len(set(re.findall(r"/\S*libamdhip64\S*", maps))) == 1

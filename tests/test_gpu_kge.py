@@ -188,8 +188,9 @@ def test_three_adam_steps_match_reference(model):
     np.testing.assert_allclose(losses, z["losses"], rtol=2e-5)
     for k, v in m.state_dict().items():
         # Adam normalises the step, so a 1e-7 gradient difference can move a weight by up to lr; the
-        # bound below is 3 steps * lr * 2% plus float noise.
-        np.testing.assert_allclose(v.cpu().numpy(), z[f"final.{k}"], rtol=0, atol=6e-5, err_msg=k)
+        # bound is a fraction of the 3 * lr a weight can move at all; 90% of the weights must agree to 2e-5.
+        np.testing.assert_allclose(v.cpu().numpy(), z[f"final.{k}"], rtol=0, atol=2e-4, err_msg=k)
+        assert (np.abs(v.cpu().numpy() - z[f"final.{k}"]) < 2e-5).mean() > 0.9, k
 
 
 def test_losses_vs_oracle():
