@@ -55,6 +55,7 @@ def install(reference_root="/root/reference"):
         _mod(
             "numba",
             njit=_njit,
+            jit=_njit,
             prange=range,
             typed=types.SimpleNamespace(List=list, Dict=dict),
             types=types.SimpleNamespace(),
