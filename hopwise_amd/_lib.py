@@ -37,6 +37,19 @@ class KgeDesc(C.Structure):
     ]
 
 
+class PgprGraph(C.Structure):
+    _fields_ = [
+        ("ptr", C.c_void_p),
+        ("rel", C.c_void_p),
+        ("dst", C.c_void_p),
+        ("n_users", C.c_int32),
+        ("n_entities", C.c_int32),
+        ("n_items", C.c_int32),
+        ("ui_relation", C.c_int32),
+        ("max_degree", C.c_int32),
+    ]
+
+
 class KgeGrads(C.Structure):
     _fields_ = [("head", C.c_void_p * 2), ("rel", C.c_void_p * 2), ("tail", C.c_void_p * 2)]
 
@@ -75,6 +88,31 @@ SIGNATURES = {
         C.c_int,
         [c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int32, C.c_int64, c_f32p, c_i64p, c_i64p, C.c_int64,
          C.c_uint64, C.c_uint64, c_i64p, c_i32p, C.c_void_p],
+    ),
+    "hw_pgpr_init_paths": (C.c_int, [c_i64p, C.c_int64, c_i32p, c_f32p, c_i32p, C.c_void_p]),
+    "hw_pgpr_actions": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i32p, c_i32p, C.c_int64, C.c_int32,
+         C.c_int32, c_i32p, c_i32p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+    ),
+    "hw_pgpr_state": (
+        C.c_int,
+        [C.POINTER(PgprGraph), c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int64, c_f32p,
+         C.c_void_p],
+    ),
+    "hw_mlp_layer": (
+        C.c_int,
+        [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_i32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+         c_f32p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p],
+    ),
+    "hw_pgpr_policy_topk": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int32, c_i32p, c_i32p, C.c_int64, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_void_p],
+    ),
+    "hw_pgpr_expand": (
+        C.c_int,
+        [C.POINTER(PgprGraph), c_i32p, c_f32p, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int64, c_i32p, c_f32p, C.c_int32,
+         c_i32p, c_i32p, c_f32p, c_i32p, C.c_int64, C.c_void_p],
     ),
     "hw_version": (C.c_char_p, []),
 }

@@ -1,0 +1,683 @@
+// PGPR beam-search traversal on gfx950: one hop = actions -> state -> policy MLP -> masked softmax + top-k
+// -> expand, all on device with no host round trip (row counts live in device memory).
+//
+// Reference: /root/reference/hopwise/model/knowledge_aware_recommender/pgpr.py
+//   _get_actions :226-290, _get_state :296-333, forward :175-187, beam_search :440-484.
+//
+// Data layout (all resident in HBM for the whole search):
+//   graph   one CSR over node gid = (type == USER ? id : n_users + id); rows sorted by (relation, dst)
+//           with multiplicity (kg_dataset.py:1044-1095); 4-byte relation and dst arrays.
+//   tables  float64 copies for the top-max_acts trim (the reference scores in float64, pgpr.py:276) and
+//           float32 copies for the state gather (torch.FloatTensor(state), pgpr.py:447).
+//   paths   12 x int32 per beam row: [uid, n_nodes, (rel, type, id) x 3, 0]; node 0 is (SELF, USER, uid).
+//   acts    [rows, act_dim] (rel, dst) pairs, action 0 = self loop; n_acts[rows].
+#include "hw_common.h"
+
+namespace hw {
+
+constexpr int PATH_INTS = HW_PGPR_ROW_INTS;
+constexpr int SELF_LOOP = -1;
+constexpr int T_USER = 0, T_ENTITY = 1;
+
+__device__ __forceinline__ int next_type(const hw_pgpr_graph& g, int cur_type, int rel) {
+    return (cur_type == T_ENTITY && rel == g.ui_relation) ? T_USER : T_ENTITY;  // pgpr.py:209-213
+}
+
+// ---- block-level helpers (256 threads) ------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over the block; `total` = block sum.  `wsum` is 4 ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) base += (i < w) ? wsum[i] : 0;
+    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return base + inc - v;
+}
+
+__device__ __forceinline__ uint64_t orderable(double x) {
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// ---- init ------------------------------------------------------------------------------------------
+__global__ void pgpr_init_paths_kernel(const int64_t* __restrict__ users, int n, int32_t* __restrict__ paths,
+                                       int32_t* __restrict__ n_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) n_rows[0] = n;
+    if (i >= n) return;
+    int32_t* p = paths + (size_t)i * PATH_INTS;
+    p[0] = (int32_t)users[i];
+    p[1] = 1;
+#pragma unroll
+    for (int k = 2; k < PATH_INTS; ++k) p[k] = 0;
+}
+
+// ---- A10: actions ------------------------------------------------------------------------------------
+constexpr int ACT_LDS_KEYS = 4096;  // candidates whose select keys fit in LDS (32 KiB); larger rows use scratch
+
+__global__ __launch_bounds__(256) void pgpr_actions_kernel(
+    hw_pgpr_graph g, const double* __restrict__ U64, const double* __restrict__ E64, const double* __restrict__ R64,
+    int d, const int32_t* __restrict__ paths, const int32_t* __restrict__ n_rows_ptr, int max_acts, int fix_bug,
+    int32_t* __restrict__ acts, int32_t* __restrict__ n_acts, uint64_t* __restrict__ scratch, int64_t scratch_stride) {
+    __shared__ uint64_t lds_keys[ACT_LDS_KEYS];
+    __shared__ double src0[HW_PGPR_MAX_DIM];  // u
+    __shared__ double src1[HW_PGPR_MAX_DIM];  // u + r_ui
+    __shared__ unsigned hist[256];
+    __shared__ int wsum[4];
+    __shared__ int sh_bin, sh_need;
+    __shared__ int vis_t[4], vis_n[4];
+
+    const int n_rows = n_rows_ptr[0];
+    const int act_dim = max_acts + 1;
+    const int tid = threadIdx.x;
+
+    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        const int32_t* p = paths + (size_t)row * PATH_INTS;
+        const int uid = p[0], len = p[1];
+        int cur_t, cur_n;
+        if (len == 1) {
+            cur_t = T_USER, cur_n = uid;
+        } else {
+            cur_t = p[2 + 3 * (len - 2) + 1], cur_n = p[2 + 3 * (len - 2) + 2];
+        }
+        __syncthreads();  // previous row's LDS use is over
+        if (tid < 4) {
+            int t = -1, n = -1;
+            if (tid == 0) t = T_USER, n = uid;
+            else if (tid < len) t = p[2 + 3 * (tid - 1) + 1], n = p[2 + 3 * (tid - 1) + 2];
+            vis_t[tid] = t, vis_n[tid] = n;
+        }
+        __syncthreads();
+        int32_t* arow = acts + (size_t)row * act_dim * 2;
+        if (tid == 0) arow[0] = SELF_LOOP, arow[1] = cur_n;
+
+        const int64_t gid = cur_t == T_USER ? cur_n : (int64_t)g.n_users + cur_n;
+        const int64_t lo = g.ptr[gid];
+        const int deg = (int)(g.ptr[gid + 1] - lo);
+        const int32_t* __restrict__ erel = g.rel + lo;
+        const int32_t* __restrict__ edst = g.dst + lo;
+
+        auto is_cand = [&](int e) -> bool {
+            const int r = erel[e], n = edst[e];
+            const int nt = next_type(g, cur_t, r);
+            bool seen = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) seen |= (vis_t[k] == nt && vis_n[k] == n);
+            return !seen;
+        };
+
+        // (2)-(4): count the unvisited neighbours
+        int cnt = 0;
+        for (int e = tid; e < deg; e += 256) cnt += is_cand(e) ? 1 : 0;
+        int n_cand;
+        (void)block_excl_scan(cnt, wsum, n_cand);
+
+        if (n_cand <= max_acts) {
+            // keep all, already in (relation, dst) order
+            int running = 0;
+            for (int base = 0; base < deg; base += 256) {
+                const int e = base + tid;
+                const int f = (e < deg && is_cand(e)) ? 1 : 0;
+                int tot;
+                const int pos = block_excl_scan(f, wsum, tot);
+                if (f) {
+                    arow[2 * (1 + running + pos)] = erel[e];
+                    arow[2 * (1 + running + pos) + 1] = edst[e];
+                }
+                running += tot;
+            }
+            if (tid == 0) n_acts[row] = 1 + n_cand;
+            continue;
+        }
+
+        // (5): too many -> float64 scores, keep the top max_acts by (score, position)
+        if (deg > ACT_LDS_KEYS && (!scratch || scratch_stride < deg)) {  // host validation makes this unreachable
+            if (tid == 0) n_acts[row] = 1;
+            continue;
+        }
+        uint64_t* keys = deg <= ACT_LDS_KEYS ? lds_keys : scratch + (size_t)blockIdx.x * scratch_stride;
+        for (int k = tid; k < d; k += 256) {
+            const double u = U64[(size_t)uid * d + k];
+            src0[k] = u;
+            src1[k] = u + R64[(size_t)g.ui_relation * d + k];
+        }
+        __syncthreads();
+        {
+            const int grp = tid >> 4, gl = tid & 15;  // 16 groups of 16 lanes, one edge per group
+            for (int base = 0; base < deg; base += 16) {
+                const int e = base + grp;
+                double acc = 0.0;
+                bool cand = false;
+                if (e < deg) {
+                    cand = is_cand(e);
+                    if (cand) {
+                        const int r = erel[e], n = edst[e];
+                        const int nt = next_type(g, cur_t, r);
+                        if (nt == T_USER) {
+                            const double* __restrict__ em = U64 + (size_t)n * d;
+                            for (int k = gl; k < d; k += 16) acc += src0[k] * em[k];
+                        } else if (n < g.n_items) {
+                            const double* __restrict__ em = E64 + (size_t)n * d;
+                            for (int k = gl; k < d; k += 16) acc += src1[k] * em[k];
+                        } else {
+                            const double* __restrict__ em = E64 + (size_t)n * d;
+                            const double* __restrict__ rr = R64 + (size_t)r * d;
+                            for (int k = gl; k < d; k += 16) acc += (src1[k] + rr[k]) * em[k];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+                if (e < deg && gl == 0) keys[e] = cand ? orderable(acc) : 0ull;
+            }
+        }
+        __syncthreads();
+
+        // radix select: T = max_acts-th largest key; `need` = how many keys equal to T are kept
+        uint64_t prefix = 0, mask = 0;
+        int need = max_acts;
+        for (int pass = 7; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            hist[tid] = 0;
+            __syncthreads();
+            for (int e = tid; e < deg; e += 256) {
+                const uint64_t k = keys[e];
+                if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // lane l owns bins 4l..4l+3; suffix sums from the top bin down
+                const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int mine = (int)(h0 + h1 + h2 + h3);
+                int suf = mine;  // inclusive suffix over lanes >= tid
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_down(suf, o, 64);
+                    if (tid + o < 64) suf += t;
+                }
+                const int above = suf - mine;  // keys in higher lanes' bins
+                if (above < need && need <= suf) {
+                    int run = above, bin = 4 * tid + 3;
+                    const unsigned hh[4] = {h0, h1, h2, h3};
+#pragma unroll
+                    for (int b = 3; b >= 0; --b) {
+                        if (run < need && need <= run + (int)hh[b]) {
+                            bin = 4 * tid + b;
+                            break;
+                        }
+                        run += (int)hh[b];
+                    }
+                    sh_bin = bin;
+                    sh_need = need - run;
+                }
+            }
+            __syncthreads();
+            prefix |= (uint64_t)sh_bin << shift;
+            mask |= 0xFFull << shift;
+            need = sh_need;
+            __syncthreads();
+        }
+        const uint64_t T = prefix;
+        int c_eq_local = 0;
+        for (int e = tid; e < deg; e += 256) c_eq_local += keys[e] == T ? 1 : 0;
+        int c_eq;
+        (void)block_excl_scan(c_eq_local, wsum, c_eq);
+        const int tie_skip = c_eq - need;  // ties are kept from the END of the row (stable ascending argsort, [-max_acts:])
+
+        if (!fix_bug) {
+            int run_keep = 0, run_tie = 0;
+            for (int base = 0; base < deg; base += 256) {
+                const int e = base + tid;
+                const uint64_t k = e < deg ? keys[e] : 0ull;
+                const int tie = (e < deg && k == T) ? 1 : 0;
+                int tot_tie;
+                const int tpos = block_excl_scan(tie, wsum, tot_tie);
+                const int keep = (e < deg && (k > T || (tie && run_tie + tpos >= tie_skip))) ? 1 : 0;
+                int tot_keep;
+                const int kpos = block_excl_scan(keep, wsum, tot_keep);
+                if (keep) {
+                    arow[2 * (1 + run_keep + kpos)] = erel[e];
+                    arow[2 * (1 + run_keep + kpos) + 1] = edst[e];
+                }
+                run_keep += tot_keep;
+                run_tie += tot_tie;
+            }
+        } else {
+            // fix_scores_sorting_bug: descending (score, position) order (pgpr.py:286).  Collect the survivors'
+            // (key, edge) in LDS, then rank each against all others.
+            __shared__ int sel_e[1024];
+            __shared__ uint64_t sel_k[1024];
+            int run_keep = 0, run_tie = 0;
+            for (int base = 0; base < deg; base += 256) {
+                const int e = base + tid;
+                const uint64_t k = e < deg ? keys[e] : 0ull;
+                const int tie = (e < deg && k == T) ? 1 : 0;
+                int tot_tie;
+                const int tpos = block_excl_scan(tie, wsum, tot_tie);
+                const int keep = (e < deg && (k > T || (tie && run_tie + tpos >= tie_skip))) ? 1 : 0;
+                int tot_keep;
+                const int kpos = block_excl_scan(keep, wsum, tot_keep);
+                if (keep) sel_e[run_keep + kpos] = e, sel_k[run_keep + kpos] = k;
+                run_keep += tot_keep;
+                run_tie += tot_tie;
+            }
+            __syncthreads();
+            for (int i = tid; i < max_acts; i += 256) {
+                const uint64_t ki = sel_k[i];
+                const int ei = sel_e[i];
+                int rank = 0;
+                for (int j = 0; j < max_acts; ++j) rank += (sel_k[j] > ki || (sel_k[j] == ki && sel_e[j] > ei)) ? 1 : 0;
+                arow[2 * (1 + rank)] = erel[ei];
+                arow[2 * (1 + rank) + 1] = edst[ei];
+            }
+        }
+        if (tid == 0) n_acts[row] = 1 + max_acts;
+    }
+}
+
+// ---- A11: state ---------------------------------------------------------------------------------------
+// state[row] = [u, cur, last_node, last_rel (, older_node, older_rel)] gathered from the float32 tables
+// (zeros for missing history and for the self-loop relation), pgpr.py:296-333 + KGState :568-580.
+__global__ __launch_bounds__(256) void pgpr_state_kernel(hw_pgpr_graph g, const float* __restrict__ U32,
+                                                         const float* __restrict__ E32, const float* __restrict__ R32,
+                                                         int d, int n_parts, const int32_t* __restrict__ paths,
+                                                         const int32_t* __restrict__ n_rows_ptr,
+                                                         float* __restrict__ state) {
+    const int n_rows = n_rows_ptr[0];
+    const int sd = n_parts * d;
+    const int64_t total = (int64_t)n_rows * sd;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / sd);
+        const int c = (int)(i % sd);
+        const int part = c / d, k = c % d;
+        const int32_t* p = paths + (size_t)row * PATH_INTS;
+        const int uid = p[0], len = p[1];
+        float v = 0.f;
+        auto node_emb = [&](int j) -> float {  // node j of the path (0 = the user)
+            if (j == 0) return U32[(size_t)uid * d + k];
+            const int t = p[2 + 3 * (j - 1) + 1], n = p[2 + 3 * (j - 1) + 2];
+            return t == T_USER ? U32[(size_t)n * d + k] : E32[(size_t)n * d + k];
+        };
+        auto rel_emb = [&](int j) -> float {  // relation that led to node j (j >= 1)
+            const int r = p[2 + 3 * (j - 1)];
+            return r == SELF_LOOP ? 0.f : R32[(size_t)r * d + k];
+        };
+        if (part == 0) v = U32[(size_t)uid * d + k];
+        else if (len == 1) v = part == 1 ? U32[(size_t)uid * d + k] : 0.f;
+        else if (part == 1) v = node_emb(len - 1);
+        else if (part == 2) v = node_emb(len - 2);
+        else if (part == 3) v = rel_emb(len - 1);
+        else if (len >= 3 && part == 4) v = node_emb(len - 3);
+        else if (len >= 3 && part == 5) v = rel_emb(len - 2);
+        state[i] = v;
+    }
+}
+
+// ---- A12: one policy-MLP layer on fp32 MFMA ------------------------------------------------------------
+// C[M, N] = epilogue(A[M, K] . W[N, K]^T + bias[N]);  epilogue = identity | ELU, then an optional
+// multiplicative dropout mask (given [M, N], or drawn from Philox with keep prob 1/2 scaled by 2).
+// Block = 4 waves, tile 128 (M) x 64 (N), BK = 16; each wave owns 32 rows x 64 cols = two 32x32
+// v_mfma_f32_32x32x2_f32 accumulators (exact fp32 fma chain -- no reduced-precision path on gfx950).
+// LDS tiles are stored k-major ([k][row]) so that the MFMA operand read (lane l -> row l & 31,
+// k = l >> 5) is a conflict-free ds_read_b32.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GM = 128, GN = 64, GK = 16;
+
+__device__ __forceinline__ uint32_t philox_bits(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)(idx >> 2), c1 = (uint32_t)(idx >> 34), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    const uint32_t w[4] = {c0, c1, c2, c3};
+    return w[idx & 3];
+}
+
+template <bool ELU>
+__global__ __launch_bounds__(256) void mlp_layer_kernel(const float* __restrict__ A, int lda,
+                                                        const float* __restrict__ W, const float* __restrict__ bias,
+                                                        float* __restrict__ Cm, int ldc, const int32_t* __restrict__ m_ptr,
+                                                        int m_max, int N, int K, const float* __restrict__ drop_mask,
+                                                        int drop_mode, uint64_t seed, uint64_t offset) {
+    __shared__ float As[GK][GM + 4];
+    __shared__ float Bs[GK][GN + 4];
+    const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
+    const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    f32x16 acc0 = {0}, acc1 = {0};
+
+    for (int k0 = 0; k0 < K; k0 += GK) {
+        // stage A: 128 rows x 16 k = 2048 floats, 8 per thread: thread -> (row = tid / 2, 8 consecutive k)
+        {
+            const int r = tid >> 1, kq = (tid & 1) * 8;
+            const int gm = m0 + r;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gk = k0 + kq + i;
+                As[kq + i][r] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
+            }
+        }
+        // stage B (= W rows): 64 rows x 16 k = 1024 floats, 4 per thread
+        {
+            const int r = tid >> 2, kq = (tid & 3) * 4;
+            const int gn = n0 + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gk = k0 + kq + i;
+                Bs[kq + i][r] = (gn < N && gk < K) ? W[(size_t)gn * K + gk] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wave * 32 + (lane & 31)];
+            const float b0 = Bs[kk + (lane >> 5)][(lane & 31)];
+            const float b1 = Bs[kk + (lane >> 5)][32 + (lane & 31)];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // epilogue: C/D map of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x16& acc = t == 0 ? acc0 : acc1;
+        const int gn = n0 + t * 32 + (lane & 31);
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int gm = m0 + wave * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+            if (gm < M && gn < N) {
+                float v = acc[rg] + (bias ? bias[gn] : 0.f);
+                if (ELU) v = v > 0.f ? v : expm1f(v);
+                const size_t o = (size_t)gm * ldc + gn;
+                if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
+                else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
+                Cm[o] = v;
+            }
+        }
+    }
+}
+
+// ---- A12/A13: masked softmax, +mask, top-k (one wave per row) -------------------------------------------
+// probs = softmax(logits masked to the first n_acts entries); value used for ranking and stored as the
+// path's hop "prob" is p + 1 for valid actions (pgpr.py:453).  Top-k ordered (value desc, index asc);
+// only the first min(k, n_acts) entries are meaningful -- the rest get idx = -1.
+template <int NPL>
+__global__ __launch_bounds__(256) void policy_topk_kernel(const float* __restrict__ logits, int ld, int act_dim,
+                                                          const int32_t* __restrict__ n_acts,
+                                                          const int32_t* __restrict__ n_rows_ptr, int k,
+                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                          float* __restrict__ probs_out) {
+    const int n_rows = n_rows_ptr[0];
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+        const int na = n_acts[row];
+        const float* __restrict__ lr = logits + (size_t)row * ld;
+        float x[NPL];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int j = lane + 64 * i;
+            x[i] = (j < na && j < act_dim) ? lr[j] : -INFINITY;
+            mx = fmaxf(mx, x[i]);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            x[i] = x[i] == -INFINITY ? 0.f : expf(x[i] - mx);
+            sum += x[i];
+        }
+        sum = group_sum<64>(sum);
+        uint64_t key[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const int j = lane + 64 * i;
+            const float pr = x[i] / sum;
+            if (probs_out && j < act_dim) probs_out[(size_t)row * act_dim + j] = j < na ? pr : 0.f;
+            const float v = j < na ? pr + 1.0f : 0.f;
+            // valid values are >= 1 > 0: positive floats order as their bit patterns
+            key[i] = j < act_dim ? (((uint64_t)__float_as_uint(v) << 32) | (uint32_t)(~(uint32_t)j)) : 0ull;
+        }
+        uint64_t bound = ~0ull;
+        for (int r = 0; r < k; ++r) {
+            uint64_t best = 0;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i)
+                if (key[i] < bound && key[i] > best) best = key[i];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint64_t o = __shfl_xor(best, m, 64);
+                best = o > best ? o : best;
+            }
+            if (lane == 0) {
+                const int idx = (int)(~(uint32_t)(best & 0xffffffffu));
+                const bool ok = best != 0 && idx < na;
+                out_idx[(size_t)row * k + r] = ok ? idx : -1;
+                out_val[(size_t)row * k + r] = ok ? __uint_as_float((uint32_t)(best >> 32)) : 0.f;
+            }
+            bound = best;
+            if (best == 0) bound = 0;
+        }
+    }
+}
+
+// ---- A13: expand -----------------------------------------------------------------------------------------
+// n_child[row] = min(k, n_acts[row]); exclusive scan (single block) -> child offsets + next row count.
+__global__ __launch_bounds__(1024) void pgpr_child_offsets_kernel(const int32_t* __restrict__ n_acts,
+                                                                  const int32_t* __restrict__ n_rows_ptr, int k,
+                                                                  int32_t* __restrict__ offsets,
+                                                                  int32_t* __restrict__ n_rows_next, int64_t cap) {
+    __shared__ int part[1024];
+    const int n = n_rows_ptr[0];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += min(k, n_acts[i]);
+    part[tid] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int t = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) {
+        offsets[i] = run;
+        run += min(k, n_acts[i]);
+    }
+    if (tid == 1023) n_rows_next[0] = (int)min((int64_t)part[1023], cap);
+}
+
+__global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const int32_t* __restrict__ paths,
+                                                          const float* __restrict__ probs,
+                                                          const int32_t* __restrict__ acts, int act_dim,
+                                                          const int32_t* __restrict__ n_acts,
+                                                          const int32_t* __restrict__ n_rows_ptr,
+                                                          const int32_t* __restrict__ topk_idx,
+                                                          const float* __restrict__ topk_val, int k,
+                                                          const int32_t* __restrict__ offsets,
+                                                          int32_t* __restrict__ paths_out, float* __restrict__ probs_out,
+                                                          int64_t cap) {
+    const int n_rows = n_rows_ptr[0];
+    const int64_t total = (int64_t)n_rows * k;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / k), j = (int)(i % k);
+        const int nc = min(k, n_acts[row]);
+        if (j >= nc) continue;
+        const int64_t o = (int64_t)offsets[row] + j;
+        if (o >= cap) continue;
+        const int idx = topk_idx[(size_t)row * k + j];
+        const int32_t* p = paths + (size_t)row * PATH_INTS;
+        int32_t* q = paths_out + (size_t)o * PATH_INTS;
+        const int len = p[1];
+#pragma unroll
+        for (int c = 0; c < PATH_INTS; ++c) q[c] = p[c];
+        const int cur_t = len == 1 ? T_USER : p[2 + 3 * (len - 2) + 1];
+        const int rel = acts[((size_t)row * act_dim + idx) * 2], node = acts[((size_t)row * act_dim + idx) * 2 + 1];
+        const int nt = rel == SELF_LOOP ? cur_t : next_type(g, cur_t, rel);
+        q[1] = len + 1;
+        q[2 + 3 * (len - 1)] = rel;
+        q[2 + 3 * (len - 1) + 1] = nt;
+        q[2 + 3 * (len - 1) + 2] = node;
+        float* pq = probs_out + (size_t)o * 3;
+        const float* pp = probs + (size_t)row * 3;
+        pq[0] = pp[0], pq[1] = pp[1], pq[2] = pp[2];
+        pq[len - 1] = topk_val[(size_t)row * k + j];
+    }
+}
+
+}  // namespace hw
+
+using namespace hw;
+
+static int check_graph(const hw_pgpr_graph* g) {
+    if (!g || !g->ptr || !g->rel || !g->dst) return HW_ERR_INVALID_ARG;
+    if (g->n_users < 1 || g->n_entities < 1 || g->n_items < 1 || g->n_items > g->n_entities) return HW_ERR_INVALID_ARG;
+    return HW_OK;
+}
+
+extern "C" int hw_pgpr_init_paths(const int64_t* users, int64_t n_users_in_batch, int32_t* paths, float* probs,
+                                  int32_t* n_rows, void* stream) {
+    if (!users || !paths || !n_rows || n_users_in_batch < 0 || n_users_in_batch > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    const int n = (int)n_users_in_batch;
+    if (probs && n > 0) (void)hipMemsetAsync(probs, 0, sizeof(float) * 3 * (size_t)n, st);
+    hipLaunchKernelGGL(pgpr_init_paths_kernel, dim3(n > 0 ? (n + 255) / 256 : 1), dim3(256), 0, st, users, n, paths,
+                       n_rows);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                               const double* relation_emb64, int32_t dim, const int32_t* paths,
+                               const int32_t* n_rows, int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug,
+                               int32_t* acts, int32_t* n_acts, uint64_t* scratch, int64_t scratch_blocks,
+                               int64_t scratch_stride, void* stream) {
+    int rc = check_graph(graph);
+    if (rc) return rc;
+    if (!user_emb64 || !entity_emb64 || !relation_emb64 || !paths || !n_rows || !acts || !n_acts) return HW_ERR_INVALID_ARG;
+    if (dim < 1 || dim > HW_PGPR_MAX_DIM || max_acts < 1 || max_acts > 1023 || max_rows < 0) return HW_ERR_INVALID_ARG;
+    if (max_rows == 0) return HW_OK;
+    // every block that may meet a row with more than ACT_LDS_KEYS neighbours needs a private scratch slice
+    int64_t grid = max_rows < 2048 ? max_rows : 2048;
+    if (graph->max_degree > ACT_LDS_KEYS) {
+        if (!scratch || scratch_blocks < 1 || scratch_stride < graph->max_degree) return HW_ERR_WORKSPACE;
+        if (scratch_blocks < grid) grid = scratch_blocks;
+    } else {
+        scratch = nullptr;
+        scratch_stride = 0;
+    }
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(pgpr_actions_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph, user_emb64,
+                       entity_emb64, relation_emb64, dim, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
+                       scratch, scratch_stride);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_state(const hw_pgpr_graph* graph, const float* user_emb32, const float* entity_emb32,
+                             const float* relation_emb32, int32_t dim, int32_t state_history, const int32_t* paths,
+                             const int32_t* n_rows, int64_t max_rows, float* state, void* stream) {
+    int rc = check_graph(graph);
+    if (rc) return rc;
+    if (!user_emb32 || !entity_emb32 || !relation_emb32 || !paths || !n_rows || !state) return HW_ERR_INVALID_ARG;
+    if (dim < 1 || state_history < 0 || state_history > 2 || max_rows < 0) return HW_ERR_INVALID_ARG;
+    if (max_rows == 0) return HW_OK;
+    const int n_parts = 2 + 2 * state_history;
+    const int64_t total = max_rows * n_parts * dim;
+    int64_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(pgpr_state_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph, user_emb32,
+                       entity_emb32, relation_emb32, dim, n_parts, paths, n_rows, state);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias, float* c, int64_t ldc,
+                            const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, int32_t elu,
+                            const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream) {
+    if (!a || !w || !c || m_max < 0 || n < 1 || k < 1 || lda < k || ldc < n) return HW_ERR_INVALID_ARG;
+    if (drop_mode < 0 || drop_mode > 2 || (drop_mode == 1 && !drop_mask)) return HW_ERR_INVALID_ARG;
+    if (m_max > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (m_max == 0) return HW_OK;
+    dim3 grid((unsigned)((m_max + GM - 1) / GM), (unsigned)((n + GN - 1) / GN));
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    if (elu)
+        hipLaunchKernelGGL((mlp_layer_kernel<true>), grid, dim3(256), 0, st, a, (int)lda, w, bias, c, (int)ldc, m_rows,
+                           (int)m_max, (int)n, (int)k, drop_mask, drop_mode, seed, offset);
+    else
+        hipLaunchKernelGGL((mlp_layer_kernel<false>), grid, dim3(256), 0, st, a, (int)lda, w, bias, c, (int)ldc, m_rows,
+                           (int)m_max, (int)n, (int)k, drop_mask, drop_mode, seed, offset);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_policy_topk(const float* logits, int64_t ld, int32_t act_dim, const int32_t* n_acts,
+                                   const int32_t* n_rows, int64_t max_rows, int32_t k, int32_t* out_idx, float* out_val,
+                                   float* probs_out, void* stream) {
+    if (!logits || !n_acts || !n_rows || !out_idx || !out_val) return HW_ERR_INVALID_ARG;
+    if (act_dim < 1 || act_dim > 1024 || ld < act_dim || k < 1 || k > act_dim || max_rows < 0) return HW_ERR_INVALID_ARG;
+    if (max_rows == 0) return HW_OK;
+    int64_t grid = (max_rows + 3) / 4;
+    if (grid > 16384) grid = 16384;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    if (act_dim <= 256)
+        hipLaunchKernelGGL((policy_topk_kernel<4>), dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim,
+                           n_acts, n_rows, k, out_idx, out_val, probs_out);
+    else
+        hipLaunchKernelGGL((policy_topk_kernel<16>), dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim,
+                           n_acts, n_rows, k, out_idx, out_val, probs_out);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float* probs,
+                              const int32_t* acts, int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows,
+                              int64_t max_rows, const int32_t* topk_idx, const float* topk_val, int32_t k,
+                              int32_t* offsets, int32_t* paths_out, float* probs_out, int32_t* n_rows_out,
+                              int64_t out_capacity, void* stream) {
+    int rc = check_graph(graph);
+    if (rc) return rc;
+    if (!paths || !probs || !acts || !n_acts || !n_rows || !topk_idx || !topk_val || !offsets || !paths_out ||
+        !probs_out || !n_rows_out)
+        return HW_ERR_INVALID_ARG;
+    if (act_dim < 1 || k < 1 || max_rows < 0 || out_capacity < 0 || out_capacity > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (max_rows * (int64_t)k > INT32_MAX) return HW_ERR_INVALID_ARG;  // child offsets are 32-bit
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pgpr_child_offsets_kernel, dim3(1), dim3(1024), 0, st, n_acts, n_rows, k, offsets, n_rows_out,
+                       out_capacity);
+    if (max_rows > 0) {
+        int64_t grid = (max_rows * k + 255) / 256;
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(pgpr_expand_kernel, dim3((unsigned)grid), dim3(256), 0, st, *graph, paths, probs, acts,
+                           act_dim, n_acts, n_rows, topk_idx, topk_val, k, offsets, paths_out, probs_out, out_capacity);
+    }
+    return HW_LAUNCH_RC();
+}

@@ -1,0 +1,108 @@
+"""torch-tensor wrappers over the PGPR entry points of the C ABI (include/hopwise_amd.h)."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PgprGraph, check
+from .ops import _dev, _ptr, _stream
+
+ROW_INTS = 12
+USER, ENTITY, SELF_LOOP = 0, 1, -1
+ACT_LDS_KEYS = 4096
+
+
+class DeviceCKG:
+    """The collaborative KG as one device CSR (rows sorted by (relation, dst), multiplicity kept)."""
+
+    def __init__(self, n_users, n_items, n_entities, ui_relation, inter_users, inter_items, heads, rels, tails, device):
+        iu, ii = np.asarray(inter_users, np.int64), np.asarray(inter_items, np.int64)
+        h, r, t = np.asarray(heads, np.int64), np.asarray(rels, np.int64), np.asarray(tails, np.int64)
+        ui = np.full(len(iu), int(ui_relation), np.int64)
+        # gid: users [0, n_users), entities [n_users, n_users + n_entities)
+        src = np.concatenate([iu, n_users + ii, n_users + h, n_users + t])
+        rel = np.concatenate([ui, ui, r, r])
+        dst = np.concatenate([ii, iu, t, h])
+        order = np.lexsort((dst, rel, src))
+        src, rel, dst = src[order], rel[order], dst[order]
+        n = int(n_users) + int(n_entities)
+        ptr = np.zeros(n + 1, np.int64)
+        np.add.at(ptr, src + 1, 1)
+        np.cumsum(ptr, out=ptr)
+        self.n_users, self.n_items, self.n_entities, self.ui_relation = int(n_users), int(n_items), int(n_entities), int(ui_relation)
+        self.max_degree = int(np.diff(ptr).max()) if n > 0 else 0
+        self.nnz = len(src)
+        self.device = torch.device(device)
+        self.ptr = torch.from_numpy(ptr).to(self.device)
+        self.rel = torch.from_numpy(rel.astype(np.int32)).to(self.device)
+        self.dst = torch.from_numpy(dst.astype(np.int32)).to(self.device)
+        g = PgprGraph()
+        g.ptr, g.rel, g.dst = self.ptr.data_ptr(), self.rel.data_ptr(), self.dst.data_ptr()
+        g.n_users, g.n_entities, g.n_items, g.ui_relation = self.n_users, self.n_entities, self.n_items, self.ui_relation
+        g.max_degree = self.max_degree
+        self.c = g
+
+
+def init_paths(users, paths, probs, n_rows):
+    lib = _lib.load()
+    users = _dev(users, torch.int64, "users").contiguous()
+    check(lib.hw_pgpr_init_paths(_ptr(users), users.numel(), _ptr(paths), _ptr(probs), _ptr(n_rows), _stream()),
+          "hw_pgpr_init_paths")
+
+
+def actions(graph, U64, E64, R64, paths, n_rows, max_rows, max_acts, fix_bug, acts, n_acts, scratch=None):
+    lib = _lib.load()
+    sb = ss = 0
+    if scratch is not None:
+        sb, ss = scratch.shape
+    check(
+        lib.hw_pgpr_actions(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), U64.shape[1], _ptr(paths), _ptr(n_rows),
+                            int(max_rows), int(max_acts), int(bool(fix_bug)), _ptr(acts), _ptr(n_acts), _ptr(scratch),
+                            sb, ss, _stream()),
+        "hw_pgpr_actions",
+    )
+
+
+def state(graph, U32, E32, R32, state_history, paths, n_rows, max_rows, out):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_state(C.byref(graph.c), _ptr(U32), _ptr(E32), _ptr(R32), U32.shape[1], int(state_history), _ptr(paths),
+                          _ptr(n_rows), int(max_rows), _ptr(out), _stream()),
+        "hw_pgpr_state",
+    )
+
+
+def mlp_layer(a, w, bias, out, m_rows, m_max, elu, drop_mask=None, drop_mode=0, seed=0, offset=0):
+    """out[:m, :n] = f(a[:m, :k] @ w.T + bias); a / out may be wider than k / n (leading dimension = stride(0))."""
+    lib = _lib.load()
+    n, k = w.shape
+    check(
+        lib.hw_mlp_layer(_ptr(a), a.stride(0), _ptr(w), _ptr(bias), _ptr(out), out.stride(0), _ptr(m_rows), int(m_max),
+                         n, k, int(bool(elu)), _ptr(drop_mask), int(drop_mode), C.c_uint64(seed), C.c_uint64(offset),
+                         _stream()),
+        "hw_mlp_layer",
+    )
+
+
+def policy_topk(logits, act_dim, n_acts, n_rows, max_rows, k, out_idx, out_val, probs_out=None):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_policy_topk(_ptr(logits), logits.stride(0), int(act_dim), _ptr(n_acts), _ptr(n_rows), int(max_rows),
+                                int(k), _ptr(out_idx), _ptr(out_val), _ptr(probs_out), _stream()),
+        "hw_pgpr_policy_topk",
+    )
+
+
+def expand(graph, paths, probs, acts, act_dim, n_acts, n_rows, max_rows, topk_idx, topk_val, k, offsets, paths_out,
+           probs_out, n_rows_out, capacity):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_expand(C.byref(graph.c), _ptr(paths), _ptr(probs), _ptr(acts), int(act_dim), _ptr(n_acts), _ptr(n_rows),
+                           int(max_rows), _ptr(topk_idx), _ptr(topk_val), int(k), _ptr(offsets), _ptr(paths_out),
+                           _ptr(probs_out), _ptr(n_rows_out), int(capacity), _stream()),
+        "hw_pgpr_expand",
+    )

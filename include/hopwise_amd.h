@@ -139,6 +139,68 @@ int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, int64_t n_ke
                   int64_t n_alias, uint64_t seed, uint64_t offset,
                   int64_t* out, int32_t* oob_counter, void* stream);
 
+/* ---- PGPR beam-search traversal --------------------------------------------------------------------
+ * Device restatement of model/knowledge_aware_recommender/pgpr.py beam_search (:440-484) and the
+ * per-path primitives it calls.  Node types: 0 = user, 1 = entity; the self-loop relation is -1.
+ * A beam row ("path") is HW_PGPR_ROW_INTS int32: [uid, n_nodes, (rel, type, id) x 3, 0]; its hop
+ * probabilities are 3 floats.  Row counts live in device memory (int32 *n_rows) so that a whole
+ * multi-hop search is enqueued without a host round trip; `max_rows` bounds every launch. */
+#define HW_PGPR_ROW_INTS 12
+#define HW_PGPR_MAX_DIM 512
+
+/* Collaborative KG as one CSR over node gid = (type == user ? id : n_users + id), rows sorted by
+ * (relation, dst) with multiplicity -- what dataset.ckg_dict_graph() holds (kg_dataset.py:1044-1095). */
+typedef struct {
+    const int64_t* ptr;  /* [n_users + n_entities + 1] */
+    const int32_t* rel;  /* [nnz] */
+    const int32_t* dst;  /* [nnz] */
+    int32_t n_users, n_entities, n_items, ui_relation;
+    int32_t max_degree;  /* largest row length (sizes the trim scratch) */
+} hw_pgpr_graph;
+
+/* reset(): one single-node path per user (pgpr.py:215-221). */
+int hw_pgpr_init_paths(const int64_t* users, int64_t n_users_in_batch, int32_t* paths, float* probs,
+                       int32_t* n_rows, void* stream);
+
+/* _get_actions (pgpr.py:226-290): acts[row] = [(self, cur)] + unvisited neighbours in (rel, dst) order; when
+ * more than max_acts remain, the max_acts with the largest float64 score (ties: later CSR position wins),
+ * re-sorted by (rel, dst) or, with fix_scores_sorting_bug, in descending score order.
+ * acts: int32 [max_rows, max_acts + 1, 2]; n_acts: int32 [max_rows].
+ * scratch: uint64 [scratch_blocks * scratch_stride], needed when graph->max_degree > 4096
+ * (scratch_stride >= max_degree). */
+int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                    const double* relation_emb64, int32_t dim, const int32_t* paths, const int32_t* n_rows,
+                    int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug,
+                    int32_t* acts, int32_t* n_acts, uint64_t* scratch, int64_t scratch_blocks,
+                    int64_t scratch_stride, void* stream);
+
+/* _get_state (pgpr.py:296-333): state [max_rows, (2 + 2*state_history) * dim] float32. */
+int hw_pgpr_state(const hw_pgpr_graph* graph, const float* user_emb32, const float* entity_emb32,
+                  const float* relation_emb32, int32_t dim, int32_t state_history, const int32_t* paths,
+                  const int32_t* n_rows, int64_t max_rows, float* state, void* stream);
+
+/* One Linear (+ ELU) (+ dropout) layer of the policy network (pgpr.py:175-187) on fp32 MFMA:
+ * c[m, n] = f(a[m, :] . w[n, :] + bias[n]).  m_rows (nullable) = device row count, m_max bounds the grid.
+ * drop_mode 0: none; 1: multiply by drop_mask[m, n]; 2: Philox keep-prob 1/2, kept values x2. */
+int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias, float* c, int64_t ldc,
+                 const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, int32_t elu,
+                 const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream);
+
+/* logits -> masked softmax -> (+1 on valid actions, pgpr.py:453) -> top-k (value desc, index asc).
+ * out_idx/out_val [max_rows, k]; entries past min(k, n_acts[row]) are idx = -1.  probs_out (nullable)
+ * receives the plain softmax [max_rows, act_dim]. */
+int hw_pgpr_policy_topk(const float* logits, int64_t ld, int32_t act_dim, const int32_t* n_acts,
+                        const int32_t* n_rows, int64_t max_rows, int32_t k, int32_t* out_idx, float* out_val,
+                        float* probs_out, void* stream);
+
+/* Emit the children of every row in row order, top-k order inside a row (pgpr.py:460-479).
+ * offsets: int32 [max_rows] workspace; n_rows_out[0] = number of children (capped at out_capacity). */
+int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float* probs,
+                   const int32_t* acts, int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows,
+                   int64_t max_rows, const int32_t* topk_idx, const float* topk_val, int32_t k,
+                   int32_t* offsets, int32_t* paths_out, float* probs_out, int32_t* n_rows_out,
+                   int64_t out_capacity, void* stream);
+
 const char* hw_version(void);
 
 #ifdef __cplusplus

@@ -49,3 +49,32 @@ def load_tables(model_obj, tables, device):
     sd = {k + ".weight": torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in tables.items()}
     model_obj.load_state_dict(sd)
     return model_obj
+
+
+class FakeKGDataset(FakeDataset):
+    """What PGPR reads from a KnowledgeBasedDataset: id counts, the five graph arrays, positives, preloaded tables."""
+
+    uid_field, iid_field = "user_id", "item_id"
+
+    def __init__(self, n_users, n_items, n_entities, n_relations, ui_relation_id, inter_users, inter_items, heads, rels,
+                 tails, positives, user_emb, entity_emb, relation_emb):
+        super().__init__(n_users, n_items, n_entities, n_relations)
+        self.field2token_id = {"relation_id": {self.ui_relation: int(ui_relation_id)}}
+        self.inter_feat = {"user_id": np.asarray(inter_users), "item_id": np.asarray(inter_items)}
+        self.head_entities, self.relations, self.tail_entities = np.asarray(heads), np.asarray(rels), np.asarray(tails)
+        self._positives = np.asarray(positives)
+        self._w = {"user_embedding_id": user_emb, "entity_embedding_id": entity_emb, "relation_embedding_id": relation_emb}
+
+    def history_item_matrix(self):
+        return self._positives, None, None
+
+    def get_preload_weight(self, name):
+        return self._w[name]
+
+
+def pgpr_config(device, max_acts=250, state_history=1, hops=(25, 5, 1), fix_bug=False, topk=(10,), dropout="identity",
+                hidden=(512, 256)):
+    return dict(FIELDS, device=device, topk=list(topk), state_history=state_history, max_acts=max_acts,
+                hidden_sizes=list(hidden), beam_search_hop=list(hops), fix_scores_sorting_bug=fix_bug,
+                policy_dropout=dropout, gamma=0.99, action_dropout=0.0, max_path_len=3, weight_factor=1e-3,
+                path_constraint=[])
