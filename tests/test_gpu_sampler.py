@@ -1,0 +1,125 @@
+"""Device negative sampler: the properties the reference guarantees (sampler.py:140-183) + distribution checks.
+
+Stream equality with numpy is impossible by construction; what is pinned instead: support,
+rejection of used ids, output layout, uniformity / popularity frequencies, error behaviour, determinism per
+(seed, call counter)."""
+
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def kg_dataset(z):
+    return types.SimpleNamespace(head_entities=z["heads"], tail_entities=z["tails"], entity_num=int(z["entity_num"]),
+                                 head_entity_field="head_id", tail_entity_field="tail_id")
+
+
+def rec_datasets(z):
+    out = []
+    for p in ("train", "valid", "test"):
+        out.append(types.SimpleNamespace(uid_field="user_id", iid_field="item_id", user_num=int(z["rec.user_num"]),
+                                         item_num=int(z["rec.item_num"]),
+                                         inter_feat={"user_id": z[f"rec.{p}.users"], "item_id": z[f"rec.{p}.items"]}))
+    return out
+
+
+def test_kg_sampler_properties_on_reference_fixture():
+    from hopwise_amd.sampler import KGSampler
+
+    z = np.load(os.path.join(GOLDEN, "sampler.npz"))
+    s = KGSampler(kg_dataset(z), "uniform", device=dev(), seed=7)
+    used = [set() for _ in range(s.entity_num)]
+    for h, t in zip(z["heads"], z["tails"]):
+        used[int(h)].add(int(t))
+    keys = z["kg.uniform.keys"]
+    for num in (1, 3, 64):
+        v = s.sample_by_entity_ids(keys, num).cpu().numpy()
+        assert v.shape == (len(keys) * num,) and v.dtype == np.int64
+        assert v.min() >= 1 and v.max() < s.entity_num
+        for j in range(num):
+            for i, k in enumerate(keys):
+                assert int(v[j * len(keys) + i]) not in used[int(k)]
+    # the dense head (entity 7 has used 50 of 59 ids): only the 9 free ids may appear, all of them do, uniformly
+    v = s.sample_by_entity_ids(np.full(9000, 7), 1).cpu().numpy()
+    free = sorted(set(range(1, s.entity_num)) - used[7])
+    cnt = np.array([(v == f).sum() for f in free])
+    assert cnt.sum() == 9000
+    exp = 9000 / len(free)
+    assert ((cnt - exp) ** 2 / exp).sum() < 40  # chi-square, 8 dof: P(>40) ~ 3e-6
+    with pytest.raises(ValueError):
+        s.sample_by_entity_ids(np.array([s.entity_num + 5]), 1)
+
+
+def test_sampler_determinism_and_streams():
+    from hopwise_amd import ops
+
+    ptr = torch.zeros(11, dtype=torch.int64, device=dev())
+    idx = torch.zeros(0, dtype=torch.int64, device=dev())
+    keys = torch.arange(1, 9, device=dev())
+    a = ops.neg_sample(ptr, idx, keys, 5, 1000, seed=3, offset=1)
+    b = ops.neg_sample(ptr, idx, keys, 5, 1000, seed=3, offset=1)
+    c = ops.neg_sample(ptr, idx, keys, 5, 1000, seed=3, offset=2)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    big = ops.neg_sample(ptr, idx, torch.ones(200000, dtype=torch.int64, device=dev()), 1, 101, seed=1, offset=0).cpu().numpy()
+    cnt = np.bincount(big, minlength=101)[1:]
+    assert cnt.min() > 0 and ((cnt - 2000.0) ** 2 / 2000.0).sum() < 180  # 99 dof
+
+
+def test_rec_sampler_phases_and_popularity():
+    from hopwise_amd.sampler import Sampler
+
+    z = np.load(os.path.join(GOLDEN, "sampler.npz"))
+    ds = rec_datasets(z)
+    phases = ["train", "valid", "test"]
+    s = Sampler(phases, ds, "uniform", device=dev())
+    cum = [set() for _ in range(ds[0].user_num)]
+    for p, d in zip(phases, ds):
+        for u, i in zip(d.inter_feat["user_id"], d.inter_feat["item_id"]):
+            cum[int(u)].add(int(i))
+        sp = s.set_phase(p)
+        keys = z[f"rec.uniform.{p}.keys"]
+        v = sp.sample_by_user_ids(keys, None, 40).cpu().numpy()
+        for j in range(40):
+            for i, k in enumerate(keys):
+                x = int(v[j * len(keys) + i])
+                assert 1 <= x < ds[0].item_num and x not in cum[int(k)]
+    with pytest.raises(ValueError):
+        s.set_phase("nope")
+    with pytest.raises(ValueError):
+        s.set_phase("train").sample_by_user_ids(np.array([-1]), None, 1)
+    # popularity: frequencies follow count^alpha over ids that occur, restricted to the key's free ids
+    alpha = 0.5
+    sp = Sampler(phases, ds, "popularity", alpha=alpha, device=dev()).set_phase("train")
+    items = np.concatenate([d.inter_feat["item_id"] for d in ds])
+    ids, counts = np.unique(items, return_counts=True)
+    w = np.power(counts / len(items), alpha)
+    key = int(ds[0].inter_feat["user_id"][0])
+    used = {int(i) for u, i in zip(ds[0].inter_feat["user_id"], ds[0].inter_feat["item_id"]) if int(u) == key}
+    allowed = np.array([i not in used for i in ids])
+    p = np.where(allowed, w, 0.0)
+    p /= p.sum()
+    n = 120000
+    v = sp.sample_by_user_ids(np.full(n, key), None, 1).cpu().numpy()
+    got = np.array([(v == i).sum() for i in ids]) / n
+    assert set(np.unique(v)) <= set(ids[allowed].tolist())
+    np.testing.assert_allclose(got, p, atol=4 * np.sqrt(p.max() / n) + 1e-3)
+
+
+def test_sampler_rejects_saturated_key():
+    from hopwise_amd.sampler import KGSampler
+
+    n = 6
+    heads = np.array([2, 2, 2, 2, 2, 3])
+    tails = np.array([1, 2, 3, 4, 5, 1])
+    with pytest.raises(ValueError):
+        KGSampler(types.SimpleNamespace(head_entities=heads, tail_entities=tails, entity_num=n), device=dev())
