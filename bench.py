@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-variant", action="store_true")
+    ap.add_argument("--no-pgpr", action="store_true")
+    ap.add_argument("--pgpr-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--entities", type=int, default=0, help="override n_entities (HBM-resident variant, e.g. 2600000)")
     args = ap.parse_args()
@@ -206,6 +208,24 @@ def main():
         }
         gpu_scores = ops.kge_score_grouped_raw(desc, users, None, kg.ui_relation, t_idx).cpu().numpy()
         np.testing.assert_allclose(gpu_scores, outb, rtol=1e-4, atol=1e-5)  # same inputs, same answers
+    if not args.no_pgpr:
+        # second half of BASELINE.json's metric: PGPR paths expanded / s (configs[2]); every rank searches its own users
+        import bench_pgpr
+
+        torch.cuda.empty_cache()
+        pg = bench_pgpr.run(dev, n_users=32, steps=args.pgpr_steps, warmup=1,
+                            cpu_users=(1 if rank == 0 and world == 1 and not args.no_cpu_baseline else 0), rank=rank)
+        if world > 1:
+            tv = torch.tensor([pg["value"]], device=dev, dtype=torch.float64)
+            tm = torch.tensor([pg["ms_per_step"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            # whole-job rate on the slowest rank's clock
+            tp = torch.tensor([pg["paths_per_step"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(tp, op=dist.ReduceOp.SUM)
+            pg["value"] = float(tp.item() / (tm.item() * 1e-3))
+            pg["ms_per_step"] = float(tm.item())
+            pg["paths_per_step"] = float(tp.item())
+        out["pgpr"] = pg
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

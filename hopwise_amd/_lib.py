@@ -114,6 +114,12 @@ SIGNATURES = {
         [C.POINTER(PgprGraph), c_i32p, c_f32p, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int64, c_i32p, c_f32p, C.c_int32,
          c_i32p, c_i32p, c_f32p, c_i32p, C.c_int64, C.c_void_p],
     ),
+    "hw_pgpr_collect": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p, C.c_int64,
+         c_i32p, c_f32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_i32p, c_f32p, c_i32p,
+         C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_void_p],
+    ),
     "hw_version": (C.c_char_p, []),
 }
 

@@ -9,7 +9,7 @@
 //           with multiplicity (kg_dataset.py:1044-1095); 4-byte relation and dst arrays.
 //   tables  float64 copies for the top-max_acts trim (the reference scores in float64, pgpr.py:276) and
 //           float32 copies for the state gather (torch.FloatTensor(state), pgpr.py:447).
-//   paths   12 x int32 per beam row: [uid, n_nodes, (rel, type, id) x 3, 0]; node 0 is (SELF, USER, uid).
+//   paths   12 x int32 per beam row: [uid, n_nodes, (rel, type, id) x 3, batch index]; node 0 is (SELF, USER, uid).
 //   acts    [rows, act_dim] (rel, dst) pairs, action 0 = self loop; n_acts[rows].
 #include "hw_common.h"
 
@@ -64,6 +64,7 @@ __global__ void pgpr_init_paths_kernel(const int64_t* __restrict__ users, int n,
     p[1] = 1;
 #pragma unroll
     for (int k = 2; k < PATH_INTS; ++k) p[k] = 0;
+    p[PATH_INTS - 1] = i;  // batch index of the root user; copied to every descendant (used by collect_scores)
 }
 
 // ---- A10: actions ------------------------------------------------------------------------------------

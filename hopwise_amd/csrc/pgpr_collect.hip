@@ -1,0 +1,249 @@
+// PGPR.collect_scores on the device (pgpr.py:486-552): filter leaf paths, keep the most probable path per
+// (user, item), rank each user's items by (score, prob), and fill the [batch, n_items] result matrix --
+// including the reference's quirks (row numbering by order of users that have a surviving item; when fewer
+// than max(topk) items survive, the list is padded with the best unseen items, reversed, and zip() with the
+// shorter path list drops the tail -- so the padded items displace the best path items).
+//
+// Work split: (1) mark: one thread per leaf path -> atomicMax of (prob bits, ~leaf index) into best[slot, item]
+//             (2) select: one block per user slot -> score row in float64, top-kmax of candidates, pads
+//             (3) rows + fill: row numbering scan, scatter into results.
+#include "hw_common.h"
+
+namespace hw {
+
+constexpr int CPATH_INTS = HW_PGPR_ROW_INTS;
+
+__global__ void collect_slots_kernel(const int64_t* __restrict__ users, int n, int32_t* __restrict__ first_idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t u = users[i];
+    int f = i;
+    for (int j = 0; j < i; ++j)
+        if (users[j] == u) {
+            f = j;
+            break;
+        }
+    first_idx[i] = f;
+}
+
+__device__ __forceinline__ bool bit_test(const uint32_t* __restrict__ bits, int64_t words, int uid, int item) {
+    return (bits[(size_t)uid * words + (item >> 5)] >> (item & 31)) & 1u;
+}
+
+__global__ __launch_bounds__(256) void collect_mark_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf,
+                                                           const float* __restrict__ probs,
+                                                           const int32_t* __restrict__ n_leaf_ptr, int n_nodes,
+                                                           const int32_t* __restrict__ first_idx,
+                                                           const uint32_t* __restrict__ pos_bits, int64_t pos_words,
+                                                           unsigned long long* __restrict__ best) {
+    const int n_leaf = n_leaf_ptr[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_leaf; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t* p = leaf + (size_t)i * CPATH_INTS;
+        if (p[1] != n_nodes) continue;
+        bool ok = true;
+        for (int j = 1; j < n_nodes; ++j) ok &= p[2 + 3 * (j - 1)] != -1;            // no self loop after the root
+        const int lt = p[2 + 3 * (n_nodes - 2) + 1], pid = p[2 + 3 * (n_nodes - 2) + 2];
+        ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
+        if (!ok) continue;
+        const int uid = p[0];
+        if (bit_test(pos_bits, pos_words, uid, pid)) continue;                         // already a train positive
+        const float* q = probs + (size_t)i * 3;
+        float pp = q[0];
+        for (int j = 1; j < n_nodes - 1; ++j) pp = pp * q[j];                          // reduce(mul) in float32
+        const int slot = first_idx[p[11]];
+        const unsigned long long key = ((unsigned long long)__float_as_uint(pp) << 32) | (uint32_t)(~(uint32_t)i);
+        atomicMax(best + (size_t)slot * g.n_items + pid, key);
+    }
+}
+
+__device__ __forceinline__ uint64_t ord64(double x) {
+    uint64_t u = (uint64_t)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+// 128-bit max over the block of (hi, lo); returns winner in (hi, lo) for every thread.  4 waves.
+__device__ __forceinline__ void block_max128(uint64_t& hi, uint64_t& lo, uint64_t* sh) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint64_t ohi = __shfl_xor(hi, m, 64), olo = __shfl_xor(lo, m, 64);
+        if (ohi > hi || (ohi == hi && olo > lo)) hi = ohi, lo = olo;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[2 * (threadIdx.x >> 6)] = hi, sh[2 * (threadIdx.x >> 6) + 1] = lo;
+    __syncthreads();
+    hi = sh[0], lo = sh[1];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (sh[2 * w] > hi || (sh[2 * w] == hi && sh[2 * w + 1] > lo)) hi = sh[2 * w], lo = sh[2 * w + 1];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void collect_select_kernel(
+    hw_pgpr_graph g, const double* __restrict__ U64, const double* __restrict__ E64, const double* __restrict__ R64, int d,
+    const int64_t* __restrict__ users, const int32_t* __restrict__ first_idx, const uint32_t* __restrict__ pos_bits,
+    int64_t pos_words, const unsigned long long* __restrict__ best, double* __restrict__ score_ws, int kmax,
+    int32_t* __restrict__ sel_item, double* __restrict__ sel_score, int32_t* __restrict__ sel_leaf,
+    int32_t* __restrict__ sel_count) {
+    __shared__ double src[HW_PGPR_MAX_DIM];
+    __shared__ uint64_t sh[8];
+    __shared__ int c_item[1024];
+    __shared__ int p_item[1024];
+    const int slot = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (first_idx[slot] != slot) {  // duplicate of an earlier user: no row of its own
+        if (tid == 0) sel_count[slot] = 0;
+        return;
+    }
+    const int uid = (int)users[slot];
+    for (int k = tid; k < d; k += 256) src[k] = U64[(size_t)uid * d + k] + R64[(size_t)g.ui_relation * d + k];
+    __syncthreads();
+    double* __restrict__ sc = score_ws + (size_t)slot * g.n_items;
+    const unsigned long long* __restrict__ bst = best + (size_t)slot * g.n_items;
+    {  // path_scores[uid, :] in float64 (pgpr.py:490-492), 16 lanes per item
+        const int grp = tid >> 4, gl = tid & 15;
+        for (int base = 0; base < g.n_items; base += 16) {
+            const int it = base + grp;
+            double acc = 0.0;
+            if (it < g.n_items) {
+                const double* __restrict__ em = E64 + (size_t)it * d;
+                for (int k = gl; k < d; k += 16) acc += src[k] * em[k];
+            }
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+            if (it < g.n_items && gl == 0) sc[it] = acc;
+        }
+    }
+    __syncthreads();
+    // candidates ranked by (score, prob) descending; equal keys fall back to the earlier leaf
+    int m = 0;
+    uint64_t bhi = ~0ull, blo = ~0ull;  // exclusive bound of the previous winner
+    for (int r = 0; r < kmax; ++r) {
+        uint64_t hi = 0, lo = 0;
+        for (int it = tid; it < g.n_items; it += 256) {
+            const unsigned long long k = bst[it];
+            if (k == 0) continue;
+            const uint64_t khi = ord64(sc[it]), klo = k;  // lo = (prob bits, ~leaf)
+            const bool below = khi < bhi || (khi == bhi && klo < blo);
+            if (below && (khi > hi || (khi == hi && klo > lo))) hi = khi, lo = klo;
+        }
+        // the item index is recovered from the leaf row afterwards
+        block_max128(hi, lo, sh);
+        if (hi == 0 && lo == 0) break;
+        if (tid == 0) c_item[r] = (int)(~(uint32_t)(lo & 0xffffffffu));  // leaf index for now
+        bhi = hi, blo = lo;
+        ++m;
+    }
+    // pads: best-scoring items that are not train positives (may repeat candidates; item 0 only if unpadded history)
+    const int n_pad = kmax - m;
+    if (m > 0 && n_pad > 0) {
+        uint64_t phi = ~0ull, plo = ~0ull;
+        for (int r = 0; r < n_pad; ++r) {
+            uint64_t hi = 0, lo = 0;
+            for (int it = tid; it < g.n_items; it += 256) {
+                if (bit_test(pos_bits, pos_words, uid, it)) continue;
+                // np.argsort ascending then reversed: ties resolve to the larger index first
+                const uint64_t khi = ord64(sc[it]), klo = (uint64_t)it + 1;
+                const bool below = khi < phi || (khi == phi && klo < plo);
+                if (below && (khi > hi || (khi == hi && klo > lo))) hi = khi, lo = klo;
+            }
+            block_max128(hi, lo, sh);
+            if (tid == 0) p_item[r] = (hi == 0 && lo == 0) ? -1 : (int)(lo - 1);
+            phi = hi, plo = lo;
+        }
+    }
+    __syncthreads();
+    // final pairs in the order the reference writes them: zip(reversed(top_items), reversed(top_paths)) -> m pairs
+    if (tid == 0) {
+        sel_count[slot] = m;
+        for (int j = 0; j < m; ++j) {
+            // reversed(top_items)[j]: pads first (last pad first), then candidates from the worst up
+            int item, leaf_for_item = -1;
+            if (j < n_pad) {
+                item = p_item[n_pad - 1 - j];
+            } else {
+                leaf_for_item = c_item[m - 1 - (j - n_pad)];
+                item = -2;  // resolved by the fill kernel from the leaf row
+            }
+            const int path_leaf = c_item[m - 1 - j];  // reversed(top_paths)[j]
+            sel_item[(size_t)slot * kmax + j] = item == -2 ? -2 - leaf_for_item : item;
+            sel_leaf[(size_t)slot * kmax + j] = path_leaf;
+        }
+    }
+}
+
+__global__ void collect_rows_kernel(const int32_t* __restrict__ sel_count, int n, int32_t* __restrict__ sel_row) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int r = 0;
+        for (int i = 0; i < n; ++i) sel_row[i] = sel_count[i] > 0 ? r++ : -1;
+    }
+}
+
+__global__ void collect_fill_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf, const double* __restrict__ score_ws,
+                                    int kmax, int n_nodes, int32_t* __restrict__ sel_item, double* __restrict__ sel_score,
+                                    const int32_t* __restrict__ sel_count, const int32_t* __restrict__ sel_row,
+                                    float* __restrict__ results, int n_slots) {
+    const int slot = blockIdx.x;
+    if (slot >= n_slots || threadIdx.x != 0) return;
+    const int m = sel_count[slot], row = sel_row[slot];
+    for (int j = 0; j < m; ++j) {  // sequential: later writes win, as in the reference's loop
+        int item = sel_item[(size_t)slot * kmax + j];
+        if (item <= -2) {
+            const int lf = -2 - item;
+            item = leaf[(size_t)lf * CPATH_INTS + 2 + 3 * (n_nodes - 2) + 2];
+            sel_item[(size_t)slot * kmax + j] = item;
+        }
+        if (item < 0) continue;
+        const double s = score_ws[(size_t)slot * g.n_items + item];
+        sel_score[(size_t)slot * kmax + j] = s;
+        results[(size_t)row * g.n_items + item] = (float)s;
+    }
+}
+
+__global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace hw
+
+using namespace hw;
+
+extern "C" int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                               const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                               const uint32_t* positives_bits, int64_t positives_words, const int32_t* leaf_paths,
+                               const float* leaf_probs, const int32_t* n_leaf, int64_t max_leaf, int32_t n_nodes,
+                               int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws, float* results,
+                               int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
+                               int32_t* sel_row, void* stream) {
+    if (!graph || !user_emb64 || !entity_emb64 || !relation_emb64 || !users || !positives_bits || !leaf_paths ||
+        !leaf_probs || !n_leaf || !best_ws || !score_ws || !first_idx_ws || !results || !sel_item || !sel_score ||
+        !sel_leaf || !sel_count || !sel_row)
+        return HW_ERR_INVALID_ARG;
+    if (dim < 1 || dim > HW_PGPR_MAX_DIM || n_batch < 1 || n_batch > 65535 || kmax < 1 || kmax > 1024 || n_nodes < 2 ||
+        n_nodes > 4 || max_leaf < 0 || positives_words * 32 < graph->n_items)
+        return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)n_batch;
+    const int64_t cells = n_batch * (int64_t)graph->n_items;
+    (void)hipMemsetAsync(best_ws, 0, sizeof(uint64_t) * (size_t)cells, st);
+    (void)hipMemsetAsync(sel_leaf, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st);
+    (void)hipMemsetAsync(sel_item, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st);
+    (void)hipMemsetAsync(sel_score, 0, sizeof(double) * (size_t)n_batch * kmax, st);
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((cells + 255) / 256 > 4096 ? 4096 : (cells + 255) / 256)),
+                       dim3(256), 0, st, results, cells, -INFINITY);
+    hipLaunchKernelGGL(collect_slots_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, users, nb, first_idx_ws);
+    if (max_leaf > 0) {
+        int64_t grid = (max_leaf + 255) / 256;
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(collect_mark_kernel, dim3((unsigned)grid), dim3(256), 0, st, *graph, leaf_paths, leaf_probs,
+                           n_leaf, n_nodes, first_idx_ws, positives_bits, positives_words,
+                           (unsigned long long*)best_ws);
+    }
+    hipLaunchKernelGGL(collect_select_kernel, dim3(nb), dim3(256), 0, st, *graph, user_emb64, entity_emb64,
+                       relation_emb64, dim, users, first_idx_ws, positives_bits, positives_words,
+                       (const unsigned long long*)best_ws, score_ws, kmax, sel_item, sel_score, sel_leaf, sel_count);
+    hipLaunchKernelGGL(collect_rows_kernel, dim3(1), dim3(1), 0, st, sel_count, nb, sel_row);
+    hipLaunchKernelGGL(collect_fill_kernel, dim3(nb), dim3(64), 0, st, *graph, leaf_paths, score_ws, kmax, n_nodes,
+                       sel_item, sel_score, sel_count, sel_row, results, nb);
+    return HW_LAUNCH_RC();
+}

@@ -72,6 +72,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                                  np.asarray(dataset.head_entities), np.asarray(dataset.relations),
                                  np.asarray(dataset.tail_entities), dev)
         self.positives = dataset.history_item_matrix()[0]
+        self._pos_bits = P.positives_bitset(self.positives, self.n_users, self.n_items, dev)
 
         # pretrained KGE tables: float64 as the reference keeps them (dataset.py:568-581) + float32 copies
         ue = np.asarray(dataset.get_preload_weight("user_embedding_id"), np.float64)
@@ -203,6 +204,53 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             out_p += p
             out_q += q
         return out_p, out_q
+
+    # -- A14 -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def collect_scores_device(self, users, res, n_nodes=None):
+        """scores [len(users), n_items] on the device + the selection arrays (pgpr.py:486-552)."""
+        users = users.to(self._t64[0].device, torch.int64).contiguous()
+        n_nodes = len(self.beam_search_hop) + 1 if n_nodes is None else n_nodes
+        return P.collect(self.graph, *self._t64, users, self._pos_bits, res.paths, res.probs, res._n,
+                         res.paths.shape[0], n_nodes, max(self.topk))
+
+    def explanations(self, users, res, sel):
+        """The reference's [user, item, score, path] list, in the order collect_scores appends them."""
+        cnt, item, score, leaf = (sel[k].cpu().numpy() for k in ("count", "item", "score", "leaf"))
+        ulist = users.cpu().numpy()
+        need = np.unique(leaf[leaf >= 0])
+        rows = res.paths[torch.from_numpy(need).to(res.paths.device).long()].cpu().numpy() if len(need) else np.zeros((0, 12))
+        prs = np.zeros((len(need), 3), np.float32)
+        dec, _ = self.decode_paths(rows, prs)
+        by_leaf = dict(zip(need.tolist(), dec))
+        out = []
+        for slot in range(len(ulist)):
+            for j in range(int(cnt[slot])):
+                out.append([int(ulist[slot]), int(item[slot, j]), float(score[slot, j]), by_leaf[int(leaf[slot, j])]])
+        return out
+
+    def _search_and_collect(self, users):
+        users = torch.as_tensor(users)
+        outs, expl = [], []
+        for s in range(0, users.numel(), self.user_chunk):
+            chunk = users[s : s + self.user_chunk]
+            res = self.beam_search_device(chunk)
+            scores, sel = self.collect_scores_device(chunk, res)
+            outs.append((chunk, res, scores, sel))
+        return outs
+
+    def full_sort_predict(self, interaction):  # pgpr.py:408-415
+        return torch.cat([o[2] for o in self._search_and_collect(interaction[self.USER_ID])], dim=0)
+
+    def explain(self, interaction):  # pgpr.py:417-435
+        outs = self._search_and_collect(interaction[self.USER_ID])
+        scores = torch.cat([o[2] for o in outs], dim=0)
+        expl = []
+        for chunk, res, _, sel in outs:
+            expl += self.explanations(chunk, res, sel)
+        for e in expl:
+            e[-1] = self.decode_path(e[-1])
+        return scores, expl
 
     def predict(self, interaction):
         return

@@ -106,3 +106,39 @@ def expand(graph, paths, probs, acts, act_dim, n_acts, n_rows, max_rows, topk_id
                            _ptr(probs_out), _ptr(n_rows_out), int(capacity), _stream()),
         "hw_pgpr_expand",
     )
+
+
+def positives_bitset(positives, n_users, n_items, device):
+    """Bitset [n_users, ceil(n_items / 32)] of the rows of dataset.history_item_matrix()[0] (zeros included as they
+    appear: `pid in self.positives[uid]` in the reference is a plain membership test on the padded row)."""
+    pos = positives.cpu().numpy() if isinstance(positives, torch.Tensor) else np.asarray(positives)
+    words = (int(n_items) + 31) // 32
+    bits = np.zeros((int(n_users), words), np.uint32)
+    rows = np.repeat(np.arange(pos.shape[0]), pos.shape[1])
+    vals = pos.reshape(-1).astype(np.int64)
+    ok = (vals >= 0) & (vals < n_items) & (rows < n_users)
+    np.bitwise_or.at(bits, (rows[ok], vals[ok] >> 5), (np.uint32(1) << (vals[ok] & 31).astype(np.uint32)))
+    return torch.from_numpy(bits.view(np.int32)).to(device)
+
+
+def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_leaf, max_leaf, n_nodes, kmax):
+    lib = _lib.load()
+    dev = users.device
+    B, nI = users.numel(), graph.n_items
+    best = torch.empty(B * nI, dtype=torch.int64, device=dev)
+    score_ws = torch.empty(B * nI, dtype=torch.float64, device=dev)
+    first = torch.empty(B, dtype=torch.int32, device=dev)
+    results = torch.empty((B, nI), dtype=torch.float32, device=dev)
+    sel_item = torch.empty((B, kmax), dtype=torch.int32, device=dev)
+    sel_score = torch.empty((B, kmax), dtype=torch.float64, device=dev)
+    sel_leaf = torch.empty((B, kmax), dtype=torch.int32, device=dev)
+    sel_count = torch.empty(B, dtype=torch.int32, device=dev)
+    sel_row = torch.empty(B, dtype=torch.int32, device=dev)
+    check(
+        lib.hw_pgpr_collect(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), U64.shape[1], _ptr(users), B, _ptr(pos_bits),
+                            pos_bits.shape[1], _ptr(leaf_paths), _ptr(leaf_probs), _ptr(n_leaf), int(max_leaf),
+                            int(n_nodes), int(kmax), _ptr(best), _ptr(score_ws), _ptr(first), _ptr(results),
+                            _ptr(sel_item), _ptr(sel_score), _ptr(sel_leaf), _ptr(sel_count), _ptr(sel_row), _stream()),
+        "hw_pgpr_collect",
+    )
+    return results, dict(item=sel_item, score=sel_score, leaf=sel_leaf, count=sel_count, row=sel_row)

@@ -142,7 +142,7 @@ int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, int64_t n_ke
 /* ---- PGPR beam-search traversal --------------------------------------------------------------------
  * Device restatement of model/knowledge_aware_recommender/pgpr.py beam_search (:440-484) and the
  * per-path primitives it calls.  Node types: 0 = user, 1 = entity; the self-loop relation is -1.
- * A beam row ("path") is HW_PGPR_ROW_INTS int32: [uid, n_nodes, (rel, type, id) x 3, 0]; its hop
+ * A beam row ("path") is HW_PGPR_ROW_INTS int32: [uid, n_nodes, (rel, type, id) x 3, batch index]; its hop
  * probabilities are 3 floats.  Row counts live in device memory (int32 *n_rows) so that a whole
  * multi-hop search is enqueued without a host round trip; `max_rows` bounds every launch. */
 #define HW_PGPR_ROW_INTS 12
@@ -200,6 +200,20 @@ int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float
                    int64_t max_rows, const int32_t* topk_idx, const float* topk_val, int32_t k,
                    int32_t* offsets, int32_t* paths_out, float* probs_out, int32_t* n_rows_out,
                    int64_t out_capacity, void* stream);
+
+/* collect_scores (pgpr.py:486-552) on the leaf rows of a search over `users[n_batch]`:
+ * results [n_batch, n_items] float32 (-inf where nothing is written), plus per user slot the written
+ * (item, float64 score, leaf row of the attached path) triples in writing order: sel_* [n_batch, kmax],
+ * sel_count [n_batch], sel_row [n_batch] (row of `results` the slot wrote to, -1 if none).
+ * positives_bits: bitset [n_users, positives_words] of dataset.history_item_matrix()[0] rows.
+ * Workspaces: best_ws uint64 [n_batch * n_items], score_ws double [n_batch * n_items], first_idx_ws int32 [n_batch]. */
+int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                    const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                    const uint32_t* positives_bits, int64_t positives_words, const int32_t* leaf_paths,
+                    const float* leaf_probs, const int32_t* n_leaf, int64_t max_leaf, int32_t n_nodes,
+                    int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws, float* results,
+                    int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
+                    int32_t* sel_row, void* stream);
 
 const char* hw_version(void);
 
