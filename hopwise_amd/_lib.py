@@ -120,6 +120,8 @@ SIGNATURES = {
          c_i32p, c_f32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_i32p, c_f32p, c_i32p,
          C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_void_p],
     ),
+    "hw_gather_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_f32p, c_i32p, C.c_void_p]),
+    "hw_scatter_add_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_f32p, C.c_void_p]),
     "hw_version": (C.c_char_p, []),
 }
 

@@ -351,3 +351,30 @@ def neg_sample(used_ptr, used_idx, keys, num, value_num, seed, offset, alias=Non
         "hw_neg_sample",
     )
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# row exchange primitives (row-sharded tables)
+# ------------------------------------------------------------------------------------------------
+def gather_rows(table, idx):
+    lib = _lib.load()
+    table = _dev(table, torch.float32, "table")
+    idx = _idx(idx, "idx").contiguous()
+    if table.dim() != 2 or not table.is_contiguous():
+        raise ValueError("table must be contiguous [rows, dim]")
+    out = torch.empty((idx.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+    check(lib.hw_gather_rows(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(out),
+                             _ptr(_OobCounter.get(table.device)), _stream()), "hw_gather_rows")
+    return out
+
+
+def scatter_add_rows_(table, idx, src):
+    lib = _lib.load()
+    table = _dev(table, torch.float32, "table")
+    idx = _idx(idx, "idx").contiguous()
+    src = _dev(src, torch.float32, "src").contiguous()
+    if table.dim() != 2 or not table.is_contiguous() or src.shape != (idx.numel(), table.shape[1]):
+        raise ValueError("shape mismatch")
+    check(lib.hw_scatter_add_rows(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(src),
+                                  _stream()), "hw_scatter_add_rows")
+    return table

@@ -215,6 +215,14 @@ int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_emb64, const 
                     int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
                     int32_t* sel_row, void* stream);
 
+/* ---- row exchange primitives for row-sharded tables (no reference counterpart -- the
+ * reference replicates tables under DDP, trainer/trainer.py:83-84) -------------------------------------
+ * out[i, :] = table[idx[i], :]  and  table[idx[i], :] += src[i, :] (float atomics; ids outside the shard are skipped). */
+int hw_gather_rows(const float* table, int64_t n_table_rows, int32_t dim, const int64_t* idx, int64_t n,
+                   float* out, int32_t* oob_counter, void* stream);
+int hw_scatter_add_rows(float* table, int64_t n_table_rows, int32_t dim, const int64_t* idx, int64_t n,
+                        const float* src, void* stream);
+
 const char* hw_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,162 @@
+"""world_size-2 gloo (CPU) tests of the multi-GPU host logic: row-sharded lookup (forward + backward exchange),
+the sharded KGE wrapper's id remapping and gradient routing, global top-k merge, max-over-ranks timing.
+The row gather / scatter-add primitives are replaced by torch CPU indexing here (parallel.set_row_ops) --
+only the exchange logic is under test; the HIP primitives have their own GPU tests."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import kge as okge
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cpu_gather(table, idx):
+    return table[idx]
+
+
+def _cpu_scatter_add(table, idx, src):
+    return table.index_add_(0, idx, src)
+
+
+def _cpu_topk(v, k):
+    order = np.lexsort((np.broadcast_to(np.arange(v.shape[1]), v.shape), -v.numpy().astype(np.float64)), axis=1)[:, :k]
+    order = torch.from_numpy(order.copy())
+    return torch.gather(v, 1, order), order
+
+
+class _StubModel(torch.nn.Module):
+    """Same table/field layout as hopwise_amd.model.RotatE, with a torch-CPU calculate_loss standing in for the
+    HIP scorer (the kernels cannot run in this container)."""
+
+    USER_TABLES = ("user_embedding", "user_embedding_im")
+    ENTITY_TABLES = ("entity_embedding", "entity_embedding_im")
+    RELATION_TABLES = ("relation_embedding",)
+    USER_ID, ITEM_ID, NEG_ITEM_ID = "user_id", "item_id", "neg_item_id"
+    HEAD_ENTITY_ID, RELATION_ID, TAIL_ENTITY_ID, NEG_TAIL_ENTITY_ID = "head_id", "relation_id", "tail_id", "neg_tail_id"
+
+    def __init__(self, tables, n_users, n_entities):
+        super().__init__()
+        self.n_users, self.n_entities = n_users, n_entities
+        for k, v in tables.items():
+            emb = torch.nn.Embedding(*v.shape)
+            emb.weight.data.copy_(torch.from_numpy(v))
+            setattr(self, k, emb)
+
+    def _w(self, names):
+        return tuple(getattr(self, n).weight for n in names)
+
+    def _tables(self, side):
+        head = self._w(self.USER_TABLES if side == "rec" else self.ENTITY_TABLES)
+        return head, self._w(self.RELATION_TABLES), self._w(self.ENTITY_TABLES)
+
+    def calculate_loss(self, it):
+        def score(side, h, r, t):
+            H, R, T = self._tables(side)
+            rr, ri = torch.cos(R[0][r]), torch.sin(R[0][r])
+            re = rr * H[0][h] - ri * H[1][h] - T[0][t]
+            im = rr * H[1][h] + ri * H[0][h] - T[1][t]
+            return 1.0 - torch.sqrt((re * re + im * im).sum(-1))
+
+        ui = torch.full_like(it["user_id"], self.relation_embedding.weight.shape[0] - 1)
+        bce = torch.nn.BCEWithLogitsLoss()
+        sp, sn = score("rec", it["user_id"], ui, it["item_id"]), score("rec", it["user_id"], ui, it["neg_item_id"])
+        kp, kn = score("kg", it["head_id"], it["relation_id"], it["tail_id"]), score("kg", it["head_id"], it["relation_id"], it["neg_tail_id"])
+        lab = lambda a, b: torch.cat([torch.ones_like(a), torch.zeros_like(b)])
+        return bce(torch.cat([sp, sn]), lab(sp, sn)) + bce(torch.cat([kp, kn]), lab(kp, kn))
+
+
+def _worker(rank, world_size, port, tmp):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    torch.set_num_threads(1)
+    from hopwise_amd import parallel as par
+
+    par.set_row_ops(_cpu_gather, _cpu_scatter_add)
+    try:
+        # ---- 1. lookup forward / backward against a dense table -----------------------------------------
+        rng = np.random.default_rng(0)  # same on every rank
+        N, d = 53, 6
+        full_a = torch.from_numpy(rng.standard_normal((N, d)).astype(np.float32))
+        full_b = torch.from_numpy(rng.standard_normal((N, d)).astype(np.float32))
+        sa = par.shard_rows(full_a, rank, world_size).requires_grad_(True)
+        sb = par.shard_rows(full_b, rank, world_size).requires_grad_(True)
+        ids = torch.from_numpy(np.random.default_rng(10 + rank).integers(0, N, (7, 5)))  # differs per rank, repeats
+        (ca, cb), inv = par.sharded_lookup((sa, sb), ids)
+        assert torch.equal(ca[inv], full_a[ids]) and torch.equal(cb[inv], full_b[ids])
+        w = torch.from_numpy(np.random.default_rng(20 + rank).standard_normal((7, 5, d)).astype(np.float32))
+        ((ca[inv] * w).sum() + 2.0 * (cb[inv] * w).sum()).backward()
+        # dense expectation: every rank's contribution, summed at the owner
+        all_ids = [torch.from_numpy(np.random.default_rng(10 + r).integers(0, N, (7, 5))) for r in range(world_size)]
+        all_w = [torch.from_numpy(np.random.default_rng(20 + r).standard_normal((7, 5, d)).astype(np.float32)) for r in range(world_size)]
+        dense = torch.zeros(N, d)
+        for i_, w_ in zip(all_ids, all_w):
+            dense.index_add_(0, i_.reshape(-1), w_.reshape(-1, d))
+        assert torch.allclose(sa.grad, dense[rank::world_size], atol=1e-6)
+        assert torch.allclose(sb.grad, 2 * dense[rank::world_size], atol=1e-6)
+
+        # ---- 2. sharded KGE wrapper: loss and gradients equal the unsharded model on the same batch ------
+        nU, nI, nE, nR, dim = 17, 11, 29, 5, 8
+        rng = np.random.default_rng(3)
+        tables = {k: rng.standard_normal(((nU if k.startswith("user") else nR if k.startswith("rel") else nE), dim)).astype(np.float32) * 0.3
+                  for k in okge.table_names("RotatE")}
+        def batch(r):
+            g = np.random.default_rng(100 + r)
+            return {k: torch.from_numpy(v) for k, v in dict(
+                user_id=g.integers(1, nU, 9), item_id=g.integers(1, nI, 9), neg_item_id=g.integers(1, nI, 9),
+                head_id=g.integers(1, nE, 12), relation_id=g.integers(1, nR - 1, 12), tail_id=g.integers(1, nE, 12),
+                neg_tail_id=g.integers(1, nE, 12)).items()}
+        ref = _StubModel(tables, nU, nE)
+        ref_loss = sum(ref.calculate_loss(batch(r)) for r in range(world_size)) / world_size
+        ref_loss.backward()
+        sharded = par.RowShardedKGE(_StubModel(tables, nU, nE))
+        loss = sharded.calculate_loss(batch(rank))
+        loss.backward()
+        sharded.sync_grads()
+        for n in _StubModel.USER_TABLES + _StubModel.ENTITY_TABLES:
+            want = getattr(ref, n).weight.grad[rank::world_size]
+            assert torch.allclose(getattr(sharded, "shard_" + n).grad, want, atol=1e-6), n
+        assert torch.allclose(sharded.model.relation_embedding.weight.grad, ref.relation_embedding.weight.grad, atol=1e-6)
+        lt = loss.detach().clone()
+        dist.all_reduce(lt)
+        assert abs(lt.item() / world_size - ref_loss.item()) < 1e-6
+        sd = sharded.full_state_dict()
+        for k, v in tables.items():
+            assert torch.equal(sd[k + ".weight"], torch.from_numpy(v)), k
+
+        # ---- 3. global top-k merge ---------------------------------------------------------------------------
+        rng = np.random.default_rng(5)
+        scores = rng.standard_normal((4, 40)).astype(np.float32)
+        scores[1, 7] = scores[1, 8]  # a cross-rank tie: smaller global id must win
+        mine = np.arange(rank, 40, world_size)
+        lv, lo = _cpu_topk(torch.from_numpy(scores[:, mine].copy()), 6)
+        lids = torch.from_numpy(mine)[lo]
+        tv, ti = par.merge_topk(lv, lids, 6, topk_fn=_cpu_topk)
+        rv, ri = okge.topk_desc(scores, 6)
+        assert np.array_equal(ti.numpy(), ri) and np.array_equal(tv.numpy(), rv)
+
+        # ---- 4. timing helper -----------------------------------------------------------------------------------
+        assert par.max_over_ranks(1.0 + rank, torch.device("cpu")) == float(world_size)
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        par.set_row_ops(None, None)
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
