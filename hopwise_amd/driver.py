@@ -1,0 +1,112 @@
+"""Minimal driver that reproduces the call protocol around the hot path -- batch assembly and the
+train / evaluate loops -- so the engine runs without the reference present.
+
+Reference call sites (paths under /root/reference/hopwise):
+  batch layout   data/dataloader/general_dataloader.py:46-70 (TrainDataLoader), abstract_dataloader.py:165-198
+                 (pairwise negatives: the P positives are tiled sample_num times, negative j of positive i sits at
+                 row j*P + i), knowledge_dataloader.py:51,69-75 (KGDataLoader: one negative tail per triple),
+                 :137-151 (KnowledgeBasedDataLoader RSKG: kg iterator restarts when exhausted; an epoch is
+                 len(rec loader) steps)
+  train step     trainer/trainer.py:208-268 (zero_grad -> calculate_loss (tuple => sum) -> NaN check -> backward ->
+                 clip_grad_norm_ -> step)
+  full-sort eval trainer/trainer.py:716-735 + evaluator/collector.py:173-183 (no_grad, eval(), view(-1, N),
+                 scores[:, 0] = -inf, scores[history_index] = -inf, topk(max(topk)))
+Everything here is host orchestration; arithmetic happens in the kernels behind the model and sampler objects.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .data import Interaction
+
+
+class KGBatcher:
+    """RSKG-state batches: rec positives with ``sample_num`` negatives each + KG triples with one negative tail.
+
+    ``sampler`` / ``kg_sampler`` are objects with ``sample_by_user_ids(users, items, num)`` and
+    ``sample_by_entity_ids(heads, num)`` (hopwise_amd.sampler.{Sampler, KGSampler}); they may return host or
+    device tensors."""
+
+    def __init__(self, inter_users, inter_items, heads, rels, tails, sampler, kg_sampler, train_batch_size=2048,
+                 sample_num=1, shuffle=True, seed=2020, device="cpu"):
+        self.u, self.i = torch.as_tensor(np.asarray(inter_users)), torch.as_tensor(np.asarray(inter_items))
+        self.h, self.r, self.t = (torch.as_tensor(np.asarray(x)) for x in (heads, rels, tails))
+        self.sampler, self.kg_sampler = sampler, kg_sampler
+        self.times = int(sample_num)
+        self.rec_step = max(int(train_batch_size) // self.times, 1)  # positives per batch (general_dataloader.py:46-55)
+        self.kg_step = int(train_batch_size)  # knowledge_dataloader.py:64-67
+        self.shuffle = shuffle
+        self.gen = torch.Generator().manual_seed(seed)
+        self.device = torch.device(device)
+        self._kg_perm, self._kg_pos = None, 0
+
+    def __len__(self):
+        return (len(self.u) + self.rec_step - 1) // self.rec_step
+
+    def _next_kg(self):
+        if self._kg_perm is None or self._kg_pos >= len(self.h):  # restart when exhausted (:138-142)
+            self._kg_perm = torch.randperm(len(self.h), generator=self.gen)  # the kg loader always shuffles (:44-47)
+            self._kg_pos = 0
+        idx = self._kg_perm[self._kg_pos : self._kg_pos + self.kg_step]
+        self._kg_pos += self.kg_step
+        return idx
+
+    def __iter__(self):
+        n = len(self.u)
+        perm = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        for s in range(0, n, self.rec_step):
+            idx = perm[s : s + self.rec_step]
+            users, items = self.u[idx], self.i[idx]
+            neg = self.sampler.sample_by_user_ids(users, items, self.times)
+            kidx = self._next_kg()
+            heads = self.h[kidx]
+            neg_t = self.kg_sampler.sample_by_entity_ids(heads, 1)
+            dev = self.device
+            yield Interaction({
+                "user_id": users.repeat(self.times).to(dev),
+                "item_id": items.repeat(self.times).to(dev),
+                "neg_item_id": torch.as_tensor(neg).to(dev),
+                "head_id": heads.to(dev),
+                "relation_id": self.r[kidx].to(dev),
+                "tail_id": self.t[kidx].to(dev),
+                "neg_tail_id": torch.as_tensor(neg_t).to(dev),
+            })
+
+
+def train_epoch(model, batches, optimizer, clip_grad_norm=None, device=None):
+    """One epoch the way Trainer._train_epoch drives a model.  Returns the summed loss (float)."""
+    model.train()
+    total = None
+    for interaction in batches:
+        if device is not None:
+            interaction = interaction.to(device)
+        optimizer.zero_grad()
+        losses = model.calculate_loss(interaction)
+        loss = sum(losses) if isinstance(losses, tuple) else losses
+        total = loss.detach() if total is None else total + loss.detach()
+        if torch.isnan(loss):
+            raise ValueError("Training loss is nan")  # trainer.py:337-339
+        loss.backward()
+        if clip_grad_norm:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), **clip_grad_norm)
+        optimizer.step()
+    return float(total.item()) if total is not None else 0.0
+
+
+@torch.no_grad()
+def full_sort_topk(model, interaction, history_index=None, k=10, kg=False):
+    """Scores -> mask -> top-k on the device.  Returns (values [B, k], indices [B, k], masked scores [B, N])."""
+    model.eval()
+    if kg:
+        scores = model.full_sort_predict_kg(interaction)
+        n = model.n_entities
+    else:
+        scores = model.full_sort_predict(interaction)
+        n = model.n_items
+    scores = scores.view(-1, n).contiguous()
+    ops.mask_scores_(scores, history_index)
+    val, idx = ops.topk_rows(scores, k)
+    return val, idx, scores

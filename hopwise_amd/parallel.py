@@ -96,7 +96,7 @@ class _ShardedLookup(torch.autograd.Function):
         ctx.plan, ctx.d_each = plan, d_each
         ctx.shapes = [s.shape for s in shards]
         ctx.save_for_backward(*shards)
-        return tuple(compact.split(d_each, dim=1)) if len(shards) > 1 else (compact,)
+        return tuple(c.contiguous() for c in compact.split(d_each, dim=1)) if len(shards) > 1 else (compact,)
 
     @staticmethod
     def backward(ctx, *grads):

@@ -1,0 +1,56 @@
+"""Batch assembly (A8) against the layout the reference's dataloaders produce; CPU only, with the oracle samplers."""
+
+import numpy as np
+import torch
+
+from hopwise_amd.driver import KGBatcher
+from oracle import sampler as osamp
+
+
+class _S:
+    def __init__(self, s):
+        self.s = s
+
+    def sample_by_user_ids(self, users, items, num):
+        return torch.from_numpy(self.s.sample_by_key_ids(np.asarray(users), num))
+
+    def sample_by_entity_ids(self, heads, num=1):
+        return torch.from_numpy(self.s.sample_by_key_ids(np.asarray(heads), num))
+
+
+def test_rskg_batch_layout():
+    rng = np.random.default_rng(0)
+    nU, nI, nE, nR = 30, 25, 60, 6
+    users, items = rng.integers(1, nU, 200), rng.integers(1, nI, 200)
+    heads, rels, tails = rng.integers(1, nE, 90), rng.integers(1, nR - 1, 90), rng.integers(1, nE, 90)
+    rec = osamp.make_rec_samplers([users], [items], nU, nI)[0]
+    kgs = osamp.make_kg_sampler(heads, tails, nE)
+    np.random.seed(0)
+    K, bs = 4, 32
+    b = KGBatcher(users, items, heads, rels, tails, _S(rec), _S(kgs), train_batch_size=bs, sample_num=K, seed=1)
+    P = bs // K
+    assert len(b) == (200 + P - 1) // P  # epoch length = len(rec loader) (knowledge_dataloader.py:147-151)
+    seen_pairs, n_kg = [], 0
+    used_u = [set() for _ in range(nU)]
+    for u, i in zip(users, items):
+        used_u[u].add(i)
+    used_h = [set() for _ in range(nE)]
+    for h, t in zip(heads, tails):
+        used_h[h].add(t)
+    for it in b:
+        u, i, n = (it[k].numpy() for k in ("user_id", "item_id", "neg_item_id"))
+        p = len(u) // K
+        assert len(u) == len(i) == len(n) and len(u) % K == 0 and p <= P
+        # tile layout: row j*p + r repeats positive r (abstract_dataloader.py:192-198 + Interaction.repeat)
+        for j in range(K):
+            assert np.array_equal(u[j * p : (j + 1) * p], u[:p]) and np.array_equal(i[j * p : (j + 1) * p], i[:p])
+            for r in range(p):
+                assert int(n[j * p + r]) not in used_u[int(u[r])] and 1 <= n[j * p + r] < nI
+        seen_pairs += list(zip(u[:p], i[:p]))
+        h, r, t, nt = (it[k].numpy() for k in ("head_id", "relation_id", "tail_id", "neg_tail_id"))
+        assert len(h) == len(r) == len(t) == len(nt) <= bs
+        for hh, rr, tt, nn in zip(h, r, t, nt):
+            assert int(nn) not in used_h[int(hh)]
+        n_kg += len(h)
+    assert sorted(seen_pairs) == sorted(zip(users, items))  # every interaction exactly once per epoch
+    assert n_kg >= len(b) * 1  # kg iterator restarted as often as needed (90 triples < 25 steps * 32)
