@@ -87,16 +87,15 @@ def main():
     uptr, uidx = synthetic.used_csr(kg.inter_users, kg.inter_items, kg.n_users)
     uptr, uidx = torch.from_numpy(uptr).to(dev), torch.from_numpy(uidx).to(dev)
     n_items = kg.n_items if args.entities == 0 else nE  # HBM variant draws negatives over the whole big table
-    idx = torch.empty((1 + K_NEG, B_POS), dtype=torch.int64, device=dev)  # j-major: row 0 positives
-    idx[0] = pos
-    neg_flat = idx[1:].view(-1)
-    t_idx = idx.t()  # [B, 1+K] view, strides (1, B)
+    t_idx = torch.empty((B_POS, 1 + K_NEG), dtype=torch.int64, device=dev)  # one row of tail ids per (h, r) group
+    t_idx[:, 0] = pos
+    neg_view = t_idx[:, 1:]  # the sampler writes its [keys, draws] output straight into the grouped buffer
     ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     loss_box = [None]
 
     def step(i, timed=False):
-        ops.neg_sample(uptr, uidx, users, K_NEG, n_items, seed=2024 + rank, offset=i, out=neg_flat)
+        ops.neg_sample(uptr, uidx, users, K_NEG, n_items, seed=2024 + rank, offset=i, out=neg_view)
         if timed:
             ev_a[i].record()
         scores = ops.kge_score_grouped_raw(desc, users, None, kg.ui_relation, t_idx)
@@ -171,7 +170,7 @@ def main():
         big_re = torch.randn(nbig, DIM, device=dev) * 0.01
         big_im = torch.randn(nbig, DIM, device=dev) * 0.01
         bdesc = ops.make_desc("RotatE", head, rel, (big_re, big_im), margin=1.0)
-        bidx = torch.randint(1, nbig, (1 + K_NEG, B_POS), device=dev, dtype=torch.int64).t()
+        bidx = torch.randint(1, nbig, (B_POS, 1 + K_NEG), device=dev, dtype=torch.int64)
         for _ in range(3):
             ops.kge_score_grouped_raw(bdesc, users, None, kg.ui_relation, bidx)
         ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

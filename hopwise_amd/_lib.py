@@ -87,7 +87,7 @@ SIGNATURES = {
     "hw_neg_sample": (
         C.c_int,
         [c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int32, C.c_int64, c_f32p, c_i64p, c_i64p, C.c_int64,
-         C.c_uint64, C.c_uint64, c_i64p, c_i32p, C.c_void_p],
+         C.c_uint64, C.c_uint64, c_i64p, C.c_int64, C.c_int64, c_i32p, C.c_void_p],
     ),
     "hw_pgpr_init_paths": (C.c_int, [c_i64p, C.c_int64, c_i32p, c_f32p, c_i32p, C.c_void_p]),
     "hw_pgpr_actions": (

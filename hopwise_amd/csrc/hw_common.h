@@ -17,12 +17,70 @@ namespace hw {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ---- sub-wave butterfly sum over G lanes (G power of two, 1..64); every lane gets the total ----
+
+// ---- DPP helpers ------------------------------------------------------------------------------------
+// Cross-lane adds inside a 16-lane row cost one VALU op with a DPP modifier (no LDS-crossbar round trip):
+// quad_perm for xor 1 / xor 2, row_half_mirror / row_mirror to finish the row.  Crossing rows (xor 16 / 32)
+// goes through ds_bpermute (__shfl_xor).  Callers keep the whole wave active around these (EXEC all ones).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// sum over aligned groups of W lanes (W = 1, 2, 4, 8, 16) inside a DPP row; every lane gets its group's total.
+// xor 1 / xor 2 are quad_perm; once quads are uniform row_half_mirror (i -> 7 - i) reaches the other quad of an
+// 8-lane group, and once 8-lane groups are uniform row_mirror (i -> 15 - i) reaches the other half of the row.
+template <int W>
+__device__ __forceinline__ float dpp_group_sum(float v) {
+    if constexpr (W >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    if constexpr (W >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    if constexpr (W >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
+    if constexpr (W >= 16) v += dpp_mov<0x140>(v); // row_mirror
+    return v;
+}
+
+// ---- sub-wave sum over G lanes (G power of two, 1..64); every lane gets the total ----
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, HW_WAVE);
-    return v;
+    for (int m = G / 2; m >= 16; m >>= 1) v += __shfl_xor(v, m, HW_WAVE);
+    return dpp_group_sum<(G < 16 ? G : 16)>(v);
+}
+
+// Reduce U partial sums (one per tail) over the G lanes of a sub-wave group with a reduce-scatter butterfly:
+// while more than one value is live, lanes whose bit `m` is clear keep the lower half of the values and ship the
+// upper half to lane ^ m (and vice versa).  U = 4, G = 64: 2 + 1 + 1 ds_bpermute and 4 DPP adds instead of 4 x 6
+// ds_bpermute.  Returns this lane's total; `which` = index of the tail it belongs to.  The G / U lanes that share
+// `which` all hold the same total.
+template <int G, int U>
+__device__ __forceinline__ float group_reduce_multi(float (&p)[U], int gl, int& which) {
+    static_assert((G & (G - 1)) == 0 && (U & (U - 1)) == 0 && U <= G, "shape");
+    constexpr int REM = G / U;  // lanes that share one value after the scatter phase
+    which = 0;
+    int live = U;
+    int m = G / 2;
+#pragma unroll
+    for (; live > 1; live >>= 1, m >>= 1) {
+        const bool upper = (gl & m) != 0;
+#pragma unroll
+        for (int i = 0; i < live / 2; ++i) {
+            const float keep = upper ? p[i + live / 2] : p[i];
+            const float send = upper ? p[i] : p[i + live / 2];
+            p[i] = keep + __shfl_xor(send, m, HW_WAVE);
+        }
+        which = which * 2 + (upper ? 1 : 0);
+    }
+    float v = p[0];
+#pragma unroll
+    for (int mm = REM / 2; mm >= 16; mm >>= 1) v += __shfl_xor(v, mm, HW_WAVE);  // masks that cross DPP rows
+    return dpp_group_sum<(REM < 16 ? REM : 16)>(v);
+}
+
+// branch-free clamp into [0, n); `bad` accumulates whether anything was out of range (reported once per wave)
+__device__ __forceinline__ int clamp_row_flag(int64_t id, int64_t n, bool& bad) {
+    const int64_t c = id < 0 ? 0 : (id >= n ? n - 1 : id);
+    bad |= (c != id);
+    return (int)c;
 }
 
 // clamp an id into [0, n) and count violations (ids outside the table never reach a load address)
@@ -42,15 +100,25 @@ template <int G, int NE, bool VEC>
 struct Row {
     float v[NE];
 
+    // Branch-free: lanes past the end of the row re-read the last chunk / element (always in bounds) and the
+    // value is then zeroed with a select.  A load inside a divergent branch makes hipcc wait for it right there
+    // (vmcnt(0) before the phi moves), which serialises the U rows a wave is supposed to keep in flight.
     __device__ __forceinline__ void load(const float* __restrict__ base, int dim, int gl) {
+        load_raw(base, dim, gl);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] = col(i, dim, gl) >= 0 ? v[i] : 0.f;
+    }
+
+    // Same loads without the zeroing: padding slots hold copies of valid data; the caller masks their
+    // contribution (Scorer::partial with MASK = true).
+    __device__ __forceinline__ void load_raw(const float* __restrict__ base, int dim, int gl) {
         if constexpr (VEC) {
             const int d4 = dim >> 2;
             const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(base);
 #pragma unroll
             for (int c = 0; c < NE / 4; ++c) {
                 const int q = gl + c * G;
-                f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                if (q < d4) x = p[q];
+                const f32x4 x = p[q < d4 ? q : d4 - 1];
                 v[4 * c + 0] = x.x;
                 v[4 * c + 1] = x.y;
                 v[4 * c + 2] = x.z;
@@ -60,10 +128,13 @@ struct Row {
 #pragma unroll
             for (int c = 0; c < NE; ++c) {
                 const int e = gl + c * G;
-                v[c] = (e < dim) ? base[e] : 0.f;
+                v[c] = base[e < dim ? e : dim - 1];
             }
         }
     }
+
+    // validity of the load unit (float4 chunk or element) that slot i belongs to
+    __device__ __forceinline__ static bool slot_valid(int i, int dim, int gl) { return col(i, dim, gl) >= 0; }
 
     // column of slot i, or -1 when the slot lies past the end of the row
     __device__ __forceinline__ static int col(int i, int dim, int gl) {

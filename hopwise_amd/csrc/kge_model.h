@@ -84,27 +84,39 @@ struct Scorer {
         }
     }
 
-    // This lane's share of sum_d f(Q_d, t_d).  Padding slots contribute 0 for every model except
-    // TransE with eps != 0, which is why `dim`/`gl` are needed there.
+    // This lane's share of sum_d f(Q_d, t_d).  Query padding slots are 0.  With RAW = false the tail rows are
+    // zero-padded too (Row::load); with RAW = true they were loaded with Row::load_raw and padding slots hold
+    // junk, so models whose f(0, t) != 0 (TransE, RotatE) mask those slots here -- one select per load unit.
+    template <bool RAW = false>
     __device__ __forceinline__ float partial(const R* t, float eps, int dim, int gl) const {
         float s = 0.f;
+        constexpr int UNIT = VEC ? 4 : 1;
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            if constexpr (MODEL == HW_TRANSE) {
-                float df = (q[0].v[i] - t[0].v[i]) + eps;
-                if (eps != 0.f && R::col(i, dim, gl) < 0) df = 0.f;
-                s = fmaf(df, df, s);
-            } else if constexpr (MODEL == HW_DISTMULT) {
-                s = fmaf(q[0].v[i], t[0].v[i], s);
-            } else if constexpr (MODEL == HW_ROTATE) {
-                const float a = q[0].v[i] - t[0].v[i];
-                const float b = q[1].v[i] - t[1].v[i];
-                s = fmaf(a, a, s);
-                s = fmaf(b, b, s);
-            } else {
-                s = fmaf(q[0].v[i], t[0].v[i], s);
-                s = fmaf(q[1].v[i], t[1].v[i], s);
+        for (int c = 0; c < NE / UNIT; ++c) {
+            float sc = 0.f;
+#pragma unroll
+            for (int k = 0; k < UNIT; ++k) {
+                const int i = c * UNIT + k;
+                if constexpr (MODEL == HW_TRANSE) {
+                    const float df = (q[0].v[i] - t[0].v[i]) + eps;
+                    sc = fmaf(df, df, sc);
+                } else if constexpr (MODEL == HW_DISTMULT) {
+                    sc = fmaf(q[0].v[i], t[0].v[i], sc);
+                } else if constexpr (MODEL == HW_ROTATE) {
+                    const float a = q[0].v[i] - t[0].v[i];
+                    const float b = q[1].v[i] - t[1].v[i];
+                    sc = fmaf(a, a, sc);
+                    sc = fmaf(b, b, sc);
+                } else {
+                    sc = fmaf(q[0].v[i], t[0].v[i], sc);
+                    sc = fmaf(q[1].v[i], t[1].v[i], sc);
+                }
             }
+            if constexpr (MODEL == HW_TRANSE || MODEL == HW_ROTATE) {
+                // padding: f(0, junk) != 0 when RAW; f(0, 0) = eps^2 != 0 for TransE with eps even when zero-padded
+                if (RAW || MODEL == HW_TRANSE) sc = R::slot_valid(c * UNIT, dim, gl) ? sc : 0.f;
+            }
+            s += sc;
         }
         return s;
     }

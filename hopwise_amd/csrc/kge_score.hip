@@ -33,35 +33,156 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     const int64_t b = task / S;
     const int s = (int)(task % S);
 
-    const int h = clamp_row(h_idx[b], d.n_head, oob);
-    const int r = clamp_row(r_idx ? r_idx[b] : r_fixed, d.n_rel, oob);
+    bool bad = false;
+    const int h = clamp_row_flag(h_idx[b], d.n_head, bad);
+    const int r = clamp_row_flag(r_idx ? r_idx[b] : r_fixed, d.n_rel, bad);
     SC sc;
     sc.template build<false>(d, h, r, gl, nullptr, nullptr);
 
     const int64_t* __restrict__ tb = t_idx + b * tsb;
     float* __restrict__ ob = out + b * osb;
-    const int step = S * NS;
 
-    for (int j0 = s * NS; j0 < ntail; j0 += step * U) {  // wave-uniform trip count
-        int jj[U];
-        int tj[U];
+    // This wave's tails, in processing order: q = 0, 1, ... -> j(q) = ((q / NS) * S + s) * NS + q % NS.
+    // Lane l prefetches the id of tail q = chunk * 64 + l (one coalesced-ish load per 64 tails, off the
+    // critical path), the row loads then pick their id with a cross-lane read.
+    auto j_of = [&](int q) { return ((q / NS) * S + s) * NS + (q % NS); };
+    for (int q0 = 0; j_of(q0) < ntail; q0 += HW_WAVE) {  // wave-uniform: j_of is monotone in q for q % NS == 0
+        const int jq = j_of(q0 + lane);
+        const int tpre = jq < ntail ? clamp_row_flag(tb[(int64_t)jq * tsj], d.n_tail, bad) : 0;
+#pragma unroll 1
+        for (int k = 0; k < HW_WAVE / NS; k += U) {  // k counts rows of NS tails inside the chunk
+            if (j_of(q0 + k * NS) >= ntail) break;   // wave-uniform
+            int jj[U];
+            R t[U][MT::NT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            jj[u] = j0 + u * step + sub;
-            tj[u] = jj[u] < ntail ? clamp_row(tb[(int64_t)jj[u] * tsj], d.n_tail, oob) : 0;
+            for (int u = 0; u < U; ++u) {
+                const int ql = (k + u) * NS + sub;  // position inside the 64-tail chunk
+                jj[u] = j_of(q0 + ql);
+                int tj;
+                if constexpr (NS == 1) tj = __builtin_amdgcn_readlane(tpre, ql);  // wave-uniform -> scalar row base
+                else tj = __shfl(tpre, ql, HW_WAVE);
+#pragma unroll
+                for (int kk = 0; kk < MT::NT; ++kk) t[u][kk].load_raw(d.tail[kk] + (size_t)tj * d.dim, d.dim, gl);
+            }
+            float p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) p[u] = sc.template partial<true>(t[u], d.eps, d.dim, gl);
+            int which;
+            const float tot = group_reduce_multi<G, U>(p, gl, which);
+            // one writer lane per tail: the first lane of the sub-block that ended up owning it
+            int jw = jj[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) jw = which == u ? jj[u] : jw;
+            if ((gl & (G / U - 1)) == 0 && jw < ntail) ob[(int64_t)jw * osj] = SC::finalize(tot, d.margin);
         }
-        R t[U][MT::NT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int k = 0; k < MT::NT; ++k) t[u][k].load(d.tail[k] + (size_t)tj[u] * d.dim, d.dim, gl);
+    }
+    if (oob && __any(bad)) {
+        if (lane == 0) atomicAdd(oob, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped scorer, XCD-partitioned: tails are routed by id so that each XCD's private L2 only ever sees
+// 1/8 of the tail table.  Block bid works for partition p = bid % 8 (blocks are dealt round-robin over the
+// 8 XCDs, MI355X_MICROARCH.md 'Workgroup dispatch'); its 4 waves take groups (bid / 8) * 4 + wave and score
+// only the tails with (id & 7) == p.  Placement is a speed assumption only: every (group, tail) pair is
+// scored exactly once whatever XCD a block lands on.  ml-1m-small: 22 MB of entity rows -> 2.75 MB per
+// XCD, inside the 4 MB L2, instead of streaming from Infinity Cache.
+// Each wave compacts the ids of its partition into a small LDS list (ballot + prefix popcount) and drains
+// it 64 entries at a time with the same U-rows-in-flight loop as the plain kernel.
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, int G, int NE, bool VEC, int U>
+__global__ __launch_bounds__(256) void kge_score_grouped_xcd_kernel(
+    hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
+    const int64_t* __restrict__ t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail,
+    float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob) {
+    using SC = Scorer<MODEL, G, NE, VEC>;
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, VEC>;
+    constexpr int NS = HW_WAVE / G;
+    __shared__ int sel_id[4][128];
+    __shared__ int sel_j[4][128];
+
+    const int lane = threadIdx.x & (HW_WAVE - 1);
+    const int wave = threadIdx.x / HW_WAVE;
+    const int sub = lane / G, gl = lane % G;
+    const int part = blockIdx.x & 7;
+    const int64_t b = (int64_t)(blockIdx.x >> 3) * 4 + wave;
+    if (b >= n_groups) return;  // wave-uniform; no block-wide barrier is used below
+
+    bool bad = false;
+    const int h = clamp_row_flag(h_idx[b], d.n_head, bad);
+    const int r = clamp_row_flag(r_idx ? r_idx[b] : r_fixed, d.n_rel, bad);
+    SC sc;
+    sc.template build<false>(d, h, r, gl, nullptr, nullptr);
+
+    const int64_t* __restrict__ tb = t_idx + b * tsb;
+    float* __restrict__ ob = out + b * osb;
+    int* __restrict__ lid = sel_id[wave];
+    int* __restrict__ lj = sel_j[wave];
+    int cnt = 0;  // entries waiting in the list (wave-uniform)
+
+    for (int j0 = 0; j0 < ntail; j0 += HW_WAVE) {
+        const int j = j0 + lane;
+        int id = 0;
+        bool mine = false;
+        if (j < ntail) {
+            id = clamp_row_flag(tb[(int64_t)j * tsj], d.n_tail, bad);
+            mine = (id & 7) == part;
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float p = sc.partial(t[u], d.eps, d.dim, gl);
-            p = group_sum<G>(p);
-            if (gl == 0 && jj[u] < ntail) ob[(int64_t)jj[u] * osj] = SC::finalize(p, d.margin);
+        const unsigned long long mask = __ballot(mine);
+        if (mine) {
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            lid[pos] = id;
+            lj[pos] = j;
         }
+        cnt += __popcll(mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool last = j0 + HW_WAVE >= ntail;
+        while (cnt >= HW_WAVE || (last && cnt > 0)) {
+            const int n_now = cnt < HW_WAVE ? cnt : HW_WAVE;
+#pragma unroll 1
+            for (int k = 0; k * NS < n_now; k += U) {
+                int jj[U];
+                bool ok[U];
+                R t[U][MT::NT];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ql = (k + u) * NS + sub;
+                    ok[u] = ql < n_now;
+                    const int tj = ok[u] ? lid[ql] : 0;
+                    jj[u] = ok[u] ? lj[ql] : 0;
+#pragma unroll
+                    for (int kk = 0; kk < MT::NT; ++kk) t[u][kk].load_raw(d.tail[kk] + (size_t)tj * d.dim, d.dim, gl);
+                }
+                float p[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) p[u] = sc.template partial<true>(t[u], d.eps, d.dim, gl);
+                int which;
+                const float tot = group_reduce_multi<G, U>(p, gl, which);
+                int jw = jj[0];
+                bool okw = ok[0];
+#pragma unroll
+                for (int u = 1; u < U; ++u) {
+                    jw = which == u ? jj[u] : jw;
+                    okw = which == u ? ok[u] : okw;
+                }
+                if ((gl & (G / U - 1)) == 0 && okw) ob[(int64_t)jw * osj] = SC::finalize(tot, d.margin);
+            }
+            // keep the (at most 63) entries that did not fit this round
+            const int rest = cnt - n_now;
+            int mid = 0, mj = 0;
+            if (lane < rest) mid = lid[n_now + lane], mj = lj[n_now + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) lid[lane] = mid, lj[lane] = mj;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cnt = rest;
+        }
+    }
+    if (oob && __any(bad)) {
+        if (lane == 0) atomicAdd(oob, 1);
     }
 }
 
@@ -107,13 +228,13 @@ __global__ __launch_bounds__(256) void kge_full_sort_kernel(
             n[u] = nb + u * NS + sub;
             const int64_t row = n[u] < n1 ? n[u] : n0;
 #pragma unroll
-            for (int k = 0; k < MT::NT; ++k) t[u][k].load(d.tail[k] + (size_t)row * d.dim, d.dim, gl);
+            for (int k = 0; k < MT::NT; ++k) t[u][k].load_raw(d.tail[k] + (size_t)row * d.dim, d.dim, gl);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int q = 0; q < HB; ++q) {
-                float p = sc[q].partial(t[u], d.eps, d.dim, gl);
+                float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl);
                 p = group_sum<G>(p);
                 const int bi = hb * HB + q;
                 if (gl == 0 && n[u] < n1 && bi < n_heads) out[(int64_t)bi * ld + (n[u] - lo)] = SC::finalize(p, d.margin);
@@ -199,8 +320,32 @@ extern "C" int hw_kge_score_grouped(const hw_kge_desc* desc, const int64_t* h_id
     if (n_groups == 0 || n_tail_per_group == 0) return HW_OK;
     const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
     const int ntail = (int)n_tail_per_group;
-    constexpr int U = 4;
     const int NS = HW_WAVE / shape.G;
+    hipStream_t st = (hipStream_t)stream;
+    HW_CLEAR_ERR();
+    // Variant: groups with many tails are routed by tail id to XCD-local L2 slices; short groups (predict,
+    // pos/neg pairs) use the plain kernel.  HW_GROUPED_VARIANT = 0 (plain) / 1 (xcd) overrides for experiments.
+    int variant = env_int("HW_GROUPED_VARIANT", -1);
+    if (variant < 0) {
+        // tail rows the launch can touch: up to 4 MiB they sit in every XCD's L2 anyway; beyond the 256 MiB
+        // Infinity Cache nothing is resident and the plain kernel's lower overhead wins (measured, profiles/r1)
+        const int nt = (desc->model == HW_ROTATE || desc->model == HW_COMPLEX) ? 2 : 1;
+        const double footprint = (double)desc->n_tail * desc->dim * 4.0 * nt;
+        variant = (ntail >= 64 && footprint > 6.0e6 && footprint <= 256.0e6) ? 1 : 0;
+    }
+    if (variant == 1) {
+        const int64_t n_blocks = ((n_groups + 3) / 4) * 8;
+        if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+#define CALLX(MODEL, G_, NE_, VEC_)                                                                                 \
+    hipLaunchKernelGGL((kge_score_grouped_xcd_kernel<MODEL, G_, NE_, VEC_, 4>), dim3((unsigned)n_blocks), dim3(256), \
+                       0, st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, out,    \
+                       o_stride_b, o_stride_j, oob_counter)
+        HW_DISPATCH_MODEL(desc->model, shape, CALLX);
+#undef CALLX
+        return HW_LAUNCH_RC();
+    }
+    const bool u8 = env_int("HW_GROUPED_U", 4) == 8;
+    constexpr int U = 4;
     // splits per group: enough waves to fill 256 CUs x 32 wave slots, but keep >= U*NS tails per wave
     // so the (h, r) query build is amortised.
     int S = env_int("HW_GROUPED_SPLITS", 0);
@@ -213,12 +358,16 @@ extern "C" int hw_kge_score_grouped(const hw_kge_desc* desc, const int64_t* h_id
     const int64_t n_tasks = n_groups * S;
     const int64_t n_blocks = (n_tasks + 3) / 4;
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
-    HW_CLEAR_ERR();
-    hipStream_t st = (hipStream_t)stream;
 #define CALL(MODEL, G_, NE_, VEC_)                                                                              \
     hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U>), dim3((unsigned)n_blocks), dim3(256), 0, \
                        st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, out,  \
                        o_stride_b, o_stride_j, oob_counter)
+    if (u8 && desc->model == HW_ROTATE && shape.vec && shape.G == 64 && shape.NE == 4) {  // experiment hook
+        hipLaunchKernelGGL((kge_score_grouped_kernel<HW_ROTATE, 64, 4, true, 8>), dim3((unsigned)n_blocks), dim3(256), 0,
+                           st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, out,
+                           o_stride_b, o_stride_j, oob_counter);
+        return HW_LAUNCH_RC();
+    }
     HW_DISPATCH_MODEL(desc->model, shape, CALL);
 #undef CALL
     return HW_LAUNCH_RC();

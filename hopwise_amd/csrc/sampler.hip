@@ -50,13 +50,14 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(
     const int64_t* __restrict__ keys, int64_t n_keys, int64_t total, int64_t value_num,
     const float* __restrict__ alias_prob, const int64_t* __restrict__ alias_keys,
     const int64_t* __restrict__ alias_alias, int64_t n_alias, uint64_t seed, uint64_t offset,
-    int64_t* __restrict__ out, int32_t* oob) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t* __restrict__ out, int64_t out_stride_key, int64_t out_stride_draw, int32_t* oob) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // e = j * n_keys + i: the reference's position
     if (e >= total) return;
+    const int64_t o = (e % n_keys) * out_stride_key + (e / n_keys) * out_stride_draw;
     int64_t key = keys[e % n_keys];
     if (key < 0 || key >= n_key_space) {  // the reference raises ValueError (sampler.py:286-291,352-357)
         if (oob) atomicAdd(oob, 1);
-        out[e] = 0;
+        out[o] = 0;
         return;
     }
     const int64_t lo = used_ptr[key], hi = used_ptr[key + 1];
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(
         }
     }
     if (!ok && oob) atomicAdd(oob, 1);  // a key that has used (almost) every id; the reference would spin
-    out[e] = v;
+    out[o] = v;
 }
 
 }  // namespace hw
@@ -96,8 +97,8 @@ using namespace hw;
 extern "C" int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, int64_t n_key_space,
                              const int64_t* keys, int64_t n_keys, int32_t num, int64_t value_num,
                              const float* alias_prob, const int64_t* alias_keys, const int64_t* alias_alias,
-                             int64_t n_alias, uint64_t seed, uint64_t offset, int64_t* out, int32_t* oob_counter,
-                             void* stream) {
+                             int64_t n_alias, uint64_t seed, uint64_t offset, int64_t* out, int64_t out_stride_key,
+                             int64_t out_stride_draw, int32_t* oob_counter, void* stream) {
     if (!used_ptr || !keys || !out || n_key_space < 1 || n_keys < 0 || num < 0) return HW_ERR_INVALID_ARG;
     if (value_num < 2 || value_num > 0xffffffffll) return HW_ERR_INVALID_ARG;
     if (alias_prob && (!alias_keys || !alias_alias || n_alias < 1)) return HW_ERR_INVALID_ARG;
@@ -107,7 +108,7 @@ extern "C" int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, i
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(neg_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        used_ptr, used_idx, n_key_space, keys, n_keys, total, value_num, alias_prob, alias_keys,
-                       alias_alias, n_alias, seed, offset, out, oob_counter);
+                       alias_alias, n_alias, seed, offset, out, out_stride_key, out_stride_draw, oob_counter);
     return HW_LAUNCH_RC();
 }
 

@@ -326,16 +326,22 @@ def topk_rows(scores, k):
 # ------------------------------------------------------------------------------------------------
 def neg_sample(used_ptr, used_idx, keys, num, value_num, seed, offset, alias=None, out=None):
     """out[j*len(keys)+i]: j-th negative of keys[i], never in used(keys[i]) (sampler.py:140-183).
-    ``out`` (optional, contiguous int64 [num*len(keys)]) lets the draw land directly in a grouped index buffer."""
+    ``out`` (optional int64): either flat contiguous [num*len(keys)] (the reference layout) or a 2-D
+    [len(keys), num] view with any strides -- the draws then land directly in a grouped index buffer."""
     lib = _lib.load()
     used_ptr = _idx(used_ptr, "used_ptr").contiguous()
     used_idx = _idx(used_idx, "used_idx").contiguous()
     keys = _idx(keys, "keys").contiguous()
+    sk, sd = 1, keys.numel()
     if out is None:
         out = torch.empty(keys.numel() * int(num), dtype=torch.int64, device=keys.device)
     else:
         out = _idx(out, "out")
-        if not out.is_contiguous() or out.numel() != keys.numel() * int(num):
+        if out.dim() == 2:
+            if tuple(out.shape) != (keys.numel(), int(num)):
+                raise ValueError("2-D out must be [len(keys), num]")
+            sk, sd = out.stride(0), out.stride(1)
+        elif not out.is_contiguous() or out.numel() != keys.numel() * int(num):
             raise ValueError("out must be contiguous with num*len(keys) elements")
     ap = ak = aa = None
     na = 0
@@ -347,7 +353,8 @@ def neg_sample(used_ptr, used_idx, keys, num, value_num, seed, offset, alias=Non
     check(
         lib.hw_neg_sample(_ptr(used_ptr), _ptr(used_idx), used_ptr.numel() - 1, _ptr(keys), keys.numel(), int(num),
                           int(value_num), _ptr(ap), _ptr(ak), _ptr(aa), na, C.c_uint64(seed & (2**64 - 1)),
-                          C.c_uint64(offset & (2**64 - 1)), _ptr(out), _ptr(_OobCounter.get(keys.device)), _stream()),
+                          C.c_uint64(offset & (2**64 - 1)), _ptr(out), sk, sd, _ptr(_OobCounter.get(keys.device)),
+                          _stream()),
         "hw_neg_sample",
     )
     return out

@@ -129,15 +129,18 @@ int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld
 
 /* ---- negative sampling ----------------------------------------------------------------------------
  * Device restatement of AbstractSampler.sample_by_key_ids (sampler/sampler.py:140-183) for
- * KGSampler (:294-357) and Sampler (:186-291): for key i and draw j, out[j*n_keys + i] is uniform over
- * [1, value_num) minus used(keys[i]), by rejection.  used sets are a CSR (used_ptr[n_key_space+1],
+ * KGSampler (:294-357) and Sampler (:186-291): for key i and draw j, the value written to
+ * out[i*out_stride_key + j*out_stride_draw] is uniform over [1, value_num) minus used(keys[i]), by rejection.
+ * (out_stride_key, out_stride_draw) = (1, n_keys) is the reference's layout value_ids[j*n_keys + i];
+ * (num, 1) gives a row per key, which the grouped scorer reads with coalesced id loads.  used sets are a CSR (used_ptr[n_key_space+1],
  * used_idx sorted ascending inside each row).  Philox4x32-10 counter RNG keyed by (seed, offset).
  * alias_prob/alias_keys/alias_alias (nullable) switch to the popularity distribution (:68-116). */
 int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, int64_t n_key_space,
                   const int64_t* keys, int64_t n_keys, int32_t num, int64_t value_num,
                   const float* alias_prob, const int64_t* alias_keys, const int64_t* alias_alias,
                   int64_t n_alias, uint64_t seed, uint64_t offset,
-                  int64_t* out, int32_t* oob_counter, void* stream);
+                  int64_t* out, int64_t out_stride_key, int64_t out_stride_draw,
+                  int32_t* oob_counter, void* stream);
 
 /* ---- PGPR beam-search traversal --------------------------------------------------------------------
  * Device restatement of model/knowledge_aware_recommender/pgpr.py beam_search (:440-484) and the

@@ -39,7 +39,7 @@ def test_argument_validation_without_gpu():
     assert lib.hw_kge_score_grouped(C.byref(d), None, None, 0, None, 0, 0, 1, 1, None, 0, 0, None, None) == -1
     assert lib.hw_topk_rows(None, 1, 1, 1, 1, None, None, None) == -1
     assert lib.hw_loss_bce_logits(None, 1, 1, None, None, None, None) == -1
-    assert lib.hw_neg_sample(None, None, 1, None, 0, 1, 2, None, None, None, 0, 0, 0, None, None, None) == -1
+    assert lib.hw_neg_sample(None, None, 1, None, 0, 1, 2, None, None, None, 0, 0, 0, None, 1, 1, None, None) == -1
 
 
 def test_no_cpu_fallback_in_product():
