@@ -77,7 +77,8 @@ def main():
     ent_re, ent_im = xavier(nE), xavier(nE)
     theta = (torch.rand(kg.n_relations, DIM, generator=g) * (2 * np.pi)).to(dev)
     head, rel, tail = (user_re, user_im), (theta,), (ent_re, ent_im)
-    desc = ops.make_desc("RotatE", head, rel, tail, margin=1.0)
+    # rec side: tails are items, i.e. entity rows [0, n_items) (what the model class passes for `side == "rec"`)
+    desc = ops.make_desc("RotatE", head, rel, tail, margin=1.0, tail_rows=(kg.n_items if args.entities == 0 else None))
 
     # batches differ per rank; sampler "used" sets = the user's interacted items
     rng = np.random.default_rng(2024 + rank)

@@ -54,6 +54,7 @@ class _GatherKGE(KnowledgeRecommender):
 
     input_type = InputType.PAIRWISE
     MODEL = None  # "TransE" | "RotatE" | "ComplEx" | "DistMult"
+    _narrow_rec_tails = True  # False when the tables handed to the kernels are compact lookups (parallel.py)
     USER_TABLES = ()  # attribute names, slot order
     ENTITY_TABLES = ()
     RELATION_TABLES = ()
@@ -92,8 +93,10 @@ class _GatherKGE(KnowledgeRecommender):
 
     def _score(self, side, h_idx, r_idx, r_fixed, t_idx, eps=0.0, j_major_out=False):
         head, rel, tail = self._tables(side)
+        # rec-side tails are items = the first n_items entity rows (kg_dataset.py:556-588)
+        tail_rows = self.n_items if (side == "rec" and self._narrow_rec_tails) else None
         return ops.kge_score_grouped(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, self.margin, eps,
-                                     j_major_out)
+                                     j_major_out, tail_rows)
 
     @staticmethod
     def _pair(pos, neg):

@@ -35,8 +35,11 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0) -> KgeDesc:
-    """Describe one scorer call.  ``head``/``rel``/``tail`` are tuples of [rows, dim] fp32 tables."""
+def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0, tail_rows=None) -> KgeDesc:
+    """Describe one scorer call.  ``head``/``rel``/``tail`` are tuples of [rows, dim] fp32 tables.
+    ``tail_rows`` (optional) narrows the tail id space to [0, tail_rows) -- e.g. n_items on the rec side, where
+    tails are items, the first rows of the entity table; ids are clamped to it and the launcher sizes its
+    cache strategy from it."""
     nh, nr, nt = _N_SLOT[model]
     if (len(head), len(rel), len(tail)) != (nh, nr, nt):
         raise ValueError(f"{model} takes {nh}/{nr}/{nt} head/rel/tail tables")
@@ -55,6 +58,10 @@ def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0
             arr[k] = t.data_ptr()
     d.dim = dim
     d.n_head, d.n_rel, d.n_tail = head[0].shape[0], rel[0].shape[0], tail[0].shape[0]
+    if tail_rows is not None:
+        if not 1 <= int(tail_rows) <= tail[0].shape[0]:
+            raise ValueError("tail_rows out of range")
+        d.n_tail = int(tail_rows)
     d.margin = float(margin)
     d.eps = float(eps)
     return d
@@ -130,12 +137,12 @@ class KgeScoreGrouped(torch.autograd.Function):
     are both head and tail) -- its gradient buffer is then shared and returned once."""
 
     @staticmethod
-    def forward(ctx, model, margin, eps, h_idx, r_idx, r_fixed, t_idx, j_major_out, *tables):
+    def forward(ctx, model, margin, eps, h_idx, r_idx, r_fixed, t_idx, j_major_out, tail_rows, *tables):
         nh, nr, nt = _N_SLOT[model]
         head, rel, tail = tables[:nh], tables[nh : nh + nr], tables[nh + nr :]
-        desc = make_desc(model, head, rel, tail, margin, eps)
+        desc = make_desc(model, head, rel, tail, margin, eps, tail_rows)
         out = kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, t_idx, j_major_out)
-        ctx.model, ctx.margin, ctx.eps, ctx.r_fixed = model, margin, eps, r_fixed
+        ctx.model, ctx.margin, ctx.eps, ctx.r_fixed, ctx.tail_rows = model, margin, eps, r_fixed, tail_rows
         ctx.has_r = r_idx is not None
         ctx.save_for_backward(h_idx, t_idx, *([r_idx] if r_idx is not None else []), *tables)
         return out
@@ -154,7 +161,7 @@ class KgeScoreGrouped(torch.autograd.Function):
         model = ctx.model
         nh, nr, nt = _N_SLOT[model]
         head, rel, tail = tables[:nh], tables[nh : nh + nr], tables[nh + nr :]
-        desc = make_desc(model, head, rel, tail, ctx.margin, ctx.eps)
+        desc = make_desc(model, head, rel, tail, ctx.margin, ctx.eps, ctx.tail_rows)
         g = g.contiguous()  # [B, G] row-major
         bufs = {}
         grads_out = []
@@ -167,7 +174,7 @@ class KgeScoreGrouped(torch.autograd.Function):
                 arr[i] = None
             for i in range(n):
                 t = tables[k]
-                need = ctx.needs_input_grad[8 + k]
+                need = ctx.needs_input_grad[9 + k]
                 if need:
                     key = t.data_ptr()
                     if key in bufs:
@@ -186,12 +193,13 @@ class KgeScoreGrouped(torch.autograd.Function):
             t_idx.stride(1), B, G, _ptr(g), g.stride(0), g.stride(1), _stream(),
         )
         check(rc, "hw_kge_grad_grouped")
-        return (None,) * 8 + tuple(grads_out)
+        return (None,) * 9 + tuple(grads_out)
 
 
-def kge_score_grouped(model, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, margin=0.0, eps=0.0, j_major_out=False):
+def kge_score_grouped(model, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, margin=0.0, eps=0.0, j_major_out=False,
+                      tail_rows=None):
     return KgeScoreGrouped.apply(model, float(margin), float(eps), h_idx, r_idx, int(r_fixed), t_idx, j_major_out,
-                                 *head, *rel, *tail)
+                                 tail_rows, *head, *rel, *tail)
 
 
 def kge_full_sort(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin=0.0):

@@ -150,6 +150,7 @@ class RowShardedKGE(nn.Module):
             return head, model._w(model.RELATION_TABLES), c["entity"]
 
         model._tables = _tables
+        model._narrow_rec_tails = False  # compact tables are indexed by remapped ids, not by entity id
 
     def _shards(self, names):
         return tuple(getattr(self, "shard_" + n) for n in names)

@@ -330,3 +330,25 @@ def test_row_sharded_wrapper_single_rank_matches_plain_model(model):
     for n in plain.RELATION_TABLES:
         np.testing.assert_allclose(getattr(sh.model, n).weight.grad.cpu().numpy(),
                                    getattr(plain, n).weight.grad.cpu().numpy(), rtol=2e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("model", okge.MODELS)
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_grouped_many_tails_both_kernels(model, variant, monkeypatch):
+    """K = 300 tails per group through the plain and the XCD-partitioned kernel (ragged partitions, list carry-over)."""
+    from hopwise_amd import ops
+
+    monkeypatch.setenv("HW_GROUPED_VARIANT", variant)
+    for dim, B, K in ((200, 9, 300), (64, 5, 131), (100, 3, 700)):
+        nU, nE, nR = 50, 3000, 6
+        tables = random_tables(model, nU, nE, nR, dim, seed=K)
+        m = build(model, tables, dim, nU, 100, nE, nR)
+        rng = np.random.default_rng(K)
+        h, r = rng.integers(0, nE, B), rng.integers(0, nR, B)
+        t = rng.integers(0, nE, (B, 1 + K))
+        t[0, :40] = 8 * rng.integers(0, 300, 40) + 3  # one partition over-full, others starved
+        head, rel, tail = m._tables("kg")
+        got = ops.kge_score_grouped(model, head, rel, tail, torch.from_numpy(h).to(dev()), torch.from_numpy(r).to(dev()),
+                                    0, torch.from_numpy(t).to(dev()), m.margin)
+        ref = okge.score_grouped(model, tables, "kg", h, r, t, margin=m.margin)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
