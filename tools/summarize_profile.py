@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Turn gpurun_out/prof_<tag>/ (made by tools/collect_profile.sh) into committed summaries under profiles/<round>/:
+kernel stats CSV, per-kernel HBM traffic per launch from the PMC passes, and profiles/traffic_latest.json that
+bench.py reads for roofline.traffic.
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide (16 B/lane)
+read, i.e. half the bytes -- it is doubled here as MI355X_MICROARCH.md §HBM prescribes.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, rnd = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    f = glob.glob(os.path.join(src, pattern))
+    return f[0] if f else None
+
+
+stats = one("trace/*/*kernel_stats.csv")
+if stats:
+    shutil.copy(stats, os.path.join(dst, f"bench_kernel_stats_{tag}.csv"))
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return agg
+
+
+out = {}
+fetch, write = one("fetch/*/*counter_collection.csv"), one("write/*/*counter_collection.csv")
+if fetch and write:
+    f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(f) | set(w)):
+        if not k.startswith(("hw::", "void hw::")):
+            continue
+        fv, wv = f.get(k, [0.0]), w.get(k, [0.0])
+        # the HBM-resident variant of the grouped kernel runs under the same name: keep cache-resident launches
+        # (the most common value range) apart from it by splitting on the median
+        rows.append(dict(kernel=k, launches=len(fv), fetch_kib_raw_median=sorted(fv)[len(fv) // 2],
+                         fetch_kib_raw_max=max(fv), write_kib_median=sorted(wv)[len(wv) // 2], write_kib_max=max(wv)))
+    json.dump(rows, open(os.path.join(dst, f"pmc_traffic_{tag}.json"), "w"), indent=1)
+    for r in rows:
+        if "kge_score_grouped" in r["kernel"]:
+            out["kge_score_grouped_bytes_per_launch"] = (2.0 * r["fetch_kib_raw_median"] + r["write_kib_median"]) * 1024.0
+            out["kge_score_grouped_hbm_variant_bytes_per_launch"] = (2.0 * r["fetch_kib_raw_max"] + r["write_kib_max"]) * 1024.0
+            out["note"] = ("median over launches = ml-1m-small tables (L2 / Infinity Cache resident: fabric-side requests "
+                           "that reach HBM or hit the Infinity Cache); max = the 4.2 GB-table variant. FETCH_SIZE doubled per the gfx950 note.")
+    out["source"] = f"profiles/{rnd}/pmc_traffic_{tag}.json"
+    json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
