@@ -12,8 +12,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libhopwise_amd.so")
 
-HW_TRANSE, HW_ROTATE, HW_COMPLEX, HW_DISTMULT = 0, 1, 2, 3
-MODEL_IDS = {"TransE": HW_TRANSE, "RotatE": HW_ROTATE, "ComplEx": HW_COMPLEX, "DistMult": HW_DISTMULT}
+HW_TRANSE, HW_ROTATE, HW_COMPLEX, HW_DISTMULT, HW_RESCAL = 0, 1, 2, 3, 4
+MODEL_IDS = {"TransE": HW_TRANSE, "RotatE": HW_ROTATE, "ComplEx": HW_COMPLEX, "DistMult": HW_DISTMULT,
+             "RESCAL": HW_RESCAL}
 
 STATUS = {0: "HW_OK", -1: "HW_ERR_INVALID_ARG", -2: "HW_ERR_UNSUPPORTED", -3: "HW_ERR_LAUNCH", -4: "HW_ERR_WORKSPACE"}
 

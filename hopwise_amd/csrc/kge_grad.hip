@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
                 const float u = ((sc.q[0].v[i] - t[0].v[i]) + d.eps) * scale;
                 GQ[0][i] -= u;
                 if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, u);
-            } else if constexpr (MODEL == HW_DISTMULT) {
+            } else if constexpr (MODEL == HW_DISTMULT || MODEL == HW_RESCAL) {
                 GQ[0][i] = fmaf(scale, t[0].v[i], GQ[0][i]);
                 if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, scale * sc.q[0].v[i]);
             } else if constexpr (MODEL == HW_ROTATE) {
@@ -94,6 +94,38 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
     }
 
     const size_t ho = (size_t)h * d.dim, ro = (size_t)r * d.dim;
+    if constexpr (MODEL == HW_RESCAL) {
+        // Q = h^T M:  gh[i] = sum_j GQ[j] M[i][j]  (one wave reduction per matrix row),  gM[i][j] += h[i] GQ[j]
+        const float* __restrict__ hrow = d.head[0] + ho;
+        const float* __restrict__ mat = d.rel[0] + (size_t)r * d.dim * d.dim;
+        float* gmat = gr.rel[0] ? gr.rel[0] + (size_t)r * d.dim * d.dim : nullptr;
+        float gh[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) gh[k] = 0.f;
+        for (int i = 0; i < d.dim; ++i) {
+            R m;
+            m.load(mat + (size_t)i * d.dim, d.dim, gl);
+            float p = 0.f;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) p = fmaf(GQ[0][k], m.v[k], p);
+            p = group_sum<G>(p);
+            const float hi = hrow[i];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int c = R::col(k, d.dim, gl);
+                if (c == i) gh[k] = p;
+                if (gmat && c >= 0 && GQ[0][k] != 0.f) atomicAdd(gmat + (size_t)i * d.dim + c, hi * GQ[0][k]);
+            }
+        }
+        if (gr.head[0]) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int c = R::col(k, d.dim, gl);
+                if (c >= 0 && gh[k] != 0.f) atomicAdd(gr.head[0] + ho + c, gh[k]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int c = R::col(i, d.dim, gl);
@@ -169,6 +201,7 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
         case HW_ROTATE: BYNE(HW_ROTATE); break;
         case HW_COMPLEX: BYNE(HW_COMPLEX); break;
         case HW_DISTMULT: BYNE(HW_DISTMULT); break;
+        case HW_RESCAL: BYNE(HW_RESCAL); break;
         default: return HW_ERR_UNSUPPORTED;
     }
 #undef BYNE

@@ -13,6 +13,8 @@
 //   ComplEx  Q0 = h_re r_re
 //            Q1 = h_im r_re + h_re r_im - h_im r_im   f = Q0 t_re + Q1 t_im         s             complex.py:53-62
 //            (the 4th term multiplies t_im, exactly as the reference does -- not the paper's t_re)
+//   RESCAL   Q0 = h^T M_r  (M_r = relation row viewed [d, d])   f = Q0 * t          s             rescal.py:51-54
+//            the query build streams the d x d matrix once per (h, r) task; the per-tail work is DistMult's
 #pragma once
 #include "hw_common.h"
 
@@ -26,6 +28,10 @@ struct ModelTraits<HW_TRANSE> {
 };
 template <>
 struct ModelTraits<HW_DISTMULT> {
+    static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
+};
+template <>
+struct ModelTraits<HW_RESCAL> {
     static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
 };
 template <>
@@ -48,6 +54,24 @@ struct Scorer {
     // KEEP = true additionally returns the raw rows (the gradient kernel needs them).
     template <bool KEEP>
     __device__ __forceinline__ void build(const hw_kge_desc& d, int h, int r, int gl, R* hraw, R* rraw) {
+        if constexpr (MODEL == HW_RESCAL) {
+            const float* __restrict__ hrow = d.head[0] + (size_t)h * d.dim;
+            const float* __restrict__ mat = d.rel[0] + (size_t)r * d.dim * d.dim;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) q[0].v[i] = 0.f;
+#pragma unroll 4
+            for (int i = 0; i < d.dim; ++i) {
+                const float hi = hrow[i];  // one address per wave: broadcast load
+                R m;
+                m.load_raw(mat + (size_t)i * d.dim, d.dim, gl);
+#pragma unroll
+                for (int k = 0; k < NE; ++k) q[0].v[k] = fmaf(hi, m.v[k], q[0].v[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) q[0].v[k] = R::slot_valid(k, d.dim, gl) ? q[0].v[k] : 0.f;
+            if constexpr (KEEP) hraw[0].load(hrow, d.dim, gl);
+            return;
+        }
         R hh[MT::NH], rr[MT::NR];
         const size_t ho = (size_t)h * d.dim, ro = (size_t)r * d.dim;
 #pragma unroll
@@ -100,7 +124,7 @@ struct Scorer {
                 if constexpr (MODEL == HW_TRANSE) {
                     const float df = (q[0].v[i] - t[0].v[i]) + eps;
                     sc = fmaf(df, df, sc);
-                } else if constexpr (MODEL == HW_DISTMULT) {
+                } else if constexpr (MODEL == HW_DISTMULT || MODEL == HW_RESCAL) {
                     sc = fmaf(q[0].v[i], t[0].v[i], sc);
                 } else if constexpr (MODEL == HW_ROTATE) {
                     const float a = q[0].v[i] - t[0].v[i];

@@ -253,7 +253,8 @@ static int check_desc(const hw_kge_desc* d) {
     int nh, nr, nt;
     switch (d->model) {
         case HW_TRANSE:
-        case HW_DISTMULT: nh = 1, nr = 1, nt = 1; break;
+        case HW_DISTMULT:
+        case HW_RESCAL: nh = 1, nr = 1, nt = 1; break;
         case HW_ROTATE: nh = 2, nr = 1, nt = 2; break;
         case HW_COMPLEX: nh = 2, nr = 2, nt = 2; break;
         default: return HW_ERR_UNSUPPORTED;
@@ -296,6 +297,7 @@ static bool tables_aligned16(const hw_kge_desc* d) {
             case HW_ROTATE: HW_DISPATCH_SHAPE(HW_ROTATE, shape, CALL); break;   \
             case HW_COMPLEX: HW_DISPATCH_SHAPE(HW_COMPLEX, shape, CALL); break; \
             case HW_DISTMULT: HW_DISPATCH_SHAPE(HW_DISTMULT, shape, CALL); break; \
+            case HW_RESCAL: HW_DISPATCH_SHAPE(HW_RESCAL, shape, CALL); break;     \
             default: return HW_ERR_UNSUPPORTED;                                 \
         }                                                                       \
     } while (0)

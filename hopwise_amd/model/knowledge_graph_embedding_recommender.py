@@ -69,12 +69,15 @@ class _GatherKGE(KnowledgeRecommender):
         for n in self.ENTITY_TABLES:
             setattr(self, n, nn.Embedding(self.n_entities, self.embedding_size))
         for n in self.RELATION_TABLES:
-            setattr(self, n, nn.Embedding(self.n_relations, self.embedding_size))
+            setattr(self, n, nn.Embedding(self.n_relations, self.embedding_size * self.REL_ROW_FACTOR()))
         # extension knobs (absent from reference configs -> reference behaviour)
         self.self_adversarial = bool(_cfg(config, "self_adversarial", False))
         self.adversarial_temperature = float(_cfg(config, "adversarial_temperature", 1.0))
         self.sample_num = int(_cfg(_cfg(config, "train_neg_sample_args", {}) or {}, "sample_num", 1))
         self.apply(xavier_normal_initialization)
+
+    def REL_ROW_FACTOR(self):
+        return 1
 
     # -- table tuples in slot order ---------------------------------------------------------------
     def _w(self, names):
@@ -192,6 +195,16 @@ class DistMult(_GatherKGE):
         pos = torch.cat([rec[0], kg[0]])
         neg = torch.cat([rec[1], kg[1]])
         return ops.margin_ranking_mean(pos, neg, self.margin)
+
+
+class RESCAL(DistMult):
+    """score = h^T M_r t with M_r = relation_embedding(r).view(d, d) (rescal.py:43,51-54); MarginRankingLoss over
+    cat(rec, kg) (rescal.py:73-99); the rec side uses relation_embedding.weight[-1] (rescal.py:60,108,133)."""
+
+    MODEL = "RESCAL"
+
+    def REL_ROW_FACTOR(self):
+        return self.embedding_size
 
 
 class _BceKGE(_GatherKGE):

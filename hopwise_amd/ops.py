@@ -16,7 +16,7 @@ from ._lib import MODEL_IDS, KgeDesc, KgeGrads, check
 
 PAIRWISE_EPS = 1e-6  # torch pairwise_distance eps used by TripletMarginLoss (TransE loss path)
 
-_N_SLOT = {"TransE": (1, 1, 1), "DistMult": (1, 1, 1), "RotatE": (2, 1, 2), "ComplEx": (2, 2, 2)}
+_N_SLOT = {"TransE": (1, 1, 1), "DistMult": (1, 1, 1), "RotatE": (2, 1, 2), "ComplEx": (2, 2, 2), "RESCAL": (1, 1, 1)}
 
 
 def _stream():
@@ -53,8 +53,9 @@ def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0
         rows = tabs[0].shape[0]
         for k, t in enumerate(tabs):
             _dev(t, torch.float32, f"{slot} table")
-            if t.dim() != 2 or t.shape[1] != dim or t.shape[0] != rows or not t.is_contiguous():
-                raise ValueError(f"{slot} table {k}: need contiguous [rows, {dim}]")
+            want = dim * dim if (model == "RESCAL" and slot == "rel") else dim  # RESCAL relation rows are d x d matrices
+            if t.dim() != 2 or t.shape[1] != want or t.shape[0] != rows or not t.is_contiguous():
+                raise ValueError(f"{slot} table {k}: need contiguous [rows, {want}]")
             arr[k] = t.data_ptr()
     d.dim = dim
     d.n_head, d.n_rel, d.n_tail = head[0].shape[0], rel[0].shape[0], tail[0].shape[0]

@@ -33,11 +33,12 @@ typedef enum {
     HW_TRANSE = 0,   /* model/knowledge_graph_embedding_recommender/transe.py:55-57   */
     HW_ROTATE = 1,   /* .../rotate.py:61-69   */
     HW_COMPLEX = 2,  /* .../complex.py:53-62  */
-    HW_DISTMULT = 3  /* .../distmult.py:50-51 */
+    HW_DISTMULT = 3, /* .../distmult.py:50-51 */
+    HW_RESCAL = 4    /* .../rescal.py:51-54: h^T M_r t; rel[0] rows hold dim*dim floats (M_r row-major) */
 } hw_kge_model;
 
 /* Table set of one scorer call.  Slots with a single table leave [1] NULL.
- *   TransE/DistMult: head[0], rel[0], tail[0]
+ *   TransE/DistMult/RESCAL: head[0], rel[0], tail[0]
  *   RotatE:          head = {re, im}, rel = {theta}, tail = {re, im}
  *   ComplEx:         head = {re, im}, rel = {re, im}, tail = {re, im}
  * "head" is the user table(s) on the rec side and the entity table(s) on the kg side. */

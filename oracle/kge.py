@@ -28,6 +28,7 @@ from __future__ import annotations
 import numpy as np
 
 MODELS = ("TransE", "RotatE", "ComplEx", "DistMult")
+DENSE_MODELS = ("RESCAL",)  # same table slots as TransE; relation rows are d x d matrices (rescal.py:43)
 
 F32 = np.float32
 PAIRWISE_EPS = 1e-6  # torch.nn.functional.pairwise_distance default eps (used by TripletMarginLoss)
@@ -38,7 +39,7 @@ PAIRWISE_EPS = 1e-6  # torch.nn.functional.pairwise_distance default eps (used b
 # --------------------------------------------------------------------------------------
 def slots(model: str, side: str):
     """Names of the (head, relation, tail) tables for ``side`` in {"rec", "kg"}."""
-    if model in ("TransE", "DistMult"):
+    if model in ("TransE", "DistMult", "RESCAL"):
         head = ("user_embedding",) if side == "rec" else ("entity_embedding",)
         return head, ("relation_embedding",), ("entity_embedding",)
     if model == "RotatE":
@@ -81,6 +82,11 @@ def score_rows(model: str, H, R, T, margin: float = 0.0, eps: float = 0.0):
         return -np.sqrt(np.sum(d * d, axis=-1, dtype=F32))
     if model == "DistMult":  # distmult.py:50-51
         return np.sum(H[0] * R[0] * T[0], axis=-1, dtype=F32)
+    if model == "RESCAL":  # rescal.py:51-54: (h^T M_r) . t with M_r = relation row viewed [d, d]
+        d = H[0].shape[-1]
+        M = R[0].reshape(R[0].shape[:-1] + (d, d))
+        hr = np.einsum("...i,...ij->...j", H[0], M).astype(F32)
+        return np.sum(hr * T[0], axis=-1, dtype=F32)
     if model == "RotatE":  # rotate.py:61-69
         rr, ri = np.cos(R[0]).astype(F32), np.sin(R[0]).astype(F32)
         re = (rr * H[0] - ri * H[1]) - T[0]
@@ -119,6 +125,13 @@ def score_rows_vjp(model: str, H, R, T, g, margin: float = 0.0, eps: float = 0.0
         return (-(g * u),), (-(g * u),), ((g * u),)
     if model == "DistMult":
         return (g * R[0] * T[0],), (g * H[0] * T[0],), (g * H[0] * R[0],)
+    if model == "RESCAL":
+        d = H[0].shape[-1]
+        M = R[0].reshape(R[0].shape[:-1] + (d, d))
+        hr = np.einsum("...i,...ij->...j", H[0], M)
+        gh = g * np.einsum("...ij,...j->...i", M, T[0])
+        gM = g[..., None] * H[0][..., :, None] * T[0][..., None, :]
+        return (gh,), (gM.reshape(gM.shape[:-2] + (d * d,)),), (g * hr,)
     if model == "RotatE":
         rr, ri = np.cos(R[0]), np.sin(R[0])
         re = rr * H[0] - ri * H[1] - T[0]
@@ -224,7 +237,7 @@ def calculate_loss(model, tables, inter, margin=1.0, ui_relation=None, with_grad
         # d loss / d score_pos = -act (score = -dist), d loss / d score_neg = +act
         gp, gn = -act, act
         g = dict(p_rec=gp[:n_rec], n_rec=gn[:n_rec], p_kg=gp[n_rec:], n_kg=gn[n_rec:])
-    elif model == "DistMult":  # distmult.py:86-93
+    elif model in ("DistMult", "RESCAL"):  # distmult.py:86-93, rescal.py:89-97
         pos = np.concatenate([sp_rec, sp_kg])
         neg = np.concatenate([sn_rec, sn_kg])
         loss = margin_ranking_mean(pos, neg, margin)

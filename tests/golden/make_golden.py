@@ -76,16 +76,19 @@ def make_batch(rng, n_users, n_items, n_entities, n_relations, b_rec, b_kg):
     return {k: v.astype(np.int64) for k, v in inter.items()}
 
 
-def gen_kge(out_dir):
+def gen_kge(out_dir, only=None):
     from hopwise.model.knowledge_graph_embedding_recommender.complex import ComplEx
+    from hopwise.model.knowledge_graph_embedding_recommender.rescal import RESCAL
     from hopwise.model.knowledge_graph_embedding_recommender.distmult import DistMult
     from hopwise.model.knowledge_graph_embedding_recommender.rotate import RotatE
     from hopwise.model.knowledge_graph_embedding_recommender.transe import TransE
 
     nU, nI, nE, nR = 20, 16, 48, 5
-    classes = dict(TransE=TransE, RotatE=RotatE, ComplEx=ComplEx, DistMult=DistMult)
+    classes = dict(TransE=TransE, RotatE=RotatE, ComplEx=ComplEx, DistMult=DistMult, RESCAL=RESCAL)
     for name, cls in classes.items():
-        for d in (8, 64, 200):
+        if only and name not in only:
+            continue
+        for d in ((8, 32, 64) if name == "RESCAL" else (8, 64, 200)):
             torch.manual_seed(2024 + d)
             config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"))
             model = cls(config, FakeDataset(nU, nI, nE, nR))
@@ -235,6 +238,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("kge", "all"):
         gen_kge(HERE)
+    if what.startswith("kge:"):
+        gen_kge(HERE, only=what[4:].split(","))
     if what in ("sampler", "all"):
         gen_sampler(HERE)
     if what in ("pgpr", "all"):

@@ -38,6 +38,8 @@ def random_tables(model, n_users, n_entities, n_relations, dim, seed=0):
         rows = n_users if name.startswith("user") else (n_relations if name.startswith("relation") else n_entities)
         if model == "RotatE" and name == "relation_embedding":
             out[name] = rng.uniform(0, 2 * np.pi, (rows, dim)).astype(np.float32)
+        elif model == "RESCAL" and name == "relation_embedding":
+            out[name] = (rng.standard_normal((rows, dim * dim)) / np.sqrt(dim)).astype(np.float32)
         else:
             out[name] = (rng.standard_normal((rows, dim)) * np.sqrt(2.0 / (rows + dim))).astype(np.float32)
     return out

@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 KGE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "kge_[A-Z]*_d*.npz")))
 RTOL, ATOL = 1e-4, 1e-5
+ALL_MODELS = okge.MODELS + okge.DENSE_MODELS
 
 
 def dev():
@@ -125,7 +126,7 @@ def test_grouped_scorer_vs_oracle(model, dim):
     assert ops.oob_count(dev()) == 0
 
 
-@pytest.mark.parametrize("model", okge.MODELS)
+@pytest.mark.parametrize("model", ALL_MODELS)
 def test_full_sort_vs_oracle_ragged(model):
     # sizes chosen so that chunks, head blocks and sub-wave groups all have ragged tails
     for dim, nE, B in ((64, 1003, 1), (200, 777, 5), (100, 130, 9), (24, 67, 2)):
@@ -169,7 +170,7 @@ def test_loss_and_grads_vs_oracle(model, dim):
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
 
 
-@pytest.mark.parametrize("model", okge.MODELS)
+@pytest.mark.parametrize("model", ALL_MODELS)
 def test_three_adam_steps_match_reference(model):
     """A18: zero_grad -> calculate_loss -> backward -> Adam.step, compared with the reference run."""
     z = np.load(os.path.join(GOLDEN, f"kge_train_{model}.npz"))
@@ -352,3 +353,34 @@ def test_grouped_many_tails_both_kernels(model, variant, monkeypatch):
                                     0, torch.from_numpy(t).to(dev()), m.margin)
         ref = okge.score_grouped(model, tables, "kg", h, r, t, margin=m.margin)
         np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("dim", [4, 7, 50, 64, 100])
+def test_rescal_grouped_loss_and_grads_vs_oracle(dim):
+    """RESCAL (h^T M_r t): grouped scores, MarginRankingLoss and all gradients (incl. the d x d relation matrices)."""
+    from hopwise_amd import ops
+
+    model, nU, nI, nE, nR, Br, Bk = "RESCAL", 40, 30, 90, 5, 24, 40
+    tables = random_tables(model, nU, nE, nR, dim, seed=dim)
+    m = build(model, tables, dim, nU, nI, nE, nR)
+    rng = np.random.default_rng(dim)
+    h, r, t = rng.integers(0, nE, 11), rng.integers(0, nR, 11), rng.integers(0, nE, (11, 9))
+    head, rel, tail = m._tables("kg")
+    got = ops.kge_score_grouped(model, head, rel, tail, torch.from_numpy(h).to(dev()), torch.from_numpy(r).to(dev()), 0,
+                                torch.from_numpy(t).to(dev()), 0.0)
+    ref = okge.score_grouped(model, tables, "kg", h, r, t)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref, rtol=RTOL, atol=ATOL)
+    inter = dict(
+        user_id=rng.integers(0, nU, Br), item_id=rng.integers(0, nI, Br), neg_item_id=rng.integers(0, nI, Br),
+        head_id=rng.integers(0, nE, Bk), relation_id=rng.integers(0, nR, Bk), tail_id=rng.integers(0, nE, Bk),
+        neg_tail_id=rng.integers(0, nE, Bk),
+    )
+    loss_ref, grads_ref = okge.calculate_loss(model, tables, inter, 1.0, ui_relation=nR - 1, with_grad=True)
+    m.zero_grad()
+    loss = m.calculate_loss(to_dev(inter))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), loss_ref, rtol=1e-5)
+    for k, p in m.named_parameters():
+        ref = grads_ref[k[: -len(".weight")]]
+        scale = np.abs(ref).max() + 1e-12
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
