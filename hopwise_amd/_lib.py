@@ -106,6 +106,11 @@ SIGNATURES = {
         [c_f32p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_int64, c_i32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
          c_f32p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p],
     ),
+    "hw_gemm_f32": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_i32p, C.c_int64, C.c_int64,
+         C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p],
+    ),
     "hw_pgpr_policy_topk": (
         C.c_int,
         [c_f32p, C.c_int64, C.c_int32, c_i32p, c_i32p, C.c_int64, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_void_p],

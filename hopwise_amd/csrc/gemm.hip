@@ -1,0 +1,199 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chains -- gfx950 has no
+// TF32/xf32 path, so this is the only MFMA form that keeps the 1e-4 parity budget).
+//
+//   C[M, N] = epilogue( op(A)[M, K] . op(B)[K, N] )
+// A is either K-contiguous ([M, K] row-major) or M-contiguous ([K, M] row-major, i.e. A^T stored); B is either
+// K-contiguous ([N, K] row-major, the nn.Linear weight layout) or N-contiguous ([K, N] row-major).  That covers
+// x @ W^T, x @ W, dY^T @ X and dY @ W without materialising a transpose.
+//
+// Block = 256 threads = 2 x 2 waves, tile 128 x 128 x 16; each wave owns 64 x 64 = four 32x32 accumulators
+// (64 accumulator registers).  LDS tiles are k-major ([k][m], [k][n], row stride 132 floats) so the MFMA operand
+// read (lane l -> row l & 31, k = l >> 5) is a conflict-free ds_read_b32 and M/N-contiguous operands are staged with
+// ds_write_b128.  Two blocks fit a CU, which hides one block's staging behind the other's MFMA burst.
+// Epilogue: + bias[n], ELU, multiplicative dropout (explicit mask or Philox keep-1/2), all optional.
+#include "hw_common.h"
+
+namespace hw {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+
+__device__ __forceinline__ uint32_t philox_bits(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)(idx >> 2), c1 = (uint32_t)(idx >> 34), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    const uint32_t w[4] = {c0, c1, c2, c3};
+    return w[idx & 3];
+}
+
+// Stage one 128 x 16 operand tile into LDS (k-major).  X(row, k): row in [0, rows), k in [0, K).
+//   KC = true : X stored [rows, K] (K contiguous, leading dim ld)
+//   KC = false: X stored [K, rows] (row index contiguous, leading dim ld)
+template <bool KC>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ X, int64_t ld, int rows, int K, int r0, int k0,
+                                           bool vec_ok, float (*T)[LDT]) {
+    const int tid = threadIdx.x;
+    if constexpr (KC) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;  // float4 id: 128 rows x 4 k-quads
+            const int r = f >> 2, kq = (f & 3) * 4;
+            const int gr = r0 + r, gk = k0 + kq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gr < rows) {
+                const float* __restrict__ p = X + (size_t)gr * ld + gk;
+                if (vec_ok && gk + 3 < K) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+                    v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (gk + j < K) ? p[j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[kq + j][r] = v[j];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;  // float4 id: 16 k x 32 row-quads
+            const int k = f >> 5, rq = (f & 31) * 4;
+            const int gk = k0 + k, gr = r0 + rq;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gk < K) {
+                const float* __restrict__ p = X + (size_t)gk * ld + gr;
+                if (vec_ok && gr + 3 < rows) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(p);
+                    v[0] = x.x, v[1] = x.y, v[2] = x.z, v[3] = x.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (gr + j < rows) ? p[j] : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4*>(&T[k][rq]) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+    }
+}
+
+template <bool A_KC, bool B_KC, bool ELU>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const float* __restrict__ B, int64_t ldb,
+                                                          float* __restrict__ C, int64_t ldc,
+                                                          const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ drop_mask, int drop_mode,
+                                                          uint64_t seed, uint64_t offset, int vec_a, int vec_b) {
+    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+    const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        stage_tile<A_KC>(A, lda, M, K, m0, k0, vec_a != 0, As);
+        stage_tile<B_KC>(B, ldb, N, K, n0, k0, vec_b != 0, Bs);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + (lane >> 5);
+            const float a0 = As[kr][wm + (lane & 31)];
+            const float a1 = As[kr][wm + 32 + (lane & 31)];
+            const float b0 = Bs[kr][wn + (lane & 31)];
+            const float b1 = Bs[kr][wn + 32 + (lane & 31)];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int gn = n0 + wn + tj * 32 + (lane & 31);
+            const float bv = (bias && gn < N) ? bias[gn] : 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int gm = m0 + wm + ti * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+                if (gm < M && gn < N) {
+                    float v = acc[ti][tj][rg] + bv;
+                    if (ELU) v = v > 0.f ? v : expm1f(v);
+                    if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
+                    else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
+                    C[(size_t)gm * ldc + gn] = v;
+                }
+            }
+        }
+}
+
+static bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p) & 15) == 0 && (ld % 4) == 0; }
+
+static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, int64_t ldb, bool b_kc, float* c,
+                       int64_t ldc, const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, const float* bias,
+                       bool elu, const float* drop_mask, int drop_mode, uint64_t seed, uint64_t offset,
+                       hipStream_t st) {
+    dim3 grid((unsigned)((m_max + BM - 1) / BM), (unsigned)((n + BN - 1) / BN));
+    const int va = aligned16(a, lda), vb = aligned16(b, ldb);
+#define GO(AK, BK_, EL)                                                                                              \
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows,       \
+                       (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb)
+    if (a_kc && b_kc) {
+        if (elu) GO(true, true, true);
+        else GO(true, true, false);
+    } else if (a_kc && !b_kc) {
+        if (elu) GO(true, false, true);
+        else GO(true, false, false);
+    } else if (!a_kc && !b_kc) {
+        if (elu) GO(false, false, true);
+        else GO(false, false, false);
+    } else {
+        if (elu) GO(false, true, true);
+        else GO(false, true, false);
+    }
+#undef GO
+    return HW_OK;
+}
+
+}  // namespace hw
+
+using namespace hw;
+
+extern "C" int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, const float* b, int64_t ldb,
+                           int32_t b_k_contiguous, float* c, int64_t ldc, const int32_t* m_rows, int64_t m_max,
+                           int64_t n, int64_t k, const float* bias, int32_t elu, const float* drop_mask,
+                           int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream) {
+    if (!a || !b || !c || m_max < 0 || n < 1 || k < 1 || ldc < n) return HW_ERR_INVALID_ARG;
+    if (lda < (a_k_contiguous ? k : m_max) || ldb < (b_k_contiguous ? k : n)) return HW_ERR_INVALID_ARG;
+    if (drop_mode < 0 || drop_mode > 2 || (drop_mode == 1 && !drop_mask)) return HW_ERR_INVALID_ARG;
+    if (m_max > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (m_max == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    launch_gemm(a, lda, a_k_contiguous != 0, b, ldb, b_k_contiguous != 0, c, ldc, m_rows, m_max, n, k, bias, elu != 0,
+                drop_mask, drop_mode, seed, offset, (hipStream_t)stream);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias, float* c, int64_t ldc,
+                            const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, int32_t elu,
+                            const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream) {
+    return hw_gemm_f32(a, lda, 1, w, k, 1, c, ldc, m_rows, m_max, n, k, bias, elu, drop_mask, drop_mode, seed, offset,
+                       stream);
+}

@@ -328,98 +328,7 @@ __global__ __launch_bounds__(256) void pgpr_state_kernel(hw_pgpr_graph g, const 
     }
 }
 
-// ---- A12: one policy-MLP layer on fp32 MFMA ------------------------------------------------------------
-// C[M, N] = epilogue(A[M, K] . W[N, K]^T + bias[N]);  epilogue = identity | ELU, then an optional
-// multiplicative dropout mask (given [M, N], or drawn from Philox with keep prob 1/2 scaled by 2).
-// Block = 4 waves, tile 128 (M) x 64 (N), BK = 16; each wave owns 32 rows x 64 cols = two 32x32
-// v_mfma_f32_32x32x2_f32 accumulators (exact fp32 fma chain -- no reduced-precision path on gfx950).
-// LDS tiles are stored k-major ([k][row]) so that the MFMA operand read (lane l -> row l & 31,
-// k = l >> 5) is a conflict-free ds_read_b32.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int GM = 128, GN = 64, GK = 16;
-
-__device__ __forceinline__ uint32_t philox_bits(uint64_t seed, uint64_t offset, uint64_t idx) {
-    uint32_t c0 = (uint32_t)(idx >> 2), c1 = (uint32_t)(idx >> 34), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
-    }
-    const uint32_t w[4] = {c0, c1, c2, c3};
-    return w[idx & 3];
-}
-
-template <bool ELU>
-__global__ __launch_bounds__(256) void mlp_layer_kernel(const float* __restrict__ A, int lda,
-                                                        const float* __restrict__ W, const float* __restrict__ bias,
-                                                        float* __restrict__ Cm, int ldc, const int32_t* __restrict__ m_ptr,
-                                                        int m_max, int N, int K, const float* __restrict__ drop_mask,
-                                                        int drop_mode, uint64_t seed, uint64_t offset) {
-    __shared__ float As[GK][GM + 4];
-    __shared__ float Bs[GK][GN + 4];
-    const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
-    const int m0 = blockIdx.x * GM, n0 = blockIdx.y * GN;
-    if (m0 >= M) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    f32x16 acc0 = {0}, acc1 = {0};
-
-    for (int k0 = 0; k0 < K; k0 += GK) {
-        // stage A: 128 rows x 16 k = 2048 floats, 8 per thread: thread -> (row = tid / 2, 8 consecutive k)
-        {
-            const int r = tid >> 1, kq = (tid & 1) * 8;
-            const int gm = m0 + r;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int gk = k0 + kq + i;
-                As[kq + i][r] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
-            }
-        }
-        // stage B (= W rows): 64 rows x 16 k = 1024 floats, 4 per thread
-        {
-            const int r = tid >> 2, kq = (tid & 3) * 4;
-            const int gn = n0 + r;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gk = k0 + kq + i;
-                Bs[kq + i][r] = (gn < N && gk < K) ? W[(size_t)gn * K + gk] : 0.f;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < GK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wave * 32 + (lane & 31)];
-            const float b0 = Bs[kk + (lane >> 5)][(lane & 31)];
-            const float b1 = Bs[kk + (lane >> 5)][32 + (lane & 31)];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // epilogue: C/D map of 32x32: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const f32x16& acc = t == 0 ? acc0 : acc1;
-        const int gn = n0 + t * 32 + (lane & 31);
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int gm = m0 + wave * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-            if (gm < M && gn < N) {
-                float v = acc[rg] + (bias ? bias[gn] : 0.f);
-                if (ELU) v = v > 0.f ? v : expm1f(v);
-                const size_t o = (size_t)gm * ldc + gn;
-                if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
-                else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
-                Cm[o] = v;
-            }
-        }
-    }
-}
+// ---- A12: the policy-MLP layers run on the generic fp32-MFMA GEMM of gemm.hip (hw_mlp_layer) ---------------
 
 // ---- A12/A13: masked softmax, +mask, top-k (one wave per row) -------------------------------------------
 // probs = softmax(logits masked to the first n_acts entries); value used for ranking and stored as the
@@ -617,25 +526,6 @@ extern "C" int hw_pgpr_state(const hw_pgpr_graph* graph, const float* user_emb32
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(pgpr_state_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph, user_emb32,
                        entity_emb32, relation_emb32, dim, n_parts, paths, n_rows, state);
-    return HW_LAUNCH_RC();
-}
-
-extern "C" int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias, float* c, int64_t ldc,
-                            const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, int32_t elu,
-                            const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream) {
-    if (!a || !w || !c || m_max < 0 || n < 1 || k < 1 || lda < k || ldc < n) return HW_ERR_INVALID_ARG;
-    if (drop_mode < 0 || drop_mode > 2 || (drop_mode == 1 && !drop_mask)) return HW_ERR_INVALID_ARG;
-    if (m_max > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
-    if (m_max == 0) return HW_OK;
-    dim3 grid((unsigned)((m_max + GM - 1) / GM), (unsigned)((n + GN - 1) / GN));
-    HW_CLEAR_ERR();
-    hipStream_t st = (hipStream_t)stream;
-    if (elu)
-        hipLaunchKernelGGL((mlp_layer_kernel<true>), grid, dim3(256), 0, st, a, (int)lda, w, bias, c, (int)ldc, m_rows,
-                           (int)m_max, (int)n, (int)k, drop_mask, drop_mode, seed, offset);
-    else
-        hipLaunchKernelGGL((mlp_layer_kernel<false>), grid, dim3(256), 0, st, a, (int)lda, w, bias, c, (int)ldc, m_rows,
-                           (int)m_max, (int)n, (int)k, drop_mask, drop_mode, seed, offset);
     return HW_LAUNCH_RC();
 }
 

@@ -394,3 +394,56 @@ def scatter_add_rows_(table, idx, src):
     check(lib.hw_scatter_add_rows(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.numel(), _ptr(src),
                                   _stream()), "hw_scatter_add_rows")
     return table
+
+
+# ------------------------------------------------------------------------------------------------
+# dense fp32 GEMM on the matrix cores
+# ------------------------------------------------------------------------------------------------
+def gemm(a, b, a_k_contiguous=True, b_k_contiguous=True, bias=None, elu=False, out=None, m_rows=None,
+         drop_mask=None, drop_mode=0, seed=0, offset=0):
+    """out[M, N] = f(op(a) @ op(b) + bias).
+
+    a: [M, K] (a_k_contiguous) or [K, M] (stored transposed); b: [N, K] (b_k_contiguous, nn.Linear layout) or [K, N].
+    Rows may be strided (leading dimension = stride(0)); the inner dimension must have unit stride."""
+    lib = _lib.load()
+    a = _dev(a, torch.float32, "a")
+    b = _dev(b, torch.float32, "b")
+    if a.dim() != 2 or b.dim() != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("gemm operands must be 2-D with unit inner stride")
+    M, K = (a.shape if a_k_contiguous else (a.shape[1], a.shape[0]))
+    N, Kb = (b.shape if b_k_contiguous else (b.shape[1], b.shape[0]))
+    if K != Kb:
+        raise ValueError(f"inner dimensions differ: {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(
+        lib.hw_gemm_f32(_ptr(a), a.stride(0), int(a_k_contiguous), _ptr(b), b.stride(0), int(b_k_contiguous), _ptr(out),
+                        out.stride(0), _ptr(m_rows), M, N, K, _ptr(bias), int(bool(elu)), _ptr(drop_mask),
+                        int(drop_mode), C.c_uint64(seed), C.c_uint64(offset), _stream()),
+        "hw_gemm_f32",
+    )
+    return out
+
+
+class MatMul(torch.autograd.Function):
+    """y = x @ w^T (w in nn.Linear layout [N, K]) with both gradients on the same MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return gemm(x.contiguous(), w.contiguous(), True, True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm(gy, w.contiguous(), True, False)  # [M, N] @ [N, K]
+        if ctx.needs_input_grad[1]:
+            gw = gemm(gy, x.contiguous(), False, False)  # gy^T [N, M] @ x [M, K]
+        return gx, gw
+
+
+def matmul_nt(x, w):
+    return MatMul.apply(x, w)

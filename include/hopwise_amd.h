@@ -190,6 +190,14 @@ int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias,
                  const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, int32_t elu,
                  const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream);
 
+/* General fp32 MFMA GEMM: c[m, n] = f(op(a)[m, :] . op(b)[:, n] + bias[n]).  a is [m, k] row-major when
+ * a_k_contiguous, else stored transposed [k, m]; b is [n, k] row-major (nn.Linear weight) when b_k_contiguous, else
+ * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187). */
+int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, const float* b, int64_t ldb,
+                int32_t b_k_contiguous, float* c, int64_t ldc, const int32_t* m_rows, int64_t m_max,
+                int64_t n, int64_t k, const float* bias, int32_t elu, const float* drop_mask,
+                int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream);
+
 /* logits -> masked softmax -> (+1 on valid actions, pgpr.py:453) -> top-k (value desc, index asc).
  * out_idx/out_val [max_rows, k]; entries past min(k, n_acts[row]) are idx = -1.  probs_out (nullable)
  * receives the plain softmax [max_rows, act_dim]. */

@@ -236,3 +236,28 @@ def test_explain_end_to_end():
     assert finite.max() <= max(m.topk) and len(expl) == int(finite.sum()) or len(expl) >= int(finite.sum())
     for u, i, s, path in expl:
         assert path[0] == ("self_loop", "user", u) and len(path) == 4
+
+
+def test_gemm_all_layouts_vs_fp64():
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(1)
+    for M, K, N in ((1, 1, 1), (37, 200, 129), (300, 17, 260), (128, 128, 128), (1000, 403, 70)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = rng.standard_normal((N, K)).astype(np.float32)
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        At, Bt = torch.from_numpy(A).to(dev()), torch.from_numpy(B).to(dev())
+        AT, BT = At.t().contiguous(), Bt.t().contiguous()  # stored [K, M] and [K, N]
+        tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K))
+        np.testing.assert_allclose(ops.gemm(At, Bt, True, True).cpu().numpy(), ref, **tol)
+        np.testing.assert_allclose(ops.gemm(At, BT, True, False).cpu().numpy(), ref, **tol)
+        np.testing.assert_allclose(ops.gemm(AT, BT, False, False).cpu().numpy(), ref, **tol)
+        np.testing.assert_allclose(ops.gemm(AT, Bt, False, True).cpu().numpy(), ref, **tol)
+    # autograd wrapper
+    x = torch.randn(50, 30, device=dev(), requires_grad=True)
+    w = torch.randn(20, 30, device=dev(), requires_grad=True)
+    y = ops.matmul_nt(x, w)
+    g = torch.randn_like(y)
+    y.backward(g)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), (g.double() @ w.detach().double()).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(w.grad.cpu().numpy(), (g.double().t() @ x.detach().double()).cpu().numpy(), rtol=1e-4, atol=1e-4)
