@@ -1,2 +1,2 @@
 from .abstract_recommender import AbstractRecommender, ExplainableRecommender, KnowledgeRecommender  # noqa: F401
-from .knowledge_graph_embedding_recommender import RESCAL, ComplEx, DistMult, RotatE, TransE  # noqa: F401
+from .knowledge_graph_embedding_recommender import RESCAL, ComplEx, DistMult, RotatE, TransE, TuckER  # noqa: F401

@@ -246,3 +246,100 @@ class ComplEx(_BceKGE):
 
     def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (complex.py:167-168)
         return self.n_relations - 1
+
+
+class TuckER(KnowledgeRecommender):
+    """TuckER 1-vs-all scorer (tucker.py:21-172) on the fp32 matrix cores.
+
+    Same parameters / state_dict keys as the reference (``user_embedding`` has n_users + n_items rows, ``weights`` is
+    the [d, d, d] core, ``bn0``/``bn1``), same config keys (input_dropout, input_dropout1, input_dropout2,
+    label_smoothing), same quirks: the training target marks the UNION of the batch's positives in every row
+    (tucker.py:111-115), predict() indexes the user-table logits with the raw item id (tucker.py:139), there is no
+    full_sort_predict_kg (tucker.py:164-172 is commented out).
+    Dense products (r . W, x . E^T and their gradients) run on hw_gemm_f32; the [B, d, d] contraction with
+    hidden_dropout1 and the sigmoid + BCE with its gradient are fused kernels (csrc/tucker.hip); BatchNorm and the two
+    [B, d] dropouts are torch modules (a few hundred KB of traffic next to GBs of logits)."""
+
+    input_type = InputType.PAIRWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        d = self.embedding_size = config["embedding_size"]
+        self.ui_relation = dataset.field2token_id["relation_id"][dataset.ui_relation]
+        self.label_smoothing = config["label_smoothing"]
+        self.user_embedding = nn.Embedding(self.n_users + self.n_items, d)
+        self.entity_embedding = nn.Embedding(self.n_entities, d)
+        self.relation_embedding = nn.Embedding(self.n_relations, d)
+        self.weights = nn.Parameter(torch.empty(d, d, d).uniform_(-1, 1))
+        self.input_dropout = nn.Dropout(config["input_dropout"])
+        self.hidden_dropout1 = nn.Dropout(config["input_dropout1"])
+        self.hidden_dropout2 = nn.Dropout(config["input_dropout2"])
+        self.bn0 = nn.BatchNorm1d(d)
+        self.bn1 = nn.BatchNorm1d(d)
+        self.apply(xavier_normal_initialization)
+        self.forced_masks = None  # tests: {"rec": (m0 [B,d], m1 [B,d,d], m2 [B,d]), "kg": (...)} multiplicative masks
+
+    def _drop(self, module, x, forced):
+        if forced is not None:
+            return x * forced
+        return module(x)
+
+    def logits(self, h_idx, r_idx, table, side):
+        """Pre-sigmoid scores [B, rows(table)] of forward() (tucker.py:69-84)."""
+        d = self.embedding_size
+        fm = self.forced_masks[side] if self.forced_masks is not None else (None, None, None)
+        h = ops.embedding(self.user_embedding.weight if side == "rec" else self.entity_embedding.weight, h_idx)
+        r = ops.embedding(self.relation_embedding.weight, r_idx)
+        x = self._drop(self.input_dropout, self.bn0(h), fm[0])
+        w_mat = ops.matmul_nn(r, self.weights.view(d, d * d)).view(-1, d, d)
+        if fm[1] is not None:
+            mask1 = fm[1]
+        elif self.training and self.hidden_dropout1.p > 0:
+            keep = 1.0 - self.hidden_dropout1.p
+            mask1 = (torch.rand_like(w_mat) < keep).to(torch.float32) / keep
+        else:
+            mask1 = None
+        x = ops.tucker_contract(x, w_mat, mask1)
+        x = self._drop(self.hidden_dropout2, self.bn1(x), fm[2])
+        return ops.matmul_nt(x, table)
+
+    def forward(self, h_idx, r_idx, table, side):
+        return ops.sigmoid(self.logits(h_idx, r_idx, table, side))
+
+    def _ui(self, user):
+        return torch.full_like(user, self.ui_relation)
+
+    def calculate_loss(self, interaction):
+        user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
+        head, rel, tail = interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], interaction[self.TAIL_ENTITY_ID]
+        dev = user.device
+        item_flag = torch.zeros(self.n_users + self.n_items, dtype=torch.uint8, device=dev)
+        item_flag[item + self.n_users] = 1
+        tail_flag = torch.zeros(self.n_entities, dtype=torch.uint8, device=dev)
+        tail_flag[tail] = 1
+        if self.label_smoothing:
+            s_rec, a_rec = 1.0 - self.label_smoothing, 1.0 / self.n_items
+            s_kg, a_kg = 1.0 - self.label_smoothing, 1.0 / self.n_entities
+        else:
+            s_rec = s_kg = 1.0
+            a_rec = a_kg = 0.0
+        # the kg forward runs first in the reference (tucker.py:108-109 gather order does not matter; BN running
+        # statistics are updated by score_users first, then score_kg -- tucker.py:121-122)
+        lu = self.logits(user, self._ui(user), self.user_embedding.weight, "rec")
+        lk = self.logits(head, rel, self.entity_embedding.weight, "kg")
+        return ops.sigmoid_bce_mean(lu, item_flag, s_rec, a_rec) + ops.sigmoid_bce_mean(lk, tail_flag, s_kg, a_kg)
+
+    def predict(self, interaction):
+        user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
+        score = self.forward(user, self._ui(user), self.user_embedding.weight, "rec")
+        return score[torch.arange(user.size(0), device=user.device), item]
+
+    def predict_kg(self, interaction):
+        head, rel, tail = interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], interaction[self.TAIL_ENTITY_ID]
+        score = self.forward(head, rel, self.entity_embedding.weight, "kg")
+        return score[torch.arange(head.size(0), device=head.device), tail]
+
+    def full_sort_predict(self, interaction):
+        user = interaction[self.USER_ID]
+        score = self.forward(user, self._ui(user), self.user_embedding.weight, "rec")
+        return score[:, self.n_users :]

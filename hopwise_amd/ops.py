@@ -447,3 +447,122 @@ class MatMul(torch.autograd.Function):
 
 def matmul_nt(x, w):
     return MatMul.apply(x, w)
+
+
+class MatMulNN(torch.autograd.Function):
+    """y = x @ w with w stored [K, N] (e.g. the TuckER core viewed [d, d*d])."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return gemm(x.contiguous(), w.contiguous(), True, False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm(gy, w.contiguous(), True, True)  # [M, N] @ ([K, N])^T
+        if ctx.needs_input_grad[1]:
+            gw = gemm(x.contiguous(), gy, False, False)  # x^T [K, M] @ gy [M, N]
+        return gx, gw
+
+
+def matmul_nn(x, w):
+    return MatMulNN.apply(x, w)
+
+
+class GatherRows(torch.autograd.Function):
+    """table[idx] with a dense scatter-add backward (nn.Embedding forward/backward on the HIP row kernels)."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        return gather_rows(table, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gt = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        scatter_add_rows_(gt, idx, g.contiguous())
+        return gt, None
+
+
+def embedding(table, idx):
+    return GatherRows.apply(table, idx)
+
+
+class TuckerContract(torch.autograd.Function):
+    """out[b, :] = x[b, :] @ (w[b] * mask[b])  (tucker.py:76-79 with hidden_dropout1 fused)."""
+
+    @staticmethod
+    def forward(ctx, x, w, mask):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "x").contiguous()
+        w = _dev(w, torch.float32, "w").contiguous()
+        B, d = x.shape
+        if tuple(w.shape) != (B, d, d) or (mask is not None and tuple(mask.shape) != (B, d, d)):
+            raise ValueError("w / mask must be [B, d, d]")
+        if mask is not None:
+            mask = _dev(mask, torch.float32, "mask").contiguous()
+        out = torch.empty((B, d), dtype=torch.float32, device=x.device)
+        check(lib.hw_tucker_contract(_ptr(x), _ptr(w), _ptr(mask), B, d, _ptr(out), _stream()), "hw_tucker_contract")
+        ctx.save_for_backward(x, w, *([mask] if mask is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        x, w = saved[0], saved[1]
+        mask = saved[2] if len(saved) > 2 else None
+        B, d = x.shape
+        go = go.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        check(lib.hw_tucker_contract_grad(_ptr(x), _ptr(w), _ptr(mask), _ptr(go), B, d, _ptr(gx), _ptr(gw), _stream()),
+              "hw_tucker_contract_grad")
+        return gx, gw, None
+
+
+def tucker_contract(x, w, mask=None):
+    return TuckerContract.apply(x, w, mask)
+
+
+class SigmoidBceMean(torch.autograd.Function):
+    """BCELoss(sigmoid(logits), scale * flag[col] + add), mean over all entries (tucker.py:111-125)."""
+
+    @staticmethod
+    def forward(ctx, logits, flag, scale, add):
+        lib = _lib.load()
+        x = _dev(logits, torch.float32, "logits").contiguous()
+        if flag is not None:
+            flag = _dev(flag, torch.uint8, "flag").contiguous()
+            if flag.numel() != x.shape[1]:
+                raise ValueError("flag must have one entry per column")
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        g = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(int(lib.hw_tucker_bce_workspace_floats()), dtype=torch.float32, device=x.device)
+        check(lib.hw_tucker_sigmoid_bce(_ptr(x), x.shape[0], x.shape[1], _ptr(flag), float(scale), float(add), _ptr(loss),
+                                        None, _ptr(g), _ptr(ws), _stream()), "hw_tucker_sigmoid_bce")
+        ctx.save_for_backward(g)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (g,) = ctx.saved_tensors
+        return g * gl, None, None, None
+
+
+def sigmoid_bce_mean(logits, flag, scale, add):
+    return SigmoidBceMean.apply(logits, flag, scale, add)
+
+
+def sigmoid(x):
+    lib = _lib.load()
+    x = _dev(x, torch.float32, "x").contiguous()
+    y = torch.empty_like(x)
+    check(lib.hw_sigmoid(_ptr(x), x.numel(), _ptr(y), _stream()), "hw_sigmoid")
+    return y

@@ -198,6 +198,24 @@ int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, const float
                 int64_t n, int64_t k, const float* bias, int32_t elu, const float* drop_mask,
                 int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---- TuckER (model/knowledge_graph_embedding_recommender/tucker.py:69-127) --------------------------------
+ * The dense products run on hw_gemm_f32; these are the two memory-bound pieces around them.
+ * hw_tucker_contract: out[b, j] = sum_i x[b, i] * w[b, i, j] * mask[b, i, j]  (torch.bmm(x, hidden_dropout1(W_mat)),
+ * tucker.py:76-79); mask nullable (eval), holding 0 or 1/(1-p).  *_grad: gx (nullable) and gw (nullable) of it. */
+int hw_tucker_contract(const float* x, const float* w, const float* mask, int64_t batch, int32_t dim,
+                       float* out, void* stream);
+int hw_tucker_contract_grad(const float* x, const float* w, const float* mask, const float* gout,
+                            int64_t batch, int32_t dim, float* gx, float* gw, void* stream);
+
+/* sigmoid + nn.BCELoss(mean) against target[b, c] = target_scale * pos_flag[c] + target_add (tucker.py:111-125:
+ * the union-of-the-batch multi-hot with label smoothing).  pred / glogits nullable.  workspace:
+ * hw_tucker_bce_workspace_floats() floats. */
+int64_t hw_tucker_bce_workspace_floats(void);
+int hw_tucker_sigmoid_bce(const float* logits, int64_t n_rows, int64_t n_cols, const uint8_t* pos_flag,
+                          float target_scale, float target_add, float* loss_out, float* pred,
+                          float* glogits, float* workspace, void* stream);
+int hw_sigmoid(const float* x, int64_t n, float* y, void* stream);
+
 /* logits -> masked softmax -> (+1 on valid actions, pgpr.py:453) -> top-k (value desc, index asc).
  * out_idx/out_val [max_rows, k]; entries past min(k, n_acts[row]) are idx = -1.  probs_out (nullable)
  * receives the plain softmax [max_rows, act_dim]. */

@@ -234,6 +234,64 @@ def gen_sampler(out_dir):
     print("sampler ok")
 
 
+def gen_tucker(out_dir):
+    """TuckER: eval-mode outputs + loss + grads, and a train-mode step with recorded dropout masks."""
+    import torch.nn.functional as F
+    from hopwise.model.knowledge_graph_embedding_recommender.tucker import TuckER
+
+    from make_golden_pgpr import RecordingDropout
+
+    nU, nI, nE, nR = 20, 16, 48, 5
+    real = F.dropout
+    for d in (8, 32):
+        torch.manual_seed(500 + d)
+        config = dict(FIELDS, embedding_size=d, device=torch.device("cpu"), label_smoothing=0.1, input_dropout=0.3,
+                      input_dropout1=0.4, input_dropout2=0.5)
+        model = TuckER(config, FakeDataset(nU, nI, nE, nR))
+        with torch.no_grad():  # non-trivial BatchNorm state
+            for bn in (model.bn0, model.bn1):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.2)
+                bn.running_mean.normal_(0, 0.1)
+                bn.running_var.uniform_(0.5, 2.0)
+        rng = np.random.default_rng(40 + d)
+        inter_np = make_batch(rng, nU, nI, nE, nR, 12, 14)
+        inter_np["item_id"] = np.maximum(inter_np["item_id"], 0)
+        inter = {k: torch.from_numpy(v) for k, v in inter_np.items()}
+        out = {f"p.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        out.update({f"inter.{k}": v for k, v in inter_np.items()})
+        model.eval()
+        with torch.no_grad():
+            out["eval.predict"] = model.predict(inter).numpy()
+            out["eval.predict_kg"] = model.predict_kg(inter).numpy()
+            users = torch.tensor([1, 5, 0, 19])
+            out["eval.fs_users"] = users.numpy()
+            out["eval.fs"] = model.full_sort_predict({"user_id": users}).numpy()
+        model.zero_grad()
+        loss = model.calculate_loss(inter)
+        loss.backward()
+        out["eval.loss"] = loss.detach().numpy()
+        for k, prm in model.named_parameters():
+            out[f"eval.grad.{k}"] = prm.grad.numpy().copy()
+        model.train()
+        rec = RecordingDropout(7 + d)
+        F.dropout = rec
+        model.zero_grad()
+        loss = model.calculate_loss(inter)
+        loss.backward()
+        F.dropout = real
+        out["train.loss"] = loss.detach().numpy()
+        for i, m in enumerate(rec.masks):
+            out[f"train.mask{i}"] = m
+        for k, prm in model.named_parameters():
+            out[f"train.grad.{k}"] = prm.grad.numpy().copy()
+        for k, v in model.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out[f"train.after.{k}"] = v.numpy().copy()
+        np.savez_compressed(os.path.join(out_dir, f"tucker_d{d}.npz"), **out)
+        print("tucker", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("kge", "all"):
@@ -242,6 +300,8 @@ if __name__ == "__main__":
         gen_kge(HERE, only=what[4:].split(","))
     if what in ("sampler", "all"):
         gen_sampler(HERE)
+    if what in ("tucker", "all"):
+        gen_tucker(HERE)
     if what in ("pgpr", "all"):
         from make_golden_pgpr import gen_pgpr
 

@@ -1,0 +1,97 @@
+"""TuckER on the MFMA path vs the reference goldens (eval + train with recorded dropout masks) and the oracle."""
+
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tucker as ot
+from tests.helpers import FakeDataset, make_config
+from tests.test_oracle_golden_tucker import FILES, NE, NI, NR, NU, load
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def build(p, d, nU=NU, nI=NI, nE=NE, nR=NR):
+    from hopwise_amd.model import TuckER
+
+    cfg = make_config(dev(), d, 1.0, label_smoothing=0.1, input_dropout=0.3, input_dropout1=0.4, input_dropout2=0.5)
+    m = TuckER(cfg, FakeDataset(nU, nI, nE, nR)).to(dev())
+    m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in p.items()})
+    return m
+
+
+def check_grads(m, z, prefix, rtol=3e-4):
+    for k, prm in m.named_parameters():
+        ref = z[f"{prefix}.grad.{k}"]
+        scale = np.abs(ref).max() + 1e-12
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), ref, rtol=rtol, atol=3e-6 * scale + 1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_tucker_vs_reference(path):
+    z, p, inter = load(path)
+    d = p["relation_embedding.weight"].shape[1]
+    m = build(p, d)
+    it = {k: torch.from_numpy(v).to(dev()) for k, v in inter.items()}
+    m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m.predict(it).cpu().numpy(), z["eval.predict"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(m.predict_kg(it).cpu().numpy(), z["eval.predict_kg"], rtol=1e-4, atol=1e-6)
+        fs = m.full_sort_predict({"user_id": torch.from_numpy(z["eval.fs_users"]).to(dev())})
+        np.testing.assert_allclose(fs.cpu().numpy(), z["eval.fs"], rtol=1e-4, atol=1e-6)
+    m.zero_grad()
+    loss = m.calculate_loss(it)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["eval.loss"], rtol=1e-5)
+    check_grads(m, z, "eval")
+    # one training-mode step with the reference's dropout masks
+    m.train()
+    t = lambda a: torch.from_numpy(a).to(dev())
+    m.forced_masks = {"rec": (t(z["train.mask0"]), t(z["train.mask1"]), t(z["train.mask2"])),
+                      "kg": (t(z["train.mask3"]), t(z["train.mask4"]), t(z["train.mask5"]))}
+    m.zero_grad()
+    loss = m.calculate_loss(it)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["train.loss"], rtol=1e-5)
+    check_grads(m, z, "train")
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), z[f"train.after.{k}"], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_tucker_vs_oracle_larger():
+    """d = 200 (BASELINE config 5's width) on a ragged id space; eval-mode scores and loss vs the numpy oracle."""
+    rng = np.random.default_rng(0)
+    nU, nI, nE, nR, d, B = 300, 170, 900, 9, 200, 70
+    from hopwise_amd.model import TuckER
+
+    cfg = make_config(dev(), d, 1.0, label_smoothing=0.1, input_dropout=0.3, input_dropout1=0.4, input_dropout2=0.5)
+    torch.manual_seed(1)
+    m = TuckER(cfg, FakeDataset(nU, nI, nE, nR)).to(dev())
+    with torch.no_grad():
+        m.weights.mul_(0.05)
+        m.bn0.running_mean.normal_(0, 0.1)
+        m.bn1.running_var.uniform_(0.5, 2.0)
+    p = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
+    inter = dict(user_id=rng.integers(1, nU, B), item_id=rng.integers(1, nI, B), head_id=rng.integers(1, nE, B),
+                 relation_id=rng.integers(1, nR - 1, B), tail_id=rng.integers(1, nE, B))
+    it = {k: torch.from_numpy(v).to(dev()) for k, v in inter.items()}
+    m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(m.predict_kg(it).cpu().numpy(), ot.predict_kg(p, inter), rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(m.full_sort_predict(it).cpu().numpy(), ot.full_sort_predict(p, inter["user_id"], nU, nR - 1),
+                                   rtol=2e-4, atol=1e-6)
+        loss = m.calculate_loss(it)
+    np.testing.assert_allclose(loss.item(), ot.calculate_loss(p, inter, nU, nI, nE, nR - 1, 0.1), rtol=2e-5)
+    # a training step runs (Philox-free torch dropout masks) and produces finite gradients everywhere
+    m.train()
+    m.zero_grad()
+    m.calculate_loss(it).backward()
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters())
