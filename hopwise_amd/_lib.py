@@ -109,7 +109,7 @@ SIGNATURES = {
     "hw_gemm_f32": (
         C.c_int,
         [c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_i32p, C.c_int64, C.c_int64,
-         C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p],
+         C.c_int64, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_uint64, C.c_uint64, c_f32p, C.c_int64, C.c_void_p],
     ),
     "hw_tucker_contract": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, C.c_void_p]),
     "hw_tucker_contract_grad": (

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                                                           const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ drop_mask, int drop_mode,
-                                                          uint64_t seed, uint64_t offset, int vec_a, int vec_b) {
+                                                          uint64_t seed, uint64_t offset, int vec_a, int vec_b,
+                                                          int k_len, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float As[BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
     const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
@@ -105,9 +106,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 
-    for (int k0 = 0; k0 < K; k0 += BK) {
-        stage_tile<A_KC>(A, lda, M, K, m0, k0, vec_a != 0, As);
-        stage_tile<B_KC>(B, ldb, N, K, n0, k0, vec_b != 0, Bs);
+    // split-K: blockIdx.z owns k in [z * k_len, min(K, (z + 1) * k_len)); partial sums go to `partial[z]`
+    const int k_begin = blockIdx.z * k_len;
+    const int k_end = min(K, k_begin + k_len);
+    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+        stage_tile<A_KC>(A, lda, M, k_end, m0, k0, vec_a != 0, As);
+        stage_tile<B_KC>(B, ldb, N, k_end, n0, k0, vec_b != 0, Bs);
         __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -133,7 +137,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
                 const int gm = m0 + wm + ti * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-                if (gm < M && gn < N) {
+                if (gm < M && gn < N && partial) {
+                    partial[((size_t)blockIdx.z * m_max + gm) * N + gn] = acc[ti][tj][rg];
+                } else if (gm < M && gn < N) {
                     float v = acc[ti][tj][rg] + bv;
                     if (ELU) v = v > 0.f ? v : expm1f(v);
                     if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
@@ -144,17 +150,56 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
         }
 }
 
+// second stage of split-K: C = epilogue(sum_z partial[z]) in fixed z order (deterministic)
+template <bool ELU>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
+                                                                 const int32_t* __restrict__ m_ptr, int m_max, int N,
+                                                                 float* __restrict__ C, int64_t ldc,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ drop_mask, int drop_mode,
+                                                                 uint64_t seed, uint64_t offset) {
+    const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
+    const int64_t total = (int64_t)M * N;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int gm = (int)(i / N), gn = (int)(i % N);
+        float v = 0.f;
+        for (int z = 0; z < splits; ++z) v += partial[((size_t)z * m_max + gm) * N + gn];
+        v += bias ? bias[gn] : 0.f;
+        if (ELU) v = v > 0.f ? v : expm1f(v);
+        if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
+        else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
+        C[(size_t)gm * ldc + gn] = v;
+    }
+}
+
 static bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p) & 15) == 0 && (ld % 4) == 0; }
 
 static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, int64_t ldb, bool b_kc, float* c,
                        int64_t ldc, const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, const float* bias,
                        bool elu, const float* drop_mask, int drop_mode, uint64_t seed, uint64_t offset,
-                       hipStream_t st) {
-    dim3 grid((unsigned)((m_max + BM - 1) / BM), (unsigned)((n + BN - 1) / BN));
+                       float* workspace, int64_t workspace_floats, hipStream_t st) {
+    const int64_t gm = (m_max + BM - 1) / BM, gn = (n + BN - 1) / BN;
+    // split-K when the output grid cannot fill the chip and K is long (e.g. dX = dY [2048, 144779] . E [144779, 200])
+    int splits = 1;
+    if (workspace && gm * gn < 256 && k >= 64 * BK) {
+        int64_t want = (768 + gm * gn - 1) / (gm * gn);
+        const int64_t kmax = k / (8 * BK);
+        if (want > kmax) want = kmax;
+        const int64_t fit = workspace_floats / (m_max * n);
+        if (want > fit) want = fit;
+        if (want > 1) splits = (int)want;
+    }
+    int k_len = (int)k;
+    if (splits > 1) {
+        k_len = (int)(((k + splits - 1) / splits + BK - 1) / BK * BK);
+        splits = (int)((k + k_len - 1) / k_len);
+    }
+    float* partial = splits > 1 ? workspace : nullptr;
+    dim3 grid((unsigned)gm, (unsigned)gn, (unsigned)splits);
     const int va = aligned16(a, lda), vb = aligned16(b, ldb);
 #define GO(AK, BK_, EL)                                                                                              \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows,       \
-                       (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb)
+                       (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial)
     if (a_kc && b_kc) {
         if (elu) GO(true, true, true);
         else GO(true, true, false);
@@ -169,6 +214,16 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
         else GO(false, true, false);
     }
 #undef GO
+    if (splits > 1) {
+        int64_t rg = (m_max * n + 255) / 256;
+        if (rg > 4096) rg = 4096;
+        if (elu)
+            hipLaunchKernelGGL((gemm_splitk_reduce_kernel<true>), dim3((unsigned)rg), dim3(256), 0, st, partial, splits,
+                               m_rows, (int)m_max, (int)n, c, ldc, bias, drop_mask, drop_mode, seed, offset);
+        else
+            hipLaunchKernelGGL((gemm_splitk_reduce_kernel<false>), dim3((unsigned)rg), dim3(256), 0, st, partial, splits,
+                               m_rows, (int)m_max, (int)n, c, ldc, bias, drop_mask, drop_mode, seed, offset);
+    }
     return HW_OK;
 }
 
@@ -179,7 +234,8 @@ using namespace hw;
 extern "C" int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, const float* b, int64_t ldb,
                            int32_t b_k_contiguous, float* c, int64_t ldc, const int32_t* m_rows, int64_t m_max,
                            int64_t n, int64_t k, const float* bias, int32_t elu, const float* drop_mask,
-                           int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream) {
+                           int32_t drop_mode, uint64_t seed, uint64_t offset, float* workspace,
+                           int64_t workspace_floats, void* stream) {
     if (!a || !b || !c || m_max < 0 || n < 1 || k < 1 || ldc < n) return HW_ERR_INVALID_ARG;
     if (lda < (a_k_contiguous ? k : m_max) || ldb < (b_k_contiguous ? k : n)) return HW_ERR_INVALID_ARG;
     if (drop_mode < 0 || drop_mode > 2 || (drop_mode == 1 && !drop_mask)) return HW_ERR_INVALID_ARG;
@@ -187,7 +243,7 @@ extern "C" int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, 
     if (m_max == 0) return HW_OK;
     HW_CLEAR_ERR();
     launch_gemm(a, lda, a_k_contiguous != 0, b, ldb, b_k_contiguous != 0, c, ldc, m_rows, m_max, n, k, bias, elu != 0,
-                drop_mask, drop_mode, seed, offset, (hipStream_t)stream);
+                drop_mask, drop_mode, seed, offset, workspace, workspace ? workspace_floats : 0, (hipStream_t)stream);
     return HW_LAUNCH_RC();
 }
 
@@ -195,5 +251,5 @@ extern "C" int hw_mlp_layer(const float* a, int64_t lda, const float* w, const f
                             const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, int32_t elu,
                             const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream) {
     return hw_gemm_f32(a, lda, 1, w, k, 1, c, ldc, m_rows, m_max, n, k, bias, elu, drop_mask, drop_mode, seed, offset,
-                       stream);
+                       nullptr, 0, stream);
 }

@@ -416,10 +416,15 @@ def gemm(a, b, a_k_contiguous=True, b_k_contiguous=True, bias=None, elu=False, o
         raise ValueError(f"inner dimensions differ: {K} vs {Kb}")
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ws, ws_n = None, 0
+    if ((M + 127) // 128) * ((N + 127) // 128) < 256 and K >= 1024:  # long-K, small output: give split-K room
+        splits = min(max(768 // (((M + 127) // 128) * ((N + 127) // 128)), 2), K // 128)
+        ws_n = splits * M * N
+        ws = torch.empty(ws_n, dtype=torch.float32, device=a.device)
     check(
         lib.hw_gemm_f32(_ptr(a), a.stride(0), int(a_k_contiguous), _ptr(b), b.stride(0), int(b_k_contiguous), _ptr(out),
                         out.stride(0), _ptr(m_rows), M, N, K, _ptr(bias), int(bool(elu)), _ptr(drop_mask),
-                        int(drop_mode), C.c_uint64(seed), C.c_uint64(offset), _stream()),
+                        int(drop_mode), C.c_uint64(seed), C.c_uint64(offset), _ptr(ws), ws_n, _stream()),
         "hw_gemm_f32",
     )
     return out

@@ -192,11 +192,14 @@ int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias,
 
 /* General fp32 MFMA GEMM: c[m, n] = f(op(a)[m, :] . op(b)[:, n] + bias[n]).  a is [m, k] row-major when
  * a_k_contiguous, else stored transposed [k, m]; b is [n, k] row-major (nn.Linear weight) when b_k_contiguous, else
- * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187). */
+ * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187).
+ * workspace (nullable, workspace_floats >= 2 * m_max * n to be useful) enables deterministic split-K for
+ * long-K / small-output products (partial slabs summed in fixed order). */
 int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, const float* b, int64_t ldb,
                 int32_t b_k_contiguous, float* c, int64_t ldc, const int32_t* m_rows, int64_t m_max,
                 int64_t n, int64_t k, const float* bias, int32_t elu, const float* drop_mask,
-                int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream);
+                int32_t drop_mode, uint64_t seed, uint64_t offset, float* workspace,
+                int64_t workspace_floats, void* stream);
 
 /* ---- TuckER (model/knowledge_graph_embedding_recommender/tucker.py:69-127) --------------------------------
  * The dense products run on hw_gemm_f32; these are the two memory-bound pieces around them.

@@ -242,7 +242,7 @@ def test_gemm_all_layouts_vs_fp64():
     from hopwise_amd import ops
 
     rng = np.random.default_rng(1)
-    for M, K, N in ((1, 1, 1), (37, 200, 129), (300, 17, 260), (128, 128, 128), (1000, 403, 70)):
+    for M, K, N in ((1, 1, 1), (37, 200, 129), (300, 17, 260), (128, 128, 128), (1000, 403, 70), (130, 5003, 40)):
         A = rng.standard_normal((M, K)).astype(np.float32)
         B = rng.standard_normal((N, K)).astype(np.float32)
         ref = A.astype(np.float64) @ B.astype(np.float64).T
