@@ -51,6 +51,11 @@ class PgprGraph(C.Structure):
     ]
 
 
+class CafeNode(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("parent", "rel", "eh_is_entity", "k", "is_leaf", "lp_row", "depth", "vocab", "cap", "slot_off")]
+
+
 class KgeGrads(C.Structure):
     _fields_ = [("head", C.c_void_p * 2), ("rel", C.c_void_p * 2), ("tail", C.c_void_p * 2)]
 
@@ -137,6 +142,12 @@ SIGNATURES = {
     ),
     "hw_gather_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_f32p, c_i32p, C.c_void_p]),
     "hw_scatter_add_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_f32p, C.c_void_p]),
+    "hw_log_softmax_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_void_p]),
+    "hw_cafe_execute": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, c_i32p, c_i64p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_void_p,
+         C.c_int64, C.c_int32, c_i32p, c_f32p, c_i32p, c_i64p, C.c_void_p],
+    ),
     "hw_version": (C.c_char_p, []),
 }
 

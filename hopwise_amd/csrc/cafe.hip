@@ -1,0 +1,207 @@
+// CAFE inference primitives (model/knowledge_aware_recommender/cafe.py):
+//   * row-wise log_softmax over an entity vocabulary (cafe.py:597-598, :819-820);
+//   * the program interpreter: for every tree node, in order, and for every parent path, in order, take the
+//     neighbours of the path's tail under the node's relation (KGMask.get_ids :734-750), drop the ids already
+//     picked at this node (visited_ids) and -- at leaves -- the excluded items, keep the top-k by the node's
+//     log-probabilities, append (SymbolicNetwork.infer_with_path :587-642 and MetaProgramExecutor.execute
+//     :790-857 are this same loop with different k and exclusion rules).
+// One workgroup interprets one user's whole program; the sequential dependence (visited / excluded sets grow while
+// parent paths are consumed in order) stays inside the workgroup, users run in parallel.
+#include "hw_common.h"
+
+namespace hw {
+
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x, int64_t ld, int n_cols,
+                                                               float* __restrict__ y, int64_t ldy) {
+    __shared__ float red[4];
+    const float* __restrict__ r = x + (size_t)blockIdx.x * ld;
+    float* __restrict__ o = y + (size_t)blockIdx.x * ldy;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < n_cols; c += 256) m = fmaxf(m, r[c]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < n_cols; c += 256) s += expf(r[c] - m);
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float ls = logf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int c = threadIdx.x; c < n_cols; c += 256) o[c] = (r[c] - m) - ls;
+}
+
+__device__ __forceinline__ uint64_t lp_key(float v, uint32_t id) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)(~id);
+}
+
+__device__ __forceinline__ bool bit_get(const uint32_t* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
+
+constexpr int CAFE_BIT_WORDS = 8192;  // 262 144 ids per LDS bitmap (2 x 32 KiB)
+constexpr int CAFE_MAX_NODES = 128;
+
+__global__ __launch_bounds__(256) void cafe_execute_kernel(
+    hw_pgpr_graph g, const hw_cafe_node* __restrict__ nodes, const int32_t* __restrict__ node_ptr,
+    const int64_t* __restrict__ users, const float* __restrict__ logprobs, int64_t lp_ld,
+    const uint32_t* __restrict__ excluded_init, int64_t bit_words, int grow_excluded,
+    int32_t* __restrict__ out_ids, float* __restrict__ out_vals, int32_t* __restrict__ out_count,
+    const int64_t* __restrict__ slot_ptr) {
+    __shared__ uint32_t vis[CAFE_BIT_WORDS];
+    __shared__ uint32_t excl[CAFE_BIT_WORDS];
+    __shared__ int counts[CAFE_MAX_NODES];
+    __shared__ uint64_t red[4];
+    __shared__ uint64_t sh_win;
+    __shared__ int sh_lo, sh_hi;
+    __shared__ long long sh_base;
+    const int task = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int uid = (int)users[task];
+    const int n0 = node_ptr[task], n1 = node_ptr[task + 1];
+    const int64_t slot0 = slot_ptr[task];
+    for (int w = tid; w < bit_words; w += 256) excl[w] = excluded_init[(size_t)task * bit_words + w];
+    __syncthreads();
+
+    for (int ni = n0; ni < n1; ++ni) {
+        const hw_cafe_node nd = nodes[ni];
+        for (int w = tid; w < bit_words; w += 256) vis[w] = 0u;  // visited_ids = [] at every node
+        __syncthreads();
+        const int depth = nd.depth;  // this node appends element depth - 1 of the id list after the user
+        const int n_parent = nd.parent < 0 ? 1 : counts[nd.parent];
+        const int p_off = nd.parent < 0 ? 0 : nodes[n0 + nd.parent].slot_off;
+        const int32_t* p_ids = out_ids + (slot0 + p_off) * 3;
+        const float* p_vals = out_vals + (slot0 + p_off) * 3;
+        int32_t* c_ids = out_ids + (slot0 + nd.slot_off) * 3;
+        float* c_vals = out_vals + (slot0 + nd.slot_off) * 3;
+        const float* __restrict__ lp = logprobs + (size_t)nd.lp_row * lp_ld;
+        int n_out = 0;
+        for (int pp = 0; pp < n_parent && n_out < nd.cap; ++pp) {
+            if (tid == 0) {
+                // thread 0 is the only reader of what thread 0 wrote earlier in this launch (parent paths)
+                const int last = nd.parent < 0 ? uid : p_ids[(size_t)pp * 3 + depth - 2];
+                // adjacency of (the RELATION's head type, last) under nd.rel: the lookup type comes from the relation,
+                // not from the node (cafe.py:603 kg_mask.get_ids(module.eh_name, path[-1], ...))
+                int lo = 0, hi = 0;
+                long long base = 0;
+                const int64_t n_type = nd.eh_is_entity ? g.n_entities : g.n_users;
+                if (last >= 0 && last < n_type) {
+                    const int64_t gid = nd.eh_is_entity ? (int64_t)g.n_users + last : last;
+                    const int64_t a = g.ptr[gid], b = g.ptr[gid + 1];
+                    int64_t l = a, h = b;
+                    while (l < h) {  // first edge with rel >= nd.rel
+                        const int64_t m = (l + h) >> 1;
+                        if (g.rel[m] < nd.rel) l = m + 1;
+                        else h = m;
+                    }
+                    lo = (int)(l - a);
+                    h = b;
+                    while (l < h) {  // first edge with rel > nd.rel
+                        const int64_t m = (l + h) >> 1;
+                        if (g.rel[m] <= nd.rel) l = m + 1;
+                        else h = m;
+                    }
+                    hi = (int)(l - a);
+                    base = a;
+                }
+                sh_lo = lo, sh_hi = hi, sh_base = base;
+            }
+            __syncthreads();
+            const int lo = sh_lo, hi = sh_hi;
+            const int32_t* __restrict__ dst = g.dst + sh_base;
+            const int first = n_out;
+            uint64_t bound = ~0ull;
+            for (int r = 0; r < nd.k && n_out < nd.cap; ++r) {
+                uint64_t best = 0;
+                for (int e = lo + tid; e < hi; e += 256) {
+                    const int id = dst[e];
+                    if (e > lo && dst[e - 1] == id) continue;  // set(): the adjacency keeps multiplicity
+                    if (id < 0 || id >= nd.vocab) continue;
+                    if ((vis[id >> 5] >> (id & 31)) & 1u) continue;
+                    if (nd.is_leaf && ((excl[id >> 5] >> (id & 31)) & 1u)) continue;
+                    const uint64_t key = lp_key(lp[id], (uint32_t)id);
+                    if (key < bound && key > best) best = key;
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const uint64_t o = __shfl_xor(best, m, 64);
+                    best = o > best ? o : best;
+                }
+                __syncthreads();
+                if ((tid & 63) == 0) red[tid >> 6] = best;
+                __syncthreads();
+                if (tid == 0) {
+                    uint64_t w = red[0];
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) w = red[i] > w ? red[i] : w;
+                    sh_win = w;
+                    if (w != 0) {
+                        const int id = (int)(~(uint32_t)(w & 0xffffffffu));
+                        int32_t* q = c_ids + (size_t)n_out * 3;
+                        float* v = c_vals + (size_t)n_out * 3;
+                        for (int j = 0; j < depth - 1; ++j) {
+                            q[j] = p_ids[(size_t)pp * 3 + j];
+                            v[j] = p_vals[(size_t)pp * 3 + j];
+                        }
+                        q[depth - 1] = id;
+                        v[depth - 1] = lp[id];
+                    }
+                }
+                __syncthreads();
+                const uint64_t w = sh_win;
+                if (w == 0) break;
+                bound = w;
+                ++n_out;
+            }
+            // this parent's picks become visited (and, at executor leaves, excluded) before the next parent
+            if (tid == 0) {
+                for (int i = first; i < n_out; ++i) {
+                    const int id = c_ids[(size_t)i * 3 + depth - 1];
+                    vis[id >> 5] |= 1u << (id & 31);
+                    if (nd.is_leaf && grow_excluded) excl[id >> 5] |= 1u << (id & 31);
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            counts[ni - n0] = n_out;
+            out_count[ni] = n_out;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace hw
+
+using namespace hw;
+
+extern "C" int hw_log_softmax_rows(const float* x, int64_t ld, int64_t n_rows, int64_t n_cols, float* y, int64_t ldy,
+                                   void* stream) {
+    if (!x || !y || n_rows < 0 || n_cols < 1 || ld < n_cols || ldy < n_cols || n_cols > INT32_MAX || n_rows > INT32_MAX)
+        return HW_ERR_INVALID_ARG;
+    if (n_rows == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, x, ld,
+                       (int)n_cols, y, ldy);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
+                               const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task,
+                               const float* logprobs, int64_t logprob_ld, const uint32_t* excluded_init,
+                               int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
+                               int32_t* out_count, const int64_t* slot_ptr, void* stream) {
+    if (!graph || !graph->ptr || !graph->rel || !graph->dst || !nodes || !node_ptr || !users || !logprobs ||
+        !excluded_init || !out_ids || !out_vals || !out_count || !slot_ptr)
+        return HW_ERR_INVALID_ARG;
+    if (n_tasks < 0 || n_tasks > INT32_MAX || bit_words < 1) return HW_ERR_INVALID_ARG;
+    if (bit_words > CAFE_BIT_WORDS || max_nodes_per_task > CAFE_MAX_NODES) return HW_ERR_UNSUPPORTED;
+    if (n_tasks == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(cafe_execute_kernel, dim3((unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, *graph, nodes,
+                       node_ptr, users, logprobs, logprob_ld, excluded_init, bit_words, grow_excluded, out_ids, out_vals,
+                       out_count, slot_ptr);
+    return HW_LAUNCH_RC();
+}

@@ -84,7 +84,7 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ X, int64_t 
     }
 }
 
-template <bool A_KC, bool B_KC, bool ELU>
+template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc,
@@ -141,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                     partial[((size_t)blockIdx.z * m_max + gm) * N + gn] = acc[ti][tj][rg];
                 } else if (gm < M && gn < N) {
                     float v = acc[ti][tj][rg] + bv;
-                    if (ELU) v = v > 0.f ? v : expm1f(v);
+                    if (ACT == 1) v = v > 0.f ? v : expm1f(v);
+                    if (ACT == 2) v = fmaxf(v, 0.f);
                     if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
                     else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
                     C[(size_t)gm * ldc + gn] = v;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
 }
 
 // second stage of split-K: C = epilogue(sum_z partial[z]) in fixed z order (deterministic)
-template <bool ELU>
+template <int ACT>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
                                                                  const int32_t* __restrict__ m_ptr, int m_max, int N,
                                                                  float* __restrict__ C, int64_t ldc,
@@ -165,7 +166,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
         float v = 0.f;
         for (int z = 0; z < splits; ++z) v += partial[((size_t)z * m_max + gm) * N + gn];
         v += bias ? bias[gn] : 0.f;
-        if (ELU) v = v > 0.f ? v : expm1f(v);
+        if (ACT == 1) v = v > 0.f ? v : expm1f(v);
+        if (ACT == 2) v = fmaxf(v, 0.f);
         if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
         else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
         C[(size_t)gm * ldc + gn] = v;
@@ -176,7 +178,7 @@ static bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p) & 15) 
 
 static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, int64_t ldb, bool b_kc, float* c,
                        int64_t ldc, const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, const float* bias,
-                       bool elu, const float* drop_mask, int drop_mode, uint64_t seed, uint64_t offset,
+                       int act, const float* drop_mask, int drop_mode, uint64_t seed, uint64_t offset,
                        float* workspace, int64_t workspace_floats, hipStream_t st) {
     const int64_t gm = (m_max + BM - 1) / BM, gn = (n + BN - 1) / BN;
     // split-K when the output grid cannot fill the chip and K is long (e.g. dX = dY [2048, 144779] . E [144779, 200])
@@ -200,29 +202,28 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
 #define GO(AK, BK_, EL)                                                                                              \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows,       \
                        (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial)
-    if (a_kc && b_kc) {
-        if (elu) GO(true, true, true);
-        else GO(true, true, false);
-    } else if (a_kc && !b_kc) {
-        if (elu) GO(true, false, true);
-        else GO(true, false, false);
-    } else if (!a_kc && !b_kc) {
-        if (elu) GO(false, false, true);
-        else GO(false, false, false);
-    } else {
-        if (elu) GO(false, true, true);
-        else GO(false, true, false);
-    }
+#define GO3(AK, BK_)              \
+    do {                          \
+        if (act == 1) GO(AK, BK_, 1);      \
+        else if (act == 2) GO(AK, BK_, 2); \
+        else GO(AK, BK_, 0);               \
+    } while (0)
+    if (a_kc && b_kc) GO3(true, true);
+    else if (a_kc && !b_kc) GO3(true, false);
+    else if (!a_kc && !b_kc) GO3(false, false);
+    else GO3(false, true);
+#undef GO3
 #undef GO
     if (splits > 1) {
         int64_t rg = (m_max * n + 255) / 256;
         if (rg > 4096) rg = 4096;
-        if (elu)
-            hipLaunchKernelGGL((gemm_splitk_reduce_kernel<true>), dim3((unsigned)rg), dim3(256), 0, st, partial, splits,
-                               m_rows, (int)m_max, (int)n, c, ldc, bias, drop_mask, drop_mode, seed, offset);
-        else
-            hipLaunchKernelGGL((gemm_splitk_reduce_kernel<false>), dim3((unsigned)rg), dim3(256), 0, st, partial, splits,
-                               m_rows, (int)m_max, (int)n, c, ldc, bias, drop_mask, drop_mode, seed, offset);
+#define RED(ACT_)                                                                                                  \
+    hipLaunchKernelGGL((gemm_splitk_reduce_kernel<ACT_>), dim3((unsigned)rg), dim3(256), 0, st, partial, splits, m_rows, \
+                       (int)m_max, (int)n, c, ldc, bias, drop_mask, drop_mode, seed, offset)
+        if (act == 1) RED(1);
+        else if (act == 2) RED(2);
+        else RED(0);
+#undef RED
     }
     return HW_OK;
 }
@@ -238,11 +239,11 @@ extern "C" int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, 
                            int64_t workspace_floats, void* stream) {
     if (!a || !b || !c || m_max < 0 || n < 1 || k < 1 || ldc < n) return HW_ERR_INVALID_ARG;
     if (lda < (a_k_contiguous ? k : m_max) || ldb < (b_k_contiguous ? k : n)) return HW_ERR_INVALID_ARG;
-    if (drop_mode < 0 || drop_mode > 2 || (drop_mode == 1 && !drop_mask)) return HW_ERR_INVALID_ARG;
+    if (drop_mode < 0 || drop_mode > 2 || (drop_mode == 1 && !drop_mask) || elu < 0 || elu > 2) return HW_ERR_INVALID_ARG;
     if (m_max > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
     if (m_max == 0) return HW_OK;
     HW_CLEAR_ERR();
-    launch_gemm(a, lda, a_k_contiguous != 0, b, ldb, b_k_contiguous != 0, c, ldc, m_rows, m_max, n, k, bias, elu != 0,
+    launch_gemm(a, lda, a_k_contiguous != 0, b, ldb, b_k_contiguous != 0, c, ldc, m_rows, m_max, n, k, bias, elu,
                 drop_mask, drop_mode, seed, offset, workspace, workspace ? workspace_floats : 0, (hipStream_t)stream);
     return HW_LAUNCH_RC();
 }

@@ -1,0 +1,371 @@
+"""CAFE inference (coarse-to-fine neural-symbolic reasoning) on the gfx950 kernels.
+
+Reference: /root/reference/hopwise/model/knowledge_aware_recommender/cafe.py -- CAFE :26-480, SymbolicNetwork
+:483-642, RelationModule :645-667, DeepRelationModule :670-699, KGMask :723-774, MetaProgramExecutor :777-867,
+NeuralProgramLayout / TreeNode :870-964.
+
+Same: ``CAFE(config, dataset)``; config keys (CAFE.yaml); one neural module per relation stored under
+``model.<relation>.*`` (state_dict compatible); ``_infer_paths`` / ``run_program`` / ``full_sort_predict`` / ``explain``
+semantics, including: the neighbour lookup uses the RELATION's head type, not the node's (cafe.py:603,823); visited ids
+are per tree node; at executor leaves every pick joins the user's excluded set; ``execute`` keeps ``manual_topk = 5``
+children per parent (adaptive_topk is False in run_program, cafe.py:790); result scores are the product of the three
+log-probabilities (cafe.py:436).
+
+Different by design: a user's whole program is interpreted by one workgroup (hw_cafe_execute) against
+log-probability rows produced by the fp32 MFMA GEMM + a row log_softmax kernel, for all users of a batch at once;
+the graph is a device CSR; nothing runs per user on the host except the final sort of a few hundred leaf paths.
+
+Not built this round: training (calculate_loss, the replay memory and the bidirectional BFS path sampler,
+cafe.py:134-330) -- SURVEY.md §8(f)3.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from .. import pgpr_ops as P
+from ..utils import InputType
+from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
+
+
+class RelationModule(nn.Module):
+    def __init__(self, embedding_size, info):
+        super().__init__()
+        self.name, self.eh_name, self.et_name = info["name"], info["entity_head"], info["entity_tail"]
+        self.fc1 = nn.Linear(embedding_size * 2, 256)
+        self.bn1 = nn.BatchNorm1d(256)
+        self.fc2 = nn.Linear(256, embedding_size)
+        self.dropout = nn.Dropout(0.5)
+
+    def forward(self, inputs):  # cafe.py:656-667
+        eh_vec, user_vec = inputs
+        x = torch.cat([eh_vec, user_vec], dim=-1)
+        x = self.bn1(self.dropout(ops.gemm(x.contiguous(), self.fc1.weight, bias=self.fc1.bias, elu="relu")))
+        return ops.gemm(x.contiguous(), self.fc2.weight, bias=self.fc2.bias) + eh_vec
+
+
+class DeepRelationModule(nn.Module):
+    def __init__(self, embedding_size, info, use_dropout):
+        super().__init__()
+        self.name, self.eh_name, self.et_name = info["name"], info["entity_head"], info["entity_tail"]
+        n = embedding_size * 2
+        self.fc1 = nn.Linear(n, 256)
+        self.bn1 = nn.BatchNorm1d(256)
+        self.fc2 = nn.Linear(256, n)
+        self.bn2 = nn.BatchNorm1d(n)
+        self.fc3 = nn.Linear(n, embedding_size)
+        self.dropout = nn.Dropout(0.5) if use_dropout else None
+
+    def forward(self, inputs):  # cafe.py:686-699; the three Linear layers run on the MFMA GEMM
+        eh_vec, user_vec = inputs
+        feature = torch.cat([eh_vec, user_vec], dim=-1).contiguous()
+        x = ops.gemm(feature, self.fc1.weight, bias=self.fc1.bias, elu="relu")
+        if self.dropout is not None:
+            x = self.dropout(x)
+        x = self.bn1(x)
+        x = F.relu(ops.gemm(x.contiguous(), self.fc2.weight, bias=self.fc2.bias) + feature)
+        if self.dropout is not None:
+            x = self.dropout(x)
+        x = self.bn2(x)
+        return ops.gemm(x.contiguous(), self.fc3.weight, bias=self.fc3.bias)
+
+
+class SymbolicNetwork(nn.Module):
+    def __init__(self, relation_info, embedding_size, deep_module, use_dropout):
+        super().__init__()
+        for name, info in relation_info.items():
+            mod = DeepRelationModule(embedding_size, info, use_dropout) if deep_module else RelationModule(embedding_size, info)
+            setattr(self, name, mod)  # relation names contain dots; the reference registers them the same way
+
+
+class TreeNode:
+    def __init__(self, level, entity, relation):
+        self.level, self.entity, self.relation = level, entity, relation
+        self.parent, self.children, self.sample_size = None, {}, 0
+
+    def get_children(self):
+        return list(self.children.values())
+
+    def has_children(self):
+        return len(self.children) > 0
+
+
+def build_layout(metapaths):
+    """NeuralProgramLayout.__init__ (cafe.py:873-888): the prefix tree of the metapaths."""
+    root = TreeNode(0, "user", None)
+    for mp in metapaths:
+        node = root
+        for i in range(1, len(mp)):
+            if mp[i] not in node.children:
+                node.children[mp[i]] = TreeNode(i, mp[i][1], mp[i][0])
+                node.children[mp[i]].parent = node
+            node = node.children[mp[i]]
+    return root
+
+
+class CAFE(KnowledgeRecommender, ExplainableRecommender):
+    input_type = InputType.USERWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        dev = torch.device(self.device)
+        self.raw_metapaths = config["path_constraint"]
+        self.rank_weight = config["rank_weight"]
+        self.deep_module = config["deep_module"]
+        self.use_dropout = config["use_dropout"]
+        self.topk_candidates = config["topk_candidates"]
+        self.sample_size = config["sample_size"]
+        self.topk_paths = config["topk_paths"]
+        self.ui_relation = dataset.ui_relation
+        self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
+        ue = np.asarray(dataset.get_preload_weight("user_embedding_id"))
+        ee = np.asarray(dataset.get_preload_weight("entity_embedding_id"))
+        re_ = np.asarray(dataset.get_preload_weight("relation_embedding_id"))
+        self.user_embedding = torch.from_numpy(ue).to(dev, torch.float32).contiguous()
+        self.entity_embedding = torch.from_numpy(ee).to(dev, torch.float32).contiguous()
+        self.relation_embedding = torch.from_numpy(re_).to(dev, torch.float32).contiguous()
+        self.embedding_size = self.user_embedding.shape[1]
+        self.embeddings = {"user": self.user_embedding, "entity": self.entity_embedding}
+        self.relation2rid = dataset.field2token_id["relation_id"]
+        self.rid2relation = {v: k for k, v in self.relation2rid.items()}
+        self.positives = np.asarray(dataset.history_item_matrix()[0])
+
+        inter = dataset.inter_feat
+        self.graph = P.DeviceCKG(self.n_users, self.n_items, self.n_entities, self.ui_relation_id,
+                                 np.asarray(inter[dataset.uid_field]), np.asarray(inter[dataset.iid_field]),
+                                 np.asarray(dataset.head_entities), np.asarray(dataset.relations),
+                                 np.asarray(dataset.tail_entities), dev, ui_bidirectional=False)
+
+        self.relation_info = {}
+        for name in self.rid2relation.values():
+            if name == "[PAD]":
+                continue
+            if name == f"{dataset.ui_relation}_r":
+                raise ValueError("The ui_relation name should not end with '_r'.")
+            head = "user" if name == dataset.ui_relation else "entity"
+            self.relation_info.setdefault(name, {"name": name, "entity_head": head, "entity_tail": "entity"})
+        self.metapaths = [[(n[0], n[1]) for n in mp] for mp in self.raw_metapaths]
+        self.model = SymbolicNetwork(self.relation_info, self.embedding_size, self.deep_module, self.use_dropout)
+        self.rng = np.random.default_rng()
+        self._vocab = {"user": self.n_users, "entity": self.n_entities}
+        self._bit_words = (max(self.n_users, self.n_entities) + 31) // 32
+
+    # ------------------------------------------------------------------------------------------------
+    def _module(self, relation):
+        return getattr(self.model, relation)
+
+    def _excluded_bits(self, users_np, exclude):
+        """Bitset [B, words] of the ids excluded at leaves: the user's train positives without the 0 padding for the
+        executor (cafe.py:421-422), nothing for infer_with_path -- there the reference subtracts a torch tensor from a
+        set of ints (cafe.py:606-607), which removes nothing because tensor elements hash by identity."""
+        bits = np.zeros((len(users_np), self._bit_words), np.uint32)
+        for i, u in enumerate(users_np):
+            if not exclude:
+                break
+            pos = self.positives[int(u)]
+            pos = pos[pos != 0]
+            pos = pos[(pos >= 0) & (pos < self._bit_words * 32)]
+            np.bitwise_or.at(bits[i], pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
+        return torch.from_numpy(bits.view(np.int32)).to(self.user_embedding.device)
+
+    @torch.no_grad()
+    def _run_programs(self, users, programs, ks, grow_excluded, exclude):
+        """programs[b] = list of (parent index, relation name) in execution order for user b; ks[b][i] = k of node i.
+        Returns per user a list of (count, ids [count, depth], vals [count, depth]) per node."""
+        dev = self.user_embedding.device
+        users_np = users.cpu().numpy()
+        B = len(users_np)
+        # 1) node vectors, level by level, batched by relation across users
+        vecs = [[None] * len(p) for p in programs]
+        user_vec = self.user_embedding[users.to(dev)]
+        depth_of = [[0] * len(p) for p in programs]
+        max_depth = 0
+        for b, prog in enumerate(programs):
+            for i, (par, _) in enumerate(prog):
+                depth_of[b][i] = 1 if par < 0 else depth_of[b][par] + 1
+                max_depth = max(max_depth, depth_of[b][i])
+        for dep in range(1, max_depth + 1):
+            by_rel = {}
+            for b, prog in enumerate(programs):
+                for i, (par, rel) in enumerate(prog):
+                    if depth_of[b][i] == dep:
+                        by_rel.setdefault(rel, []).append((b, i, par))
+            for rel, lst in by_rel.items():
+                eh = torch.stack([user_vec[b] if par < 0 else vecs[b][par] for b, i, par in lst])
+                uv = torch.stack([user_vec[b] for b, i, par in lst])
+                out = self._module(rel)((eh, uv)).view(len(lst), -1)
+                for j, (b, i, par) in enumerate(lst):
+                    vecs[b][i] = out[j]
+        # 2) log-probabilities of every node over its tail vocabulary: one GEMM per entity type + row log_softmax
+        rows = [(b, i) for b, prog in enumerate(programs) for i in range(len(prog))]
+        width = max(self.n_users, self.n_entities)
+        lp = torch.empty((max(len(rows), 1), width), dtype=torch.float32, device=dev)
+        row_of = {}
+        by_type = {}
+        for r, (b, i) in enumerate(rows):
+            row_of[(b, i)] = r
+            by_type.setdefault(self._module(programs[b][i][1]).et_name, []).append(r)
+        for et, rs in by_type.items():
+            idx = torch.tensor(rs, device=dev)
+            v = torch.stack([vecs[rows[r][0]][rows[r][1]] for r in rs]).contiguous()
+            sc = ops.gemm(v, self.embeddings[et])  # [n, d] @ E^T
+            lp[idx, : self._vocab[et]] = P.log_softmax_rows(sc)
+        # 3) interpret
+        nodes = np.zeros(len(rows), P.CAFE_NODE_DTYPE)
+        node_ptr, slot_ptr = [0], [0]
+        r = 0
+        for b, prog in enumerate(programs):
+            caps, off = [], 0
+            for i, (par, rel) in enumerate(prog):
+                mod = self._module(rel)
+                k = int(ks[b][i])
+                cap = (1 if par < 0 else caps[par]) * k
+                caps.append(cap)
+                leaf = not any(pp == i for pp, _ in prog)
+                nodes[r] = (par, self.relation2rid[rel], int(mod.eh_name == "entity"), k, int(leaf), row_of[(b, i)],
+                            depth_of[b][i], self._vocab[mod.et_name], cap, off)
+                off += cap
+                r += 1
+            node_ptr.append(r)
+            slot_ptr.append(slot_ptr[-1] + off)
+        excl = self._excluded_bits(users_np, exclude)
+        ids, vals, counts = P.cafe_execute(self.graph, nodes, node_ptr, users.to(dev, torch.int64).contiguous(), lp, excl,
+                                           grow_excluded, slot_ptr, slot_ptr[-1])
+        ids, vals, counts = ids.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
+        out = []
+        for b, prog in enumerate(programs):
+            per = []
+            for i in range(len(prog)):
+                nd = nodes[node_ptr[b] + i]
+                s0 = slot_ptr[b] + nd["slot_off"]
+                c, dep = int(counts[node_ptr[b] + i]), int(nd["depth"])
+                per.append((c, ids[s0 : s0 + c, :dep], vals[s0 : s0 + c, :dep]))
+            out.append(per)
+        return out
+
+    # -- SymbolicNetwork.infer_with_path for every (user, metapath) ------------------------------------------
+    def _infer_paths(self, users, kg_mask=None):
+        users = torch.as_tensor(users)
+        users_np = users.cpu().numpy()
+        sample_sizes = [self.topk_paths, 5, 1]
+        predictions = {int(u): {} for u in users_np}
+        # one task per (user, metapath): a chain program
+        task_users, programs, ks, owner = [], [], [], []
+        for u in users_np:
+            for mpid, mp in enumerate(self.metapaths):
+                task_users.append(int(u))
+                programs.append([(i - 1, mp[i + 1][0]) for i in range(len(mp) - 1)])
+                ks.append([sample_sizes[i] for i in range(len(mp) - 1)])
+                owner.append((int(u), mpid))
+        res = self._run_programs(torch.tensor(task_users), programs, ks, grow_excluded=False, exclude=False)
+        for (u, mpid), per in zip(owner, res):
+            if any(c == 0 for c, _, _ in per):  # an empty level aborts the whole metapath (cafe.py:586, :638-639)
+                predictions[u][mpid] = []
+                continue
+            c, ids, vals = per[-1]
+            predictions[u][mpid] = [([u] + [int(x) for x in ids[j]], [np.float32(x) for x in vals[j]]) for j in range(c)]
+        return predictions
+
+    def _estimate_path_count(self, users):
+        """Only feeds sample sizes that execute() ignores (adaptive_topk=False, cafe.py:790); kept for API parity as a
+        uniform count."""
+        return {int(u): np.zeros(len(self.metapaths)) for u in torch.as_tensor(users).cpu().numpy()}
+
+    # -- MetaProgramExecutor.execute + collect_results + run_program ----------------------------------------------
+    def _bfs_program(self):
+        """Nodes of the layout tree in the executor's BFS order (children of a node visited in self.rng.permutation
+        order, cafe.py:807-808) as (parent index, relation), plus per-node relation / entity chains for the output."""
+        root = build_layout(self.metapaths)
+        order, index = [], {}
+        queue = [(c, -1) for c in root.get_children()]
+        while queue:
+            node, par = queue.pop(0)
+            index[id(node)] = len(order)
+            order.append((par, node.relation, node))
+            kids = node.get_children()
+            kids = [kids[j] for j in self.rng.permutation(len(kids))] if len(kids) > 1 else kids
+            queue.extend((k, index[id(node)]) for k in kids)
+        return order
+
+    def _leaf_chains(self):
+        """Relation chains of the leaves in collect_results order: plain BFS over the layout tree (cafe.py:859-867)."""
+        root = build_layout(self.metapaths)
+        leaves, queue = [], root.get_children()
+        while queue:
+            node = queue.pop(0)
+            queue.extend(node.get_children())
+            if not node.has_children():
+                chain, n = [], node
+                while n.parent is not None:
+                    chain.append(n.relation)
+                    n = n.parent
+                leaves.append(tuple(reversed(chain)))
+        return leaves
+
+    def run_program(self, users, path_counts=None, predicted_paths=None, manual_topk=5):
+        """(scores [B, n_items], [[user, item, score, path], ...]) -- cafe.py:406-447.  Paths carry relation NAMES."""
+        users = torch.as_tensor(users)
+        users_np = users.cpu().numpy()
+        orders = [self._bfs_program() for _ in users_np]
+        programs = [[(par, rel) for par, rel, _ in o] for o in orders]
+        ks = [[manual_topk] * len(o) for o in orders]
+        res = self._run_programs(users, programs, ks, grow_excluded=True, exclude=True)
+        leaves = self._leaf_chains()
+        results = torch.full((len(users_np), self.n_items), -torch.inf)
+        collected = []
+        for b, (u, order, per) in enumerate(zip(users_np, orders, res)):
+            u = int(u)
+            index_of_chain = {_chain_of(order, i): i for i in range(len(order))}
+            tmp, inst = [], {}
+            for chain in leaves:
+                c, ids, vals = per[index_of_chain[chain]]
+                for j in range(c):
+                    score = np.float32(vals[j][0])
+                    for x in vals[j][1:]:
+                        score = np.float32(score * np.float32(x))  # reduce(mul) over np.float32 (cafe.py:425)
+                    item = int(ids[j][-1])
+                    tmp.append((item, score))
+                    path = [("self_loop", "user", u)]
+                    for jj, rel in enumerate(chain):
+                        path.append((rel, self._module(rel).et_name, int(ids[j][jj])))
+                    inst[item] = path  # a later path to the same item replaces the earlier one (cafe.py:433)
+            for item, score in sorted(tmp, key=lambda x: x[1], reverse=True):
+                if item < self.n_items and results[b, item] < score:
+                    results[b, item] = float(score)
+                    collected.append([u, item, score, inst[item]])
+        return results, collected
+
+    def full_sort_predict(self, interaction):
+        scores, paths = self.run_program(interaction[self.USER_ID])
+        # convert_path_relations (cafe.py:341-348): relation names -> ids
+        paths = [[u, i, sc, [p[0]] + [(self.relation2rid[r], t, e) for r, t, e in p[1:]]] for u, i, sc, p in paths]
+        return scores, paths
+
+    def explain(self, interaction):
+        scores, explanations = self.run_program(interaction[self.USER_ID])
+        for e in explanations:
+            e[-1] = self.decode_path(e[-1])
+        return scores, explanations
+
+    def decode_path(self, path):
+        return path
+
+    def predict(self, interaction):
+        return
+
+    def calculate_loss(self, interaction):
+        raise NotImplementedError("CAFE training is not built yet (SURVEY.md §8(f)3); load a trained checkpoint")
+
+
+def _chain_of(order, i):
+    """Relation chain (root -> node) of node i of a BFS-ordered program."""
+    chain = []
+    while i >= 0:
+        par, rel, _ = order[i]
+        chain.append(rel)
+        i = par
+    return tuple(reversed(chain))

@@ -401,7 +401,7 @@ def scatter_add_rows_(table, idx, src):
 # ------------------------------------------------------------------------------------------------
 def gemm(a, b, a_k_contiguous=True, b_k_contiguous=True, bias=None, elu=False, out=None, m_rows=None,
          drop_mask=None, drop_mode=0, seed=0, offset=0):
-    """out[M, N] = f(op(a) @ op(b) + bias).
+    """out[M, N] = f(op(a) @ op(b) + bias);  elu: False / True (ELU) / "relu".
 
     a: [M, K] (a_k_contiguous) or [K, M] (stored transposed); b: [N, K] (b_k_contiguous, nn.Linear layout) or [K, N].
     Rows may be strided (leading dimension = stride(0)); the inner dimension must have unit stride."""
@@ -423,7 +423,7 @@ def gemm(a, b, a_k_contiguous=True, b_k_contiguous=True, bias=None, elu=False, o
         ws = torch.empty(ws_n, dtype=torch.float32, device=a.device)
     check(
         lib.hw_gemm_f32(_ptr(a), a.stride(0), int(a_k_contiguous), _ptr(b), b.stride(0), int(b_k_contiguous), _ptr(out),
-                        out.stride(0), _ptr(m_rows), M, N, K, _ptr(bias), int(bool(elu)), _ptr(drop_mask),
+                        out.stride(0), _ptr(m_rows), M, N, K, _ptr(bias), (2 if elu == "relu" else int(bool(elu))), _ptr(drop_mask),
                         int(drop_mode), C.c_uint64(seed), C.c_uint64(offset), _ptr(ws), ws_n, _stream()),
         "hw_gemm_f32",
     )

@@ -19,14 +19,20 @@ ACT_LDS_KEYS = 4096
 class DeviceCKG:
     """The collaborative KG as one device CSR (rows sorted by (relation, dst), multiplicity kept)."""
 
-    def __init__(self, n_users, n_items, n_entities, ui_relation, inter_users, inter_items, heads, rels, tails, device):
+    def __init__(self, n_users, n_items, n_entities, ui_relation, inter_users, inter_items, heads, rels, tails, device,
+                 ui_bidirectional=True):
         iu, ii = np.asarray(inter_users, np.int64), np.asarray(inter_items, np.int64)
         h, r, t = np.asarray(heads, np.int64), np.asarray(rels, np.int64), np.asarray(tails, np.int64)
         ui = np.full(len(iu), int(ui_relation), np.int64)
         # gid: users [0, n_users), entities [n_users, n_users + n_entities)
-        src = np.concatenate([iu, n_users + ii, n_users + h, n_users + t])
-        rel = np.concatenate([ui, ui, r, r])
-        dst = np.concatenate([ii, iu, t, h])
+        if ui_bidirectional:
+            src = np.concatenate([iu, n_users + ii, n_users + h, n_users + t])
+            rel = np.concatenate([ui, ui, r, r])
+            dst = np.concatenate([ii, iu, t, h])
+        else:  # CAFE's graph: ckg_dict_graph(ui_bidirectional=False) has no item -> user edges (cafe.py:86)
+            src = np.concatenate([iu, n_users + h, n_users + t])
+            rel = np.concatenate([ui, r, r])
+            dst = np.concatenate([ii, t, h])
         order = np.lexsort((dst, rel, src))
         src, rel, dst = src[order], rel[order], dst[order]
         n = int(n_users) + int(n_entities)
@@ -142,3 +148,39 @@ def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_lea
         "hw_pgpr_collect",
     )
     return results, dict(item=sel_item, score=sel_score, leaf=sel_leaf, count=sel_count, row=sel_row)
+
+
+def log_softmax_rows(x, n_cols=None, out=None):
+    lib = _lib.load()
+    x = _dev(x, torch.float32, "x")
+    n_cols = x.shape[1] if n_cols is None else n_cols
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.hw_log_softmax_rows(_ptr(x), x.stride(0), x.shape[0], int(n_cols), _ptr(out), out.stride(0), _stream()),
+          "hw_log_softmax_rows")
+    return out
+
+
+def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, grow_excluded, slot_ptr_np, n_slots):
+    """Run the program interpreter.  nodes_np: structured array of CafeNode fields; returns (ids [n_slots, 3] int32,
+    vals [n_slots, 3] float32, counts [n_nodes] int32) on the device."""
+    lib = _lib.load()
+    dev = users.device
+    nodes = torch.from_numpy(nodes_np.view(np.int32).reshape(-1, 10).copy()).to(dev)
+    node_ptr = torch.from_numpy(np.asarray(node_ptr_np, np.int32)).to(dev)
+    slot_ptr = torch.from_numpy(np.asarray(slot_ptr_np, np.int64)).to(dev)
+    ids = torch.zeros((max(n_slots, 1), 3), dtype=torch.int32, device=dev)
+    vals = torch.zeros((max(n_slots, 1), 3), dtype=torch.float32, device=dev)
+    counts = torch.zeros(max(len(nodes_np), 1), dtype=torch.int32, device=dev)
+    max_nodes = int(np.diff(node_ptr_np).max()) if len(node_ptr_np) > 1 else 0
+    check(
+        lib.hw_cafe_execute(C.byref(graph.c), _ptr(nodes), _ptr(node_ptr), _ptr(users), users.numel(), max_nodes,
+                            _ptr(logprobs), logprobs.stride(0), _ptr(excluded_bits), excluded_bits.shape[1],
+                            int(bool(grow_excluded)), _ptr(ids), _ptr(vals), _ptr(counts), _ptr(slot_ptr), _stream()),
+        "hw_cafe_execute",
+    )
+    return ids, vals, counts
+
+
+CAFE_NODE_DTYPE = np.dtype([(n, np.int32) for n in
+                            ("parent", "rel", "eh_is_entity", "k", "is_leaf", "lp_row", "depth", "vocab", "cap", "slot_off")])

@@ -194,7 +194,8 @@ int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias,
  * a_k_contiguous, else stored transposed [k, m]; b is [n, k] row-major (nn.Linear weight) when b_k_contiguous, else
  * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187).
  * workspace (nullable, workspace_floats >= 2 * m_max * n to be useful) enables deterministic split-K for
- * long-K / small-output products (partial slabs summed in fixed order). */
+ * long-K / small-output products (partial slabs summed in fixed order).  `elu` selects the activation:
+ * 0 none, 1 ELU, 2 ReLU. */
 int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, const float* b, int64_t ldb,
                 int32_t b_k_contiguous, float* c, int64_t ldc, const int32_t* m_rows, int64_t m_max,
                 int64_t n, int64_t k, const float* bias, int32_t elu, const float* drop_mask,
@@ -255,6 +256,36 @@ int hw_gather_rows(const float* table, int64_t n_table_rows, int32_t dim, const 
                    float* out, int32_t* oob_counter, void* stream);
 int hw_scatter_add_rows(float* table, int64_t n_table_rows, int32_t dim, const int64_t* idx, int64_t n,
                         const float* src, void* stream);
+
+/* ---- CAFE inference (model/knowledge_aware_recommender/cafe.py) ----------------------------------------------
+ * y[r, :] = log_softmax(x[r, :]) (cafe.py:597-598, :819-820). */
+int hw_log_softmax_rows(const float* x, int64_t ld, int64_t n_rows, int64_t n_cols, float* y, int64_t ldy,
+                        void* stream);
+
+/* One node of a user's reasoning program, in execution order (the chain of a metapath for
+ * SymbolicNetwork.infer_with_path :587-642, the BFS order of the layout tree for MetaProgramExecutor.execute :790-857). */
+typedef struct {
+    int32_t parent;        /* index (within the task) of the node whose paths are extended; -1 = the user root */
+    int32_t rel;           /* relation id followed */
+    int32_t eh_is_entity;  /* type the parent's tail id is looked up as: the relation's head type (0 user, 1 entity) */
+    int32_t k;             /* children kept per parent path */
+    int32_t is_leaf;       /* drop excluded ids here (and add the picks to the exclusion set when grow_excluded) */
+    int32_t lp_row;        /* row of `logprobs` holding this node's log-probabilities over its tail vocabulary */
+    int32_t depth;         /* 1-based: number of ids after the user once this node has appended its pick */
+    int32_t vocab;         /* size of the tail vocabulary (ids >= vocab are ignored) */
+    int32_t cap;           /* capacity (paths) of this node's output slots */
+    int32_t slot_off;      /* first output slot of this node, relative to the task's slot_ptr */
+} hw_cafe_node;
+
+/* Interpret every task's program: for each node in order and each parent path in order, candidates = distinct
+ * neighbours of the path's tail under node.rel, minus ids already picked at this node, minus (leaves) the excluded
+ * set; keep the top-k by logprobs[node.lp_row] (value desc, id asc); append.  Outputs per slot: 3 ids (after the
+ * user) and 3 log-probs; out_count[node] paths per node.  excluded_init: bitset [n_tasks, bit_words]. */
+int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
+                    const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task,
+                    const float* logprobs, int64_t logprob_ld, const uint32_t* excluded_init,
+                    int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
+                    int32_t* out_count, const int64_t* slot_ptr, void* stream);
 
 const char* hw_version(void);
 

@@ -29,7 +29,8 @@ class CKG:
     UI relation, every KG triple in both directions under the SAME relation id.  Stored as two CSRs whose
     rows are sorted by (relation, neighbour) -- the order PGPR puts un-trimmed actions in (pgpr.py:259)."""
 
-    def __init__(self, n_users, n_entities, ui_relation, inter_users, inter_items, heads, rels, tails):
+    def __init__(self, n_users, n_entities, ui_relation, inter_users, inter_items, heads, rels, tails,
+                 ui_bidirectional=True):
         self.n_users, self.n_entities, self.ui_relation = int(n_users), int(n_entities), int(ui_relation)
         iu, ii = np.asarray(inter_users, np.int64), np.asarray(inter_items, np.int64)
         h, r, t = np.asarray(heads, np.int64), np.asarray(rels, np.int64), np.asarray(tails, np.int64)
@@ -38,10 +39,14 @@ class CKG:
         # user rows: (user) -[ui]-> item, appended in interaction order
         self.user_ptr, self.user_rel, self.user_dst, self.user_ins = self._csr(iu, ui, ii, np.arange(nx), n_users)
         # entity rows: item -[ui]-> user (interaction k at sequence k); triple k appends h->t then t->h
-        src = np.concatenate([ii, h, t])
-        rel = np.concatenate([ui, r, r])
-        dst = np.concatenate([iu, t, h])
-        seq = np.concatenate([np.arange(nx), nx + 2 * np.arange(nt), nx + 2 * np.arange(nt) + 1])
+        if ui_bidirectional:
+            src = np.concatenate([ii, h, t])
+            rel = np.concatenate([ui, r, r])
+            dst = np.concatenate([iu, t, h])
+            seq = np.concatenate([np.arange(nx), nx + 2 * np.arange(nt), nx + 2 * np.arange(nt) + 1])
+        else:  # CAFE: dataset.ckg_dict_graph(ui_bidirectional=False), cafe.py:86
+            src, rel, dst = np.concatenate([h, t]), np.concatenate([r, r]), np.concatenate([t, h])
+            seq = np.concatenate([2 * np.arange(nt), 2 * np.arange(nt) + 1])
         self.ent_ptr, self.ent_rel, self.ent_dst, self.ent_ins = self._csr(src, rel, dst, seq, n_entities)
 
     @staticmethod

@@ -292,6 +292,91 @@ def gen_tucker(out_dir):
         print("tucker", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks))
 
 
+def gen_cafe(out_dir):
+    """CAFE inference on the reference fixture: module outputs, infer_with_path for every (user, metapath), executor +
+    run_program with the child permutation patched to the identity, eval mode."""
+    import pickle
+
+    from hopwise.config import Config
+    from hopwise.data import create_dataset, data_preparation
+    from hopwise.model.knowledge_aware_recommender.cafe import KGMask
+    from hopwise.utils import get_model, init_seed
+
+    os.makedirs("/tmp/scratch", exist_ok=True)
+    os.chdir("/tmp/scratch")
+    config = Config(model="CAFE", dataset="test", config_file_list=["/root/reference/tests/model/test_model.yaml"],
+                    config_dict={"data_path": "/root/reference/tests/test_data/", "user_inter_num_interval": [1, 10],
+                                 "device": "cpu", "checkpoint_dir": "/tmp/scratch/saved"})
+    init_seed(config["seed"], config["reproducibility"])
+    dataset = create_dataset(config)
+    train_data, valid_data, test_data = data_preparation(config, dataset)
+    ds = train_data._dataset
+    model = get_model("CAFE")(config, ds).to("cpu")
+    torch.manual_seed(77)
+    with torch.no_grad():  # non-trivial BatchNorm statistics
+        for m in model.model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 2.0)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    model.eval()
+
+    class IdentityRng:
+        def permutation(self, x):
+            return list(x) if not isinstance(x, (int, np.integer)) else np.arange(x)
+
+        def __getattr__(self, k):
+            return getattr(np.random.default_rng(0), k)
+
+    model.rng = IdentityRng()
+    out = {}
+    used = sorted({r for mp in model.metapaths for r, _ in mp[1:]})
+    for k, v in model.state_dict().items():
+        if any(k.startswith(f"model.{r}.") for r in used) and "num_batches" not in k:
+            out[f"p.{k}"] = v.numpy().copy()
+    out["relation_names"] = np.array([str(model.rid2relation[i]) for i in range(len(model.rid2relation))])
+    out["metapaths"] = np.array([[str(r) for r, _ in mp[1:]] for mp in model.metapaths])
+    out["inter_users"] = ds.inter_feat[ds.uid_field].numpy().astype(np.int64)
+    out["inter_items"] = ds.inter_feat[ds.iid_field].numpy().astype(np.int64)
+    out["heads"] = np.asarray(ds.head_entities).astype(np.int32)
+    out["rels"] = np.asarray(ds.relations).astype(np.int32)
+    out["tails"] = np.asarray(ds.tail_entities).astype(np.int32)
+    out["n_users"], out["n_items"], out["n_entities"] = np.int64(ds.user_num), np.int64(ds.item_num), np.int64(ds.entity_num)
+    out["ui_relation"] = np.int64(model.ui_relation_id)
+    out["user_emb"], out["entity_emb"] = model.user_embedding.numpy(), model.entity_embedding.numpy()
+    out["positives"] = model.positives.numpy().astype(np.int64)
+    out["topk_paths"] = np.int64(model.topk_paths)
+    active = np.unique(out["inter_users"])
+    users = torch.from_numpy(np.concatenate([active[:10], [0]]).astype(np.int64))
+    out["users"] = users.numpy()
+    kgm = KGMask(model.graph_dict, model.ui_relation_id)
+    with torch.no_grad():
+        # module outputs for a few (relation, input) pairs
+        uv = model.user_embedding[users]
+        ev = model.entity_embedding[torch.arange(3, 3 + len(users))]
+        for r in used[:6]:
+            out[f"mod.{r}"] = getattr(model.model, r)((ev, uv)).numpy()
+        out["mod.inputs_e"], out["mod.inputs_u"] = ev.numpy(), uv.numpy()
+        infer = {}
+        for u in users.tolist():
+            for mpid, mp in enumerate(model.metapaths):
+                res = model.model.infer_with_path(mp, u, kgm, excluded_pids=model.positives[u], topk_paths=model.topk_paths)
+                infer[(u, mpid)] = ([list(map(int, p)) for p, _ in res], [[float(x) for x in v] for _, v in res])
+        scores, collected = model.run_program(users, model._estimate_path_count(users), model._infer_paths(users, kgm))
+    out["infer.keys"] = np.array([[u, m] for (u, m) in infer], np.int64)
+    out["infer.off"] = np.cumsum([0] + [len(v[0]) for v in infer.values()]).astype(np.int64)
+    out["infer.paths"] = np.array([p for v in infer.values() for p in v[0]], np.int64).reshape(-1, 4)
+    out["infer.vals"] = np.array([p for v in infer.values() for p in v[1]], np.float32).reshape(-1, 3)
+    out["run.scores"] = scores.numpy()
+    out["run.uis"] = np.array([[c[0], c[1]] for c in collected], np.int64).reshape(-1, 2)
+    out["run.score"] = np.array([c[2] for c in collected], np.float32)
+    out["run.path_ids"] = np.array([[n[2] for n in c[3]] for c in collected], np.int64).reshape(-1, 4)
+    out["run.path_rels"] = np.array([[str(n[0]) for n in c[3][1:]] for c in collected]).reshape(-1, 3)
+    np.savez_compressed(os.path.join(out_dir, "cafe_default.npz"), **out)
+    print("cafe", len(infer), out["infer.paths"].shape, scores.shape, len(collected))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("kge", "all"):
@@ -300,6 +385,8 @@ if __name__ == "__main__":
         gen_kge(HERE, only=what[4:].split(","))
     if what in ("sampler", "all"):
         gen_sampler(HERE)
+    if what in ("cafe", "all"):
+        gen_cafe(HERE)
     if what in ("tucker", "all"):
         gen_tucker(HERE)
     if what in ("pgpr", "all"):
