@@ -36,11 +36,20 @@ def build():
                topk_candidates=10, sample_size=500, topk_paths=int(z["topk_paths"]), max_user_trials=50,
                load_embeddings=True)
     m = CAFE(cfg, ds).to(dev())
-    sd = m.state_dict()
-    for k in z.files:
-        if k.startswith("p."):
-            sd[k[2:]] = torch.from_numpy(z[k])
-    m.load_state_dict(sd)
+    # relation names contain dots, which nn.Module.load_state_dict cannot route ("model.film.actor.film.fc1.weight"):
+    # assign tensor by tensor instead
+    rels = sorted(m.relation_info, key=len, reverse=True)
+    with torch.no_grad():
+        for k in z.files:
+            if not k.startswith("p.model."):
+                continue
+            rest = k[len("p.model."):]
+            rel = next(r for r in rels if rest.startswith(r + "."))
+            obj = m._module(rel)
+            *path, leaf = rest[len(rel) + 1:].split(".")
+            for a in path:
+                obj = getattr(obj, a)
+            getattr(obj, leaf).copy_(torch.from_numpy(z[k]))
     m.eval()
     m.rng = IdentityRng()
     return z, orc, m
