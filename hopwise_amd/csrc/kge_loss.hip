@@ -223,9 +223,15 @@ extern "C" int hw_loss_self_adversarial(const float* scores, int64_t n_groups, i
     const float inv_b = 1.0f / (float)n_groups;
     hipLaunchKernelGGL(self_adv_kernel, dim3((unsigned)((n_groups + 3) / 4)), dim3(256), 0, st, scores, n_groups,
                        (int)n_cols, alpha, inv_b, gscores, group_loss);
-    const int grid = loss_grid(n_groups);
-    hipLaunchKernelGGL(sum_partial_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, group_loss, n_groups, workspace);
-    hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_b, loss_out);
+    if (n_groups <= 65536) {
+        // few groups: one block adds the per-group losses in a fixed order (saves a launch on the step's critical path)
+        hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, group_loss, (int)n_groups, inv_b,
+                           loss_out);
+    } else {
+        const int grid = loss_grid(n_groups);
+        hipLaunchKernelGGL(sum_partial_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, group_loss, n_groups, workspace);
+        hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_b, loss_out);
+    }
     return HW_LAUNCH_RC();
 }
 

@@ -51,10 +51,18 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(
     const float* __restrict__ alias_prob, const int64_t* __restrict__ alias_keys,
     const int64_t* __restrict__ alias_alias, int64_t n_alias, uint64_t seed, uint64_t offset,
     int64_t* __restrict__ out, int64_t out_stride_key, int64_t out_stride_draw, int32_t* oob) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // e = j * n_keys + i: the reference's position
-    if (e >= total) return;
-    const int64_t o = (e % n_keys) * out_stride_key + (e / n_keys) * out_stride_draw;
-    int64_t key = keys[e % n_keys];
+    const int64_t tpos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tpos >= total) return;
+    // Thread -> (key i, draw j): follow the OUTPUT layout so that stores coalesce and, in the row-per-key layout, a wave
+    // works on one key (its used list stays in L1).  The random stream is tied to the reference position
+    // e = j * n_keys + i either way, so the values drawn do not depend on the layout or the launch geometry.
+    const int64_t num = total / n_keys;
+    const bool key_major = out_stride_draw <= out_stride_key;
+    const int64_t i = key_major ? tpos / num : tpos % n_keys;
+    const int64_t j = key_major ? tpos % num : tpos / n_keys;
+    const int64_t e = j * n_keys + i;
+    const int64_t o = i * out_stride_key + j * out_stride_draw;
+    int64_t key = keys[i];
     if (key < 0 || key >= n_key_space) {  // the reference raises ValueError (sampler.py:286-291,352-357)
         if (oob) atomicAdd(oob, 1);
         out[o] = 0;
