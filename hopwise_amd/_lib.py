@@ -76,7 +76,7 @@ SIGNATURES = {
     "hw_kge_grad_grouped": (
         C.c_int,
         [C.POINTER(KgeDesc), C.POINTER(KgeGrads), c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int64,
-         C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_void_p],
+         C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_void_p],
     ),
     "hw_loss_workspace_floats": (C.c_int64, []),
     "hw_loss_bce_logits": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),

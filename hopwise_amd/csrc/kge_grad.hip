@@ -21,11 +21,26 @@
 
 namespace hw {
 
+constexpr int REL_REPLICAS = 64;
+
+// grad_rel[k][r_fixed, :] += sum over replicas (fixed order -> the replica stage adds no run-to-run noise of its own)
+__global__ void rel_replica_reduce_kernel(const float* __restrict__ rep, int n_tables, int64_t row_len,
+                                          float* __restrict__ g0, float* __restrict__ g1, int64_t r_fixed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= row_len * n_tables) return;
+    const int k = (int)(i / row_len);
+    const int64_t c = i % row_len;
+    float s = 0.f;
+    for (int q = 0; q < REL_REPLICAS; ++q) s += rep[((size_t)q * n_tables + k) * row_len + c];
+    float* gdst = k == 0 ? g0 : g1;
+    if (gdst) gdst[(size_t)r_fixed * row_len + c] += s;
+}
+
 template <int MODEL, int NE>
 __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
     hw_kge_desc d, hw_kge_grads gr, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx,
     int64_t r_fixed, const int64_t* __restrict__ t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
-    const float* __restrict__ g, int64_t gsb, int64_t gsj) {
+    const float* __restrict__ g, int64_t gsb, int64_t gsj, float* __restrict__ rel_replicas) {
     constexpr int G = 64;
     using SC = Scorer<MODEL, G, NE, false>;
     using MT = ModelTraits<MODEL>;
@@ -42,6 +57,15 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
     SC sc;
     R hraw[2], rraw[2];
     sc.template build<true>(d, h, r, gl, hraw, rraw);
+    // Fixed relation (rec side: every group uses the [UI-Relation] row): thousands of waves adding into ONE row run
+    // an order of magnitude below the atomic rate (MI355X_MICROARCH.md 'Global float atomics', contention row), so the
+    // relation gradient goes to one of REL_REPLICAS scratch rows picked by task id and is summed afterwards.
+    const size_t rel_row_len = MODEL == HW_RESCAL ? (size_t)d.dim * d.dim : (size_t)d.dim;
+    if (rel_replicas) {
+        const size_t rep = (size_t)(task % REL_REPLICAS) * rel_row_len * MT::NR;
+        gr.rel[0] = rel_replicas + rep - (size_t)r * rel_row_len;  // so that "+ r * row_len" lands in the replica
+        if constexpr (MT::NR == 2) gr.rel[1] = rel_replicas + rep + rel_row_len - (size_t)r * rel_row_len;
+    }
 
     float GQ[MT::NQ][NE];
 #pragma unroll
@@ -164,7 +188,7 @@ using namespace hw;
 extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* grads, const int64_t* h_idx,
                                    const int64_t* r_idx, int64_t r_fixed, const int64_t* t_idx, int64_t t_stride_b,
                                    int64_t t_stride_j, int64_t n_groups, int64_t n_tail_per_group, const float* g,
-                                   int64_t g_stride_b, int64_t g_stride_j, void* stream) {
+                                   int64_t g_stride_b, int64_t g_stride_j, float* rel_workspace, void* stream) {
     if (!desc || !grads || !h_idx || !t_idx || !g) return HW_ERR_INVALID_ARG;
     if (desc->dim < 1 || desc->dim > HW_MAX_DIM || n_groups < 0 || n_tail_per_group < 0) return HW_ERR_INVALID_ARG;
     if (desc->n_head < 1 || desc->n_rel < 1 || desc->n_tail < 1) return HW_ERR_INVALID_ARG;
@@ -186,10 +210,15 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     const int NE = desc->dim <= 64 ? 1 : (desc->dim <= 256 ? 4 : 16);
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
+    // replica scratch only when the relation is fixed, has a gradient, and enough tasks collide on it
+    const int n_rel_tab = desc->model == HW_COMPLEX ? 2 : 1;
+    const int64_t rel_row_len = desc->model == HW_RESCAL ? (int64_t)desc->dim * desc->dim : desc->dim;
+    float* replicas = (!r_idx && rel_workspace && grads->rel[0] && n_tasks >= 256) ? rel_workspace : nullptr;
+    if (replicas) (void)hipMemsetAsync(replicas, 0, sizeof(float) * REL_REPLICAS * n_rel_tab * rel_row_len, st);
 #define CALL(MODEL, NE_)                                                                                           \
     hipLaunchKernelGGL((kge_grad_grouped_kernel<MODEL, NE_>), dim3((unsigned)n_blocks), dim3(256), 0, st, *desc,     \
                        *grads, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, g,          \
-                       g_stride_b, g_stride_j)
+                       g_stride_b, g_stride_j, replicas)
 #define BYNE(MODEL)                        \
     do {                                   \
         if (NE == 1) CALL(MODEL, 1);       \
@@ -206,5 +235,11 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     }
 #undef BYNE
 #undef CALL
+    if (replicas) {
+        const int64_t n = rel_row_len * n_rel_tab;
+        const int64_t rf = r_fixed < 0 ? 0 : (r_fixed >= desc->n_rel ? desc->n_rel - 1 : r_fixed);
+        hipLaunchKernelGGL(rel_replica_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, replicas,
+                           n_rel_tab, rel_row_len, grads->rel[0], grads->rel[1], rf);
+    }
     return HW_LAUNCH_RC();
 }

@@ -89,13 +89,15 @@ int hw_kge_full_sort(const hw_kge_desc* desc,
 
 /* Backward of hw_kge_score_grouped: given g[b, j] = dLoss/dscore[b, j] (same strides as `out`),
  * atomically accumulates the row gradients into `grads`.  Replaces autograd through
- * nn.Embedding + <Model>.forward (dense embedding_dense_backward in the reference). */
+ * nn.Embedding + <Model>.forward (dense embedding_dense_backward in the reference).
+ * rel_workspace (nullable): 64 * (relation tables) * (relation row length) floats; used when r_idx == NULL so that
+ * the fixed relation row is not hammered by every wave (the adds go to 64 replica rows, summed afterwards). */
 int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* grads,
                         const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
                         const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
                         int64_t n_groups, int64_t n_tail_per_group,
                         const float* g, int64_t g_stride_b, int64_t g_stride_j,
-                        void* stream);
+                        float* rel_workspace, void* stream);
 
 /* ---- losses on score vectors (deterministic two-stage reductions) ---------------------------------
  * `workspace` must hold at least hw_loss_workspace_floats() floats. */
