@@ -96,9 +96,15 @@ SIGNATURES = {
          C.c_uint64, C.c_uint64, c_i64p, C.c_int64, C.c_int64, c_i32p, C.c_void_p],
     ),
     "hw_pgpr_init_paths": (C.c_int, [c_i64p, C.c_int64, c_i32p, c_f32p, c_i32p, C.c_void_p]),
+    "hw_pgpr_rel_entity_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hw_pgpr_user_scores": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p, C.c_void_p,
+         C.c_void_p, C.c_void_p],
+    ),
     "hw_pgpr_actions": (
         C.c_int,
-        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i32p, c_i32p, C.c_int64, C.c_int32,
+        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, c_i32p, c_i32p, C.c_int64, C.c_int32,
          C.c_int32, c_i32p, c_i32p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
     ),
     "hw_pgpr_state": (

@@ -71,12 +71,11 @@ __global__ void pgpr_init_paths_kernel(const int64_t* __restrict__ users, int n,
 constexpr int ACT_LDS_KEYS = 4096;  // candidates whose select keys fit in LDS (32 KiB); larger rows use scratch
 
 __global__ __launch_bounds__(256) void pgpr_actions_kernel(
-    hw_pgpr_graph g, const double* __restrict__ U64, const double* __restrict__ E64, const double* __restrict__ R64,
-    int d, const int32_t* __restrict__ paths, const int32_t* __restrict__ n_rows_ptr, int max_acts, int fix_bug,
-    int32_t* __restrict__ acts, int32_t* __restrict__ n_acts, uint64_t* __restrict__ scratch, int64_t scratch_stride) {
+    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+    const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
+    const int32_t* __restrict__ n_rows_ptr, int max_acts, int fix_bug, int32_t* __restrict__ acts,
+    int32_t* __restrict__ n_acts, uint64_t* __restrict__ scratch, int64_t scratch_stride) {
     __shared__ uint64_t lds_keys[ACT_LDS_KEYS];
-    __shared__ double src0[HW_PGPR_MAX_DIM];  // u
-    __shared__ double src1[HW_PGPR_MAX_DIM];  // u + r_ui
     __shared__ unsigned hist[256];
     __shared__ int wsum[4];
     __shared__ int sh_bin, sh_need;
@@ -151,39 +150,28 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
             continue;
         }
         uint64_t* keys = deg <= ACT_LDS_KEYS ? lds_keys : scratch + (size_t)blockIdx.x * scratch_stride;
-        for (int k = tid; k < d; k += 256) {
-            const double u = U64[(size_t)uid * d + k];
-            src0[k] = u;
-            src1[k] = u + R64[(size_t)g.ui_relation * d + k];
-        }
-        __syncthreads();
+        // float64 score of every candidate (pgpr.py:266-281) from the per-search tables built by hw_pgpr_user_scores:
+        //   next is a user            u . U[n]                      = score_user[b, n]
+        //   next is an item           (u + r_ui) . E[n]             = score_entity[b, n]
+        //   next is another entity    (u + r_ui + r) . E[n]         = score_entity[b, n] + score_rel_entity[r, n]
+        // (b = batch index of the path's root user).  One or two 8-byte lookups per edge instead of a d-long
+        // dot product over gathered float64 rows.
         {
-            const int grp = tid >> 4, gl = tid & 15;  // 16 groups of 16 lanes, one edge per group
-            for (int base = 0; base < deg; base += 16) {
-                const int e = base + grp;
-                double acc = 0.0;
-                bool cand = false;
-                if (e < deg) {
-                    cand = is_cand(e);
-                    if (cand) {
-                        const int r = erel[e], n = edst[e];
-                        const int nt = next_type(g, cur_t, r);
-                        if (nt == T_USER) {
-                            const double* __restrict__ em = U64 + (size_t)n * d;
-                            for (int k = gl; k < d; k += 16) acc += src0[k] * em[k];
-                        } else if (n < g.n_items) {
-                            const double* __restrict__ em = E64 + (size_t)n * d;
-                            for (int k = gl; k < d; k += 16) acc += src1[k] * em[k];
-                        } else {
-                            const double* __restrict__ em = E64 + (size_t)n * d;
-                            const double* __restrict__ rr = R64 + (size_t)r * d;
-                            for (int k = gl; k < d; k += 16) acc += (src1[k] + rr[k]) * em[k];
-                        }
-                    }
+            const int b = p[PATH_INTS - 1];
+            const double* __restrict__ su = score_user + (size_t)b * g.n_users;
+            const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
+            for (int e = tid; e < deg; e += 256) {
+                uint64_t key = 0ull;
+                if (is_cand(e)) {
+                    const int r = erel[e], n = edst[e];
+                    const int nt = next_type(g, cur_t, r);
+                    double sc;
+                    if (nt == T_USER) sc = su[n];
+                    else if (n < g.n_items) sc = se[n];
+                    else sc = se[n] + score_rel_entity[(size_t)r * g.n_entities + n];
+                    key = orderable(sc);
                 }
-#pragma unroll
-                for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-                if (e < deg && gl == 0) keys[e] = cand ? orderable(acc) : 0ull;
+                keys[e] = key;
             }
         }
         __syncthreads();
@@ -288,6 +276,45 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
         }
         if (tid == 0) n_acts[row] = 1 + max_acts;
     }
+}
+
+// ---- float64 score tables for the trim --------------------------------------------------------------------
+// src[s, :] rows: 0 = U[user_s] (mode 0), U[user_s] + R[ui] (mode 1)
+__global__ void pgpr_user_src_kernel(const double* __restrict__ U64, const double* __restrict__ R64, int d,
+                                     int ui_relation, const int64_t* __restrict__ users, int n, int n_users_table,
+                                     double* __restrict__ src0, double* __restrict__ src1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    const int s = i / d, k = i % d;
+    int64_t u = users[s];
+    u = u < 0 ? 0 : (u >= n_users_table ? n_users_table - 1 : u);
+    const double v = U64[(size_t)u * d + k];
+    src0[i] = v;
+    src1[i] = v + R64[(size_t)ui_relation * d + k];
+}
+
+// out[s, n] = sum_k src[s, k] * T[n, k]   (float64, k ascending: one fixed summation order)
+constexpr int DOT_SB = 8;
+__global__ __launch_bounds__(256) void batched_dot64_kernel(const double* __restrict__ src, int n_src,
+                                                            const double* __restrict__ T, int n_rows, int d,
+                                                            double* __restrict__ out) {
+    __shared__ double sv[DOT_SB][HW_PGPR_MAX_DIM];
+    const int s0 = blockIdx.y * DOT_SB;
+    const int ns = min(DOT_SB, n_src - s0);
+    for (int i = threadIdx.x; i < ns * d; i += 256) sv[i / d][i % d] = src[(size_t)(s0 + i / d) * d + i % d];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_rows) return;
+    double acc[DOT_SB];
+#pragma unroll
+    for (int q = 0; q < DOT_SB; ++q) acc[q] = 0.0;
+    const double* __restrict__ t = T + (size_t)n * d;
+    for (int k = 0; k < d; ++k) {
+        const double tv = t[k];
+#pragma unroll
+        for (int q = 0; q < DOT_SB; ++q) acc[q] = fma(sv[q][k], tv, acc[q]);
+    }
+    for (int q = 0; q < ns; ++q) out[(size_t)(s0 + q) * n_rows + n] = acc[q];
 }
 
 // ---- A11: state ---------------------------------------------------------------------------------------
@@ -485,15 +512,54 @@ extern "C" int hw_pgpr_init_paths(const int64_t* users, int64_t n_users_in_batch
     return HW_LAUNCH_RC();
 }
 
-extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
-                               const double* relation_emb64, int32_t dim, const int32_t* paths,
-                               const int32_t* n_rows, int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug,
-                               int32_t* acts, int32_t* n_acts, uint64_t* scratch, int64_t scratch_blocks,
-                               int64_t scratch_stride, void* stream) {
+static int launch_dot64(const double* src, int64_t n_src, const double* T, int64_t n_rows, int dim, double* out,
+                        hipStream_t st) {
+    dim3 grid((unsigned)((n_rows + 255) / 256), (unsigned)((n_src + DOT_SB - 1) / DOT_SB));
+    hipLaunchKernelGGL(batched_dot64_kernel, grid, dim3(256), 0, st, src, (int)n_src, T, (int)n_rows, dim, out);
+    return HW_OK;
+}
+
+extern "C" int hw_pgpr_rel_entity_scores(const double* relation_emb64, const double* entity_emb64, int64_t n_relations,
+                                         int64_t n_entities, int32_t dim, double* out, void* stream) {
+    if (!relation_emb64 || !entity_emb64 || !out || n_relations < 1 || n_entities < 1 || dim < 1 ||
+        dim > HW_PGPR_MAX_DIM)
+        return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    launch_dot64(relation_emb64, n_relations, entity_emb64, n_entities, dim, out, (hipStream_t)stream);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_user_scores(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                                   const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                                   double* src_workspace, double* score_user, double* score_entity, void* stream) {
     int rc = check_graph(graph);
     if (rc) return rc;
-    if (!user_emb64 || !entity_emb64 || !relation_emb64 || !paths || !n_rows || !acts || !n_acts) return HW_ERR_INVALID_ARG;
-    if (dim < 1 || dim > HW_PGPR_MAX_DIM || max_acts < 1 || max_acts > 1023 || max_rows < 0) return HW_ERR_INVALID_ARG;
+    if (!user_emb64 || !entity_emb64 || !relation_emb64 || !users || !src_workspace || !score_user || !score_entity)
+        return HW_ERR_INVALID_ARG;
+    if (dim < 1 || dim > HW_PGPR_MAX_DIM || n_batch < 0 || n_batch > INT32_MAX / HW_PGPR_MAX_DIM) return HW_ERR_INVALID_ARG;
+    if (n_batch == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    double* src0 = src_workspace;
+    double* src1 = src_workspace + (size_t)n_batch * dim;
+    const int total = (int)(n_batch * dim);
+    hipLaunchKernelGGL(pgpr_user_src_kernel, dim3((total + 255) / 256), dim3(256), 0, st, user_emb64, relation_emb64, dim,
+                       graph->ui_relation, users, (int)n_batch, graph->n_users, src0, src1);
+    launch_dot64(src0, n_batch, user_emb64, graph->n_users, dim, score_user, st);
+    launch_dot64(src1, n_batch, entity_emb64, graph->n_entities, dim, score_entity, st);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_user, const double* score_entity,
+                               const double* score_rel_entity, const int32_t* paths, const int32_t* n_rows,
+                               int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug, int32_t* acts,
+                               int32_t* n_acts, uint64_t* scratch, int64_t scratch_blocks, int64_t scratch_stride,
+                               void* stream) {
+    int rc = check_graph(graph);
+    if (rc) return rc;
+    if (!score_user || !score_entity || !score_rel_entity || !paths || !n_rows || !acts || !n_acts)
+        return HW_ERR_INVALID_ARG;
+    if (max_acts < 1 || max_acts > 1023 || max_rows < 0) return HW_ERR_INVALID_ARG;
     if (max_rows == 0) return HW_OK;
     // every block that may meet a row with more than ACT_LDS_KEYS neighbours needs a private scratch slice
     int64_t grid = max_rows < 2048 ? max_rows : 2048;
@@ -505,8 +571,8 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* user_em
         scratch_stride = 0;
     }
     HW_CLEAR_ERR();
-    hipLaunchKernelGGL(pgpr_actions_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph, user_emb64,
-                       entity_emb64, relation_emb64, dim, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
+    hipLaunchKernelGGL(pgpr_actions_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph, score_user,
+                       score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
                        scratch, scratch_stride);
     return HW_LAUNCH_RC();
 }

@@ -81,6 +81,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.embedding_size = ue.shape[1]
         self._t64 = tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (ue, ee, re_))
         self._t32 = tuple(t.to(torch.float32).contiguous() for t in self._t64)
+        self._score_rel_entity = P.rel_entity_scores(self._t64[2], self._t64[1])  # R[r] . E[n], float64, once
         self.state_dim = (2 + 2 * self.state_history) * self.embedding_size
 
         self.l1 = nn.Linear(self.state_dim, self.hidden_sizes[0])
@@ -153,6 +154,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         U32, E32, R32 = self._t32
         nr = buf["n_rows"]
         P.init_paths(users, buf["paths"][0], buf["probs"][0], nr[0:1])
+        score_user, score_entity = P.user_scores(g, U64, E64, R64, users)  # float64 trim tables of this batch
         trace = []
         for hop, k in enumerate(hops):
             rmax = buf["rows"][hop]
@@ -161,8 +163,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 # the reference refreshes state_pool at the end of hops 0 and 1 only (pgpr.py:481); with at most
                 # three hops every hop sees a fresh state, which is the same thing.
                 P.state(g, U32, E32, R32, self.state_history, paths, n_rows, rmax, buf["state"])
-            P.actions(g, U64, E64, R64, paths, n_rows, rmax, self.max_acts, self.fix_scores_sorting_bug, buf["acts"],
-                      buf["n_acts"], buf["scratch"])
+            P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, rmax, self.max_acts,
+                      self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"])
             self._policy_logits(buf, n_rows, rmax, drops, hop)
             P.policy_topk(buf["logits"], self.act_dim, buf["n_acts"], n_rows, rmax, k, buf["tk_idx"], buf["tk_val"])
             P.expand(g, paths, probs, buf["acts"], self.act_dim, buf["n_acts"], n_rows, rmax, buf["tk_idx"],

@@ -60,15 +60,38 @@ def init_paths(users, paths, probs, n_rows):
           "hw_pgpr_init_paths")
 
 
-def actions(graph, U64, E64, R64, paths, n_rows, max_rows, max_acts, fix_bug, acts, n_acts, scratch=None):
+def rel_entity_scores(R64, E64):
+    """score_rel_entity[r, n] = R[r] . E[n] in float64 (once per model)."""
+    lib = _lib.load()
+    out = torch.empty((R64.shape[0], E64.shape[0]), dtype=torch.float64, device=R64.device)
+    check(lib.hw_pgpr_rel_entity_scores(_ptr(R64), _ptr(E64), R64.shape[0], E64.shape[0], R64.shape[1], _ptr(out),
+                                        _stream()), "hw_pgpr_rel_entity_scores")
+    return out
+
+
+def user_scores(graph, U64, E64, R64, users):
+    """(score_user [B, n_users], score_entity [B, n_entities]) float64 for the root users of a search batch."""
+    lib = _lib.load()
+    users = _dev(users, torch.int64, "users").contiguous()
+    B, d = users.numel(), U64.shape[1]
+    ws = torch.empty(2 * B * d, dtype=torch.float64, device=users.device)
+    su = torch.empty((B, graph.n_users), dtype=torch.float64, device=users.device)
+    se = torch.empty((B, graph.n_entities), dtype=torch.float64, device=users.device)
+    check(lib.hw_pgpr_user_scores(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), d, _ptr(users), B, _ptr(ws),
+                                  _ptr(su), _ptr(se), _stream()), "hw_pgpr_user_scores")
+    return su, se
+
+
+def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, max_rows, max_acts, fix_bug, acts, n_acts,
+            scratch=None):
     lib = _lib.load()
     sb = ss = 0
     if scratch is not None:
         sb, ss = scratch.shape
     check(
-        lib.hw_pgpr_actions(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), U64.shape[1], _ptr(paths), _ptr(n_rows),
-                            int(max_rows), int(max_acts), int(bool(fix_bug)), _ptr(acts), _ptr(n_acts), _ptr(scratch),
-                            sb, ss, _stream()),
+        lib.hw_pgpr_actions(C.byref(graph.c), _ptr(score_user), _ptr(score_entity), _ptr(score_rel_entity), _ptr(paths),
+                            _ptr(n_rows), int(max_rows), int(max_acts), int(bool(fix_bug)), _ptr(acts), _ptr(n_acts),
+                            _ptr(scratch), sb, ss, _stream()),
         "hw_pgpr_actions",
     )
 

@@ -168,14 +168,26 @@ typedef struct {
 int hw_pgpr_init_paths(const int64_t* users, int64_t n_users_in_batch, int32_t* paths, float* probs,
                        int32_t* n_rows, void* stream);
 
+/* Float64 score tables for the top-max_acts trim of _get_actions (pgpr.py:263-284).  The reference scores a
+ * candidate (r, n) of a path rooted at user u as u.U[n], (u + r_ui).E[n] or (u + r_ui + r).E[n]; these are
+ *   score_user[b, n] = U[users[b]] . U[n],  score_entity[b, n] = (U[users[b]] + R[ui]) . E[n]    (per search batch)
+ *   score_rel_entity[r, n] = R[r] . E[n]                                                          (once per model)
+ * so that a candidate costs one or two lookups.  src_workspace: 2 * n_batch * dim doubles. */
+int hw_pgpr_rel_entity_scores(const double* relation_emb64, const double* entity_emb64, int64_t n_relations,
+                              int64_t n_entities, int32_t dim, double* out, void* stream);
+int hw_pgpr_user_scores(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                        const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                        double* src_workspace, double* score_user, double* score_entity, void* stream);
+
 /* _get_actions (pgpr.py:226-290): acts[row] = [(self, cur)] + unvisited neighbours in (rel, dst) order; when
  * more than max_acts remain, the max_acts with the largest float64 score (ties: later CSR position wins),
- * re-sorted by (rel, dst) or, with fix_scores_sorting_bug, in descending score order.
+ * re-sorted by (rel, dst) or, with fix_scores_sorting_bug, in descending score order.  The row's batch index
+ * (path record int 11) selects its rows of score_user [n_batch, n_users] / score_entity [n_batch, n_entities].
  * acts: int32 [max_rows, max_acts + 1, 2]; n_acts: int32 [max_rows].
  * scratch: uint64 [scratch_blocks * scratch_stride], needed when graph->max_degree > 4096
  * (scratch_stride >= max_degree). */
-int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
-                    const double* relation_emb64, int32_t dim, const int32_t* paths, const int32_t* n_rows,
+int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_user, const double* score_entity,
+                    const double* score_rel_entity, const int32_t* paths, const int32_t* n_rows,
                     int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug,
                     int32_t* acts, int32_t* n_acts, uint64_t* scratch, int64_t scratch_blocks,
                     int64_t scratch_stride, void* stream);

@@ -53,11 +53,15 @@ def test_actions_and_state_kernels(tag):
     g, z, orc, m = build_model(tag)
     paths = prim_paths(z)
     n = len(paths)
-    rec = torch.from_numpy(paths_to_records(paths)).to(dev())
+    recs = paths_to_records(paths)
+    roots = sorted({p[0][2] for p in paths})
+    recs[:, 11] = [roots.index(p[0][2]) for p in paths]  # batch index of the root user
+    rec = torch.from_numpy(recs).to(dev())
     n_rows = torch.tensor([n], dtype=torch.int32, device=dev())
     acts = torch.full((n, m.act_dim, 2), -7, dtype=torch.int32, device=dev())
     n_acts = torch.zeros(n, dtype=torch.int32, device=dev())
-    P.actions(m.graph, *m._t64, rec, n_rows, n, m.max_acts, m.fix_scores_sorting_bug, acts, n_acts, None)
+    su, se = P.user_scores(m.graph, *m._t64, torch.tensor(roots, device=dev()))
+    P.actions(m.graph, su, se, m._score_rel_entity, rec, n_rows, n, m.max_acts, m.fix_scores_sorting_bug, acts, n_acts, None)
     st = torch.empty((n, m.state_dim), dtype=torch.float32, device=dev())
     P.state(m.graph, *m._t32, m.state_history, rec, n_rows, n, st)
     acts, n_acts, st = acts.cpu().numpy(), n_acts.cpu().numpy(), st.cpu().numpy()
