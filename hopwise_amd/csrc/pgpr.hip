@@ -422,6 +422,106 @@ __global__ __launch_bounds__(256) void policy_topk_kernel(const float* __restric
     }
 }
 
+// Fast path for act_dim <= 256 (the reference default, max_acts = 250): all 256 slots of a row live in one wave
+// (4 per lane) and are ranked by ONE bitonic sort instead of k arg-max rounds.  p + 1 lies in [1, 2], so its 23
+// mantissa bits order the values; with the 8-bit action index underneath, a 32-bit key gives exactly
+// (value desc, index asc).  p + 1 == 2 only happens for a single valid action (softmax of one logit); that row needs
+// no sort.  21 of the 36 compare-exchange steps cross lanes (4 x ds_bpermute each); the rest are register swaps.
+__device__ __forceinline__ void cmpx(uint32_t& a, uint32_t& b, bool desc) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = desc ? hi : lo;
+    b = desc ? lo : hi;
+}
+
+__global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __restrict__ logits, int ld, int act_dim,
+                                                               const int32_t* __restrict__ n_acts,
+                                                               const int32_t* __restrict__ n_rows_ptr, int k,
+                                                               int32_t* __restrict__ out_idx, float* __restrict__ out_val,
+                                                               float* __restrict__ probs_out) {
+    const int n_rows = n_rows_ptr[0];
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+        const int na = n_acts[row];
+        const float* __restrict__ lr = logits + (size_t)row * ld;
+        float x[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = lane * 4 + i;  // blocked layout: element j of the row
+            x[i] = (j < na && j < act_dim) ? lr[j] : -INFINITY;
+            mx = fmaxf(mx, x[i]);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i] = x[i] == -INFINITY ? 0.f : expf(x[i] - mx);
+            sum += x[i];
+        }
+        sum = group_sum<64>(sum);
+        uint32_t key[4];
+        bool two = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = lane * 4 + i;
+            const float pr = x[i] / sum;
+            if (probs_out && j < act_dim) probs_out[(size_t)row * act_dim + j] = j < na ? pr : 0.f;
+            const uint32_t bits = __float_as_uint(pr + 1.0f);  // [1, 2]: 0x3F800000 .. 0x40000000
+            const bool valid = j < na && j < act_dim;
+            // p + 1 rounds to exactly 2.0 when p >= 1 - 2^-25; such a row cannot also hold 1.99999988 (the
+            // probabilities sum to 1), so 2.0 shares the top mantissa code and a row flag tells them apart
+            two |= valid && bits >= 0x40000000u;
+            const uint32_t mant = bits >= 0x40000000u ? 0x7FFFFFu : (bits & 0x7FFFFFu);
+            key[i] = valid ? ((mant << 8) | (uint32_t)(255 - j)) + 0x80000000u : 0u;
+        }
+        const bool row_has_two = __any(two);
+        // bitonic sort, descending overall: element index e = lane * 4 + i
+#pragma unroll
+        for (int size = 2; size <= 256; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                if (stride >= 4) {
+                    const int lm = stride >> 2;  // partner lane = lane ^ lm, same register
+                    const bool upper = (lane & lm) != 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = lane * 4 + i;
+                        const bool desc = (e & size) == 0;  // blocks alternate direction; final pass (size 256) is all desc
+                        const uint32_t o = __shfl_xor(key[i], lm, 64);
+                        const bool take_max = desc ? !upper : upper;
+                        key[i] = take_max ? (key[i] > o ? key[i] : o) : (key[i] < o ? key[i] : o);
+                    }
+                } else {
+                    // partners inside the lane: registers i and i ^ stride
+                    const int e0 = lane * 4;
+                    if (stride == 2) {
+                        cmpx(key[0], key[2], ((e0 + 0) & size) == 0);
+                        cmpx(key[1], key[3], ((e0 + 1) & size) == 0);
+                    } else {
+                        cmpx(key[0], key[1], ((e0 + 0) & size) == 0);
+                        cmpx(key[2], key[3], ((e0 + 2) & size) == 0);
+                    }
+                }
+            }
+        }
+        // ranks 4*lane .. 4*lane+3 are in key[0..3]; emit the first k
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rnk = lane * 4 + i;
+            if (rnk < k) {
+                const uint32_t kk = key[i];
+                const bool ok = kk != 0u;
+                const int idx = 255 - (int)(kk & 0xFFu);
+                const uint32_t mant = (kk & 0x7FFFFFFFu) >> 8;
+                const float v = (row_has_two && mant == 0x7FFFFFu) ? 2.0f : __uint_as_float(0x3F800000u | mant);
+                out_idx[(size_t)row * k + rnk] = ok ? idx : -1;
+                out_val[(size_t)row * k + rnk] = ok ? v : 0.f;
+            }
+        }
+    }
+}
+
 // ---- A13: expand -----------------------------------------------------------------------------------------
 // n_child[row] = min(k, n_acts[row]); exclusive scan (single block) -> child offsets + next row count.
 __global__ __launch_bounds__(1024) void pgpr_child_offsets_kernel(const int32_t* __restrict__ n_acts,
@@ -605,7 +705,10 @@ extern "C" int hw_pgpr_policy_topk(const float* logits, int64_t ld, int32_t act_
     if (grid > 16384) grid = 16384;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
-    if (act_dim <= 256)
+    if (act_dim <= 256 && k > 8)
+        hipLaunchKernelGGL(policy_topk_sort_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim, n_acts,
+                           n_rows, k, out_idx, out_val, probs_out);
+    else if (act_dim <= 256)
         hipLaunchKernelGGL((policy_topk_kernel<4>), dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim,
                            n_acts, n_rows, k, out_idx, out_val, probs_out);
     else

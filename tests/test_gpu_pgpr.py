@@ -97,22 +97,22 @@ def test_policy_forward_kernels(tag):
                    logits=torch.empty(n, m.act_dim, device=dev()))
         drops = None if d1 is None else [(torch.from_numpy(d1).to(dev()), torch.from_numpy(d2).to(dev()))]
         m._policy_logits(buf, n_rows, n, drops, 0)
-        k = min(5, m.act_dim)
-        idx = torch.empty((n, k), dtype=torch.int32, device=dev())
-        val = torch.empty((n, k), dtype=torch.float32, device=dev())
-        probs = torch.empty((n, m.act_dim), dtype=torch.float32, device=dev())
-        P.policy_topk(buf["logits"], m.act_dim, n_acts, n_rows, n, k, idx, val, probs)
-        np.testing.assert_allclose(probs.cpu().numpy(), want, rtol=1e-4, atol=1e-7)
-        # top-k of the kernel == top-k of its own probs under (value desc, index asc), on p + 1
-        pp = probs.cpu().numpy()
-        na = n_acts.cpu().numpy()
-        key = np.where(np.arange(m.act_dim)[None, :] < na[:, None], pp + np.float32(1.0), np.float32(0.0))
-        order = np.lexsort((np.broadcast_to(np.arange(m.act_dim), key.shape), -key.astype(np.float64)), axis=1)[:, :k]
-        gi = idx.cpu().numpy()
-        for r in range(n):
-            kk = min(k, na[r])
-            assert list(gi[r, :kk]) == list(order[r, :kk]) and all(gi[r, kk:] == -1)
-            np.testing.assert_array_equal(val.cpu().numpy()[r, :kk], key[r, order[r, :kk]])
+        for k in sorted({min(5, m.act_dim), min(21, m.act_dim), min(64, m.act_dim), m.act_dim}):  # arg-max and sort kernels
+            idx = torch.empty((n, k), dtype=torch.int32, device=dev())
+            val = torch.empty((n, k), dtype=torch.float32, device=dev())
+            probs = torch.empty((n, m.act_dim), dtype=torch.float32, device=dev())
+            P.policy_topk(buf["logits"], m.act_dim, n_acts, n_rows, n, k, idx, val, probs)
+            np.testing.assert_allclose(probs.cpu().numpy(), want, rtol=1e-4, atol=1e-7)
+            # top-k of the kernel == top-k of its own probs under (value desc, index asc), on p + 1
+            pp = probs.cpu().numpy()
+            na = n_acts.cpu().numpy()
+            key = np.where(np.arange(m.act_dim)[None, :] < na[:, None], pp + np.float32(1.0), np.float32(0.0))
+            order = np.lexsort((np.broadcast_to(np.arange(m.act_dim), key.shape), -key.astype(np.float64)), axis=1)[:, :k]
+            gi = idx.cpu().numpy()
+            for r in range(n):
+                kk = min(k, na[r])
+                assert list(gi[r, :kk]) == list(order[r, :kk]) and all(gi[r, kk:] == -1), (k, r)
+                np.testing.assert_array_equal(val.cpu().numpy()[r, :kk], key[r, order[r, :kk]])
 
 
 def safe_leaves(orc, users, hops, tol=2e-6):
@@ -265,3 +265,31 @@ def test_gemm_all_layouts_vs_fp64():
     y.backward(g)
     np.testing.assert_allclose(x.grad.cpu().numpy(), (g.double() @ w.detach().double()).cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(w.grad.cpu().numpy(), (g.double().t() @ x.detach().double()).cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_policy_topk_sort_edge_cases():
+    """Saturated rows (one probability rounds p + 1 to 2.0), equal logits (index-ascending ties), single action."""
+    from hopwise_amd import pgpr_ops as P
+
+    act_dim, k = 251, 64
+    logits = np.zeros((5, act_dim), np.float32)
+    logits[0, 7] = 40.0  # p[7] = 1 - tiny -> p + 1 == 2.0, everything else collapses onto 1.0
+    logits[1, :] = 0.5  # all equal
+    logits[2, :] = np.linspace(-3, 3, act_dim)
+    logits[3, 0] = 1.0
+    logits[4, :] = np.random.default_rng(0).standard_normal(act_dim)
+    na = np.array([100, 251, 251, 1, 37], np.int32)
+    lt = torch.from_numpy(logits).to(dev())
+    idx = torch.empty((5, k), dtype=torch.int32, device=dev())
+    val = torch.empty((5, k), dtype=torch.float32, device=dev())
+    probs = torch.empty((5, act_dim), dtype=torch.float32, device=dev())
+    P.policy_topk(lt, act_dim, torch.from_numpy(na).to(dev()), torch.tensor([5], dtype=torch.int32, device=dev()), 5, k,
+                  idx, val, probs)
+    pp, gi, gv = probs.cpu().numpy(), idx.cpu().numpy(), val.cpu().numpy()
+    key = np.where(np.arange(act_dim)[None, :] < na[:, None], pp + np.float32(1.0), np.float32(0.0))
+    order = np.lexsort((np.broadcast_to(np.arange(act_dim), key.shape), -key.astype(np.float64)), axis=1)[:, :k]
+    for r in range(5):
+        kk = min(k, na[r])
+        assert list(gi[r, :kk]) == list(order[r, :kk]) and all(gi[r, kk:] == -1), r
+        np.testing.assert_array_equal(gv[r, :kk], key[r, order[r, :kk]])
+    assert gv[0, 0] == 2.0 and gi[0, 0] == 7 and gv[3, 0] == 2.0
