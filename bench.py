@@ -237,7 +237,7 @@ def main():
         import bench_pgpr
 
         torch.cuda.empty_cache()
-        pg = bench_pgpr.run(dev, n_users=32, steps=args.pgpr_steps, warmup=1,
+        pg = bench_pgpr.run(dev, n_users=64, steps=args.pgpr_steps, warmup=1,
                             cpu_users=(1 if rank == 0 and world == 1 and not args.no_cpu_baseline else 0), rank=rank)
         if world > 1:
             rdev = dev if dist.get_backend() == "nccl" else "cpu"

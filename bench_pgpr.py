@@ -115,7 +115,7 @@ def run(dev, n_users=32, steps=5, warmup=1, cpu_users=0, rank=0):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--users", type=int, default=32)
+    ap.add_argument("--users", type=int, default=64)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu-users", type=int, default=0)
     a = ap.parse_args()

@@ -523,33 +523,68 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
 }
 
 // ---- A13: expand -----------------------------------------------------------------------------------------
-// n_child[row] = min(k, n_acts[row]); exclusive scan (single block) -> child offsets + next row count.
-__global__ __launch_bounds__(1024) void pgpr_child_offsets_kernel(const int32_t* __restrict__ n_acts,
+// n_child[row] = min(k, n_acts[row]); exclusive scan -> child offsets + next row count.  Three small launches:
+// per-block sums (1024 rows per block), one block scans the block sums, every block rescans its rows with its base.
+constexpr int OFF_ROWS_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void pgpr_offsets_partial_kernel(const int32_t* __restrict__ n_acts,
                                                                   const int32_t* __restrict__ n_rows_ptr, int k,
-                                                                  int32_t* __restrict__ offsets,
-                                                                  int32_t* __restrict__ n_rows_next, int64_t cap) {
-    __shared__ int part[1024];
+                                                                  int32_t* __restrict__ block_sums) {
+    __shared__ int wsum[4];
     const int n = n_rows_ptr[0];
-    const int tid = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    const int base = blockIdx.x * OFF_ROWS_PER_BLOCK;
     int s = 0;
-    for (int i = lo; i < hi; ++i) s += min(k, n_acts[i]);
-    part[tid] = s;
+    for (int i = threadIdx.x; i < OFF_ROWS_PER_BLOCK; i += 256) {
+        const int r = base + i;
+        s += r < n ? min(k, n_acts[r]) : 0;
+    }
+    int total;
+    (void)block_excl_scan(s, wsum, total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void pgpr_offsets_scan_kernel(int32_t* __restrict__ block_sums, int n_blocks,
+                                                                 int32_t* __restrict__ n_rows_next, int64_t cap) {
+    __shared__ int part[1024];
+    // n_blocks <= 1024 * 64: each thread owns a contiguous run of block sums
+    const int per = (n_blocks + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * per, n_blocks), hi = min(lo + per, n_blocks);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += block_sums[i];
+    part[threadIdx.x] = s;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
     for (int o = 1; o < 1024; o <<= 1) {
-        const int t = tid >= o ? part[tid - o] : 0;
+        const int t = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
         __syncthreads();
-        part[tid] += t;
+        part[threadIdx.x] += t;
         __syncthreads();
     }
-    int run = part[tid] - s;
+    int run = part[threadIdx.x] - s;
     for (int i = lo; i < hi; ++i) {
-        offsets[i] = run;
-        run += min(k, n_acts[i]);
+        const int v = block_sums[i];
+        block_sums[i] = run;  // exclusive base of block i
+        run += v;
     }
-    if (tid == 1023) n_rows_next[0] = (int)min((int64_t)part[1023], cap);
+    if (threadIdx.x == 1023) n_rows_next[0] = (int)min((int64_t)part[1023], cap);
+}
+
+__global__ __launch_bounds__(256) void pgpr_offsets_final_kernel(const int32_t* __restrict__ n_acts,
+                                                                const int32_t* __restrict__ n_rows_ptr, int k,
+                                                                const int32_t* __restrict__ block_base,
+                                                                int32_t* __restrict__ offsets) {
+    __shared__ int wsum[4];
+    const int n = n_rows_ptr[0];
+    const int base = blockIdx.x * OFF_ROWS_PER_BLOCK;
+    if (base >= n) return;
+    int run = block_base[blockIdx.x];
+    for (int c = 0; c < OFF_ROWS_PER_BLOCK; c += 256) {  // uniform trip count: block_excl_scan synchronises
+        const int r = base + c + threadIdx.x;
+        const int v = r < n ? min(k, n_acts[r]) : 0;
+        int total;
+        const int ex = block_excl_scan(v, wsum, total);
+        if (r < n) offsets[r] = run + ex;
+        run += total;
+    }
 }
 
 __global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const int32_t* __restrict__ paths,
@@ -571,18 +606,21 @@ __global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const
         const int64_t o = (int64_t)offsets[row] + j;
         if (o >= cap) continue;
         const int idx = topk_idx[(size_t)row * k + j];
-        const int32_t* p = paths + (size_t)row * PATH_INTS;
-        int32_t* q = paths_out + (size_t)o * PATH_INTS;
-        const int len = p[1];
-#pragma unroll
-        for (int c = 0; c < PATH_INTS; ++c) q[c] = p[c];
-        const int cur_t = len == 1 ? T_USER : p[2 + 3 * (len - 2) + 1];
+        // 48-byte record: three 16-byte loads / stores (records are 16-byte aligned: 48 = 3 x 16)
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4* __restrict__ pv = reinterpret_cast<const i32x4*>(paths + (size_t)row * PATH_INTS);
+        i32x4 rec[3] = {pv[0], pv[1], pv[2]};
+        int* f = reinterpret_cast<int*>(rec);
+        const int len = f[1];
+        const int cur_t = len == 1 ? T_USER : f[2 + 3 * (len - 2) + 1];
         const int rel = acts[((size_t)row * act_dim + idx) * 2], node = acts[((size_t)row * act_dim + idx) * 2 + 1];
         const int nt = rel == SELF_LOOP ? cur_t : next_type(g, cur_t, rel);
-        q[1] = len + 1;
-        q[2 + 3 * (len - 1)] = rel;
-        q[2 + 3 * (len - 1) + 1] = nt;
-        q[2 + 3 * (len - 1) + 2] = node;
+        f[1] = len + 1;
+        f[2 + 3 * (len - 1)] = rel;
+        f[2 + 3 * (len - 1) + 1] = nt;
+        f[2 + 3 * (len - 1) + 2] = node;
+        i32x4* __restrict__ qv = reinterpret_cast<i32x4*>(paths_out + (size_t)o * PATH_INTS);
+        qv[0] = rec[0], qv[1] = rec[1], qv[2] = rec[2];
         float* pq = probs_out + (size_t)o * 3;
         const float* pp = probs + (size_t)row * 3;
         pq[0] = pp[0], pq[1] = pp[1], pq[2] = pp[2];
@@ -720,8 +758,8 @@ extern "C" int hw_pgpr_policy_topk(const float* logits, int64_t ld, int32_t act_
 extern "C" int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float* probs,
                               const int32_t* acts, int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows,
                               int64_t max_rows, const int32_t* topk_idx, const float* topk_val, int32_t k,
-                              int32_t* offsets, int32_t* paths_out, float* probs_out, int32_t* n_rows_out,
-                              int64_t out_capacity, void* stream) {
+                              int32_t* offsets, int32_t* block_sums_ws, int32_t* paths_out, float* probs_out,
+                              int32_t* n_rows_out, int64_t out_capacity, void* stream) {
     int rc = check_graph(graph);
     if (rc) return rc;
     if (!paths || !probs || !acts || !n_acts || !n_rows || !topk_idx || !topk_val || !offsets || !paths_out ||
@@ -731,8 +769,16 @@ extern "C" int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, 
     if (max_rows * (int64_t)k > INT32_MAX) return HW_ERR_INVALID_ARG;  // child offsets are 32-bit
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pgpr_child_offsets_kernel, dim3(1), dim3(1024), 0, st, n_acts, n_rows, k, offsets, n_rows_out,
-                       out_capacity);
+    {
+        const int nb = (int)((max_rows + OFF_ROWS_PER_BLOCK - 1) / OFF_ROWS_PER_BLOCK);
+        if (nb > 65536 || !block_sums_ws) return HW_ERR_WORKSPACE;
+        const int nb1 = nb < 1 ? 1 : nb;
+        hipLaunchKernelGGL(pgpr_offsets_partial_kernel, dim3(nb1), dim3(256), 0, st, n_acts, n_rows, k, block_sums_ws);
+        hipLaunchKernelGGL(pgpr_offsets_scan_kernel, dim3(1), dim3(1024), 0, st, block_sums_ws, nb1, n_rows_out,
+                           out_capacity);
+        hipLaunchKernelGGL(pgpr_offsets_final_kernel, dim3(nb1), dim3(256), 0, st, n_acts, n_rows, k, block_sums_ws,
+                           offsets);
+    }
     if (max_rows > 0) {
         int64_t grid = (max_rows * k + 255) / 256;
         if (grid > 16384) grid = 16384;

@@ -129,9 +129,11 @@ def policy_topk(logits, act_dim, n_acts, n_rows, max_rows, k, out_idx, out_val, 
 def expand(graph, paths, probs, acts, act_dim, n_acts, n_rows, max_rows, topk_idx, topk_val, k, offsets, paths_out,
            probs_out, n_rows_out, capacity):
     lib = _lib.load()
+    block_sums = torch.empty((int(max_rows) + 1023) // 1024 + 1, dtype=torch.int32, device=paths.device)
     check(
         lib.hw_pgpr_expand(C.byref(graph.c), _ptr(paths), _ptr(probs), _ptr(acts), int(act_dim), _ptr(n_acts), _ptr(n_rows),
-                           int(max_rows), _ptr(topk_idx), _ptr(topk_val), int(k), _ptr(offsets), _ptr(paths_out),
+                           int(max_rows), _ptr(topk_idx), _ptr(topk_val), int(k), _ptr(offsets), _ptr(block_sums),
+                           _ptr(paths_out),
                            _ptr(probs_out), _ptr(n_rows_out), int(capacity), _stream()),
         "hw_pgpr_expand",
     )

@@ -242,12 +242,13 @@ int hw_pgpr_policy_topk(const float* logits, int64_t ld, int32_t act_dim, const 
                         float* probs_out, void* stream);
 
 /* Emit the children of every row in row order, top-k order inside a row (pgpr.py:460-479).
- * offsets: int32 [max_rows] workspace; n_rows_out[0] = number of children (capped at out_capacity). */
+ * offsets: int32 [max_rows] workspace; block_sums_ws: int32 [ceil(max_rows / 1024)] workspace;
+ * n_rows_out[0] = number of children (capped at out_capacity). */
 int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float* probs,
                    const int32_t* acts, int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows,
                    int64_t max_rows, const int32_t* topk_idx, const float* topk_val, int32_t k,
-                   int32_t* offsets, int32_t* paths_out, float* probs_out, int32_t* n_rows_out,
-                   int64_t out_capacity, void* stream);
+                   int32_t* offsets, int32_t* block_sums_ws, int32_t* paths_out, float* probs_out,
+                   int32_t* n_rows_out, int64_t out_capacity, void* stream);
 
 /* collect_scores (pgpr.py:486-552) on the leaf rows of a search over `users[n_batch]`:
  * results [n_batch, n_items] float32 (-inf where nothing is written), plus per user slot the written
