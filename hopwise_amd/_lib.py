@@ -73,6 +73,12 @@ SIGNATURES = {
         [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64,
          c_i32p, C.c_void_p],
     ),
+    "hw_kge_full_sort_topk_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
+    "hw_kge_full_sort_topk": (
+        C.c_int,
+        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64,
+         C.c_int32, C.c_int32, C.c_void_p, C.c_int64, c_f32p, c_i64p, C.c_void_p],
+    ),
     "hw_kge_grad_grouped": (
         C.c_int,
         [C.POINTER(KgeDesc), C.POINTER(KgeGrads), c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int64,

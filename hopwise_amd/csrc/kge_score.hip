@@ -244,6 +244,177 @@ __global__ __launch_bounds__(256) void kge_full_sort_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// full sort fused with the evaluation mask and a first-stage top-k: the [B, N] score matrix
+// is never written.  A wave scores a sub-chunk of SUB = 128 consecutive tails for HB heads into LDS, applies the
+// mask (column `mask_col` and the history bitmap -> -inf, trainer.py:731-734), and keeps the k best of the
+// sub-chunk per head by k wave arg-max rounds on (value desc, index asc) keys.  A second small kernel ranks the
+// N / 128 * k candidates of every head.  Exactly the top-k of the full masked row as long as k <= 128.
+// ------------------------------------------------------------------------------------------------
+constexpr int FS_SUB = 128;
+
+__device__ __forceinline__ uint64_t score_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)(~idx);
+}
+
+template <int MODEL, int G, int NE, bool VEC, int HB>
+__global__ __launch_bounds__(256) void kge_full_sort_topk_kernel(
+    hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
+    int n_heads, int64_t lo, int64_t hi, const uint32_t* __restrict__ mask_bits, int64_t mask_words, int64_t mask_col,
+    int k, float* __restrict__ cand_val, int64_t* __restrict__ cand_idx, int64_t n_sub) {
+    using SC = Scorer<MODEL, G, NE, VEC>;
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, VEC>;
+    constexpr int NS = HW_WAVE / G;
+    constexpr int U = 2;
+    __shared__ float lds_sc[4][HB][FS_SUB];
+
+    const int lane = threadIdx.x & (HW_WAVE - 1);
+    const int wave = threadIdx.x / HW_WAVE;
+    const int sub = lane / G, gl = lane % G;
+    const int n_hb = (n_heads + HB - 1) / HB;
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_sub * n_hb) return;
+    const int hb = (int)(task % n_hb);
+    const int64_t c = task / n_hb;
+
+    SC sc[HB];
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+        const int bi = min(hb * HB + q, n_heads - 1);
+        const int h = clamp_row(h_idx[bi], d.n_head, nullptr);
+        const int r = clamp_row(r_idx ? r_idx[bi] : r_fixed, d.n_rel, nullptr);
+        sc[q].template build<false>(d, h, r, gl, nullptr, nullptr);
+    }
+    const int64_t n0 = lo + c * FS_SUB;
+    const int64_t n1 = min(n0 + FS_SUB, hi);
+    float(*my)[FS_SUB] = lds_sc[wave];
+    for (int64_t nb = n0; nb < n1; nb += NS * U) {
+        int64_t n[U];
+        R t[U][MT::NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            n[u] = nb + u * NS + sub;
+            const int64_t row = n[u] < n1 ? n[u] : n0;
+#pragma unroll
+            for (int kk = 0; kk < MT::NT; ++kk) t[u][kk].load_raw(d.tail[kk] + (size_t)row * d.dim, d.dim, gl);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl);
+                p = group_sum<G>(p);
+                if (gl == 0 && n[u] < n1) my[q][n[u] - n0] = SC::finalize(p, d.margin);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // mask + k arg-max rounds per head; lane l owns sub-chunk positions l and l + 64
+    const int len = (int)(n1 - n0);
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+        const int bi = hb * HB + q;
+        if (bi >= n_heads) break;  // wave-uniform
+        uint64_t key[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int pos = lane + 64 * e;
+            key[e] = 0ull;
+            if (pos < len) {
+                const int64_t col = n0 + pos - lo;  // column of the [B, N] matrix
+                float v = my[q][pos];
+                const bool masked = (col == mask_col) ||
+                                    (mask_bits && ((mask_bits[(size_t)bi * mask_words + (col >> 5)] >> (col & 31)) & 1u));
+                if (masked) v = -INFINITY;
+                key[e] = score_key(v, (uint32_t)col);
+            }
+        }
+        uint64_t bound = ~0ull;
+        for (int r = 0; r < k; ++r) {
+            uint64_t best = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (key[e] < bound && key[e] > best) best = key[e];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint64_t o = __shfl_xor(best, m, 64);
+                best = o > best ? o : best;
+            }
+            if (lane == 0) {
+                const size_t o = ((size_t)bi * n_sub + c) * k + r;
+                if (best == 0) {
+                    cand_val[o] = -INFINITY;
+                    cand_idx[o] = -1;
+                } else {
+                    const uint32_t col = ~(uint32_t)(best & 0xffffffffu);
+                    uint32_t u = (uint32_t)(best >> 32);  // undo the order-preserving map: the masked value
+                    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+                    cand_val[o] = __uint_as_float(u);
+                    cand_idx[o] = col;
+                }
+            }
+            bound = best;
+            if (best == 0) bound = 0;
+        }
+    }
+}
+
+// rank the candidates of one head: block per row, k rounds, key = (value, ~global index)
+__global__ __launch_bounds__(256) void topk_candidates_kernel(const float* __restrict__ cand_val,
+                                                              const int64_t* __restrict__ cand_idx, int64_t n_cand,
+                                                              int k, float* __restrict__ out_val,
+                                                              int64_t* __restrict__ out_idx) {
+    __shared__ uint64_t red[4];
+    __shared__ uint64_t winner;
+    const float* __restrict__ v = cand_val + (size_t)blockIdx.x * n_cand;
+    const int64_t* __restrict__ ix = cand_idx + (size_t)blockIdx.x * n_cand;
+    uint64_t bound = ~0ull;
+    for (int r = 0; r < k; ++r) {
+        uint64_t best = 0;
+        for (int64_t i = threadIdx.x; i < n_cand; i += 256) {
+            if (ix[i] < 0) continue;
+            const uint64_t key = score_key(v[i], (uint32_t)ix[i]);
+            if (key < bound && key > best) best = key;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t o = __shfl_xor(best, m, 64);
+            best = o > best ? o : best;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t w = red[0];
+            for (int i = 1; i < 4; ++i) w = red[i] > w ? red[i] : w;
+            winner = w;
+            const size_t o = (size_t)blockIdx.x * k + r;
+            if (w == 0) {
+                out_val[o] = -INFINITY;
+                out_idx[o] = -1;
+            } else {
+                uint32_t u = (uint32_t)(w >> 32);
+                u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+                out_val[o] = __uint_as_float(u);
+                out_idx[o] = (int64_t)(~(uint32_t)(w & 0xffffffffu));
+            }
+        }
+        __syncthreads();
+        bound = winner;
+    }
+}
+
+__global__ void build_mask_bits_kernel(const int64_t* __restrict__ hr, const int64_t* __restrict__ hc, int64_t n_hist,
+                                       int64_t n_rows, int64_t n_cols, int64_t words, uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hist) return;
+    const int64_t r = hr[i], c = hc[i];
+    if (r >= 0 && r < n_rows && c >= 0 && c < n_cols) atomicOr(bits + (size_t)r * words + (c >> 5), 1u << (c & 31));
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
 static int check_desc(const hw_kge_desc* d) {
@@ -420,5 +591,58 @@ extern "C" int hw_kge_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, c
     } while (0)
     HW_DISPATCH_MODEL(desc->model, shape, CALL);
 #undef CALL
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int64_t hw_kge_full_sort_topk_workspace_bytes(int64_t n_heads, int64_t n_tails, int32_t k) {
+    const int64_t words = (n_tails + 31) / 32, n_sub = (n_tails + FS_SUB - 1) / FS_SUB;
+    return n_heads * words * 4 + n_heads * n_sub * k * (4 + 8) + 64;
+}
+
+extern "C" int hw_kge_full_sort_topk(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                                     int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
+                                     const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k,
+                                     void* workspace, int64_t workspace_bytes, float* out_val, int64_t* out_idx,
+                                     void* stream) {
+    int rc = check_desc(desc);
+    if (rc) return rc;
+    if (!h_idx || !out_val || !out_idx || !workspace || n_heads < 1 || n_heads > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (tail_lo < 0 || tail_hi > desc->n_tail || tail_lo >= tail_hi || k < 1 || k > FS_SUB) return HW_ERR_INVALID_ARG;
+    if (n_hist < 0 || (n_hist > 0 && (!hist_rows || !hist_cols))) return HW_ERR_INVALID_ARG;
+    const int64_t n = tail_hi - tail_lo;
+    if (n > 0xffffffffll) return HW_ERR_INVALID_ARG;
+    if (workspace_bytes < hw_kge_full_sort_topk_workspace_bytes(n_heads, n, k)) return HW_ERR_WORKSPACE;
+    const int64_t words = (n + 31) / 32, n_sub = (n + FS_SUB - 1) / FS_SUB;
+    uint32_t* bits = (uint32_t*)workspace;
+    int64_t* cand_idx = (int64_t*)((char*)workspace + ((n_heads * words * 4 + 15) / 16) * 16);
+    float* cand_val = (float*)(cand_idx + n_heads * n_sub * k);
+    const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
+    hipStream_t st = (hipStream_t)stream;
+    HW_CLEAR_ERR();
+    (void)hipMemsetAsync(bits, 0, (size_t)n_heads * words * 4, st);
+    if (n_hist > 0)
+        hipLaunchKernelGGL(build_mask_bits_kernel, dim3((unsigned)((n_hist + 255) / 256)), dim3(256), 0, st, hist_rows,
+                           hist_cols, n_hist, n_heads, n, words, bits);
+    const bool hb4 = n_heads > 1;
+    const int n_hb = hb4 ? (int)((n_heads + 3) / 4) : 1;
+    const int64_t n_blocks = (n_sub * n_hb + 3) / 4;
+    if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    const int nh = (int)n_heads;
+    const int64_t mask_col = mask_first_col ? 0 : -1;
+#define CALL(MODEL, G_, NE_, VEC_)                                                                                    \
+    do {                                                                                                              \
+        if (hb4)                                                                                                      \
+            hipLaunchKernelGGL((kge_full_sort_topk_kernel<MODEL, G_, NE_, VEC_, 4>), dim3((unsigned)n_blocks),         \
+                               dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, bits, words,      \
+                               mask_col, k, cand_val, cand_idx, n_sub);                                                \
+        else                                                                                                          \
+            hipLaunchKernelGGL((kge_full_sort_topk_kernel<MODEL, G_, NE_, VEC_, 1>), dim3((unsigned)n_blocks),         \
+                               dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, bits, words,      \
+                               mask_col, k, cand_val, cand_idx, n_sub);                                                \
+    } while (0)
+    HW_DISPATCH_MODEL(desc->model, shape, CALL);
+#undef CALL
+    hipLaunchKernelGGL(topk_candidates_kernel, dim3((unsigned)n_heads), dim3(256), 0, st, cand_val, cand_idx, n_sub * k, k,
+                       out_val, out_idx);
     return HW_LAUNCH_RC();
 }

@@ -142,6 +142,17 @@ class _GatherKGE(KnowledgeRecommender):
         return ops.kge_full_sort(self.MODEL, head, rel, tail, interaction[self.HEAD_ENTITY_ID],
                                  interaction[self.RELATION_ID], 0, 0, self.n_entities, self.margin)
 
+    def full_sort_topk(self, interaction, k, history_index=None, kg=False):
+        """Top-k of the masked full sort (trainer.py:731-734 + collector.py:173-183) without the [B, N] matrix."""
+        if kg:
+            head, rel, tail = self._tables("kg")
+            return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, interaction[self.HEAD_ENTITY_ID],
+                                          interaction[self.RELATION_ID], 0, 0, self.n_entities, k, history_index, True,
+                                          self.margin)
+        head, rel, tail = self._tables("rec")
+        return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, interaction[self.USER_ID], None,
+                                      self._rec_rel_full_sort(), 0, self.n_items, k, history_index, True, self.margin)
+
     # -- extension: grouped negatives ---------------------------------------------------------------
     def score_grouped(self, side, h_idx, r_idx, t_idx):
         """scores [B, 1+K] of B (h, r) groups against t_idx [B, 1+K] (column 0 = positive)."""

@@ -211,6 +211,30 @@ def kge_full_sort(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin=
     return kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi)
 
 
+def kge_full_sort_topk(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, k, history_index=None, mask_first_col=True,
+                       margin=0.0):
+    """Masked top-k of the full sort without the [B, N] matrix: (values [B, k], column indices [B, k])."""
+    lib = _lib.load()
+    desc = make_desc(model, head, rel, tail, margin, 0.0)
+    h_idx = _idx(h_idx, "h_idx").contiguous()
+    if r_idx is not None:
+        r_idx = _idx(r_idx, "r_idx").contiguous()
+    B = h_idx.shape[0]
+    hr = hc = None
+    nh = 0
+    if history_index is not None:
+        hr, hc = _idx(history_index[0], "history rows").contiguous(), _idx(history_index[1], "history cols").contiguous()
+        nh = hr.numel()
+    nbytes = int(lib.hw_kge_full_sort_topk_workspace_bytes(B, hi - lo, int(k)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=h_idx.device)
+    val = torch.empty((B, k), dtype=torch.float32, device=h_idx.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=h_idx.device)
+    check(lib.hw_kge_full_sort_topk(C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, int(lo), int(hi), _ptr(hr),
+                                    _ptr(hc), nh, int(bool(mask_first_col)), int(k), _ptr(ws), nbytes, _ptr(val), _ptr(idx),
+                                    _stream()), "hw_kge_full_sort_topk")
+    return val, idx
+
+
 # ------------------------------------------------------------------------------------------------
 # losses
 # ------------------------------------------------------------------------------------------------

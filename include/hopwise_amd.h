@@ -87,6 +87,17 @@ int hw_kge_full_sort(const hw_kge_desc* desc,
                      float* out, int64_t out_ld,
                      int32_t* oob_counter, void* stream);
 
+/* Full sort fused with the evaluation mask and top-k (KGTrainer._full_sort_batch_eval trainer.py:716-735 +
+ * Collector.eval_batch_collect collector.py:173-183): scores every tail in [tail_lo, tail_hi), sets column 0 (when
+ * mask_first_col) and every (hist_rows[i], hist_cols[i]) to -inf, and returns the k best (value desc, index asc)
+ * columns per head without materialising the [n_heads, n_tails] matrix.  k <= 128.
+ * workspace: hw_kge_full_sort_topk_workspace_bytes(n_heads, n_tails, k) bytes. */
+int64_t hw_kge_full_sort_topk_workspace_bytes(int64_t n_heads, int64_t n_tails, int32_t k);
+int hw_kge_full_sort_topk(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                          int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
+                          const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k,
+                          void* workspace, int64_t workspace_bytes, float* out_val, int64_t* out_idx, void* stream);
+
 /* Backward of hw_kge_score_grouped: given g[b, j] = dLoss/dscore[b, j] (same strides as `out`),
  * atomically accumulates the row gradients into `grads`.  Replaces autograd through
  * nn.Embedding + <Model>.forward (dense embedding_dense_backward in the reference).

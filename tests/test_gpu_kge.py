@@ -384,3 +384,27 @@ def test_rescal_grouped_loss_and_grads_vs_oracle(dim):
         ref = grads_ref[k[: -len(".weight")]]
         scale = np.abs(ref).max() + 1e-12
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_fused_full_sort_topk_equals_unfused(model):
+    """hw_kge_full_sort_topk == full sort -> mask -> top-k, values and indices, rec and kg side."""
+    from hopwise_amd import ops
+
+    for dim, nE, nI, B, k in ((64, 1003, 700, 1, 10), (200 if model != "RESCAL" else 48, 777, 300, 5, 100), (24, 200, 130, 9, 128)):
+        nU, nR = 50, 6
+        tables = random_tables(model, nU, nE, nR, dim, seed=dim + B)
+        m = build(model, tables, dim, nU, nI, nE, nR)
+        rng = np.random.default_rng(B)
+        users = torch.from_numpy(rng.integers(0, nU, B)).to(dev())
+        heads = torch.from_numpy(rng.integers(0, nE, B)).to(dev())
+        rels = torch.from_numpy(rng.integers(0, nR, B)).to(dev())
+        hist = (torch.from_numpy(rng.integers(0, B, 40)).to(dev()), torch.from_numpy(rng.integers(0, nI, 40)).to(dev()))
+        with torch.no_grad():
+            for kg, inter, n in ((False, {"user_id": users}, nI), (True, {"head_id": heads, "relation_id": rels}, nE)):
+                full = (m.full_sort_predict_kg(inter) if kg else m.full_sort_predict(inter)).view(B, n).contiguous()
+                ops.mask_scores_(full, hist)
+                rv, ri = ops.topk_rows(full, min(k, n))
+                fv, fi = m.full_sort_topk(inter, min(k, n), hist, kg=kg)
+                np.testing.assert_array_equal(fi.cpu().numpy(), ri.cpu().numpy())
+                np.testing.assert_array_equal(fv.cpu().numpy(), rv.cpu().numpy())
