@@ -52,3 +52,29 @@ def test_train_and_eval_protocol(model_name, sample_num):
     rels = torch.tensor([1, 2], device=dev)
     val, idx, masked = full_sort_topk(model, {"head_id": heads, "relation_id": rels}, None, k=5, kg=True)
     assert tuple(masked.shape) == (2, kg.n_entities)
+
+
+def test_train_from_atomic_files():
+    """(f)2: .inter/.kg/.link -> KGFiles -> device samplers -> RotatE epoch -> fused full-sort top-k."""
+    import os
+
+    import hopwise_amd.model as M
+    from hopwise_amd.data.kg_files import KGFiles
+    from hopwise_amd.driver import KGBatcher, train_epoch
+    from hopwise_amd.sampler import KGSampler, Sampler
+
+    dev = torch.device("cuda", 0)
+    ds = KGFiles(os.path.join(os.path.dirname(__file__), "golden", "atomic"), "kg_reverse_r", kg_reverse_r=True)
+    rec = Sampler("train", ds, device=dev).set_phase("train")
+    kgs = KGSampler(ds, device=dev)
+    torch.manual_seed(0)
+    model = M.RotatE(make_config(dev, 16, 2.0, train_neg_sample_args={"sample_num": 2}), ds).to(dev)
+    assert model.n_entities == ds.entity_num and model.n_relations == ds.relation_num
+    opt = torch.optim.Adam(model.parameters(), lr=5e-2)
+    b = KGBatcher(ds.inter_feat["user_id"], ds.inter_feat["item_id"], ds.head_entities, ds.relations,
+                  ds.tail_entities, rec, kgs, train_batch_size=4, sample_num=2, device=dev)
+    losses = [train_epoch(model, b, opt) / len(b) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    users = torch.arange(1, ds.user_num, device=dev)
+    scores = model.full_sort_predict({"user_id": users}).view(len(users), -1)
+    assert scores.shape[1] == ds.item_num and torch.isfinite(scores).all()
