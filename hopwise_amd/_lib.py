@@ -146,6 +146,34 @@ SIGNATURES = {
         [C.POINTER(PgprGraph), c_i32p, c_f32p, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int64, c_i32p, c_f32p, C.c_int32,
          c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, C.c_int64, C.c_void_p],
     ),
+    "hw_pgpr_action_dropout": (
+        C.c_int,
+        [c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p],
+    ),
+    "hw_pgpr_policy_sample": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int32, C.c_void_p, c_i32p, C.c_int64, c_i32p, C.c_uint64, C.c_uint64, c_f32p, c_i32p,
+         c_f32p, c_f32p, c_f32p, C.c_void_p],
+    ),
+    "hw_pgpr_policy_grad": (
+        C.c_int,
+        [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_float, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p],
+    ),
+    "hw_act_dropout_backward": (
+        C.c_int,
+        [c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_uint64, C.c_uint64, c_f32p, C.c_void_p],
+    ),
+    "hw_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_void_p]),
+    "hw_pgpr_reward": (
+        C.c_int,
+        [c_i32p, C.c_int64, c_i32p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,
+         C.c_void_p, C.c_void_p],
+    ),
+    "hw_pgpr_reinforce_loss": (
+        C.c_int,
+        [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int64, C.c_double, C.c_double, C.c_void_p, c_f32p, c_f32p,
+         C.c_void_p],
+    ),
     "hw_pgpr_collect": (
         C.c_int,
         [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p, C.c_int64,

@@ -19,22 +19,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
 
-__device__ __forceinline__ uint32_t philox_bits(uint64_t seed, uint64_t offset, uint64_t idx) {
-    uint32_t c0 = (uint32_t)(idx >> 2), c1 = (uint32_t)(idx >> 34), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
-        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
-    }
-    const uint32_t w[4] = {c0, c1, c2, c3};
-    return w[idx & 3];
-}
-
 // Stage one 128 x 16 operand tile into LDS (k-major).  X(row, k): row in [0, rows), k in [0, K).
 //   KC = true : X stored [rows, K] (K contiguous, leading dim ld)
 //   KC = false: X stored [K, rows] (row index contiguous, leading dim ld)

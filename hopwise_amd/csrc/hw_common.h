@@ -17,6 +17,24 @@ namespace hw {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// One 32-bit word of the Philox4x32-10 stream keyed by `seed`: word idx & 3 of block (idx >> 2, offset).
+__device__ __forceinline__ uint32_t philox_bits(uint64_t seed, uint64_t offset, uint64_t idx) {
+    uint32_t c0 = (uint32_t)(idx >> 2), c1 = (uint32_t)(idx >> 34), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    const uint32_t w[4] = {c0, c1, c2, c3};
+    return w[idx & 3];
+}
+
+
 
 // ---- DPP helpers ------------------------------------------------------------------------------------
 // Cross-lane adds inside a 16-lane row cost one VALU op with a DPP modifier (no LDS-crossbar round trip):

@@ -99,6 +99,13 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
             int t = -1, n = -1;
             if (tid == 0) t = T_USER, n = uid;
             else if (tid < len) t = p[2 + 3 * (tid - 1) + 1], n = p[2 + 3 * (tid - 1) + 2];
+            if ((fix_bug & 2) && tid < len) {
+                // bit 1 (training): the start user and its self-loop copies carry a tensor id in the reference and
+                // never compare equal to a graph id -> they are not "visited"
+                bool lead = true;
+                for (int j = 1; j <= tid; ++j) lead = lead && p[2 + 3 * (j - 1)] == SELF_LOOP;
+                if (lead) t = -1;
+            }
             vis_t[tid] = t, vis_n[tid] = n;
         }
         __syncthreads();
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
         (void)block_excl_scan(c_eq_local, wsum, c_eq);
         const int tie_skip = c_eq - need;  // ties are kept from the END of the row (stable ascending argsort, [-max_acts:])
 
-        if (!fix_bug) {
+        if (!(fix_bug & 1)) {
             int run_keep = 0, run_tie = 0;
             for (int base = 0; base < deg; base += 256) {
                 const int e = base + tid;

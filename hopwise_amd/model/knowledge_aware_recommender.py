@@ -46,6 +46,24 @@ class BeamResult:
         return self.paths[:n].cpu().numpy(), self.probs[:n].cpu().numpy()
 
 
+class _EpisodeLoss(torch.autograd.Function):
+    """loss = PGPR.update() of one device episode; backward = the hand-written gradient pass."""
+
+    @staticmethod
+    def forward(ctx, model, users, *params):
+        ep = model.episode_device(users)
+        ctx.model, ctx.ep = model, ep
+        model.last_loss_parts = ep["loss"]
+        return ep["loss"][0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads = ctx.model._episode_backward(ctx.ep)
+        scale = grad_out.to(torch.float32)
+        ctx.ep = None
+        return (None, None) + tuple(g * scale for g in grads)
+
+
 class PGPR(KnowledgeRecommender, ExplainableRecommender):
     input_type = InputType.USERWISE
 
@@ -90,6 +108,23 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.critic = nn.Linear(self.hidden_sizes[1], 1)
         self._drop_calls = 0
         self._seed = int(_cfg(config, "seed", 2020))
+
+        # training (pgpr.py:40-46, 90-104)
+        self.gamma = float(_cfg(config, "gamma", 0.99))
+        self.action_dropout = float(_cfg(config, "action_dropout", 0.0))
+        self.weight_factor = float(_cfg(config, "weight_factor", 1e-3))
+        self.max_path_len = int(_cfg(config, "max_path_len", 3))
+        if not 1 <= self.max_path_len <= 3:
+            raise ValueError("max_path_len must be 1..3 (a path record holds at most 4 nodes)")
+        rel2id = dataset.field2token_id["relation_id"]
+        pats = []
+        for constraint in _cfg(config, "path_constraint", None) or []:
+            names = [node[0] for node in constraint if node[0] is not None]
+            names = [n[:-2] if n.endswith("_r") else n for n in names]  # the reference strips "_r" on the pattern side only
+            if len(names) <= 3:
+                pats.append([1 + len(names)] + [int(rel2id.get(n, -2)) for n in names] + [-2] * (3 - len(names)))
+        self._patterns = torch.tensor(pats, dtype=torch.int32, device=dev).view(-1, 4) if pats else None
+        self.last_loss_parts = None
 
     # ------------------------------------------------------------------------------------------------
     def _alloc(self, B, hops):
@@ -179,6 +214,121 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         res.n_rows_per_hop = nr
         res.trace = trace
         return res
+
+    # -- training: one REINFORCE episode per batch (pgpr.py:120-203, 335-396) ---------------------------------------
+    def _head_params(self):
+        return (torch.cat([self.actor.weight, self.critic.weight], 0).detach().contiguous(),
+                torch.cat([self.actor.bias, self.critic.bias], 0).detach().contiguous())
+
+    @torch.no_grad()
+    def episode_device(self, users, forced_acts=None, act_masks=None, drops=None):
+        """Roll the policy out for ``max_path_len`` steps on the device and evaluate update()'s loss.
+
+        forced_acts (int32 [T, B]), act_masks (uint8 [T, B, act_dim]) and drops (per step (mask1, mask2)) replace the
+        device random streams -- what the parity tests use to replay the reference's trajectory.  Returns the episode
+        record that :meth:`_episode_backward` consumes."""
+        dev = self._t64[0].device
+        users = users.to(dev, torch.int64).contiguous()
+        B, T, A = users.numel(), self.max_path_len, self.act_dim
+        g = self.graph
+        U64, E64, R64 = self._t64
+        U32, E32, R32 = self._t32
+        H1, H2 = self.hidden_sizes
+        i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        ep = dict(B=B, T=T, state=f32(T * B, self.state_dim), x1=f32(T * B, H1), x2=f32(T * B, H2),
+                  head=f32(T * B, A + 1), probs=f32(T * B, A), acts=i32(T * B), logp=f32(T * B), entropy=f32(T * B),
+                  value=f32(T * B), mask=torch.empty((T * B, A), dtype=torch.uint8, device=dev),
+                  rewards=torch.empty(T * B, dtype=torch.float64, device=dev), drop=[], calls=[], n_acts=i32(T * B),
+                  paths=[i32(B, P.ROW_INTS) for _ in range(T + 1)])
+        probs3 = [f32(B, 3) for _ in range(2)]
+        nr = torch.zeros(T + 1, dtype=torch.int32, device=dev)
+        acts_buf, n_acts, offsets = i32(B, A, 2), i32(B), i32(B)
+        scratch = None
+        if g.max_degree > P.ACT_LDS_KEYS:
+            scratch = torch.empty((min(2048, B), g.max_degree), dtype=torch.int64, device=dev)
+        head_w, head_b = self._head_params()
+        P.init_paths(users, ep["paths"][0], probs3[0], nr[0:1])
+        score_user, score_entity = P.user_scores(g, U64, E64, R64, users)
+        scales = torch.empty(B, dtype=torch.float64, device=dev)
+        for t in range(T):
+            sl = slice(t * B, (t + 1) * B)
+            paths, n_rows = ep["paths"][t], nr[t : t + 1]
+            P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, B, self.max_acts,
+                      self.fix_scores_sorting_bug, acts_buf, n_acts, scratch, start_user_revisitable=True)
+            self._drop_calls += 1
+            call = self._drop_calls
+            ep["calls"].append(call)
+            ep["n_acts"][sl].copy_(n_acts)
+            if act_masks is not None:
+                ep["mask"][sl].copy_(act_masks[t])
+            else:
+                P.action_dropout(n_acts, n_rows, B, A, self.action_dropout, self._seed, 4 * call + 2, ep["mask"][sl])
+            P.state(g, U32, E32, R32, self.state_history, paths, n_rows, B, ep["state"][sl])
+            if drops is not None:
+                modes = [(drops[t][0], 1, 0), (drops[t][1], 1, 0)]
+            elif self.policy_dropout == "reference":
+                modes = [(None, 2, 4 * call), (None, 2, 4 * call + 1)]
+            else:
+                modes = [(None, 0, 0), (None, 0, 0)]
+            ep["drop"].append(modes)
+            P.mlp_layer(ep["state"][sl], self.l1.weight, self.l1.bias, ep["x1"][sl], n_rows, B, True, modes[0][0],
+                        modes[0][1], self._seed, modes[0][2])
+            P.mlp_layer(ep["x1"][sl], self.l2.weight, self.l2.bias, ep["x2"][sl], n_rows, B, True, modes[1][0],
+                        modes[1][1], self._seed, modes[1][2])
+            P.mlp_layer(ep["x2"][sl], head_w, head_b, ep["head"][sl], n_rows, B, False)
+            P.policy_sample(ep["head"][sl], A, ep["mask"][sl], n_rows, B, ep["probs"][sl], ep["acts"][sl], ep["logp"][sl],
+                            ep["entropy"][sl], ep["value"][sl], self._seed, 4 * call + 3,
+                            None if forced_acts is None else forced_acts[t].contiguous())
+            P.expand(g, paths, probs3[t % 2], acts_buf, A, n_acts, n_rows, B, ep["acts"][sl].view(B, 1),
+                     ep["logp"][sl].view(B, 1), 1, offsets, ep["paths"][t + 1], probs3[(t + 1) % 2], nr[t + 1 : t + 2], B)
+            P.reward(ep["paths"][t + 1], B, self._patterns, score_entity, self.n_items, scales, t == 0, ep["rewards"][sl])
+        ep["raw_rewards"] = ep["rewards"].clone()
+        ep["loss"] = torch.empty(4, dtype=torch.float64, device=dev)
+        ep["coef_actor"], ep["dvalue"] = f32(T * B), f32(T * B)
+        P.reinforce_loss(ep["rewards"], ep["value"], ep["logp"], ep["entropy"], T, B, self.gamma, self.weight_factor,
+                         ep["loss"], ep["coef_actor"], ep["dvalue"])
+        ep["head_w"] = head_w
+        return ep
+
+    @torch.no_grad()
+    def _episode_backward(self, ep):
+        """Gradients of update()'s loss w.r.t. (l1.w, l1.b, l2.w, l2.b, actor.w, actor.b, critic.w, critic.b): the
+        head gradient per row, then one stacked GEMM pass over all T * B rows."""
+        from ..ops import gemm
+
+        B, T, A = ep["B"], ep["T"], self.act_dim
+        n = T * B
+        dhead = torch.empty_like(ep["head"])
+        P.policy_grad(ep["probs"], A, ep["acts"], ep["coef_actor"], self.weight_factor / B, ep["dvalue"], n, dhead)
+        g_head_w = gemm(dhead, ep["x2"], a_k_contiguous=False, b_k_contiguous=False)
+        g_head_b = P.colsum(dhead)
+        dx2 = gemm(dhead, ep["head_w"], b_k_contiguous=False)  # [n, H2]
+        for t in range(T):
+            sl = slice(t * B, (t + 1) * B)
+            mask, mode, off = ep["drop"][t][1]
+            P.act_dropout_backward(dx2[sl], ep["x2"][sl], 1, mask, mode, self._seed, off, out=dx2[sl])
+        g_w2 = gemm(dx2, ep["x1"], a_k_contiguous=False, b_k_contiguous=False)
+        g_b2 = P.colsum(dx2)
+        dx1 = gemm(dx2, self.l2.weight.detach(), b_k_contiguous=False)  # [n, H1]
+        for t in range(T):
+            sl = slice(t * B, (t + 1) * B)
+            mask, mode, off = ep["drop"][t][0]
+            P.act_dropout_backward(dx1[sl], ep["x1"][sl], 1, mask, mode, self._seed, off, out=dx1[sl])
+        g_w1 = gemm(dx1, ep["state"], a_k_contiguous=False, b_k_contiguous=False)
+        g_b1 = P.colsum(dx1)
+        return (g_w1, g_b1, g_w2, g_b2, g_head_w[:A].contiguous(), g_head_b[:A].contiguous(),
+                g_head_w[A:].contiguous(), g_head_b[A:].contiguous())
+
+    def calculate_loss(self, interaction):
+        """pgpr.py:189-203: roll out, update(); the float64 loss carries a grad_fn over the eight policy tensors."""
+        users = interaction[self.USER_ID]
+        users = users[users != 0]
+        if users.numel() == 0:
+            return sum(p.sum() for p in self.parameters()).double() * 0.0
+        params = (self.l1.weight, self.l1.bias, self.l2.weight, self.l2.bias, self.actor.weight, self.actor.bias,
+                  self.critic.weight, self.critic.bias)
+        return _EpisodeLoss.apply(self, users, *params)
 
     # -- reference-format helpers ----------------------------------------------------------------------
     @staticmethod

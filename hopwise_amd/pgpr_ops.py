@@ -83,14 +83,14 @@ def user_scores(graph, U64, E64, R64, users):
 
 
 def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, max_rows, max_acts, fix_bug, acts, n_acts,
-            scratch=None):
+            scratch=None, start_user_revisitable=False):
     lib = _lib.load()
     sb = ss = 0
     if scratch is not None:
         sb, ss = scratch.shape
     check(
         lib.hw_pgpr_actions(C.byref(graph.c), _ptr(score_user), _ptr(score_entity), _ptr(score_rel_entity), _ptr(paths),
-                            _ptr(n_rows), int(max_rows), int(max_acts), int(bool(fix_bug)), _ptr(acts), _ptr(n_acts),
+                            _ptr(n_rows), int(max_rows), int(max_acts), int(bool(fix_bug)) | (2 if start_user_revisitable else 0), _ptr(acts), _ptr(n_acts),
                             _ptr(scratch), sb, ss, _stream()),
         "hw_pgpr_actions",
     )
@@ -209,3 +209,74 @@ def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, g
 
 CAFE_NODE_DTYPE = np.dtype([(n, np.int32) for n in
                             ("parent", "rel", "eh_is_entity", "k", "is_leaf", "lp_row", "depth", "vocab", "cap", "slot_off")])
+
+
+# ---- policy-gradient training (csrc/pgpr_train.hip) ---------------------------------------------------------------
+def action_dropout(n_acts, n_rows, max_rows, act_dim, dropout, seed, offset, mask):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_action_dropout(_ptr(n_acts), _ptr(n_rows), int(max_rows), int(act_dim), float(dropout),
+                                   C.c_uint64(seed), C.c_uint64(offset), _ptr(mask), _stream()),
+        "hw_pgpr_action_dropout",
+    )
+
+
+def policy_sample(head, act_dim, mask, n_rows, max_rows, probs, acts, logp, entropy, value, seed=0, offset=0,
+                  forced_acts=None):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_policy_sample(_ptr(head), head.stride(0), int(act_dim), _ptr(mask), _ptr(n_rows), int(max_rows),
+                                  _ptr(forced_acts), C.c_uint64(seed), C.c_uint64(offset), _ptr(probs), _ptr(acts),
+                                  _ptr(logp), _ptr(entropy), _ptr(value), _stream()),
+        "hw_pgpr_policy_sample",
+    )
+
+
+def policy_grad(probs, act_dim, acts, coef_actor, coef_entropy, dvalue, n_rows, dhead):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_policy_grad(_ptr(probs), int(act_dim), _ptr(acts), _ptr(coef_actor), float(coef_entropy),
+                                _ptr(dvalue), int(n_rows), _ptr(dhead), dhead.stride(0), _stream()),
+        "hw_pgpr_policy_grad",
+    )
+
+
+def act_dropout_backward(dy, y, act, drop_mask=None, drop_mode=0, seed=0, offset=0, out=None):
+    """dx for y = dropout(act(pre)); dy / y contiguous [m, n]; act: 0 none, 1 ELU, 2 ReLU."""
+    lib = _lib.load()
+    if not (dy.is_contiguous() and y.is_contiguous()):
+        raise ValueError("act_dropout_backward wants contiguous operands")
+    out = torch.empty_like(dy) if out is None else out
+    check(
+        lib.hw_act_dropout_backward(_ptr(dy), _ptr(y), dy.shape[0], dy.shape[1], int(act), _ptr(drop_mask),
+                                    int(drop_mode), C.c_uint64(seed), C.c_uint64(offset), _ptr(out), _stream()),
+        "hw_act_dropout_backward",
+    )
+    return out
+
+
+def colsum(x, out=None):
+    lib = _lib.load()
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device) if out is None else out
+    check(lib.hw_colsum_f32(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), _stream()), "hw_colsum_f32")
+    return out
+
+
+def reward(paths, n_rows, patterns, score_entity, n_items, scales, compute_scales, out):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_reward(_ptr(paths), int(n_rows), _ptr(patterns), 0 if patterns is None else patterns.shape[0],
+                           _ptr(score_entity), score_entity.shape[1], int(n_items), _ptr(scales), score_entity.shape[0],
+                           int(bool(compute_scales)), _ptr(out), _stream()),
+        "hw_pgpr_reward",
+    )
+
+
+def reinforce_loss(rewards, values, logp, entropy, n_steps, n_batch, gamma, weight_factor, loss_out, coef_actor, dvalue):
+    lib = _lib.load()
+    check(
+        lib.hw_pgpr_reinforce_loss(_ptr(rewards), _ptr(values), _ptr(logp), _ptr(entropy), int(n_steps), int(n_batch),
+                                   float(gamma), float(weight_factor), _ptr(loss_out), _ptr(coef_actor), _ptr(dvalue),
+                                   _stream()),
+        "hw_pgpr_reinforce_loss",
+    )

@@ -196,7 +196,13 @@ int hw_pgpr_user_scores(const hw_pgpr_graph* graph, const double* user_emb64, co
  * (path record int 11) selects its rows of score_user [n_batch, n_users] / score_entity [n_batch, n_entities].
  * acts: int32 [max_rows, max_acts + 1, 2]; n_acts: int32 [max_rows].
  * scratch: uint64 [scratch_blocks * scratch_stride], needed when graph->max_degree > 4096
- * (scratch_stride >= max_degree). */
+ * (scratch_stride >= max_degree).
+ * fix_scores_sorting_bug is a bit set: bit 0 = config fix_scores_sorting_bug; bit 1 = the start user is NOT in the
+ * visited set -- the reference's training episodes keep the user id as a 0-dim tensor in path[0] (reset(), pgpr.py:215-216),
+ * whose hash never matches an int (the tensor also rides along leading self-loop steps), so only calculate_loss lets
+ * a path return to its own user. */
+#define HW_PGPR_FIX_SORTING 1
+#define HW_PGPR_START_USER_REVISITABLE 2
 int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_user, const double* score_entity,
                     const double* score_rel_entity, const int32_t* paths, const int32_t* n_rows,
                     int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug,
@@ -274,6 +280,53 @@ int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_emb64, const 
                     int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws, float* results,
                     int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
                     int32_t* sel_row, void* stream);
+
+/* ---- PGPR policy-gradient training (pgpr.py:120-203, 335-396) --------------------------------------------------
+ * One episode = max_path_len steps of: actions -> action dropout -> state -> policy MLP -> Categorical draw ->
+ * step -> reward; then update().  The policy head is ONE matrix [act_dim + 1, hidden]: rows 0..act_dim-1 the actor,
+ * the last row the critic, so `head` rows are [act_dim logits, value] with leading dimension ld >= act_dim + 1. */
+
+/* batch_action_mask (pgpr.py:384-396): mask u8 [max_rows, act_dim]; rows with n_acts >= 5 keep action 0 and a uniform
+ * random subset of int((n - 1) * (1 - dropout)) of the others (smallest Philox keys; key of (row, j) is word
+ * row * act_dim + j of the (seed, offset) stream), other rows keep their n_acts actions. */
+int hw_pgpr_action_dropout(const int32_t* n_acts, const int32_t* n_rows, int64_t max_rows, int32_t act_dim,
+                           double dropout, uint64_t seed, uint64_t offset, uint8_t* mask, void* stream);
+
+/* select_action (pgpr.py:120-135) after the MLP: probs = softmax(masked logits) [max_rows, act_dim]; acts =
+ * Categorical draw by inverse CDF (u = top 24 bits of Philox word `row`) or forced_acts (nullable, replay);
+ * logp / entropy with torch.distributions.Categorical's clamp_probs semantics; value = head[row, act_dim]. */
+int hw_pgpr_policy_sample(const float* head, int64_t ld, int32_t act_dim, const uint8_t* mask, const int32_t* n_rows,
+                          int64_t max_rows, const int32_t* forced_acts, uint64_t seed, uint64_t offset, float* probs,
+                          int32_t* acts, float* logp, float* entropy, float* value, void* stream);
+
+/* d loss / d head for loss = sum_rows(-coef_actor * logp - coef_entropy * entropy) + critic: dhead [n_rows, ld]. */
+int hw_pgpr_policy_grad(const float* probs, int32_t act_dim, const int32_t* acts, const float* coef_actor,
+                        float coef_entropy, const float* dvalue, int64_t n_rows, float* dhead, int64_t ld,
+                        void* stream);
+
+/* dx = dy * d/dpre[dropout(act(pre))] recovered from y = dropout(act(pre)) (act 1 ELU, 2 ReLU, 0 none; drop modes as
+ * hw_gemm_f32, mode 2 regenerates the Philox mask of the forward call with the same seed / offset). */
+int hw_act_dropout_backward(const float* dy, const float* y, int64_t m_rows, int64_t n, int32_t act,
+                            const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, float* dx,
+                            void* stream);
+
+/* out[n] = column sums of x[m_rows, n] (bias gradients), deterministic order. */
+int hw_colsum_f32(const float* x, int64_t ld, int64_t m_rows, int64_t n, float* out, void* stream);
+
+/* _get_reward (pgpr.py:339-357) for paths [n_rows, HW_PGPR_ROW_INTS]: 0 unless the path has more than 2 nodes, its
+ * relation sequence equals a pattern (patterns int32 [n_patterns, 4] = (n_nodes, rel, rel, rel), self loop = -1)
+ * and it ends on an item; then max(score_entity[b, item] / scales[b], 0), float64.  scales_ws double [n_batch] =
+ * u_p_scales (pgpr.py:85-88) = max over the n_items columns of score_entity, filled when compute_scales != 0. */
+int hw_pgpr_reward(const int32_t* paths, int64_t n_rows, const int32_t* patterns, int32_t n_patterns,
+                   const double* score_entity, int64_t n_entities, int64_t n_items, double* scales_ws,
+                   int64_t n_batch, int32_t compute_scales, double* reward, void* stream);
+
+/* update() (pgpr.py:137-173): rewards float64 [n_steps, n_batch] -> discounted returns in place; loss_out double[4] =
+ * (loss, actor, critic, entropy); coef_actor = advantage / n_batch and dvalue = -2 advantage / n_batch feed
+ * hw_pgpr_policy_grad. */
+int hw_pgpr_reinforce_loss(double* rewards, const float* values, const float* logp, const float* entropy, int32_t n_steps,
+                           int64_t n_batch, double gamma, double weight_factor, double* loss_out, float* coef_actor,
+                           float* dvalue, void* stream);
 
 /* ---- row exchange primitives for row-sharded tables (no reference counterpart -- the
  * reference replicates tables under DDP, trainer/trainer.py:83-84) -------------------------------------

@@ -98,6 +98,7 @@ class PGPROracle:
         #   "stable" -- the build's convention, platform independent: candidates in (relation, neighbour)
         #               order, rank by (score, position) -- the later position wins a tie.
         self.tie_rule = tie_rule
+        self.start_user_revisitable = False
         self.g = graph
         self.n_items = int(n_items)
         self.U = np.asarray(user_emb, np.float64)
@@ -116,7 +117,16 @@ class PGPROracle:
     def _candidates(self, path, order):
         _, ctype, cid = path[-1]
         rels, dsts = self.g.neighbours(ctype, cid, order)
-        visited = {(t, n) for _, t, n in path}
+        # calculate_loss keeps the start user id as a 0-dim tensor (reset(), pgpr.py:215-216): its hash never equals an
+        # int's, so training episodes (start_user_revisitable) do not count path[0] as visited; beam_search does.
+        # The tensor id also rides along self-loop actions taken at the start (pgpr.py:229), so the whole leading
+        # run of self loops is invisible to the filter.
+        lead = 0
+        if self.start_user_revisitable:
+            lead = 1
+            while lead < len(path) and path[lead][0] == SELF_LOOP:
+                lead += 1
+        visited = {(t, n) for _, t, n in path[lead:]}
         return [(int(r), int(n)) for r, n in zip(rels, dsts) if (self.g.next_type(ctype, r), int(n)) not in visited]
 
     def _cand_scores(self, path, cand):

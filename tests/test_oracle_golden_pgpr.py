@@ -9,7 +9,7 @@ import pytest
 from oracle import pgpr as op
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-TAGS = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "pgpr_*.npz")) if "graph" not in p)
+TAGS = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN, "pgpr_*.npz")) if "graph" not in p and "train" not in p)
 
 
 def load_oracle(tag, tie_rule="numpy"):
