@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libhopwise_amd.so")
 
 HW_TRANSE, HW_ROTATE, HW_COMPLEX, HW_DISTMULT, HW_RESCAL = 0, 1, 2, 3, 4
 MODEL_IDS = {"TransE": HW_TRANSE, "RotatE": HW_ROTATE, "ComplEx": HW_COMPLEX, "DistMult": HW_DISTMULT,
-             "RESCAL": HW_RESCAL}
+             "RESCAL": HW_RESCAL, "TorusE": 5, "TransH": 6, "TransD": 7, "Analogy": 8, "HolE": 9}
 
 STATUS = {0: "HW_OK", -1: "HW_ERR_INVALID_ARG", -2: "HW_ERR_UNSUPPORTED", -3: "HW_ERR_LAUNCH", -4: "HW_ERR_WORKSPACE"}
 
@@ -23,13 +23,16 @@ c_i64p = C.c_void_p
 c_i32p = C.c_void_p
 
 
+MAX_TABLES = 3  # HW_KGE_MAX_TABLES
+
+
 class KgeDesc(C.Structure):
     _fields_ = [
         ("model", C.c_int32),
         ("dim", C.c_int32),
-        ("head", C.c_void_p * 2),
-        ("rel", C.c_void_p * 2),
-        ("tail", C.c_void_p * 2),
+        ("head", C.c_void_p * MAX_TABLES),
+        ("rel", C.c_void_p * MAX_TABLES),
+        ("tail", C.c_void_p * MAX_TABLES),
         ("n_head", C.c_int64),
         ("n_rel", C.c_int64),
         ("n_tail", C.c_int64),
@@ -57,7 +60,7 @@ class CafeNode(C.Structure):
 
 
 class KgeGrads(C.Structure):
-    _fields_ = [("head", C.c_void_p * 2), ("rel", C.c_void_p * 2), ("tail", C.c_void_p * 2)]
+    _fields_ = [("head", C.c_void_p * MAX_TABLES), ("rel", C.c_void_p * MAX_TABLES), ("tail", C.c_void_p * MAX_TABLES)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol declared in
@@ -87,6 +90,10 @@ SIGNATURES = {
     "hw_loss_workspace_floats": (C.c_int64, []),
     "hw_loss_bce_logits": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hw_loss_margin_ranking": (
+        C.c_int,
+        [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],
+    ),
+    "hw_loss_margin_ranking_sigmoid": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],
     ),

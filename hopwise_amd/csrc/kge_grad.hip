@@ -17,6 +17,15 @@
 //            gh_re = gQ0 c + gQ1 s, gh_im = -gQ0 s + gQ1 c, gtheta = gQ0 (-s h_re - c h_im) + gQ1 (-s h_im + c h_re)
 //   ComplEx  gQ0 = g t_re, gQ1 = g t_im, gt_re = g Q0, gt_im = g Q1
 //            gh_re = gQ0 r_re + gQ1 r_im, gh_im = gQ1 (r_re - r_im), gr_re = gQ0 h_re + gQ1 h_im, gr_im = gQ1 (h_re - h_im)
+//   TransH   d = (Q0 - t c) + eps, u = g d/n      gQ0 = -u, gt = u c, gc = u t (+ gQ0 h at the end)
+//            gh = gQ0 c, gr = gQ0, c = 1 - s w (s = sum w):  gw_k = -s gc_k - sum_i gc_i w_i
+//   TransD   d = (Q0 - t - rv sigma) + eps, sigma = t.tv, u = g d/n, beta = sum_i u_i rv_i
+//            gQ0 = -u, gt = u + beta tv, gtv = beta t, g(rv) += u sigma;  rho = sum_i gQ0_i rv_i
+//            gh = gQ0 + rho hv, ghv = rho h, gr = gQ0, grv = gQ0 (h.hv) + g(rv)
+//   Analogy  gQk = g t_k, gt_k = g Q_k;  gh = gQ0 r, gr = gQ0 h, gh_re = gQ1 r_re + gQ2 r_im, gh_im = gQ2 r_re - gQ1 r_im,
+//            gr_re = gQ1 h_re + gQ2 h_im, gr_im = gQ2 h_re - gQ1 h_im
+//   HolE     gQ = g t, gt = g Q;  gh_i = sum_j gQ_j r[(j - i) mod d], gr_m = sum_j gQ_j h[(j - m) mod d]
+//   TorusE   not differentiated by the reference (its calculate_loss is TransE's) -> HW_ERR_UNSUPPORTED
 #include "kge_model.h"
 
 namespace hw {
@@ -25,14 +34,15 @@ constexpr int REL_REPLICAS = 64;
 
 // grad_rel[k][r_fixed, :] += sum over replicas (fixed order -> the replica stage adds no run-to-run noise of its own)
 __global__ void rel_replica_reduce_kernel(const float* __restrict__ rep, int n_tables, int64_t row_len,
-                                          float* __restrict__ g0, float* __restrict__ g1, int64_t r_fixed) {
+                                          float* __restrict__ g0, float* __restrict__ g1, float* __restrict__ g2,
+                                          int64_t r_fixed) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= row_len * n_tables) return;
     const int k = (int)(i / row_len);
     const int64_t c = i % row_len;
     float s = 0.f;
     for (int q = 0; q < REL_REPLICAS; ++q) s += rep[((size_t)q * n_tables + k) * row_len + c];
-    float* gdst = k == 0 ? g0 : g1;
+    float* gdst = k == 0 ? g0 : (k == 1 ? g1 : g2);
     if (gdst) gdst[(size_t)r_fixed * row_len + c] += s;
 }
 
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
     const int h = clamp_row(h_idx[b], d.n_head, nullptr);
     const int r = clamp_row(r_idx ? r_idx[b] : r_fixed, d.n_rel, nullptr);
     SC sc;
-    R hraw[2], rraw[2];
+    R hraw[HW_KGE_MAX_TABLES], rraw[HW_KGE_MAX_TABLES];
     sc.template build<true>(d, h, r, gl, hraw, rraw);
     // Fixed relation (rec side: every group uses the [UI-Relation] row): thousands of waves adding into ONE row run
     // an order of magnitude below the atomic rate (MI355X_MICROARCH.md 'Global float atomics', contention row), so the
@@ -63,8 +73,9 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
     const size_t rel_row_len = MODEL == HW_RESCAL ? (size_t)d.dim * d.dim : (size_t)d.dim;
     if (rel_replicas) {
         const size_t rep = (size_t)(task % REL_REPLICAS) * rel_row_len * MT::NR;
-        gr.rel[0] = rel_replicas + rep - (size_t)r * rel_row_len;  // so that "+ r * row_len" lands in the replica
-        if constexpr (MT::NR == 2) gr.rel[1] = rel_replicas + rep + rel_row_len - (size_t)r * rel_row_len;
+#pragma unroll
+        for (int k = 0; k < MT::NR; ++k)  // so that "+ r * row_len" lands in the replica
+            if (gr.rel[k]) gr.rel[k] = rel_replicas + rep + k * rel_row_len - (size_t)r * rel_row_len;
     }
 
     float GQ[MT::NQ][NE];
@@ -84,21 +95,50 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
 #pragma unroll
         for (int k = 0; k < MT::NT; ++k) t[k].load(d.tail[k] + (size_t)tj * d.dim, d.dim, gl);
         float scale = gs;
-        if constexpr (MODEL == HW_TRANSE || MODEL == HW_ROTATE) {
-            float p = group_sum<G>(sc.partial(t, d.eps, d.dim, gl));
+        float sig = 0.f;
+        if constexpr (MT::TWO_PASS) sig = group_sum<G>(sc.pre(t, d.dim, gl));
+        if constexpr (MODEL == HW_TRANSE || MODEL == HW_ROTATE || MODEL == HW_TRANSH || MODEL == HW_TRANSD) {
+            float p = group_sum<G>(sc.partial(t, d.eps, d.dim, gl, sig));
             const float n = sqrtf(p);
             scale = n > 0.f ? gs / n : 0.f;
         }
         const size_t to = (size_t)tj * d.dim;
+        float beta = 0.f;
+        if constexpr (MODEL == HW_TRANSD) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                if (R::col(i, d.dim, gl) < 0) continue;
+                const float u = (((sc.q[0].v[i] - t[0].v[i]) - sc.q[1].v[i] * sig) + d.eps) * scale;
+                beta = fmaf(u, sc.q[1].v[i], beta);
+            }
+            beta = group_sum<G>(beta);
+        }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int c = R::col(i, d.dim, gl);
             if (c < 0) continue;
-            if constexpr (MODEL == HW_TRANSE) {
+            if constexpr (MODEL == HW_TRANSH) {
+                const float u = ((sc.q[0].v[i] - t[0].v[i] * sc.q[1].v[i]) + d.eps) * scale;
+                GQ[0][i] -= u;
+                GQ[1][i] = fmaf(u, t[0].v[i], GQ[1][i]);
+                if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, u * sc.q[1].v[i]);
+            } else if constexpr (MODEL == HW_TRANSD) {
+                const float u = (((sc.q[0].v[i] - t[0].v[i]) - sc.q[1].v[i] * sig) + d.eps) * scale;
+                GQ[0][i] -= u;
+                GQ[1][i] = fmaf(u, sig, GQ[1][i]);
+                if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, fmaf(beta, t[1].v[i], u));
+                if (gr.tail[1]) atomicAdd(gr.tail[1] + to + c, beta * t[0].v[i]);
+            } else if constexpr (MODEL == HW_ANALOGY) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    GQ[k][i] = fmaf(scale, t[k].v[i], GQ[k][i]);
+                    if (gr.tail[k]) atomicAdd(gr.tail[k] + to + c, scale * sc.q[k].v[i]);
+                }
+            } else if constexpr (MODEL == HW_TRANSE) {
                 const float u = ((sc.q[0].v[i] - t[0].v[i]) + d.eps) * scale;
                 GQ[0][i] -= u;
                 if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, u);
-            } else if constexpr (MODEL == HW_DISTMULT || MODEL == HW_RESCAL) {
+            } else if constexpr (MODEL == HW_DISTMULT || MODEL == HW_RESCAL || MODEL == HW_HOLE) {
                 GQ[0][i] = fmaf(scale, t[0].v[i], GQ[0][i]);
                 if (gr.tail[0]) atomicAdd(gr.tail[0] + to + c, scale * sc.q[0].v[i]);
             } else if constexpr (MODEL == HW_ROTATE) {
@@ -150,11 +190,91 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
         }
         return;
     }
+    if constexpr (MODEL == HW_HOLE) {
+        // gh_i = sum_j gQ_j r[(j - i) mod d], gr_m = sum_j gQ_j h[(j - m) mod d]: gQ_j comes from its owner lane by
+        // v_readlane (j is wave-uniform), the rolled rows are gathers inside L1-resident rows; no cross-lane sums.
+        const float* __restrict__ hrow = d.head[0] + ho;
+        const float* __restrict__ rrow = d.rel[0] + ro;
+        float gh[NE], gre[NE];
+        int cc[NE];
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            gh[k] = gre[k] = 0.f;
+            const int c = R::col(k, d.dim, gl);
+            cc[k] = c < 0 ? 0 : c;
+        }
+#pragma unroll
+        for (int kq = 0; kq < NE; ++kq) {
+            for (int l = 0; l < G; ++l) {
+                const int j = l + kq * G;
+                if (j >= d.dim) break;
+                const float gq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(GQ[0][kq]), l));
+                if (gq == 0.f) continue;
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    int idx = j - cc[k];
+                    idx += idx < 0 ? d.dim : 0;
+                    gh[k] = fmaf(gq, rrow[idx], gh[k]);
+                    gre[k] = fmaf(gq, hrow[idx], gre[k]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int c = R::col(k, d.dim, gl);
+            if (c < 0) continue;
+            if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, gh[k]);
+            if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, gre[k]);
+        }
+        return;
+    }
+    if constexpr (MODEL == HW_TRANSH || MODEL == HW_TRANSD) {
+        float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (R::col(i, d.dim, gl) < 0) continue;
+            if constexpr (MODEL == HW_TRANSH) {
+                const float gc = fmaf(GQ[0][i], hraw[0].v[i], GQ[1][i]);
+                r0 += rraw[1].v[i];                    // s = sum w
+                r1 = fmaf(gc, rraw[1].v[i], r1);       // sum gc w
+            } else {
+                r0 = fmaf(hraw[0].v[i], hraw[1].v[i], r0);  // h . hv
+                r1 = fmaf(GQ[0][i], rraw[1].v[i], r1);      // rho = sum gQ0 rv
+            }
+        }
+        r0 = group_sum<G>(r0);
+        r1 = group_sum<G>(r1);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int c = R::col(i, d.dim, gl);
+            if (c < 0) continue;
+            if constexpr (MODEL == HW_TRANSH) {
+                const float gc = fmaf(GQ[0][i], hraw[0].v[i], GQ[1][i]);
+                if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, GQ[0][i] * sc.q[1].v[i]);
+                if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, GQ[0][i]);
+                if (gr.rel[1]) atomicAdd(gr.rel[1] + ro + c, -r0 * gc - r1);
+            } else {
+                if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, fmaf(r1, hraw[1].v[i], GQ[0][i]));
+                if (gr.head[1]) atomicAdd(gr.head[1] + ho + c, r1 * hraw[0].v[i]);
+                if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, GQ[0][i]);
+                if (gr.rel[1]) atomicAdd(gr.rel[1] + ro + c, fmaf(GQ[0][i], r0, GQ[1][i]));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int c = R::col(i, d.dim, gl);
         if (c < 0) continue;
-        if constexpr (MODEL == HW_TRANSE) {
+        if constexpr (MODEL == HW_ANALOGY) {
+            const float g0 = GQ[0][i], g1 = GQ[1][i], g2 = GQ[2][i];
+            if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, g0 * rraw[0].v[i]);
+            if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, g0 * hraw[0].v[i]);
+            if (gr.head[1]) atomicAdd(gr.head[1] + ho + c, g1 * rraw[1].v[i] + g2 * rraw[2].v[i]);
+            if (gr.head[2]) atomicAdd(gr.head[2] + ho + c, g2 * rraw[1].v[i] - g1 * rraw[2].v[i]);
+            if (gr.rel[1]) atomicAdd(gr.rel[1] + ro + c, g1 * hraw[1].v[i] + g2 * hraw[2].v[i]);
+            if (gr.rel[2]) atomicAdd(gr.rel[2] + ro + c, g2 * hraw[1].v[i] - g1 * hraw[2].v[i]);
+        } else if constexpr (MODEL == HW_TRANSE) {
             if (GQ[0][i] != 0.f) {
                 if (gr.head[0]) atomicAdd(gr.head[0] + ho + c, GQ[0][i]);
                 if (gr.rel[0]) atomicAdd(gr.rel[0] + ro + c, GQ[0][i]);
@@ -211,7 +331,8 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     // replica scratch only when the relation is fixed, has a gradient, and enough tasks collide on it
-    const int n_rel_tab = desc->model == HW_COMPLEX ? 2 : 1;
+    const int n_rel_tab = desc->model == HW_ANALOGY ? 3
+                          : (desc->model == HW_COMPLEX || desc->model == HW_TRANSH || desc->model == HW_TRANSD) ? 2 : 1;
     const int64_t rel_row_len = desc->model == HW_RESCAL ? (int64_t)desc->dim * desc->dim : desc->dim;
     float* replicas = (!r_idx && rel_workspace && grads->rel[0] && n_tasks >= 256) ? rel_workspace : nullptr;
     if (replicas) (void)hipMemsetAsync(replicas, 0, sizeof(float) * REL_REPLICAS * n_rel_tab * rel_row_len, st);
@@ -231,7 +352,11 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
         case HW_COMPLEX: BYNE(HW_COMPLEX); break;
         case HW_DISTMULT: BYNE(HW_DISTMULT); break;
         case HW_RESCAL: BYNE(HW_RESCAL); break;
-        default: return HW_ERR_UNSUPPORTED;
+        case HW_TRANSH: BYNE(HW_TRANSH); break;
+        case HW_TRANSD: BYNE(HW_TRANSD); break;
+        case HW_ANALOGY: BYNE(HW_ANALOGY); break;
+        case HW_HOLE: BYNE(HW_HOLE); break;
+        default: return HW_ERR_UNSUPPORTED;  // TorusE: the reference never differentiates its scorer
     }
 #undef BYNE
 #undef CALL
@@ -239,7 +364,7 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
         const int64_t n = rel_row_len * n_rel_tab;
         const int64_t rf = r_fixed < 0 ? 0 : (r_fixed >= desc->n_rel ? desc->n_rel - 1 : r_fixed);
         hipLaunchKernelGGL(rel_replica_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, replicas,
-                           n_rel_tab, rel_row_len, grads->rel[0], grads->rel[1], rf);
+                           n_rel_tab, rel_row_len, grads->rel[0], grads->rel[1], grads->rel[2], rf);
     }
     return HW_LAUNCH_RC();
 }

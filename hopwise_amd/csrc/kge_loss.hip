@@ -50,6 +50,13 @@ __global__ __launch_bounds__(LOSS_THREADS) void bce_logits_kernel(const float* _
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
+__device__ __forceinline__ float sigmoidf(float x) {
+    const float e = expf(-fabsf(x));
+    return x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
+
+// SIG: the scores go through a sigmoid first (HolE, hole.py:103); the chain rule factor is folded into gpos / gneg.
+template <bool SIG>
 __global__ __launch_bounds__(LOSS_THREADS) void margin_ranking_kernel(const float* __restrict__ pos,
                                                                       const float* __restrict__ neg, int64_t n,
                                                                       float margin, float inv_n, float* __restrict__ gpos,
@@ -57,11 +64,16 @@ __global__ __launch_bounds__(LOSS_THREADS) void margin_ranking_kernel(const floa
                                                                       float* __restrict__ partial) {
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * LOSS_THREADS) {
-        const float l = -(pos[i] - neg[i]) + margin;
+        float p = pos[i], q = neg[i], dp = 1.f, dq = 1.f;
+        if constexpr (SIG) {
+            p = sigmoidf(p), q = sigmoidf(q);
+            dp = p * (1.f - p), dq = q * (1.f - q);
+        }
+        const float l = -(p - q) + margin;
         const bool act = l > 0.f;
         acc += act ? l : 0.f;
-        if (gpos) gpos[i] = act ? -inv_n : 0.f;
-        if (gneg) gneg[i] = act ? inv_n : 0.f;
+        if (gpos) gpos[i] = act ? -inv_n * dp : 0.f;
+        if (gneg) gneg[i] = act ? inv_n * dq : 0.f;
     }
     acc = block_sum_256(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
@@ -70,11 +82,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void margin_ranking_kernel(const floa
 __device__ __forceinline__ float log_sigmoid(float x) {  // -(max(-x,0) + log1p(exp(-|x|)))
     return -(fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))));
 }
-__device__ __forceinline__ float sigmoidf(float x) {
-    const float e = expf(-fabsf(x));
-    return x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-}
-
 // one wave per group row [1 + K]
 __global__ __launch_bounds__(256) void self_adv_kernel(const float* __restrict__ sc, int64_t n_groups, int n_cols,
                                                        float alpha, float inv_b, float* __restrict__ gsc,
@@ -200,17 +207,32 @@ extern "C" int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, floa
     return HW_LAUNCH_RC();
 }
 
-extern "C" int hw_loss_margin_ranking(const float* pos, const float* neg, int64_t n, float margin, float* loss_out,
-                                      float* gpos, float* gneg, float* workspace, void* stream) {
+static int margin_ranking_launch(bool sig, const float* pos, const float* neg, int64_t n, float margin, float* loss_out,
+                                 float* gpos, float* gneg, float* workspace, void* stream) {
     if (!pos || !neg || !loss_out || !workspace || n <= 0) return HW_ERR_INVALID_ARG;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int grid = loss_grid(n);
     const float inv_n = 1.0f / (float)n;
-    hipLaunchKernelGGL(margin_ranking_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, pos, neg, n, margin, inv_n, gpos,
-                       gneg, workspace);
+    if (sig)
+        hipLaunchKernelGGL(margin_ranking_kernel<true>, dim3(grid), dim3(LOSS_THREADS), 0, st, pos, neg, n, margin, inv_n,
+                           gpos, gneg, workspace);
+    else
+        hipLaunchKernelGGL(margin_ranking_kernel<false>, dim3(grid), dim3(LOSS_THREADS), 0, st, pos, neg, n, margin, inv_n,
+                           gpos, gneg, workspace);
     hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_n, loss_out);
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_loss_margin_ranking(const float* pos, const float* neg, int64_t n, float margin, float* loss_out,
+                                      float* gpos, float* gneg, float* workspace, void* stream) {
+    return margin_ranking_launch(false, pos, neg, n, margin, loss_out, gpos, gneg, workspace, stream);
+}
+
+extern "C" int hw_loss_margin_ranking_sigmoid(const float* pos, const float* neg, int64_t n, float margin,
+                                              float* loss_out, float* gpos, float* gneg, float* workspace,
+                                              void* stream) {
+    return margin_ranking_launch(true, pos, neg, n, margin, loss_out, gpos, gneg, workspace, stream);
 }
 
 extern "C" int hw_loss_self_adversarial(const float* scores, int64_t n_groups, int64_t n_cols, float alpha,

@@ -15,6 +15,13 @@
 //            (the 4th term multiplies t_im, exactly as the reference does -- not the paper's t_re)
 //   RESCAL   Q0 = h^T M_r  (M_r = relation row viewed [d, d])   f = Q0 * t          s             rescal.py:51-54
 //            the query build streams the d x d matrix once per (h, r) task; the per-tail work is DistMult's
+// Widened set, same factorisation:
+//   TorusE   Q0 = frac(h) + frac(r)          f = min(x^2, 1 - x^2), x = Q0 - frac(t)   -4 s         toruse.py:68-79
+//   TransH   c = 1 - sum(w) w; Q0 = h c + r, Q1 = c   f = ((Q0 - t Q1) + eps)^2          -sqrt(s)     transh.py:51-55,74-75
+//   TransD   Q0 = h + rv (h.hv) + r, Q1 = rv; per tail sigma = t.tv (a first reduction, Scorer::pre)
+//                                             f = ((Q0 - t - Q1 sigma) + eps)^2          -sqrt(s)     transd.py:89-94
+//   Analogy  Q0 = h r, Q1 = h_re r_re - h_im r_im, Q2 = h_re r_im + h_im r_re   f = Q0 t + Q1 t_re + Q2 t_im   s   analogy.py:66-70
+//   HolE     Q0[j] = sum_i h[i] r[(j - i) mod d]      f = Q0 t                            s            hole.py:53-61
 #pragma once
 #include "hw_common.h"
 
@@ -24,24 +31,57 @@ template <int MODEL>
 struct ModelTraits;
 template <>
 struct ModelTraits<HW_TRANSE> {
+    static constexpr bool TWO_PASS = false;
     static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
 };
 template <>
 struct ModelTraits<HW_DISTMULT> {
+    static constexpr bool TWO_PASS = false;
     static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
 };
 template <>
 struct ModelTraits<HW_RESCAL> {
+    static constexpr bool TWO_PASS = false;
     static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
 };
 template <>
 struct ModelTraits<HW_ROTATE> {
+    static constexpr bool TWO_PASS = false;
     static constexpr int NH = 2, NR = 1, NT = 2, NQ = 2;
 };
 template <>
 struct ModelTraits<HW_COMPLEX> {
+    static constexpr bool TWO_PASS = false;
     static constexpr int NH = 2, NR = 2, NT = 2, NQ = 2;
 };
+
+template <>
+struct ModelTraits<HW_TORUSE> {
+    static constexpr bool TWO_PASS = false;
+    static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
+};
+template <>
+struct ModelTraits<HW_TRANSH> {
+    static constexpr bool TWO_PASS = false;
+    static constexpr int NH = 1, NR = 2, NT = 1, NQ = 2;
+};
+template <>
+struct ModelTraits<HW_TRANSD> {
+    static constexpr int NH = 2, NR = 2, NT = 2, NQ = 2;
+    static constexpr bool TWO_PASS = true;
+};
+template <>
+struct ModelTraits<HW_ANALOGY> {
+    static constexpr bool TWO_PASS = false;
+    static constexpr int NH = 3, NR = 3, NT = 3, NQ = 3;
+};
+template <>
+struct ModelTraits<HW_HOLE> {
+    static constexpr bool TWO_PASS = false;
+    static constexpr int NH = 1, NR = 1, NT = 1, NQ = 1;
+};
+
+__device__ __forceinline__ float fracf_(float x) { return x - truncf(x); }  // torch.frac: sign of x
 
 template <int MODEL, int G, int NE, bool VEC>
 struct Scorer {
@@ -72,15 +112,63 @@ struct Scorer {
             if constexpr (KEEP) hraw[0].load(hrow, d.dim, gl);
             return;
         }
+        if constexpr (MODEL == HW_HOLE) {
+            // circular convolution: Q[j] = sum_i h[i] r[(j - i) mod d]; h[i] is a wave-uniform load, the rolled
+            // relation row a gather inside one L1-resident row
+            const float* __restrict__ hrow = d.head[0] + (size_t)h * d.dim;
+            const float* __restrict__ rrow = d.rel[0] + (size_t)r * d.dim;
+            int cc[NE];
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                cc[k] = R::col(k, d.dim, gl);
+                q[0].v[k] = 0.f;
+            }
+#pragma unroll 2
+            for (int i = 0; i < d.dim; ++i) {
+                const float hi = hrow[i];
+#pragma unroll
+                for (int k = 0; k < NE; ++k) {
+                    int idx = (cc[k] < 0 ? 0 : cc[k]) - i;
+                    idx += idx < 0 ? d.dim : 0;
+                    q[0].v[k] = fmaf(hi, rrow[idx], q[0].v[k]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NE; ++k) q[0].v[k] = cc[k] >= 0 ? q[0].v[k] : 0.f;
+            if constexpr (KEEP) {
+                hraw[0].load(hrow, d.dim, gl);
+                rraw[0].load(rrow, d.dim, gl);
+            }
+            return;
+        }
         R hh[MT::NH], rr[MT::NR];
         const size_t ho = (size_t)h * d.dim, ro = (size_t)r * d.dim;
 #pragma unroll
         for (int k = 0; k < MT::NH; ++k) hh[k].load(d.head[k] + ho, d.dim, gl);
 #pragma unroll
         for (int k = 0; k < MT::NR; ++k) rr[k].load(d.rel[k] + ro, d.dim, gl);
+        float red = 0.f;  // TransH: sum of the norm vector; TransD: h . h_vec
+        if constexpr (MODEL == HW_TRANSH || MODEL == HW_TRANSD) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) red = MODEL == HW_TRANSH ? red + rr[1].v[i] : fmaf(hh[0].v[i], hh[1].v[i], red);
+            red = group_sum<G>(red);
+        }
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            if constexpr (MODEL == HW_TRANSE) {
+            if constexpr (MODEL == HW_TORUSE) {
+                q[0].v[i] = fracf_(hh[0].v[i]) + fracf_(rr[0].v[i]);
+            } else if constexpr (MODEL == HW_TRANSH) {
+                const float c = 1.f - red * rr[1].v[i];
+                q[0].v[i] = fmaf(hh[0].v[i], c, rr[0].v[i]);
+                q[1].v[i] = c;
+            } else if constexpr (MODEL == HW_TRANSD) {
+                q[0].v[i] = (hh[0].v[i] + rr[1].v[i] * red) + rr[0].v[i];
+                q[1].v[i] = rr[1].v[i];
+            } else if constexpr (MODEL == HW_ANALOGY) {
+                q[0].v[i] = hh[0].v[i] * rr[0].v[i];
+                q[1].v[i] = hh[1].v[i] * rr[1].v[i] - hh[2].v[i] * rr[2].v[i];
+                q[2].v[i] = hh[1].v[i] * rr[2].v[i] + hh[2].v[i] * rr[1].v[i];
+            } else if constexpr (MODEL == HW_TRANSE) {
                 q[0].v[i] = hh[0].v[i] + rr[0].v[i];
             } else if constexpr (MODEL == HW_DISTMULT) {
                 q[0].v[i] = hh[0].v[i] * rr[0].v[i];
@@ -111,8 +199,23 @@ struct Scorer {
     // This lane's share of sum_d f(Q_d, t_d).  Query padding slots are 0.  With RAW = false the tail rows are
     // zero-padded too (Row::load); with RAW = true they were loaded with Row::load_raw and padding slots hold
     // junk, so models whose f(0, t) != 0 (TransE, RotatE) mask those slots here -- one select per load unit.
+    // TWO_PASS models: this lane's share of the tail-only first reduction (TransD: t . t_vec); the kernels sum it over
+    // the group and hand the total back to partial() as `aux`.
     template <bool RAW = false>
-    __device__ __forceinline__ float partial(const R* t, float eps, int dim, int gl) const {
+    __device__ __forceinline__ float pre(const R* t, int dim, int gl) const {
+        float s = 0.f;
+        if constexpr (MODEL == HW_TRANSD) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float v = t[0].v[i] * t[1].v[i];
+                s += (!RAW || R::slot_valid(i, dim, gl)) ? v : 0.f;
+            }
+        }
+        return s;
+    }
+
+    template <bool RAW = false>
+    __device__ __forceinline__ float partial(const R* t, float eps, int dim, int gl, float aux = 0.f) const {
         float s = 0.f;
         constexpr int UNIT = VEC ? 4 : 1;
 #pragma unroll
@@ -124,7 +227,21 @@ struct Scorer {
                 if constexpr (MODEL == HW_TRANSE) {
                     const float df = (q[0].v[i] - t[0].v[i]) + eps;
                     sc = fmaf(df, df, sc);
-                } else if constexpr (MODEL == HW_DISTMULT || MODEL == HW_RESCAL) {
+                } else if constexpr (MODEL == HW_TORUSE) {
+                    const float x = q[0].v[i] - fracf_(t[0].v[i]);
+                    const float x2 = x * x;
+                    sc += fminf(x2, 1.f - x2);
+                } else if constexpr (MODEL == HW_TRANSH) {
+                    const float df = (q[0].v[i] - t[0].v[i] * q[1].v[i]) + eps;
+                    sc = fmaf(df, df, sc);
+                } else if constexpr (MODEL == HW_TRANSD) {
+                    const float df = ((q[0].v[i] - t[0].v[i]) - q[1].v[i] * aux) + eps;
+                    sc = fmaf(df, df, sc);
+                } else if constexpr (MODEL == HW_ANALOGY) {
+                    sc = fmaf(q[0].v[i], t[0].v[i], sc);
+                    sc = fmaf(q[1].v[i], t[1].v[i], sc);
+                    sc = fmaf(q[2].v[i], t[2].v[i], sc);
+                } else if constexpr (MODEL == HW_DISTMULT || MODEL == HW_RESCAL || MODEL == HW_HOLE) {
                     sc = fmaf(q[0].v[i], t[0].v[i], sc);
                 } else if constexpr (MODEL == HW_ROTATE) {
                     const float a = q[0].v[i] - t[0].v[i];
@@ -136,9 +253,11 @@ struct Scorer {
                     sc = fmaf(q[1].v[i], t[1].v[i], sc);
                 }
             }
-            if constexpr (MODEL == HW_TRANSE || MODEL == HW_ROTATE) {
-                // padding: f(0, junk) != 0 when RAW; f(0, 0) = eps^2 != 0 for TransE with eps even when zero-padded
-                if (RAW || MODEL == HW_TRANSE) sc = R::slot_valid(c * UNIT, dim, gl) ? sc : 0.f;
+            if constexpr (MODEL == HW_TRANSE || MODEL == HW_ROTATE || MODEL == HW_TORUSE || MODEL == HW_TRANSH ||
+                          MODEL == HW_TRANSD) {
+                // padding: f(0, junk) != 0 when RAW; f(0, 0) = eps^2 != 0 for the eps models even when zero-padded
+                if (RAW || MODEL == HW_TRANSE || MODEL == HW_TRANSH || MODEL == HW_TRANSD)
+                    sc = R::slot_valid(c * UNIT, dim, gl) ? sc : 0.f;
             }
             s += sc;
         }
@@ -146,7 +265,8 @@ struct Scorer {
     }
 
     __device__ __forceinline__ static float finalize(float s, float margin) {
-        if constexpr (MODEL == HW_TRANSE) return -sqrtf(s);
+        if constexpr (MODEL == HW_TRANSE || MODEL == HW_TRANSH || MODEL == HW_TRANSD) return -sqrtf(s);
+        if constexpr (MODEL == HW_TORUSE) return -(4.f * s);
         if constexpr (MODEL == HW_ROTATE) return margin - sqrtf(s);
         return s;
     }

@@ -1,0 +1,691 @@
+// KGE scoring kernels for gfx950: grouped (1 positive + K negatives per (h, r)) and full sort.
+//
+// Both are HBM/L2-gather bound: ~0.5 flop per byte.  The design goal is bytes in flight, not flops:
+//   * one embedding row is spread over G lanes (G = 64 for d = 200/256: one 16-byte load per lane per
+//     table covers the row; G = 16/32 for short rows so that a wave carries 4/2 rows per instruction);
+//   * every sub-wave group keeps U tail rows in flight (U x NT x 16-byte loads per lane) before the
+//     first one is consumed;
+//   * the (h, r) query is built once per wave task and reused for all its tails (kge_model.h).
+// No LDS is used: a tail row is consumed by exactly one group, so staging it would only add a hop
+// (cdna_hip_programming.md, 'glds vs register staging', GEMV row).
+#pragma once
+#include "kge_model.h"
+
+namespace hw {
+
+// ------------------------------------------------------------------------------------------------
+// grouped scorer.  wave task = (group b, split s of S); the NS = 64/G sub-groups of the wave and the
+// S splits interleave over the group's tails:  j = (k*S + s)*NS + sub,  k = 0, 1, ...
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, int G, int NE, bool VEC, int U>
+__global__ __launch_bounds__(256) void kge_score_grouped_kernel(
+    hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
+    const int64_t* __restrict__ t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
+    float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob) {
+    using SC = Scorer<MODEL, G, NE, VEC>;
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, VEC>;
+    constexpr int NS = HW_WAVE / G;
+
+    const int lane = threadIdx.x & (HW_WAVE - 1);
+    const int sub = lane / G, gl = lane % G;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + (threadIdx.x / HW_WAVE);
+    if (task >= n_groups * S) return;  // wave-uniform
+    const int64_t b = task / S;
+    const int s = (int)(task % S);
+
+    bool bad = false;
+    const int h = clamp_row_flag(h_idx[b], d.n_head, bad);
+    const int r = clamp_row_flag(r_idx ? r_idx[b] : r_fixed, d.n_rel, bad);
+    SC sc;
+    sc.template build<false>(d, h, r, gl, nullptr, nullptr);
+
+    const int64_t* __restrict__ tb = t_idx + b * tsb;
+    float* __restrict__ ob = out + b * osb;
+
+    // This wave's tails, in processing order: q = 0, 1, ... -> j(q) = ((q / NS) * S + s) * NS + q % NS.
+    // Lane l prefetches the id of tail q = chunk * 64 + l (one coalesced-ish load per 64 tails, off the
+    // critical path), the row loads then pick their id with a cross-lane read.
+    auto j_of = [&](int q) { return ((q / NS) * S + s) * NS + (q % NS); };
+    for (int q0 = 0; j_of(q0) < ntail; q0 += HW_WAVE) {  // wave-uniform: j_of is monotone in q for q % NS == 0
+        const int jq = j_of(q0 + lane);
+        const int tpre = jq < ntail ? clamp_row_flag(tb[(int64_t)jq * tsj], d.n_tail, bad) : 0;
+#pragma unroll 1
+        for (int k = 0; k < HW_WAVE / NS; k += U) {  // k counts rows of NS tails inside the chunk
+            if (j_of(q0 + k * NS) >= ntail) break;   // wave-uniform
+            int jj[U];
+            R t[U][MT::NT];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ql = (k + u) * NS + sub;  // position inside the 64-tail chunk
+                jj[u] = j_of(q0 + ql);
+                int tj;
+                if constexpr (NS == 1) tj = __builtin_amdgcn_readlane(tpre, ql);  // wave-uniform -> scalar row base
+                else tj = __shfl(tpre, ql, HW_WAVE);
+#pragma unroll
+                for (int kk = 0; kk < MT::NT; ++kk) t[u][kk].load_raw(d.tail[kk] + (size_t)tj * d.dim, d.dim, gl);
+            }
+            float p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float aux = 0.f;
+                if constexpr (MT::TWO_PASS) aux = group_sum<G>(sc.template pre<true>(t[u], d.dim, gl));
+                p[u] = sc.template partial<true>(t[u], d.eps, d.dim, gl, aux);
+            }
+            int which;
+            const float tot = group_reduce_multi<G, U>(p, gl, which);
+            // one writer lane per tail: the first lane of the sub-block that ended up owning it
+            int jw = jj[0];
+#pragma unroll
+            for (int u = 1; u < U; ++u) jw = which == u ? jj[u] : jw;
+            if ((gl & (G / U - 1)) == 0 && jw < ntail) ob[(int64_t)jw * osj] = SC::finalize(tot, d.margin);
+        }
+    }
+    if (oob && __any(bad)) {
+        if (lane == 0) atomicAdd(oob, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped scorer, XCD-partitioned: tails are routed by id so that each XCD's private L2 only ever sees
+// 1/8 of the tail table.  Block bid works for partition p = bid % 8 (blocks are dealt round-robin over the
+// 8 XCDs, MI355X_MICROARCH.md 'Workgroup dispatch'); its 4 waves take groups (bid / 8) * 4 + wave and score
+// only the tails with (id & 7) == p.  Placement is a speed assumption only: every (group, tail) pair is
+// scored exactly once whatever XCD a block lands on.  ml-1m-small: 22 MB of entity rows -> 2.75 MB per
+// XCD, inside the 4 MB L2, instead of streaming from Infinity Cache.
+// Each wave compacts the ids of its partition into a small LDS list (ballot + prefix popcount) and drains
+// it 64 entries at a time with the same U-rows-in-flight loop as the plain kernel.
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, int G, int NE, bool VEC, int U>
+__global__ __launch_bounds__(256) void kge_score_grouped_xcd_kernel(
+    hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
+    const int64_t* __restrict__ t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail,
+    float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob) {
+    using SC = Scorer<MODEL, G, NE, VEC>;
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, VEC>;
+    constexpr int NS = HW_WAVE / G;
+    __shared__ int sel_id[4][128];
+    __shared__ int sel_j[4][128];
+
+    const int lane = threadIdx.x & (HW_WAVE - 1);
+    const int wave = threadIdx.x / HW_WAVE;
+    const int sub = lane / G, gl = lane % G;
+    const int part = blockIdx.x & 7;
+    const int64_t b = (int64_t)(blockIdx.x >> 3) * 4 + wave;
+    if (b >= n_groups) return;  // wave-uniform; no block-wide barrier is used below
+
+    bool bad = false;
+    const int h = clamp_row_flag(h_idx[b], d.n_head, bad);
+    const int r = clamp_row_flag(r_idx ? r_idx[b] : r_fixed, d.n_rel, bad);
+    SC sc;
+    sc.template build<false>(d, h, r, gl, nullptr, nullptr);
+
+    const int64_t* __restrict__ tb = t_idx + b * tsb;
+    float* __restrict__ ob = out + b * osb;
+    int* __restrict__ lid = sel_id[wave];
+    int* __restrict__ lj = sel_j[wave];
+    int cnt = 0;  // entries waiting in the list (wave-uniform)
+
+    for (int j0 = 0; j0 < ntail; j0 += HW_WAVE) {
+        const int j = j0 + lane;
+        int id = 0;
+        bool mine = false;
+        if (j < ntail) {
+            id = clamp_row_flag(tb[(int64_t)j * tsj], d.n_tail, bad);
+            mine = (id & 7) == part;
+        }
+        const unsigned long long mask = __ballot(mine);
+        if (mine) {
+            const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            lid[pos] = id;
+            lj[pos] = j;
+        }
+        cnt += __popcll(mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool last = j0 + HW_WAVE >= ntail;
+        while (cnt >= HW_WAVE || (last && cnt > 0)) {
+            const int n_now = cnt < HW_WAVE ? cnt : HW_WAVE;
+#pragma unroll 1
+            for (int k = 0; k * NS < n_now; k += U) {
+                int jj[U];
+                bool ok[U];
+                R t[U][MT::NT];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int ql = (k + u) * NS + sub;
+                    ok[u] = ql < n_now;
+                    const int tj = ok[u] ? lid[ql] : 0;
+                    jj[u] = ok[u] ? lj[ql] : 0;
+#pragma unroll
+                    for (int kk = 0; kk < MT::NT; ++kk) t[u][kk].load_raw(d.tail[kk] + (size_t)tj * d.dim, d.dim, gl);
+                }
+                float p[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                float aux = 0.f;
+                if constexpr (MT::TWO_PASS) aux = group_sum<G>(sc.template pre<true>(t[u], d.dim, gl));
+                p[u] = sc.template partial<true>(t[u], d.eps, d.dim, gl, aux);
+            }
+                int which;
+                const float tot = group_reduce_multi<G, U>(p, gl, which);
+                int jw = jj[0];
+                bool okw = ok[0];
+#pragma unroll
+                for (int u = 1; u < U; ++u) {
+                    jw = which == u ? jj[u] : jw;
+                    okw = which == u ? ok[u] : okw;
+                }
+                if ((gl & (G / U - 1)) == 0 && okw) ob[(int64_t)jw * osj] = SC::finalize(tot, d.margin);
+            }
+            // keep the (at most 63) entries that did not fit this round
+            const int rest = cnt - n_now;
+            int mid = 0, mj = 0;
+            if (lane < rest) mid = lid[n_now + lane], mj = lj[n_now + lane];
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) lid[lane] = mid, lj[lane] = mj;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            cnt = rest;
+        }
+    }
+    if (oob && __any(bad)) {
+        if (lane == 0) atomicAdd(oob, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// full sort.  wave task = (tail chunk c, head block hb): HB queries live in registers, the chunk's
+// tail rows stream through once and are scored against all HB of them.  Head block is the fastest
+// varying task index so the waves that share a tail chunk run together (L1/L2 reuse).
+// ------------------------------------------------------------------------------------------------
+template <int MODEL, int G, int NE, bool VEC, int HB, int U>
+__global__ __launch_bounds__(256) void kge_full_sort_kernel(
+    hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
+    int n_heads, int64_t lo, int64_t hi, int chunk, float* __restrict__ out, int64_t ld, int32_t* oob) {
+    using SC = Scorer<MODEL, G, NE, VEC>;
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, VEC>;
+    constexpr int NS = HW_WAVE / G;
+
+    const int lane = threadIdx.x & (HW_WAVE - 1);
+    const int sub = lane / G, gl = lane % G;
+    const int n_hb = (n_heads + HB - 1) / HB;
+    const int64_t n_chunks = (hi - lo + chunk - 1) / chunk;
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + (threadIdx.x / HW_WAVE);
+    if (task >= n_chunks * n_hb) return;
+    const int hb = (int)(task % n_hb);
+    const int64_t c = task / n_hb;
+
+    SC sc[HB];
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+        const int bi = min(hb * HB + q, n_heads - 1);
+        const int h = clamp_row(h_idx[bi], d.n_head, oob);
+        const int r = clamp_row(r_idx ? r_idx[bi] : r_fixed, d.n_rel, oob);
+        sc[q].template build<false>(d, h, r, gl, nullptr, nullptr);
+    }
+
+    const int64_t n0 = lo + c * chunk;
+    const int64_t n1 = min(n0 + chunk, hi);
+    for (int64_t nb = n0; nb < n1; nb += NS * U) {
+        int64_t n[U];
+        R t[U][MT::NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            n[u] = nb + u * NS + sub;
+            const int64_t row = n[u] < n1 ? n[u] : n0;
+#pragma unroll
+            for (int k = 0; k < MT::NT; ++k) t[u][k].load_raw(d.tail[k] + (size_t)row * d.dim, d.dim, gl);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float aux = 0.f;  // tail-only pre-reduction (TransD: t . t_vec), shared by the HB queries
+            if constexpr (MT::TWO_PASS) aux = group_sum<G>(sc[0].template pre<true>(t[u], d.dim, gl));
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
+                p = group_sum<G>(p);
+                const int bi = hb * HB + q;
+                if (gl == 0 && n[u] < n1 && bi < n_heads) out[(int64_t)bi * ld + (n[u] - lo)] = SC::finalize(p, d.margin);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// full sort fused with the evaluation mask and a first-stage top-k: the [B, N] score matrix
+// is never written.  A wave scores a sub-chunk of SUB = 128 consecutive tails for HB heads into LDS, applies the
+// mask (column `mask_col` and the history bitmap -> -inf, trainer.py:731-734), and keeps the k best of the
+// sub-chunk per head by k wave arg-max rounds on (value desc, index asc) keys.  A second small kernel ranks the
+// N / 128 * k candidates of every head.  Exactly the top-k of the full masked row as long as k <= 128.
+// ------------------------------------------------------------------------------------------------
+constexpr int FS_SUB = 128;
+
+__device__ __forceinline__ uint64_t score_key(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)(~idx);
+}
+
+template <int MODEL, int G, int NE, bool VEC, int HB>
+__global__ __launch_bounds__(256) void kge_full_sort_topk_kernel(
+    hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
+    int n_heads, int64_t lo, int64_t hi, const uint32_t* __restrict__ mask_bits, int64_t mask_words, int64_t mask_col,
+    int k, float* __restrict__ cand_val, int64_t* __restrict__ cand_idx, int64_t n_sub) {
+    using SC = Scorer<MODEL, G, NE, VEC>;
+    using MT = ModelTraits<MODEL>;
+    using R = Row<G, NE, VEC>;
+    constexpr int NS = HW_WAVE / G;
+    constexpr int U = 2;
+    __shared__ float lds_sc[4][HB][FS_SUB];
+
+    const int lane = threadIdx.x & (HW_WAVE - 1);
+    const int wave = threadIdx.x / HW_WAVE;
+    const int sub = lane / G, gl = lane % G;
+    const int n_hb = (n_heads + HB - 1) / HB;
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= n_sub * n_hb) return;
+    const int hb = (int)(task % n_hb);
+    const int64_t c = task / n_hb;
+
+    SC sc[HB];
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+        const int bi = min(hb * HB + q, n_heads - 1);
+        const int h = clamp_row(h_idx[bi], d.n_head, nullptr);
+        const int r = clamp_row(r_idx ? r_idx[bi] : r_fixed, d.n_rel, nullptr);
+        sc[q].template build<false>(d, h, r, gl, nullptr, nullptr);
+    }
+    const int64_t n0 = lo + c * FS_SUB;
+    const int64_t n1 = min(n0 + FS_SUB, hi);
+    float(*my)[FS_SUB] = lds_sc[wave];
+    for (int64_t nb = n0; nb < n1; nb += NS * U) {
+        int64_t n[U];
+        R t[U][MT::NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            n[u] = nb + u * NS + sub;
+            const int64_t row = n[u] < n1 ? n[u] : n0;
+#pragma unroll
+            for (int kk = 0; kk < MT::NT; ++kk) t[u][kk].load_raw(d.tail[kk] + (size_t)row * d.dim, d.dim, gl);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float aux = 0.f;  // tail-only pre-reduction (TransD: t . t_vec), shared by the HB queries
+            if constexpr (MT::TWO_PASS) aux = group_sum<G>(sc[0].template pre<true>(t[u], d.dim, gl));
+#pragma unroll
+            for (int q = 0; q < HB; ++q) {
+                float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
+                p = group_sum<G>(p);
+                if (gl == 0 && n[u] < n1) my[q][n[u] - n0] = SC::finalize(p, d.margin);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // mask + k arg-max rounds per head; lane l owns sub-chunk positions l and l + 64
+    const int len = (int)(n1 - n0);
+#pragma unroll
+    for (int q = 0; q < HB; ++q) {
+        const int bi = hb * HB + q;
+        if (bi >= n_heads) break;  // wave-uniform
+        uint64_t key[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int pos = lane + 64 * e;
+            key[e] = 0ull;
+            if (pos < len) {
+                const int64_t col = n0 + pos - lo;  // column of the [B, N] matrix
+                float v = my[q][pos];
+                const bool masked = (col == mask_col) ||
+                                    (mask_bits && ((mask_bits[(size_t)bi * mask_words + (col >> 5)] >> (col & 31)) & 1u));
+                if (masked) v = -INFINITY;
+                key[e] = score_key(v, (uint32_t)col);
+            }
+        }
+        uint64_t bound = ~0ull;
+        for (int r = 0; r < k; ++r) {
+            uint64_t best = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (key[e] < bound && key[e] > best) best = key[e];
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                const uint64_t o = __shfl_xor(best, m, 64);
+                best = o > best ? o : best;
+            }
+            if (lane == 0) {
+                const size_t o = ((size_t)bi * n_sub + c) * k + r;
+                if (best == 0) {
+                    cand_val[o] = -INFINITY;
+                    cand_idx[o] = -1;
+                } else {
+                    const uint32_t col = ~(uint32_t)(best & 0xffffffffu);
+                    uint32_t u = (uint32_t)(best >> 32);  // undo the order-preserving map: the masked value
+                    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+                    cand_val[o] = __uint_as_float(u);
+                    cand_idx[o] = col;
+                }
+            }
+            bound = best;
+            if (best == 0) bound = 0;
+        }
+    }
+}
+
+// rank the candidates of one head: block per row, k rounds, key = (value, ~global index)
+static __global__ __launch_bounds__(256) void topk_candidates_kernel(const float* __restrict__ cand_val,
+                                                              const int64_t* __restrict__ cand_idx, int64_t n_cand,
+                                                              int k, float* __restrict__ out_val,
+                                                              int64_t* __restrict__ out_idx) {
+    __shared__ uint64_t red[4];
+    __shared__ uint64_t winner;
+    const float* __restrict__ v = cand_val + (size_t)blockIdx.x * n_cand;
+    const int64_t* __restrict__ ix = cand_idx + (size_t)blockIdx.x * n_cand;
+    uint64_t bound = ~0ull;
+    for (int r = 0; r < k; ++r) {
+        uint64_t best = 0;
+        for (int64_t i = threadIdx.x; i < n_cand; i += 256) {
+            if (ix[i] < 0) continue;
+            const uint64_t key = score_key(v[i], (uint32_t)ix[i]);
+            if (key < bound && key > best) best = key;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint64_t o = __shfl_xor(best, m, 64);
+            best = o > best ? o : best;
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t w = red[0];
+            for (int i = 1; i < 4; ++i) w = red[i] > w ? red[i] : w;
+            winner = w;
+            const size_t o = (size_t)blockIdx.x * k + r;
+            if (w == 0) {
+                out_val[o] = -INFINITY;
+                out_idx[o] = -1;
+            } else {
+                uint32_t u = (uint32_t)(w >> 32);
+                u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+                out_val[o] = __uint_as_float(u);
+                out_idx[o] = (int64_t)(~(uint32_t)(w & 0xffffffffu));
+            }
+        }
+        __syncthreads();
+        bound = winner;
+    }
+}
+
+static __global__ void build_mask_bits_kernel(const int64_t* __restrict__ hr, const int64_t* __restrict__ hc, int64_t n_hist,
+                                       int64_t n_rows, int64_t n_cols, int64_t words, uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_hist) return;
+    const int64_t r = hr[i], c = hc[i];
+    if (r >= 0 && r < n_rows && c >= 0 && c < n_cols) atomicOr(bits + (size_t)r * words + (c >> 5), 1u << (c & 31));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+static int check_desc(const hw_kge_desc* d) {
+    if (!d) return HW_ERR_INVALID_ARG;
+    if (d->dim < 1 || d->dim > HW_MAX_DIM) return HW_ERR_INVALID_ARG;
+    if (d->n_head < 1 || d->n_rel < 1 || d->n_tail < 1) return HW_ERR_INVALID_ARG;
+    int nh, nr, nt;
+    switch (d->model) {
+        case HW_TRANSE:
+        case HW_DISTMULT:
+        case HW_TORUSE:
+        case HW_HOLE:
+        case HW_RESCAL: nh = 1, nr = 1, nt = 1; break;
+        case HW_ROTATE: nh = 2, nr = 1, nt = 2; break;
+        case HW_COMPLEX: nh = 2, nr = 2, nt = 2; break;
+        case HW_TRANSH: nh = 1, nr = 2, nt = 1; break;
+        case HW_TRANSD: nh = 2, nr = 2, nt = 2; break;
+        case HW_ANALOGY: nh = 3, nr = 3, nt = 3; break;
+        default: return HW_ERR_UNSUPPORTED;
+    }
+    for (int k = 0; k < nh; ++k)
+        if (!d->head[k]) return HW_ERR_INVALID_ARG;
+    for (int k = 0; k < nr; ++k)
+        if (!d->rel[k]) return HW_ERR_INVALID_ARG;
+    for (int k = 0; k < nt; ++k)
+        if (!d->tail[k]) return HW_ERR_INVALID_ARG;
+    // 16-byte loads need 16-byte aligned rows: dim % 4 == 0 and aligned table bases
+    return HW_OK;
+}
+
+static bool tables_aligned16(const hw_kge_desc* d) {
+    uintptr_t m = 0;
+    for (int k = 0; k < HW_KGE_MAX_TABLES; ++k) m |= (uintptr_t)d->head[k] | (uintptr_t)d->rel[k] | (uintptr_t)d->tail[k];
+    return (m & 15) == 0;
+}
+
+#define HW_DISPATCH_SHAPE(MODEL, shape, CALL)                                   \
+    do {                                                                        \
+        if (shape.vec) {                                                        \
+            if (shape.G == 16) { CALL(MODEL, 16, 4, true); }                    \
+            else if (shape.G == 32) { CALL(MODEL, 32, 4, true); }               \
+            else if (shape.NE == 4) { CALL(MODEL, 64, 4, true); }               \
+            else if (shape.NE == 8) { CALL(MODEL, 64, 8, true); }               \
+            else { CALL(MODEL, 64, 16, true); }                                 \
+        } else {                                                                \
+            if (shape.NE == 1) { CALL(MODEL, 64, 1, false); }                   \
+            else if (shape.NE == 4) { CALL(MODEL, 64, 4, false); }              \
+            else { CALL(MODEL, 64, 16, false); }                                \
+        }                                                                       \
+    } while (0)
+
+// FAMILY 0 = the five hot-path scorers (kge_score.hip), FAMILY 1 = the widened set (kge_score_ext.hip): the impl
+// templates below are instantiated once per family so that the two translation units compile in parallel.
+#define HW_FAMILY_OF(model) ((model) <= HW_RESCAL ? 0 : 1)
+#define HW_DISPATCH_ONE(M, shape, CALL)                                         \
+    case M:                                                                     \
+        if constexpr (FAMILY == HW_FAMILY_OF(M)) HW_DISPATCH_SHAPE(M, shape, CALL); \
+        break;
+#define HW_DISPATCH_MODEL(model, shape, CALL)                                   \
+    do {                                                                        \
+        switch (model) {                                                        \
+            HW_DISPATCH_ONE(HW_TRANSE, shape, CALL)                             \
+            HW_DISPATCH_ONE(HW_ROTATE, shape, CALL)                             \
+            HW_DISPATCH_ONE(HW_COMPLEX, shape, CALL)                            \
+            HW_DISPATCH_ONE(HW_DISTMULT, shape, CALL)                           \
+            HW_DISPATCH_ONE(HW_RESCAL, shape, CALL)                             \
+            HW_DISPATCH_ONE(HW_TORUSE, shape, CALL)                             \
+            HW_DISPATCH_ONE(HW_TRANSH, shape, CALL)                             \
+            HW_DISPATCH_ONE(HW_TRANSD, shape, CALL)                             \
+            HW_DISPATCH_ONE(HW_ANALOGY, shape, CALL)                            \
+            HW_DISPATCH_ONE(HW_HOLE, shape, CALL)                               \
+            default: return HW_ERR_UNSUPPORTED;                                 \
+        }                                                                       \
+    } while (0)
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+static inline int64_t full_sort_topk_workspace_bytes(int64_t n_heads, int64_t n_tails, int32_t k) {
+    const int64_t words = (n_tails + 31) / 32, n_sub = (n_tails + FS_SUB - 1) / FS_SUB;
+    return n_heads * words * 4 + n_heads * n_sub * k * (4 + 8) + 64;
+}
+template <int FAMILY>
+static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx,
+                                    int64_t r_fixed, const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
+                                    int64_t n_groups, int64_t n_tail_per_group, float* out, int64_t o_stride_b,
+                                    int64_t o_stride_j, int32_t* oob_counter, void* stream) {
+    int rc = check_desc(desc);
+    if (rc) return rc;
+    if (!h_idx || !t_idx || !out || n_groups < 0 || n_tail_per_group < 0) return HW_ERR_INVALID_ARG;
+    if (n_tail_per_group > INT32_MAX / 2) return HW_ERR_INVALID_ARG;
+    if (n_groups == 0 || n_tail_per_group == 0) return HW_OK;
+    const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
+    const int ntail = (int)n_tail_per_group;
+    const int NS = HW_WAVE / shape.G;
+    hipStream_t st = (hipStream_t)stream;
+    HW_CLEAR_ERR();
+    // Variant: groups with many tails are routed by tail id to XCD-local L2 slices; short groups (predict,
+    // pos/neg pairs) use the plain kernel.  HW_GROUPED_VARIANT = 0 (plain) / 1 (xcd) overrides for experiments.
+    int variant = env_int("HW_GROUPED_VARIANT", -1);
+    if (variant < 0) {
+        // tail rows the launch can touch: up to 4 MiB they sit in every XCD's L2 anyway; beyond the 256 MiB
+        // Infinity Cache nothing is resident and the plain kernel's lower overhead wins (measured, profiles/r1)
+        const int nt = (desc->model == HW_ROTATE || desc->model == HW_COMPLEX || desc->model == HW_TRANSD) ? 2
+                       : desc->model == HW_ANALOGY ? 3 : 1;
+        const double footprint = (double)desc->n_tail * desc->dim * 4.0 * nt;
+        variant = (ntail >= 64 && footprint > 6.0e6 && footprint <= 256.0e6) ? 1 : 0;
+    }
+    if (variant == 1) {
+        const int64_t n_blocks = ((n_groups + 3) / 4) * 8;
+        if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+#define CALLX(MODEL, G_, NE_, VEC_)                                                                                 \
+    hipLaunchKernelGGL((kge_score_grouped_xcd_kernel<MODEL, G_, NE_, VEC_, 4>), dim3((unsigned)n_blocks), dim3(256), \
+                       0, st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, out,    \
+                       o_stride_b, o_stride_j, oob_counter)
+        HW_DISPATCH_MODEL(desc->model, shape, CALLX);
+#undef CALLX
+        return HW_LAUNCH_RC();
+    }
+    const bool u8 = env_int("HW_GROUPED_U", 4) == 8;
+    constexpr int U = 4;
+    // splits per group: enough waves to fill 256 CUs x 32 wave slots, but keep >= U*NS tails per wave
+    // so the (h, r) query build is amortised.
+    int S = env_int("HW_GROUPED_SPLITS", 0);
+    if (S <= 0) {
+        const int per_wave = U * NS * 2;
+        const int s_max = (ntail + per_wave - 1) / per_wave;
+        const int64_t want = (16384 + n_groups - 1) / n_groups;
+        S = (int)(want < 1 ? 1 : (want > s_max ? s_max : want));
+    }
+    const int64_t n_tasks = n_groups * S;
+    const int64_t n_blocks = (n_tasks + 3) / 4;
+    if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+#define CALL(MODEL, G_, NE_, VEC_)                                                                              \
+    hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U>), dim3((unsigned)n_blocks), dim3(256), 0, \
+                       st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, out,  \
+                       o_stride_b, o_stride_j, oob_counter)
+    if (u8 && desc->model == HW_ROTATE && shape.vec && shape.G == 64 && shape.NE == 4) {  // experiment hook
+        hipLaunchKernelGGL((kge_score_grouped_kernel<HW_ROTATE, 64, 4, true, 8>), dim3((unsigned)n_blocks), dim3(256), 0,
+                           st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, out,
+                           o_stride_b, o_stride_j, oob_counter);
+        return HW_LAUNCH_RC();
+    }
+    HW_DISPATCH_MODEL(desc->model, shape, CALL);
+#undef CALL
+    return HW_LAUNCH_RC();
+}
+
+template <int FAMILY>
+static int full_sort_impl(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                                int64_t n_heads, int64_t tail_lo, int64_t tail_hi, float* out, int64_t out_ld,
+                                int32_t* oob_counter, void* stream) {
+    int rc = check_desc(desc);
+    if (rc) return rc;
+    if (!h_idx || !out || n_heads < 0 || n_heads > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (tail_lo < 0 || tail_hi > desc->n_tail || tail_lo > tail_hi || out_ld < tail_hi - tail_lo)
+        return HW_ERR_INVALID_ARG;
+    if (n_heads == 0 || tail_lo == tail_hi) return HW_OK;
+    const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
+    const int NS = HW_WAVE / shape.G;
+    const int64_t n = tail_hi - tail_lo;
+    constexpr int U = 2;
+    const bool hb4 = n_heads > 1;
+    const int n_hb = hb4 ? (int)((n_heads + 3) / 4) : 1;
+    // tail rows per wave task: aim for >= 8192 tasks, at least one U-batch, at most 256 rows
+    int chunk = env_int("HW_FULLSORT_CHUNK", 0);
+    if (chunk <= 0) {
+        int64_t c = (n * n_hb + 8191) / 8192;
+        const int unit = NS * U;
+        c = ((c + unit - 1) / unit) * unit;
+        if (c < unit) c = unit;
+        if (c > 256) c = 256;
+        chunk = (int)c;
+    }
+    const int64_t n_chunks = (n + chunk - 1) / chunk;
+    const int64_t n_tasks = n_chunks * n_hb;
+    const int64_t n_blocks = (n_tasks + 3) / 4;
+    if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    const int nh = (int)n_heads;
+#define CALL(MODEL, G_, NE_, VEC_)                                                                                  \
+    do {                                                                                                            \
+        if (hb4)                                                                                                    \
+            hipLaunchKernelGGL((kge_full_sort_kernel<MODEL, G_, NE_, VEC_, 4, U>), dim3((unsigned)n_blocks),         \
+                               dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, chunk, out,     \
+                               out_ld, oob_counter);                                                                 \
+        else                                                                                                        \
+            hipLaunchKernelGGL((kge_full_sort_kernel<MODEL, G_, NE_, VEC_, 1, U>), dim3((unsigned)n_blocks),         \
+                               dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, chunk, out,     \
+                               out_ld, oob_counter);                                                                 \
+    } while (0)
+    HW_DISPATCH_MODEL(desc->model, shape, CALL);
+#undef CALL
+    return HW_LAUNCH_RC();
+}
+
+template <int FAMILY>
+static int full_sort_topk_impl(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                                     int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
+                                     const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k,
+                                     void* workspace, int64_t workspace_bytes, float* out_val, int64_t* out_idx,
+                                     void* stream) {
+    int rc = check_desc(desc);
+    if (rc) return rc;
+    if (!h_idx || !out_val || !out_idx || !workspace || n_heads < 1 || n_heads > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (tail_lo < 0 || tail_hi > desc->n_tail || tail_lo >= tail_hi || k < 1 || k > FS_SUB) return HW_ERR_INVALID_ARG;
+    if (n_hist < 0 || (n_hist > 0 && (!hist_rows || !hist_cols))) return HW_ERR_INVALID_ARG;
+    const int64_t n = tail_hi - tail_lo;
+    if (n > 0xffffffffll) return HW_ERR_INVALID_ARG;
+    if (workspace_bytes < full_sort_topk_workspace_bytes(n_heads, n, k)) return HW_ERR_WORKSPACE;
+    const int64_t words = (n + 31) / 32, n_sub = (n + FS_SUB - 1) / FS_SUB;
+    uint32_t* bits = (uint32_t*)workspace;
+    int64_t* cand_idx = (int64_t*)((char*)workspace + ((n_heads * words * 4 + 15) / 16) * 16);
+    float* cand_val = (float*)(cand_idx + n_heads * n_sub * k);
+    const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
+    hipStream_t st = (hipStream_t)stream;
+    HW_CLEAR_ERR();
+    (void)hipMemsetAsync(bits, 0, (size_t)n_heads * words * 4, st);
+    if (n_hist > 0)
+        hipLaunchKernelGGL(build_mask_bits_kernel, dim3((unsigned)((n_hist + 255) / 256)), dim3(256), 0, st, hist_rows,
+                           hist_cols, n_hist, n_heads, n, words, bits);
+    const bool hb4 = n_heads > 1;
+    const int n_hb = hb4 ? (int)((n_heads + 3) / 4) : 1;
+    const int64_t n_blocks = (n_sub * n_hb + 3) / 4;
+    if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    const int nh = (int)n_heads;
+    const int64_t mask_col = mask_first_col ? 0 : -1;
+#define CALL(MODEL, G_, NE_, VEC_)                                                                                    \
+    do {                                                                                                              \
+        if (hb4)                                                                                                      \
+            hipLaunchKernelGGL((kge_full_sort_topk_kernel<MODEL, G_, NE_, VEC_, 4>), dim3((unsigned)n_blocks),         \
+                               dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, bits, words,      \
+                               mask_col, k, cand_val, cand_idx, n_sub);                                                \
+        else                                                                                                          \
+            hipLaunchKernelGGL((kge_full_sort_topk_kernel<MODEL, G_, NE_, VEC_, 1>), dim3((unsigned)n_blocks),         \
+                               dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, bits, words,      \
+                               mask_col, k, cand_val, cand_idx, n_sub);                                                \
+    } while (0)
+    HW_DISPATCH_MODEL(desc->model, shape, CALL);
+#undef CALL
+    hipLaunchKernelGGL(topk_candidates_kernel, dim3((unsigned)n_heads), dim3(256), 0, st, cand_val, cand_idx, n_sub * k, k,
+                       out_val, out_idx);
+    return HW_LAUNCH_RC();
+}
+
+// widened-family entry points (kge_score_ext.hip)
+int ext_score_grouped(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                      const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j, int64_t n_groups,
+                      int64_t n_tail_per_group, float* out, int64_t o_stride_b, int64_t o_stride_j, int32_t* oob_counter,
+                      void* stream);
+int ext_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed, int64_t n_heads,
+                  int64_t tail_lo, int64_t tail_hi, float* out, int64_t out_ld, int32_t* oob_counter, void* stream);
+int ext_full_sort_topk(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                       int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
+                       const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k, void* workspace,
+                       int64_t workspace_bytes, float* out_val, int64_t* out_idx, void* stream);
+
+}  // namespace hw

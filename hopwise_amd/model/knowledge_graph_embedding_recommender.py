@@ -94,11 +94,13 @@ class _GatherKGE(KnowledgeRecommender):
     def _rec_rel_full_sort(self):
         return self.ui_relation
 
-    def _score(self, side, h_idx, r_idx, r_fixed, t_idx, eps=0.0, j_major_out=False):
+    LOSS_MODEL = None  # scorer used inside calculate_loss when it differs from MODEL (TorusE trains as TransE)
+
+    def _score(self, side, h_idx, r_idx, r_fixed, t_idx, eps=0.0, j_major_out=False, model=None):
         head, rel, tail = self._tables(side)
         # rec-side tails are items = the first n_items entity rows (kg_dataset.py:556-588)
         tail_rows = self.n_items if (side == "rec" and self._narrow_rec_tails) else None
-        return ops.kge_score_grouped(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, self.margin, eps,
+        return ops.kge_score_grouped(model or self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, self.margin, eps,
                                      j_major_out, tail_rows)
 
     @staticmethod
@@ -109,10 +111,11 @@ class _GatherKGE(KnowledgeRecommender):
     def _pair_scores(self, interaction, eps=0.0):
         """([2, B_rec], [2, B_kg]) score matrices: row 0 positives, row 1 negatives."""
         user = interaction[self.USER_ID]
+        m = self.LOSS_MODEL
         rec = self._score("rec", user, None, self._rec_rel_loss(),
-                          self._pair(interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]), eps, True)
+                          self._pair(interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]), eps, True, m)
         kg = self._score("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
-                         self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]), eps, True)
+                         self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]), eps, True, m)
         return rec.t(), kg.t()
 
     # -- reference API ------------------------------------------------------------------------------
@@ -257,6 +260,100 @@ class ComplEx(_BceKGE):
 
     def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (complex.py:167-168)
         return self.n_relations - 1
+
+
+class TorusE(TransE):
+    """toruse.py:21-172: predict / full sorts score on the torus (-4 sum min(x^2, 1 - x^2) of the frac parts); the
+    reference's calculate_loss (toruse.py:81-103) is TransE's triplet loss on the raw rows -- its forward() is not
+    used in training -- so the loss path runs the TransE scorer."""
+
+    MODEL = "TorusE"
+    LOSS_MODEL = "TransE"
+
+
+class TransH(TransE):
+    """transh.py:20-145.  project() multiplies by the SUM of the relation's norm vector element-wise (transh.py:74-75),
+    so the projected difference is (h - t) * (1 - sum(w) w); TripletMarginLoss over cat(rec, kg); no kg-side predictors."""
+
+    MODEL = "TransH"
+    RELATION_TABLES = ("relation_embedding", "norm_vec")
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        if self.ui_relation != self.n_relations - 1:
+            # the reference reads relation_embedding.weight[-1] and norm_vec(ui_relation): one row id only when
+            # [UI-Relation] is the last relation, which kg_dataset.py:626-631 guarantees
+            raise ValueError("TransH needs [UI-Relation] to be the last relation id")
+
+    def predict_kg(self, interaction):
+        raise NotImplementedError
+
+    def full_sort_predict_kg(self, interaction):
+        raise NotImplementedError
+
+
+class TransD(TransE):
+    """transd.py:20-217: p_r(e) = r_vec (e . e_vec) + e; TripletMarginLoss over cat(rec, kg)."""
+
+    MODEL = "TransD"
+    USER_TABLES = ("user_embedding", "user_vec_embedding")
+    ENTITY_TABLES = ("entity_embedding", "entity_vec_embedding")
+    RELATION_TABLES = ("relation_embedding", "relation_vec_embedding")
+
+    def full_sort_predict_kg(self, interaction):
+        # transd.py:200-201 reads the head's projection vector from entity_embedding (not entity_vec_embedding)
+        ent = self.entity_embedding.weight
+        _, rel, tail = self._tables("kg")
+        return ops.kge_full_sort(self.MODEL, (ent, ent), rel, tail, interaction[self.HEAD_ENTITY_ID],
+                                 interaction[self.RELATION_ID], 0, 0, self.n_entities, self.margin)
+
+    def full_sort_topk(self, interaction, k, history_index=None, kg=False):
+        if not kg:
+            return super().full_sort_topk(interaction, k, history_index, False)
+        ent = self.entity_embedding.weight
+        _, rel, tail = self._tables("kg")
+        return ops.kge_full_sort_topk(self.MODEL, (ent, ent), rel, tail, interaction[self.HEAD_ENTITY_ID],
+                                      interaction[self.RELATION_ID], 0, 0, self.n_entities, k, history_index, True,
+                                      self.margin)
+
+
+class Analogy(_GatherKGE):
+    """analogy.py:20-302: DistMult on (e) plus the complex product on (re, im), every table embedding_size wide
+    (scalar_share only sizes two unused attributes); LogisticLoss on the negated scores, rec + kg."""
+
+    MODEL = "Analogy"
+    USER_TABLES = ("user_embedding", "user_re_embedding", "user_im_embedding")
+    ENTITY_TABLES = ("entity_embedding", "entity_re_embedding", "entity_im_embedding")
+    RELATION_TABLES = ("relation_embedding", "relation_re_embedding", "relation_im_embedding")
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.margin = 0.0
+        self.scalar_share = _cfg(config, "scalar_share", 0.5)
+        self.scalar_dim = int(self.embedding_size * self.scalar_share)
+        self.complex_dim = int(self.embedding_size - self.scalar_dim)
+
+    def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (analogy.py:222-224)
+        return self.n_relations - 1
+
+    def calculate_loss(self, interaction):
+        # LogisticLoss(-pos, -neg) = mean softplus(-pos) + mean softplus(neg) (loss.py:172-190): twice the BCE-with-logits
+        # mean over cat(pos, neg) with labels (1, 0); rec and kg separately (analogy.py:196-198)
+        rec, kg = self._pair_scores(interaction)
+        return 2.0 * (ops.bce_logits_mean(rec, rec.shape[1]) + ops.bce_logits_mean(kg, kg.shape[1]))
+
+
+class HolE(TransE):
+    """hole.py:20-160: (h circular-convolved with r) . t through the rolling matrix R[i][j] = r[(j - i) mod d];
+    MarginRankingLoss(sigmoid(pos), sigmoid(neg), 1) over cat(rec, kg)."""
+
+    MODEL = "HolE"
+
+    def calculate_loss(self, interaction):
+        rec, kg = self._pair_scores(interaction)
+        pos = torch.cat([rec[0], kg[0]])
+        neg = torch.cat([rec[1], kg[1]])
+        return ops.margin_ranking_mean(pos, neg, self.margin, sigmoid=True)
 
 
 class TuckER(KnowledgeRecommender):

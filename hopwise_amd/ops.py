@@ -16,7 +16,8 @@ from ._lib import MODEL_IDS, KgeDesc, KgeGrads, check
 
 PAIRWISE_EPS = 1e-6  # torch pairwise_distance eps used by TripletMarginLoss (TransE loss path)
 
-_N_SLOT = {"TransE": (1, 1, 1), "DistMult": (1, 1, 1), "RotatE": (2, 1, 2), "ComplEx": (2, 2, 2), "RESCAL": (1, 1, 1)}
+_N_SLOT = {"TransE": (1, 1, 1), "DistMult": (1, 1, 1), "RotatE": (2, 1, 2), "ComplEx": (2, 2, 2), "RESCAL": (1, 1, 1),
+           "TorusE": (1, 1, 1), "TransH": (1, 2, 1), "TransD": (2, 2, 2), "Analogy": (3, 3, 3), "HolE": (1, 1, 1)}
 
 
 def _stream():
@@ -48,7 +49,7 @@ def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0
     dim = head[0].shape[1]
     for slot, tabs in (("head", head), ("rel", rel), ("tail", tail)):
         arr = getattr(d, slot)
-        for k in range(2):
+        for k in range(_lib.MAX_TABLES):
             arr[k] = None
         rows = tabs[0].shape[0]
         for k, t in enumerate(tabs):
@@ -171,7 +172,7 @@ class KgeScoreGrouped(torch.autograd.Function):
         k = 0
         for slot, n in slots:
             arr = getattr(gs, slot)
-            for i in range(2):
+            for i in range(_lib.MAX_TABLES):
                 arr[i] = None
             for i in range(n):
                 t = tables[k]
@@ -269,7 +270,7 @@ class MarginRankingMean(torch.autograd.Function):
     """mean(max(0, -(pos - neg) + margin)); also TransE's triplet loss on scores = -distance."""
 
     @staticmethod
-    def forward(ctx, pos, neg, margin):
+    def forward(ctx, pos, neg, margin, sigmoid=False):
         lib = _lib.load()
         ctx.shapes = (pos.shape, neg.shape)
         pos = _dev(pos, torch.float32, "pos").contiguous().view(-1)
@@ -277,18 +278,16 @@ class MarginRankingMean(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=pos.device)
         gp, gn = torch.empty_like(pos), torch.empty_like(neg)
         ws = _workspace(pos.device)
-        check(
-            lib.hw_loss_margin_ranking(_ptr(pos), _ptr(neg), pos.numel(), float(margin), _ptr(loss), _ptr(gp),
-                                       _ptr(gn), _ptr(ws), _stream()),
-            "hw_loss_margin_ranking",
-        )
+        fn = lib.hw_loss_margin_ranking_sigmoid if sigmoid else lib.hw_loss_margin_ranking
+        check(fn(_ptr(pos), _ptr(neg), pos.numel(), float(margin), _ptr(loss), _ptr(gp), _ptr(gn), _ptr(ws), _stream()),
+              "hw_loss_margin_ranking")
         ctx.save_for_backward(gp, gn)
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
         gp, gn = ctx.saved_tensors
-        return (gp * g).view(ctx.shapes[0]), (gn * g).view(ctx.shapes[1]), None
+        return (gp * g).view(ctx.shapes[0]), (gn * g).view(ctx.shapes[1]), None, None
 
 
 class SelfAdversarialMean(torch.autograd.Function):
@@ -317,8 +316,9 @@ def bce_logits_mean(x, n_pos):
     return BceLogitsMean.apply(x, n_pos)
 
 
-def margin_ranking_mean(pos, neg, margin):
-    return MarginRankingMean.apply(pos, neg, margin)
+def margin_ranking_mean(pos, neg, margin, sigmoid=False):
+    """``sigmoid=True``: the loss of sigmoid(pos) vs sigmoid(neg) (HolE)."""
+    return MarginRankingMean.apply(pos, neg, margin, sigmoid)
 
 
 def self_adversarial_mean(scores, alpha):

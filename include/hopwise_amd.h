@@ -34,34 +34,47 @@ typedef enum {
     HW_ROTATE = 1,   /* .../rotate.py:61-69   */
     HW_COMPLEX = 2,  /* .../complex.py:53-62  */
     HW_DISTMULT = 3, /* .../distmult.py:50-51 */
-    HW_RESCAL = 4    /* .../rescal.py:51-54: h^T M_r t; rel[0] rows hold dim*dim floats (M_r row-major) */
+    HW_RESCAL = 4,   /* .../rescal.py:51-54: h^T M_r t; rel[0] rows hold dim*dim floats (M_r row-major) */
+    /* widened set */
+    HW_TORUSE = 5,   /* .../toruse.py:68-79: -4 sum min(x^2, 1 - x^2), x = frac(h) + frac(r) - frac(t) (scoring only:
+                        the reference trains TorusE with TransE's triplet loss on the raw rows, toruse.py:81-103) */
+    HW_TRANSH = 6,   /* .../transh.py:51-55,74-75: -||(h - t) * c + r||, c = 1 - sum(w_r) * w_r (the reference's
+                        project() multiplies by the SUM of the norm vector, element-wise -- reproduced) */
+    HW_TRANSD = 7,   /* .../transd.py:89-94: -||h + rv (h . hv) + r - t - rv (t . tv)|| */
+    HW_ANALOGY = 8,  /* .../analogy.py:66-70: DistMult on (e) + complex product on (re, im), all of width dim */
+    HW_HOLE = 9      /* .../hole.py:53-61: (h circ-conv r) . t with R[i][j] = r[(j - i) mod d] */
 } hw_kge_model;
 
-/* Table set of one scorer call.  Slots with a single table leave [1] NULL.
- *   TransE/DistMult/RESCAL: head[0], rel[0], tail[0]
+#define HW_KGE_MAX_TABLES 3
+
+/* Table set of one scorer call.  Unused slots are NULL.
+ *   TransE/DistMult/RESCAL/TorusE/HolE: head[0], rel[0], tail[0]
  *   RotatE:          head = {re, im}, rel = {theta}, tail = {re, im}
  *   ComplEx:         head = {re, im}, rel = {re, im}, tail = {re, im}
+ *   TransH:          head = {e}, rel = {r, norm_vec}, tail = {e}
+ *   TransD:          head = {e, e_vec}, rel = {r, r_vec}, tail = {e, e_vec}
+ *   Analogy:         head = {e, re, im}, rel = {r, re, im}, tail = {e, re, im}
  * "head" is the user table(s) on the rec side and the entity table(s) on the kg side. */
 typedef struct {
     int32_t model;        /* hw_kge_model */
     int32_t dim;          /* embedding_size, 1..1024 */
-    const float* head[2];
-    const float* rel[2];
-    const float* tail[2];
+    const float* head[HW_KGE_MAX_TABLES];
+    const float* rel[HW_KGE_MAX_TABLES];
+    const float* tail[HW_KGE_MAX_TABLES];
     int64_t n_head;       /* rows of head[*] */
     int64_t n_rel;
     int64_t n_tail;
     float margin;         /* RotatE: score = margin - ||.|| (rotate.py:69) */
-    float eps;            /* TransE only: distance of (h + r - t + eps); 0 for scoring, 1e-6 inside the
+    float eps;            /* TransE / TransH / TransD: distance of (h + r - t + eps); 0 for scoring, 1e-6 inside the
                              TripletMarginLoss path (torch pairwise_distance) */
 } hw_kge_desc;
 
 /* Gradient destination tables, same slot layout as hw_kge_desc (dense [rows, dim] float32,
  * accumulated into with atomic adds; the caller zeroes them).  NULL = that slot gets no gradient. */
 typedef struct {
-    float* head[2];
-    float* rel[2];
-    float* tail[2];
+    float* head[HW_KGE_MAX_TABLES];
+    float* rel[HW_KGE_MAX_TABLES];
+    float* tail[HW_KGE_MAX_TABLES];
 } hw_kge_grads;
 
 /* ---- KGE scoring ---------------------------------------------------------------------------------
@@ -122,6 +135,10 @@ int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, float* loss_out
 /* mean(max(0, -(pos - neg) + margin)): torch MarginRankingLoss(target=+1) (distmult.py:86-93) and,
  * on scores = -distance, TripletMarginLoss (transe.py:48,96).  gpos/gneg nullable. */
 int hw_loss_margin_ranking(const float* pos, const float* neg, int64_t n, float margin,
+                           float* loss_out, float* gpos, float* gneg, float* workspace, void* stream);
+/* The same on sigmoid(pos), sigmoid(neg): HolE's MarginRankingLoss(sigmoid(.), sigmoid(.), 1) (hole.py:100-104);
+ * gpos / gneg include the sigmoid's derivative. */
+int hw_loss_margin_ranking_sigmoid(const float* pos, const float* neg, int64_t n, float margin,
                            float* loss_out, float* gpos, float* gneg, float* workspace, void* stream);
 
 /* Self-adversarial negative weighting (RotatE paper; NOT in the reference -- SURVEY.md §8 A9, opt-in):

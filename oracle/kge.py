@@ -27,8 +27,13 @@ from __future__ import annotations
 
 import numpy as np
 
+from . import kge_ext
+
 MODELS = ("TransE", "RotatE", "ComplEx", "DistMult")
 DENSE_MODELS = ("RESCAL",)  # same table slots as TransE; relation rows are d x d matrices (rescal.py:43)
+EXT_MODELS = kge_ext.EXT_MODELS  # TorusE, TransH, TransD, Analogy, HolE (oracle/kge_ext.py)
+# which of predict_kg / full_sort_predict_kg each reference class defines
+HAS_KG_PREDICT = {"TransH": (False, False)}
 
 F32 = np.float32
 PAIRWISE_EPS = 1e-6  # torch.nn.functional.pairwise_distance default eps (used by TripletMarginLoss)
@@ -39,6 +44,8 @@ PAIRWISE_EPS = 1e-6  # torch.nn.functional.pairwise_distance default eps (used b
 # --------------------------------------------------------------------------------------
 def slots(model: str, side: str):
     """Names of the (head, relation, tail) tables for ``side`` in {"rec", "kg"}."""
+    if model in EXT_MODELS:
+        return kge_ext.slots(model, side)
     if model in ("TransE", "DistMult", "RESCAL"):
         head = ("user_embedding",) if side == "rec" else ("entity_embedding",)
         return head, ("relation_embedding",), ("entity_embedding",)
@@ -75,6 +82,8 @@ def score_rows(model: str, H, R, T, margin: float = 0.0, eps: float = 0.0):
     ``eps`` is only meaningful for TransE: the loss path measures
     ``||h + r - t + eps||`` (pairwise_distance), the scorer uses eps = 0.
     """
+    if model in EXT_MODELS:
+        return kge_ext.score_rows(model, H, R, T, margin, eps)
     if model == "TransE":  # transe.py:55-57
         d = (H[0] + R[0]) - T[0]
         if eps:
@@ -112,6 +121,8 @@ def score_rows_vjp(model: str, H, R, T, g, margin: float = 0.0, eps: float = 0.0
     Returns (gH, gR, gT) tuples shaped like the inputs (after broadcasting to the
     score shape + embedding axis).
     """
+    if model in EXT_MODELS:
+        return kge_ext.score_rows_vjp(model, H, R, T, g, margin, eps)
     H = [np.asarray(x, np.float64) for x in H]
     R = [np.asarray(x, np.float64) for x in R]
     T = [np.asarray(x, np.float64) for x in T]
@@ -223,13 +234,32 @@ def calculate_loss(model, tables, inter, margin=1.0, ui_relation=None, with_grad
     Tp_kg, Tn_kg = _gather(tables, tn, pt), _gather(tables, tn, nt)
 
     n_rec, n_kg = len(u), len(h)
-    eps = PAIRWISE_EPS if model == "TransE" else 0.0
+    if model == "TorusE":  # toruse.py:81-103: the triplet loss of TransE on the raw rows; the torus scorer is unused
+        model = "TransE"
+    triplet = model in ("TransE", "TransH", "TransD")  # TripletMarginLoss(h_proj + r, t_pos_proj, t_neg_proj)
+    eps = PAIRWISE_EPS if triplet else 0.0
     sp_rec = score_rows(model, H_rec, R_rec, Tp_rec, margin, eps)
     sn_rec = score_rows(model, H_rec, R_rec, Tn_rec, margin, eps)
     sp_kg = score_rows(model, H_kg, R_kg, Tp_kg, margin, eps)
     sn_kg = score_rows(model, H_kg, R_kg, Tn_kg, margin, eps)
 
-    if model == "TransE":  # transe.py:91-96: one TripletMarginLoss over cat(rec, kg)
+    if model == "HolE":  # hole.py:100-104: MarginRankingLoss(sigmoid(pos), sigmoid(neg), 1)
+        pos = np.concatenate([sp_rec, sp_kg]).astype(np.float64)
+        neg = np.concatenate([sn_rec, sn_kg]).astype(np.float64)
+        sp, sn = 1.0 / (1.0 + np.exp(-pos)), 1.0 / (1.0 + np.exp(-neg))
+        loss = margin_ranking_mean(sp.astype(F32), sn.astype(F32), margin)
+        act = ((-(sp - sn) + margin) > 0).astype(np.float64) / (n_rec + n_kg)
+        gp, gn = -act * sp * (1 - sp), act * sn * (1 - sn)
+        g = dict(p_rec=gp[:n_rec], n_rec=gn[:n_rec], p_kg=gp[n_rec:], n_kg=gn[n_rec:])
+    elif model == "Analogy":  # analogy.py:196-198 + loss.py:172-190: mean softplus(-pos) + mean softplus(neg), rec + kg
+        def softplus(x):
+            x = np.asarray(x, np.float64)
+            return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+
+        sig = lambda x: 1.0 / (1.0 + np.exp(-np.asarray(x, np.float64)))
+        loss = F32(softplus(-sp_rec).mean() + softplus(sn_rec).mean() + softplus(-sp_kg).mean() + softplus(sn_kg).mean())
+        g = dict(p_rec=-sig(-sp_rec) / n_rec, n_rec=sig(sn_rec) / n_rec, p_kg=-sig(-sp_kg) / n_kg, n_kg=sig(sn_kg) / n_kg)
+    elif triplet:  # transe.py:91-96: one TripletMarginLoss over cat(rec, kg)
         dp = -np.concatenate([sp_rec, sp_kg])
         dn = -np.concatenate([sn_rec, sn_kg])
         loss = triplet_margin_mean(dp, dn, margin)
@@ -318,6 +348,8 @@ def full_sort_predict(model, tables, users, n_items, margin=1.0, ui_relation=Non
 def full_sort_predict_kg(model, tables, heads, rels, margin=1.0):
     """[B, n_entities] scores of every entity as tail."""
     hn, rn, tn = slots(model, "kg")
+    if model == "TransD":  # transd.py:200-201: ``head_e_vec = self.entity_embedding(user)``
+        hn = ("entity_embedding", "entity_embedding")
     H = tuple(tables[n][heads][:, None, :] for n in hn)
     R = tuple(tables[n][rels][:, None, :] for n in rn)
     T = tuple(tables[n][None, :, :] for n in tn)

@@ -83,15 +83,26 @@ def gen_kge(out_dir, only=None):
     from hopwise.model.knowledge_graph_embedding_recommender.rotate import RotatE
     from hopwise.model.knowledge_graph_embedding_recommender.transe import TransE
 
+    from hopwise.model.knowledge_graph_embedding_recommender.analogy import Analogy
+    from hopwise.model.knowledge_graph_embedding_recommender.hole import HolE
+    from hopwise.model.knowledge_graph_embedding_recommender.toruse import TorusE
+    from hopwise.model.knowledge_graph_embedding_recommender.transd import TransD
+    from hopwise.model.knowledge_graph_embedding_recommender.transh import TransH
+
     nU, nI, nE, nR = 20, 16, 48, 5
-    classes = dict(TransE=TransE, RotatE=RotatE, ComplEx=ComplEx, DistMult=DistMult, RESCAL=RESCAL)
+    classes = dict(TransE=TransE, RotatE=RotatE, ComplEx=ComplEx, DistMult=DistMult, RESCAL=RESCAL, TorusE=TorusE,
+                   TransH=TransH, TransD=TransD, Analogy=Analogy, HolE=HolE)
     for name, cls in classes.items():
         if only and name not in only:
             continue
         for d in ((8, 32, 64) if name == "RESCAL" else (8, 64, 200)):
             torch.manual_seed(2024 + d)
-            config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"))
+            config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"), scalar_share=0.5)
             model = cls(config, FakeDataset(nU, nI, nE, nR))
+            if name == "TorusE":  # xavier rows are all inside (-1, 1): spread them so that frac() matters
+                with torch.no_grad():
+                    for p_ in model.parameters():
+                        p_.mul_(6.0)
             rng = np.random.default_rng(7 + d)
             inter_np = make_batch(rng, nU, nI, nE, nR, 24, 32)
             inter = {k: torch.from_numpy(v) for k, v in inter_np.items()}
@@ -100,7 +111,10 @@ def gen_kge(out_dir, only=None):
             out.update({f"inter.{k}": v for k, v in inter_np.items()})
             with torch.no_grad():
                 out["predict"] = model.predict(inter).numpy()
-                out["predict_kg"] = model.predict_kg(inter).numpy()
+                try:
+                    out["predict_kg"] = model.predict_kg(inter).numpy()
+                except (NotImplementedError, AttributeError):  # TransH defines neither kg-side predictor
+                    pass
             model.zero_grad()
             loss = model.calculate_loss(inter)
             loss.backward()
@@ -112,12 +126,15 @@ def gen_kge(out_dir, only=None):
                 fs = model.full_sort_predict({"user_id": users}).view(len(users), nI)
                 heads = torch.tensor([3, 0, 47, 11])
                 rels = torch.tensor([1, 4, 0, 2])
-                fskg = model.full_sort_predict_kg({"head_id": heads, "relation_id": rels}).view(len(heads), nE)
+                try:
+                    fskg = model.full_sort_predict_kg({"head_id": heads, "relation_id": rels}).view(len(heads), nE)
+                    out["fskg.scores"] = fskg.numpy()
+                except (NotImplementedError, AttributeError):
+                    pass
             out["fs.users"] = users.numpy()
             out["fs.scores"] = fs.numpy()
             out["fskg.heads"] = heads.numpy()
             out["fskg.rels"] = rels.numpy()
-            out["fskg.scores"] = fskg.numpy()
             # evaluation protocol (trainer.py:731-734, collector.py:173-183)
             hist_rows = rng.integers(0, len(users), 12)
             hist_cols = rng.integers(1, nI, 12)
@@ -138,7 +155,7 @@ def gen_kge(out_dir, only=None):
         # zero_grad -> calculate_loss -> backward -> Adam(lr=1e-3).step, dense grads.
         torch.manual_seed(99)
         d = 16
-        config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"))
+        config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"), scalar_share=0.5)
         model = cls(config, FakeDataset(nU, nI, nE, nR))
         out = {f"init.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
