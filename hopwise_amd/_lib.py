@@ -93,6 +93,15 @@ SIGNATURES = {
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],
     ),
+    "hw_kge_project_rows": (
+        C.c_int,
+        [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_i64p, C.c_int64, c_f32p, C.c_void_p],
+    ),
+    "hw_kge_project_rows_grad": (
+        C.c_int,
+        [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_i64p, C.c_int64, c_f32p, c_f32p, c_f32p,
+         C.c_void_p],
+    ),
     "hw_loss_margin_ranking_sigmoid": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],

@@ -356,6 +356,86 @@ class HolE(TransE):
         return ops.margin_ranking_mean(pos, neg, self.margin, sigmoid=True)
 
 
+class TransR(KnowledgeRecommender):
+    """transr.py:20-166: entities are mapped by the relation's d x d matrix (``proj_mat_e`` rows) and scored like TransE
+    in that space; TripletMarginLoss over cat(rec, kg).  The projections run on csrc/kge_transr.hip (the only d^2 part),
+    the distances on the TransE gather kernels with the projected buffers as tables.  The reference defines predict,
+    predict_kg and full_sort_predict (no full_sort_predict_kg)."""
+
+    input_type = InputType.PAIRWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.embedding_size = config["embedding_size"]
+        self.margin = float(_cfg(config, "margin", 0.0))
+        self.ui_relation = dataset.field2token_id["relation_id"][dataset.ui_relation]
+        d = self.embedding_size
+        self.user_embedding = nn.Embedding(self.n_users, d)
+        self.entity_embedding = nn.Embedding(self.n_entities, d)
+        self.relation_embedding = nn.Embedding(self.n_relations, d)
+        self.proj_mat_e = nn.Embedding(self.n_relations, d * d)
+        self.apply(xavier_normal_initialization)
+
+    def _distances(self, head_table, h_idx, r_idx, proj_rel, tails, eps):
+        """scores [n, T] = -||M h + r - M t_j + eps|| for tails [n, T]; r_idx None = the rec side
+        (translation row relation_embedding.weight[-1], projection matrix of ui_relation)."""
+        n, T = tails.shape
+        mats = self.proj_mat_e.weight
+        if r_idx is None:
+            ph = ops.project_rows(mats, head_table, None, proj_rel, h_idx)
+            pt = ops.project_rows(mats, self.entity_embedding.weight, None, proj_rel, tails.t().reshape(-1))
+        else:
+            ph = ops.project_rows(mats, head_table, r_idx, 0, h_idx)
+            pt = ops.project_rows(mats, self.entity_embedding.weight, r_idx.repeat(T), 0, tails.t().reshape(-1))
+        rows = torch.arange(n, device=tails.device)
+        t_rows = (rows.view(1, n) + n * torch.arange(T, device=tails.device).view(T, 1)).t()  # [n, T] view, j-major
+        return ops.kge_score_grouped("TransE", (ph,), (self.relation_embedding.weight,), (pt,), rows, r_idx,
+                                     self.n_relations - 1, t_rows, 0.0, eps, True)
+
+    def forward(self, *rows):
+        raise NotImplementedError("hopwise_amd scorers gather inside the kernel; use predict / calculate_loss")
+
+    def calculate_loss(self, interaction):  # transr.py:72-104
+        rec = self._distances(self.user_embedding.weight, interaction[self.USER_ID], None, self.ui_relation,
+                              torch.stack([interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]], 1),
+                              ops.PAIRWISE_EPS)
+        kg = self._distances(self.entity_embedding.weight, interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID],
+                             0, torch.stack([interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]], 1),
+                             ops.PAIRWISE_EPS)
+        pos = torch.cat([rec[:, 0], kg[:, 0]])
+        neg = torch.cat([rec[:, 1], kg[:, 1]])
+        return ops.margin_ranking_mean(pos, neg, self.margin)
+
+    def predict(self, interaction):  # transr.py:106-122
+        return self._distances(self.user_embedding.weight, interaction[self.USER_ID], None, self.ui_relation,
+                               interaction[self.ITEM_ID].view(-1, 1), 0.0).view(-1)
+
+    def predict_kg(self, interaction):  # transr.py:124-138
+        return self._distances(self.entity_embedding.weight, interaction[self.HEAD_ENTITY_ID],
+                               interaction[self.RELATION_ID], 0, interaction[self.TAIL_ENTITY_ID].view(-1, 1), 0.0).view(-1)
+
+    def _projected_items(self):
+        d = self.embedding_size
+        m_ui = self.proj_mat_e.weight[self.ui_relation].view(d, d)
+        return ops.gemm(self.entity_embedding.weight[: self.n_items], m_ui)  # [n_items, d] = E M^T
+
+    def full_sort_predict(self, interaction):  # transr.py:140-166
+        user = interaction[self.USER_ID]
+        ph = ops.project_rows(self.proj_mat_e.weight, self.user_embedding.weight, None, self.ui_relation, user)
+        rows = torch.arange(user.numel(), device=user.device)
+        return ops.kge_full_sort("TransE", (ph,), (self.relation_embedding.weight,), (self._projected_items(),), rows, None,
+                                 self.n_relations - 1, 0, self.n_items, 0.0)
+
+    def full_sort_topk(self, interaction, k, history_index=None, kg=False):
+        if kg:
+            raise NotImplementedError  # the reference has no full_sort_predict_kg for TransR
+        user = interaction[self.USER_ID]
+        ph = ops.project_rows(self.proj_mat_e.weight, self.user_embedding.weight, None, self.ui_relation, user)
+        rows = torch.arange(user.numel(), device=user.device)
+        return ops.kge_full_sort_topk("TransE", (ph,), (self.relation_embedding.weight,), (self._projected_items(),), rows,
+                                      None, self.n_relations - 1, 0, self.n_items, k, history_index, True, 0.0)
+
+
 class TuckER(KnowledgeRecommender):
     """TuckER 1-vs-all scorer (tucker.py:21-172) on the fp32 matrix cores.
 

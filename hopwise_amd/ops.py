@@ -236,6 +236,47 @@ def kge_full_sort_topk(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, k,
     return val, idx
 
 
+class ProjectRows(torch.autograd.Function):
+    """out[i] = M[r_i] @ table[e_i] (TransR, transr.py:67-70); M rows are the [n_rel, d * d] proj_mat_e table."""
+
+    @staticmethod
+    def forward(ctx, mats, table, r_idx, r_fixed, e_idx):
+        lib = _lib.load()
+        mats = _dev(mats, torch.float32, "proj_mat_e")
+        table = _dev(table, torch.float32, "table")
+        d = table.shape[1]
+        if mats.dim() != 2 or mats.shape[1] != d * d or not mats.is_contiguous() or not table.is_contiguous():
+            raise ValueError("ProjectRows: need contiguous mats [n_rel, d*d] and table [rows, d]")
+        e_idx = _idx(e_idx, "e_idx").contiguous()
+        if r_idx is not None:
+            r_idx = _idx(r_idx, "r_idx").contiguous()
+            if r_idx.shape != e_idx.shape:
+                raise ValueError("r_idx must match e_idx")
+        out = torch.empty((e_idx.numel(), d), dtype=torch.float32, device=table.device)
+        check(lib.hw_kge_project_rows(_ptr(mats), mats.shape[0], _ptr(table), table.shape[0], d, _ptr(r_idx), int(r_fixed),
+                                      _ptr(e_idx), e_idx.numel(), _ptr(out), _stream()), "hw_kge_project_rows")
+        ctx.r_fixed, ctx.has_r = int(r_fixed), r_idx is not None
+        ctx.save_for_backward(mats, table, e_idx, *([r_idx] if r_idx is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        mats, table, e_idx = ctx.saved_tensors[:3]
+        r_idx = ctx.saved_tensors[3] if ctx.has_r else None
+        g = g.contiguous()
+        g_m = torch.zeros_like(mats) if ctx.needs_input_grad[0] else None
+        g_t = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
+        check(lib.hw_kge_project_rows_grad(_ptr(mats), mats.shape[0], _ptr(table), table.shape[0], table.shape[1],
+                                           _ptr(r_idx), ctx.r_fixed, _ptr(e_idx), e_idx.numel(), _ptr(g), _ptr(g_t),
+                                           _ptr(g_m), _stream()), "hw_kge_project_rows_grad")
+        return g_m, g_t, None, None, None
+
+
+def project_rows(mats, table, r_idx, r_fixed, e_idx):
+    return ProjectRows.apply(mats, table, r_idx, int(r_fixed), e_idx)
+
+
 # ------------------------------------------------------------------------------------------------
 # losses
 # ------------------------------------------------------------------------------------------------

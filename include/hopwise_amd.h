@@ -123,6 +123,18 @@ int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* grads,
                         const float* g, int64_t g_stride_b, int64_t g_stride_j,
                         float* rel_workspace, void* stream);
 
+/* ---- TransR projections (transr.py:67-70) ---------------------------------------------------------------------------
+ * out[i, :] = M[r_i] e_i with M[r] = mats[r] viewed [dim, dim] row-major (proj_mat_e rows), r_i = r_idx[i] or r_fixed,
+ * e_i = table[e_idx[i]].  The projected rows are then scored with the HW_TRANSE kernels (out buffers as tables). */
+int hw_kge_project_rows(const float* mats, int64_t n_rel, const float* table, int64_t n_table_rows, int32_t dim,
+                        const int64_t* r_idx, int64_t r_fixed, const int64_t* e_idx, int64_t n, float* out,
+                        void* stream);
+/* g_table[e_idx[i], :] += M[r_i]^T g_out[i, :];  g_mats[r_i] += g_out[i, :] (x) e_i.  Either destination may be NULL.
+ * g_mats needs dim <= 256. */
+int hw_kge_project_rows_grad(const float* mats, int64_t n_rel, const float* table, int64_t n_table_rows, int32_t dim,
+                             const int64_t* r_idx, int64_t r_fixed, const int64_t* e_idx, int64_t n, const float* g_out,
+                             float* g_table, float* g_mats, void* stream);
+
 /* ---- losses on score vectors (deterministic two-stage reductions) ---------------------------------
  * `workspace` must hold at least hw_loss_workspace_floats() floats. */
 int64_t hw_loss_workspace_floats(void);

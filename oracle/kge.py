@@ -33,7 +33,7 @@ MODELS = ("TransE", "RotatE", "ComplEx", "DistMult")
 DENSE_MODELS = ("RESCAL",)  # same table slots as TransE; relation rows are d x d matrices (rescal.py:43)
 EXT_MODELS = kge_ext.EXT_MODELS  # TorusE, TransH, TransD, Analogy, HolE (oracle/kge_ext.py)
 # which of predict_kg / full_sort_predict_kg each reference class defines
-HAS_KG_PREDICT = {"TransH": (False, False)}
+HAS_KG_PREDICT = {"TransH": (False, False), "TransR": (True, False)}
 
 F32 = np.float32
 PAIRWISE_EPS = 1e-6  # torch.nn.functional.pairwise_distance default eps (used by TripletMarginLoss)
@@ -236,7 +236,7 @@ def calculate_loss(model, tables, inter, margin=1.0, ui_relation=None, with_grad
     n_rec, n_kg = len(u), len(h)
     if model == "TorusE":  # toruse.py:81-103: the triplet loss of TransE on the raw rows; the torus scorer is unused
         model = "TransE"
-    triplet = model in ("TransE", "TransH", "TransD")  # TripletMarginLoss(h_proj + r, t_pos_proj, t_neg_proj)
+    triplet = model in ("TransE", "TransH", "TransD", "TransR")  # TripletMarginLoss(h_proj + r, t_pos_proj, t_neg_proj)
     eps = PAIRWISE_EPS if triplet else 0.0
     sp_rec = score_rows(model, H_rec, R_rec, Tp_rec, margin, eps)
     sn_rec = score_rows(model, H_rec, R_rec, Tn_rec, margin, eps)

@@ -11,6 +11,8 @@ Reference (paths relative to /root/reference/hopwise/model/knowledge_graph_embed
   TransD   transd.py:89-94 forward (p(e) = r_vec (e . e_vec) + e); full_sort_predict_kg :196-217 takes the head "vec" row
            from entity_embedding (restated as written)
   Analogy  analogy.py:66-70 forward; LogisticLoss (model/loss.py:172-190) on negated scores, rec + kg
+  TransR   transr.py:67-70 forward (p = M_r e with M_r = proj_mat_e(r).view(d, d)), :72-104 TripletMarginLoss; the
+           reference defines no full_sort_predict_kg for it
   HolE     hole.py:53-61 forward with the rolling matrix R[i][j] = r[(j - i) mod d]; MarginRankingLoss on sigmoid(scores)
 """
 
@@ -19,7 +21,7 @@ from __future__ import annotations
 import numpy as np
 
 F32 = np.float32
-EXT_MODELS = ("TorusE", "TransH", "TransD", "Analogy", "HolE")
+EXT_MODELS = ("TorusE", "TransH", "TransD", "Analogy", "HolE", "TransR")
 
 
 def slots(model, side):
@@ -28,6 +30,8 @@ def slots(model, side):
         return (f"{ent}_embedding",), ("relation_embedding",), ("entity_embedding",)
     if model == "TransH":
         return (f"{ent}_embedding",), ("relation_embedding", "norm_vec"), ("entity_embedding",)
+    if model == "TransR":
+        return (f"{ent}_embedding",), ("relation_embedding", "proj_mat_e"), ("entity_embedding",)
     if model == "TransD":
         return ((f"{ent}_embedding", f"{ent}_vec_embedding"), ("relation_embedding", "relation_vec_embedding"),
                 ("entity_embedding", "entity_vec_embedding"))
@@ -65,6 +69,15 @@ def score_rows(model, H, R, T, margin=0.0, eps=0.0):
     if model == "TransD":
         hp = R[1] * np.sum(H[0] * H[1], axis=-1, keepdims=True, dtype=F32) + H[0]
         tp = R[1] * np.sum(T[0] * T[1], axis=-1, keepdims=True, dtype=F32) + T[0]
+        d = (hp + R[0]) - tp
+        if eps:
+            d = d + F32(eps)
+        return -np.sqrt(np.sum(d * d, axis=-1, dtype=F32))
+    if model == "TransR":
+        dd = H[0].shape[-1]
+        M = R[1].reshape(R[1].shape[:-1] + (dd, dd))
+        hp = np.einsum("...ck,...k->...c", M, H[0]).astype(F32)
+        tp = np.einsum("...ck,...k->...c", M, T[0]).astype(F32)
         d = (hp + R[0]) - tp
         if eps:
             d = d + F32(eps)
@@ -111,6 +124,15 @@ def score_rows_vjp(model, H, R, T, g, margin=0.0, eps=0.0):
         a = -u  # dL/dd
         arv = (a * rv).sum(-1, keepdims=True)
         return ((a + arv * hv, arv * h), (a, a * sh - a * st), (-a - arv * tv, -arv * t))
+    if model == "TransR":
+        h, (r, m), t = H[0], R, T[0]
+        dd = h.shape[-1]
+        M = m.reshape(m.shape[:-1] + (dd, dd))
+        d = np.einsum("...ck,...k->...c", M, h - t) + r + eps
+        a = -g * unit(d)
+        mta = np.einsum("...ck,...c->...k", M, a)
+        gM = a[..., :, None] * (h - t)[..., None, :]
+        return (mta,), (a, gM.reshape(gM.shape[:-2] + (dd * dd,))), (-mta,)
     if model == "Analogy":
         (h, hr, hi), (r, rr, ri), (t, tr, ti) = H, R, T
         return ((g * r * t, g * (rr * tr + ri * ti), g * (rr * ti - ri * tr)),

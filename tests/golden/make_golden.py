@@ -88,14 +88,15 @@ def gen_kge(out_dir, only=None):
     from hopwise.model.knowledge_graph_embedding_recommender.toruse import TorusE
     from hopwise.model.knowledge_graph_embedding_recommender.transd import TransD
     from hopwise.model.knowledge_graph_embedding_recommender.transh import TransH
+    from hopwise.model.knowledge_graph_embedding_recommender.transr import TransR
 
     nU, nI, nE, nR = 20, 16, 48, 5
     classes = dict(TransE=TransE, RotatE=RotatE, ComplEx=ComplEx, DistMult=DistMult, RESCAL=RESCAL, TorusE=TorusE,
-                   TransH=TransH, TransD=TransD, Analogy=Analogy, HolE=HolE)
+                   TransH=TransH, TransD=TransD, Analogy=Analogy, HolE=HolE, TransR=TransR)
     for name, cls in classes.items():
         if only and name not in only:
             continue
-        for d in ((8, 32, 64) if name == "RESCAL" else (8, 64, 200)):
+        for d in ((8, 32, 64) if name in ("RESCAL", "TransR") else (8, 64, 200)):
             torch.manual_seed(2024 + d)
             config = dict(FIELDS, embedding_size=d, margin=1.0, device=torch.device("cpu"), scalar_share=0.5)
             model = cls(config, FakeDataset(nU, nI, nE, nR))

@@ -36,10 +36,10 @@ def random_tables(model, n_users, n_entities, n_relations, dim, seed=0):
     out = {}
     for name in kge.table_names(model):
         rows = n_users if name.startswith("user") else (
-            n_relations if name.startswith("relation") or name == "norm_vec" else n_entities)
+            n_relations if name.startswith("relation") or name in ("norm_vec", "proj_mat_e") else n_entities)
         if model == "RotatE" and name == "relation_embedding":
             out[name] = rng.uniform(0, 2 * np.pi, (rows, dim)).astype(np.float32)
-        elif model == "RESCAL" and name == "relation_embedding":
+        elif (model == "RESCAL" and name == "relation_embedding") or name == "proj_mat_e":
             out[name] = (rng.standard_normal((rows, dim * dim)) / np.sqrt(dim)).astype(np.float32)
         elif model == "TorusE":  # rows well outside (-1, 1) so that frac() matters
             out[name] = (rng.standard_normal((rows, dim)) * 1.5).astype(np.float32)

@@ -11,7 +11,8 @@ from tests.helpers import random_tables
 from tests.test_gpu_kge import ATOL, RTOL, build, dev, to_dev
 
 pytestmark = pytest.mark.gpu
-EXT = okge.EXT_MODELS
+EXT = tuple(m for m in okge.EXT_MODELS if m != "TransR")  # members of the gather-kernel template
+NO_KG_FULL_SORT = ("TransH", "TransR")
 
 
 def tol_for(model):
@@ -39,9 +40,9 @@ def test_grouped_scorer_vs_oracle(model, dim):
     assert ops.oob_count(dev()) == 0
 
 
-@pytest.mark.parametrize("model", EXT)
+@pytest.mark.parametrize("model", okge.EXT_MODELS)
 def test_full_sort_vs_oracle_ragged(model):
-    for dim, nE, B in ((64, 1003, 1), (200, 777, 5), (100, 130, 9), (24, 67, 2)):
+    for dim, nE, B in ((64, 1003, 1), (200 if model != "TransR" else 72, 777, 5), (100, 130, 9), (24, 67, 2)):
         nU, nR, nI = 50, 6, min(nE, 61)
         tables = random_tables(model, nU, nE, nR, dim, seed=dim + B)
         m = build(model, tables, dim, nU, nI, nE, nR)
@@ -51,7 +52,7 @@ def test_full_sort_vs_oracle_ragged(model):
             fs = m.full_sort_predict({"user_id": torch.from_numpy(users).to(dev())}).cpu().numpy()
         np.testing.assert_allclose(fs, okge.full_sort_predict(model, tables, users, nI, m.margin, nR - 1), **tol_for(model))
         kg_inter = {"head_id": torch.from_numpy(heads).to(dev()), "relation_id": torch.from_numpy(rels).to(dev())}
-        if model == "TransH":
+        if model in NO_KG_FULL_SORT:
             with pytest.raises(NotImplementedError):
                 m.full_sort_predict_kg(kg_inter)
             continue
@@ -60,8 +61,8 @@ def test_full_sort_vs_oracle_ragged(model):
         np.testing.assert_allclose(fk, okge.full_sort_predict_kg(model, tables, heads, rels, m.margin), **tol_for(model))
 
 
-@pytest.mark.parametrize("model", EXT)
-@pytest.mark.parametrize("dim", [16, 100, 200, 300])
+@pytest.mark.parametrize("model,dim", [(m, d) for m in EXT for d in (16, 100, 200, 300)]
+                         + [("TransR", d) for d in (5, 16, 64, 100, 130)])
 def test_loss_and_grads_vs_oracle(model, dim):
     nU, nI, nE, nR, Br, Bk = 40, 30, 90, 7, 64, 96
     tables = random_tables(model, nU, nE, nR, dim, seed=11)
@@ -123,11 +124,12 @@ def test_grouped_gradients_with_many_negatives(model):
             np.testing.assert_allclose(got, ref, rtol=3e-4, atol=3e-6 * scale + 1e-9, err_msg=f"{side}:{nme}")
 
 
-@pytest.mark.parametrize("model", EXT)
+@pytest.mark.parametrize("model", okge.EXT_MODELS)
 def test_fused_full_sort_topk_equals_unfused(model):
     from hopwise_amd import ops
 
-    for dim, nE, nI, B, k in ((64, 1003, 700, 1, 10), (200, 777, 300, 5, 100), (24, 200, 130, 9, 128)):
+    for dim, nE, nI, B, k in ((64, 1003, 700, 1, 10), (200 if model != "TransR" else 48, 777, 300, 5, 100),
+                              (24, 200, 130, 9, 128)):
         nU, nR = 50, 6
         tables = random_tables(model, nU, nE, nR, dim, seed=dim + B)
         m = build(model, tables, dim, nU, nI, nE, nR)
@@ -137,7 +139,7 @@ def test_fused_full_sort_topk_equals_unfused(model):
         rels = torch.from_numpy(rng.integers(0, nR, B)).to(dev())
         hist = (torch.from_numpy(rng.integers(0, B, 40)).to(dev()), torch.from_numpy(rng.integers(0, nI, 40)).to(dev()))
         sides = [(False, {"user_id": users}, nI)]
-        if model != "TransH":
+        if model not in NO_KG_FULL_SORT:
             sides.append((True, {"head_id": heads, "relation_id": rels}, nE))
         with torch.no_grad():
             for kg, inter, n in sides:
@@ -159,3 +161,33 @@ def test_toruse_scorer_has_no_gradient_path():
     out = ops.kge_score_grouped("TorusE", head, rel, tail, idx, idx, 0, idx.view(3, 1), 0.0)
     with pytest.raises(_lib.HopwiseAmdError):
         out.sum().backward()
+
+
+def test_transr_projection_primitives():
+    """hw_kge_project_rows / _grad against numpy: fixed and per-row relations, repeated rows, every dim bucket."""
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(0)
+    for d, n_rel, n_ent, n in ((5, 3, 17, 40), (64, 4, 50, 700), (100, 6, 30, 333), (256, 2, 9, 64)):
+        mats = torch.from_numpy(rng.standard_normal((n_rel, d * d)).astype(np.float32) / np.sqrt(d)).to(dev())
+        tab = torch.from_numpy(rng.standard_normal((n_ent, d)).astype(np.float32)).to(dev())
+        e = rng.integers(0, n_ent, n)
+        for r in (None, rng.integers(0, n_rel, n)):
+            mats.requires_grad_(True), tab.requires_grad_(True)
+            mats.grad = tab.grad = None
+            r_t = None if r is None else torch.from_numpy(r).to(dev())
+            out = ops.project_rows(mats, tab, r_t, n_rel - 1, torch.from_numpy(e).to(dev()))
+            rr = np.full(n, n_rel - 1) if r is None else r
+            M = mats.detach().cpu().numpy().astype(np.float64).reshape(n_rel, d, d)
+            E = tab.detach().cpu().numpy().astype(np.float64)
+            want = np.einsum("nck,nk->nc", M[rr], E[e])
+            np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+            g = rng.standard_normal((n, d)).astype(np.float32)
+            out.backward(torch.from_numpy(g).to(dev()))
+            gE = np.zeros_like(E)
+            np.add.at(gE, e, np.einsum("nck,nc->nk", M[rr], g.astype(np.float64)))
+            gM = np.zeros_like(M)
+            np.add.at(gM, rr, g.astype(np.float64)[:, :, None] * E[e][:, None, :])
+            for got, ref in ((tab.grad, gE), (mats.grad, gM.reshape(n_rel, d * d))):
+                scale = np.abs(ref).max()
+                np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=3e-6 * scale)
