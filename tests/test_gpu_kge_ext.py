@@ -169,7 +169,7 @@ def test_transr_projection_primitives():
 
     rng = np.random.default_rng(0)
     for d, n_rel, n_ent, n in ((5, 3, 17, 40), (64, 4, 50, 700), (100, 6, 30, 333), (256, 2, 9, 64)):
-        mats = torch.from_numpy(rng.standard_normal((n_rel, d * d)).astype(np.float32) / np.sqrt(d)).to(dev())
+        mats = torch.from_numpy((rng.standard_normal((n_rel, d * d)) / np.sqrt(d)).astype(np.float32)).to(dev())
         tab = torch.from_numpy(rng.standard_normal((n_ent, d)).astype(np.float32)).to(dev())
         e = rng.integers(0, n_ent, n)
         for r in (None, rng.integers(0, n_rel, n)):
