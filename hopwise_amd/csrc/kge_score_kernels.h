@@ -559,6 +559,9 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
         const int s_max = (ntail + per_wave - 1) / per_wave;
         const int64_t want = (16384 + n_groups - 1) / n_groups;
         S = (int)(want < 1 ? 1 : (want > s_max ? s_max : want));
+        // HolE / RESCAL pay d^2 per query build: every extra split repeats it, so only split when the launch would
+        // otherwise leave most of the chip idle
+        if ((desc->model == HW_HOLE || desc->model == HW_RESCAL) && n_groups >= 1024) S = 1;
     }
     const int64_t n_tasks = n_groups * S;
     const int64_t n_blocks = (n_tasks + 3) / 4;
