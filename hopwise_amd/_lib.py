@@ -102,6 +102,15 @@ SIGNATURES = {
         [c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_i64p, C.c_int64, c_f32p, c_f32p, c_f32p,
          C.c_void_p],
     ),
+    "hw_cafe_level_loss": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, c_f32p, C.c_void_p],
+    ),
+    "hw_cafe_level_loss_grad": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_i64p, c_i64p, c_i64p, C.c_float, C.c_float, c_f32p, C.c_int64,
+         C.c_void_p],
+    ),
     "hw_loss_margin_ranking_sigmoid": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],

@@ -33,6 +33,103 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
     for (int c = threadIdx.x; c < n_cols; c += 256) o[c] = (r[c] - m) - ls;
 }
 
+// ---- training: cross entropy over one level's vocabulary + the ranking term (cafe.py:541-553) -------------------------
+// Per row: lse = logsumexp(logits), ce = lse - logits[target]; rank = sigmoid(logits[neg] - logits[pos]) (the two
+// log-softmax values differ from the logits by the same lse).  Row results go to row_ws [2, n_rows]; a second
+// one-block kernel sums them in a fixed order.
+__global__ __launch_bounds__(256) void level_loss_kernel(const float* __restrict__ x, int64_t ld, int n_cols,
+                                                         const int64_t* __restrict__ target,
+                                                         const int64_t* __restrict__ pos, const int64_t* __restrict__ neg,
+                                                         int64_t n_rows, float* __restrict__ lse_out,
+                                                         float* __restrict__ row_ws) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const float* __restrict__ r = x + (size_t)row * ld;
+    float m = -INFINITY;
+    for (int c = threadIdx.x; c < n_cols; c += 256) m = fmaxf(m, r[c]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int c = threadIdx.x; c < n_cols; c += 256) s += expf(r[c] - m);
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lse = m + logf((red[0] + red[1]) + (red[2] + red[3]));
+        lse_out[row] = lse;
+        int64_t t = target[row];
+        t = t < 0 ? 0 : (t >= n_cols ? n_cols - 1 : t);
+        row_ws[row] = lse - r[t];
+        float rk = 0.f;
+        if (pos && neg) {
+            int64_t a = pos[row], b = neg[row];
+            a = a < 0 ? 0 : (a >= n_cols ? n_cols - 1 : a);
+            b = b < 0 ? 0 : (b >= n_cols ? n_cols - 1 : b);
+            const float z = r[b] - r[a];
+            const float e = expf(-fabsf(z));
+            rk = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        }
+        row_ws[n_rows + row] = rk;
+    }
+}
+
+__global__ __launch_bounds__(256) void level_loss_finish_kernel(const float* __restrict__ row_ws, int64_t n_rows,
+                                                                float* __restrict__ out) {
+    __shared__ float part[2][256];
+    float a = 0.f, b = 0.f;
+    for (int64_t i = threadIdx.x; i < n_rows; i += 256) a += row_ws[i], b += row_ws[n_rows + i];
+    part[0][threadIdx.x] = a, part[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            part[0][threadIdx.x] += part[0][threadIdx.x + s];
+            part[1][threadIdx.x] += part[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0][0] / (float)n_rows, out[1] = part[1][0] / (float)n_rows;
+}
+
+// dlogits = g_ce / n (softmax - onehot(target)) + g_rank / n r (1 - r) (onehot(neg) - onehot(pos))
+__global__ __launch_bounds__(256) void level_loss_grad_kernel(const float* __restrict__ x, int64_t ld, int n_cols,
+                                                              const float* __restrict__ lse,
+                                                              const int64_t* __restrict__ target,
+                                                              const int64_t* __restrict__ pos,
+                                                              const int64_t* __restrict__ neg, int64_t n_rows,
+                                                              float g_ce, float g_rank, float* __restrict__ dx,
+                                                              int64_t ldd) {
+    const int64_t row = blockIdx.x;
+    const float* __restrict__ r = x + (size_t)row * ld;
+    float* __restrict__ o = dx + (size_t)row * ldd;
+    const float l = lse[row];
+    const float inv_n = 1.f / (float)n_rows;
+    int64_t t = target[row];
+    t = t < 0 ? 0 : (t >= n_cols ? n_cols - 1 : t);
+    int64_t a = -1, b = -1;
+    float w = 0.f;
+    if (pos && neg) {
+        a = pos[row], b = neg[row];
+        a = a < 0 ? 0 : (a >= n_cols ? n_cols - 1 : a);
+        b = b < 0 ? 0 : (b >= n_cols ? n_cols - 1 : b);
+        const float z = r[b] - r[a];
+        const float e = expf(-fabsf(z));
+        const float sg = z >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+        w = g_rank * inv_n * sg * (1.f - sg);
+    }
+    const float gc = g_ce * inv_n;
+    for (int c = threadIdx.x; c < n_cols; c += 256) {
+        float v = gc * expf(r[c] - l);
+        if (c == t) v -= gc;
+        if (c == b) v += w;
+        if (c == a) v -= w;
+        o[c] = v;
+    }
+}
+
 __device__ __forceinline__ uint64_t lp_key(float v, uint32_t id) {
     uint32_t u = __float_as_uint(v);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -185,6 +282,32 @@ extern "C" int hw_log_softmax_rows(const float* x, int64_t ld, int64_t n_rows, i
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, x, ld,
                        (int)n_cols, y, ldy);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_cafe_level_loss(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const int64_t* target,
+                                  const int64_t* pos, const int64_t* neg, float* lse_out, float* loss_out, float* row_ws,
+                                  void* stream) {
+    if (!logits || !target || !lse_out || !loss_out || !row_ws || n_rows < 1 || n_cols < 1 || n_cols > INT32_MAX ||
+        ld < n_cols || (!pos) != (!neg))
+        return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(level_loss_kernel, dim3((unsigned)n_rows), dim3(256), 0, st, logits, ld, (int)n_cols, target, pos,
+                       neg, n_rows, lse_out, row_ws);
+    hipLaunchKernelGGL(level_loss_finish_kernel, dim3(1), dim3(256), 0, st, row_ws, n_rows, loss_out);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_cafe_level_loss_grad(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const float* lse,
+                                       const int64_t* target, const int64_t* pos, const int64_t* neg, float g_ce,
+                                       float g_rank, float* dlogits, int64_t ldd, void* stream) {
+    if (!logits || !lse || !target || !dlogits || n_rows < 1 || n_cols < 1 || n_cols > INT32_MAX || ld < n_cols ||
+        ldd < n_cols || (!pos) != (!neg))
+        return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(level_loss_grad_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                       (int)n_cols, lse, target, pos, neg, n_rows, g_ce, g_rank, dlogits, ldd);
     return HW_LAUNCH_RC();
 }
 

@@ -15,8 +15,8 @@ Different by design: a user's whole program is interpreted by one workgroup (hw_
 log-probability rows produced by the fp32 MFMA GEMM + a row log_softmax kernel, for all users of a batch at once;
 the graph is a device CSR; nothing runs per user on the host except the final sort of a few hundred leaf paths.
 
-Not built this round: training (calculate_loss, the replay memory and the bidirectional BFS path sampler,
-cafe.py:134-330) -- SURVEY.md §8(f)3.
+Training (cafe.py:143-340): the replay memory and the bidirectional BFS path sampler stay host code over a host copy
+of the CSR (as in the reference, where they walk a dict graph); ``SymbolicNetwork.forward`` runs on the device.
 """
 
 from __future__ import annotations
@@ -44,8 +44,8 @@ class RelationModule(nn.Module):
     def forward(self, inputs):  # cafe.py:656-667
         eh_vec, user_vec = inputs
         x = torch.cat([eh_vec, user_vec], dim=-1)
-        x = self.bn1(self.dropout(ops.gemm(x.contiguous(), self.fc1.weight, bias=self.fc1.bias, elu="relu")))
-        return ops.gemm(x.contiguous(), self.fc2.weight, bias=self.fc2.bias) + eh_vec
+        x = self.bn1(self.dropout(ops.linear_act(x, self.fc1.weight, self.fc1.bias, 2)))
+        return ops.linear_act(x, self.fc2.weight, self.fc2.bias) + eh_vec
 
 
 class DeepRelationModule(nn.Module):
@@ -63,15 +63,15 @@ class DeepRelationModule(nn.Module):
     def forward(self, inputs):  # cafe.py:686-699; the three Linear layers run on the MFMA GEMM
         eh_vec, user_vec = inputs
         feature = torch.cat([eh_vec, user_vec], dim=-1).contiguous()
-        x = ops.gemm(feature, self.fc1.weight, bias=self.fc1.bias, elu="relu")
+        x = ops.linear_act(feature, self.fc1.weight, self.fc1.bias, 2)
         if self.dropout is not None:
             x = self.dropout(x)
         x = self.bn1(x)
-        x = F.relu(ops.gemm(x.contiguous(), self.fc2.weight, bias=self.fc2.bias) + feature)
+        x = F.relu(ops.linear_act(x, self.fc2.weight, self.fc2.bias) + feature)
         if self.dropout is not None:
             x = self.dropout(x)
         x = self.bn2(x)
-        return ops.gemm(x.contiguous(), self.fc3.weight, bias=self.fc3.bias)
+        return ops.linear_act(x, self.fc3.weight, self.fc3.bias)
 
 
 class SymbolicNetwork(nn.Module):
@@ -80,6 +80,25 @@ class SymbolicNetwork(nn.Module):
         for name, info in relation_info.items():
             mod = DeepRelationModule(embedding_size, info, use_dropout) if deep_module else RelationModule(embedding_size, info)
             setattr(self, name, mod)  # relation names contain dots; the reference registers them the same way
+
+    def forward(self, metapath, pos_paths, neg_pids, embeddings):
+        """(reg_loss, rank_loss) of a batch of positive paths along ``metapath`` (cafe.py:526-555): the chain of relation
+        modules from the user vector, a cross entropy per level against that level's node over its entity vocabulary,
+        and sigmoid(logp[neg item] - logp[pos item]) on the last level.  The vocabulary products run on the MFMA GEMM
+        (frozen tables: only dX is formed), softmax / CE / ranking and their gradient in csrc/cafe.hip."""
+        modules = [getattr(self, relation) for relation, _ in metapath[1:]]
+        user_vec = embeddings["user"][pos_paths[:, 0]]
+        x, reg_loss, rank_loss = user_vec, 0, None
+        for i, module in enumerate(modules):
+            x = module((x, user_vec)).view(pos_paths.shape[0], -1)
+            logits = ops.matmul_nt(x, embeddings[module.et_name])
+            last = i == len(modules) - 1
+            ce, rk = ops.level_loss(logits, pos_paths[:, i + 1], pos_paths[:, -1] if last else None,
+                                    neg_pids if last else None)
+            reg_loss = reg_loss + ce
+            if last:
+                rank_loss = rk
+        return reg_loss, rank_loss
 
 
 class TreeNode:
@@ -151,6 +170,12 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
         self.metapaths = [[(n[0], n[1]) for n in mp] for mp in self.raw_metapaths]
         self.model = SymbolicNetwork(self.relation_info, self.embedding_size, self.deep_module, self.use_dropout)
         self.rng = np.random.default_rng()
+        self.path_max_user_trials = int(config["max_user_trials"]) if "max_user_trials" in config else 5
+        self.mpath_ids = list(range(len(self.metapaths)))
+        self.memory_size = 10000  # cafe.py:87
+        self.replay_memory = {m: [] for m in self.mpath_ids}
+        self._ue64, self._ee64, self._re64 = (np.asarray(x, np.float64) for x in (ue, ee, re_))
+        self._topk_user_items = None
         self._vocab = {"user": self.n_users, "entity": self.n_entities}
         self._bit_words = (max(self.n_users, self.n_entities) + 31) // 32
 
@@ -357,8 +382,104 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
     def predict(self, interaction):
         return
 
+    # -- training (cafe.py:143-340) ----------------------------------------------------------------------------------
+    def _compute_top_items(self):
+        """cafe.py:134-141: the topk_candidates best items of every user under (U + R_ui) . E_item (float64, host, once)."""
+        if self._topk_user_items is None:
+            sc = np.dot(self._ue64 + self._re64[self.ui_relation_id], self._ee64[: self.n_items].T)
+            order = np.argsort(sc, axis=1)[:, -100:][:, ::-1]
+            self._topk_user_items = order[:, : self.topk_candidates]
+        return self._topk_user_items
+
+    def _rev_rel(self, rel):
+        if rel == self.ui_relation:
+            return self.ui_relation
+        return rel[:-2] if rel.endswith("_r") else rel + "_r"
+
+    def _nbrs(self, ntype, nid, relation_name):
+        rid = self.relation2rid.get(relation_name)
+        if rid is None:
+            return np.zeros(0, np.int32)
+        return P.host_neighbours(self.graph, ntype, nid, rid)
+
+    def fast_sample_path_with_target(self, mpath_id, user_id, target_id, num_paths, sample_size=100):
+        """Bidirectional BFS between the user and the target item along a metapath (cafe.py:207-289)."""
+        metapath = self.metapaths[mpath_id]
+        path_len = len(metapath) - 1
+        mid = path_len // 2
+
+        def cap(ids):
+            return self.rng.choice(ids, size=sample_size, replace=False) if len(ids) > sample_size else ids
+
+        forward_paths = [[int(user_id)]]
+        for i in range(1, mid + 1):
+            last_entity, next_relation = metapath[i - 1][1], metapath[i][0]
+            forward_paths = [fp + [int(n)] for fp in forward_paths for n in cap(self._nbrs(last_entity, fp[-1], next_relation))]
+        backward_paths = [[int(target_id)]]
+        for i in reversed(range(mid + 2, path_len + 1)):
+            next_relation, next_entity = metapath[i]
+            backward_paths = [[int(c)] + bp for bp in backward_paths
+                              for c in cap(self._nbrs(next_entity, bp[0], self._rev_rel(next_relation)))]
+        backward_map = {}
+        next_relation, next_entity = metapath[mid + 1]
+        for bp in backward_paths:
+            for c in cap(self._nbrs(next_entity, bp[0], self._rev_rel(next_relation))):
+                backward_map.setdefault(int(c), []).append(bp)
+        final_paths = []
+        for fp_idx in self.rng.permutation(len(forward_paths)):
+            fp = forward_paths[fp_idx]
+            if fp[-1] not in backward_map:
+                continue
+            self.rng.shuffle(backward_map[fp[-1]])
+            for bp in backward_map[fp[-1]]:
+                final_paths.append(fp + bp)
+                if len(final_paths) >= num_paths:
+                    return final_paths
+        return final_paths
+
+    def _get_batch_by_user(self, users):
+        """One (metapath, positive path, negative item) per user (cafe.py:143-198).  The metapath id returned is the LAST
+        one drawn, as in the reference, which scores the whole batch with it."""
+        top_items = self._compute_top_items()
+        pos_paths, neg_pids = [], []
+        trials = {int(u): 0 for u in users}
+        top_pids = np.arange(self.topk_candidates)
+        mpid, it = 0, 0
+        while len(pos_paths) < len(users) and it < len(users):
+            user = int(users[it])
+            if trials[user] >= self.path_max_user_trials:
+                it += 1
+                continue
+            mpid = int(self.rng.choice(self.mpath_ids))
+            pidx = int(self.rng.choice(top_pids))
+            item = int(top_items[user][pidx])
+            memory = self.replay_memory[mpid]
+            if self.rng.random() < 0.5 * len(memory) / self.memory_size:
+                pos_paths.append(memory[int(self.rng.integers(len(memory)))])
+            else:
+                paths = self.fast_sample_path_with_target(mpid, user, item, 1)
+                if not paths:
+                    trials[user] += 1
+                    continue
+                pos_paths.append(paths[0])
+                memory.extend(paths)
+                del memory[: max(0, len(memory) - self.memory_size)]
+            if pidx < self.topk_candidates - 1:
+                neg_pids.append(int(top_items[user][int(self.rng.choice(np.arange(pidx + 1, self.topk_candidates)))]))
+            else:
+                neg_pids.append(int(self.rng.choice(self.n_items)))
+            it += 1
+        return mpid, np.array(pos_paths, np.int64), np.array(neg_pids, np.int64)
+
     def calculate_loss(self, interaction):
-        raise NotImplementedError("CAFE training is not built yet (SURVEY.md §8(f)3); load a trained checkpoint")
+        """(reg_loss, rank_weight * rank_loss) -- cafe.py:329-340; the trainer sums the tuple."""
+        users = interaction[self.USER_ID]
+        users = users[users != 0].cpu().numpy()
+        mpid, pos_paths, neg_pids = self._get_batch_by_user(users)
+        dev = self.user_embedding.device
+        reg_loss, rank_loss = self.model(self.metapaths[mpid], torch.from_numpy(pos_paths).to(dev),
+                                         torch.from_numpy(neg_pids).to(dev), self.embeddings)
+        return reg_loss, rank_loss * self.rank_weight
 
 
 def _chain_of(order, i):

@@ -546,6 +546,73 @@ def matmul_nn(x, w):
     return MatMulNN.apply(x, w)
 
 
+class LinearAct(torch.autograd.Function):
+    """y = act(x @ w^T + b) (nn.Linear + optional ReLU / ELU) with the backward on the HIP kernels: the activation's
+    derivative is recovered from y, the three gradients are two GEMMs and a column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x, w = x.contiguous(), w.contiguous()
+        y = gemm(x, w, True, True, bias=b, elu={0: False, 1: True, 2: "relu"}[act])
+        ctx.act = act
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import pgpr_ops as P
+
+        x, w, y = ctx.saved_tensors
+        gy = gy.contiguous()
+        g = P.act_dropout_backward(gy, y, ctx.act) if ctx.act else gy
+        gx = gemm(g, w, True, False) if ctx.needs_input_grad[0] else None
+        gw = gemm(g, x, False, False) if ctx.needs_input_grad[1] else None
+        gb = P.colsum(g) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb, None
+
+
+def linear_act(x, w, b, act=0):
+    """act: 0 none, 1 ELU, 2 ReLU."""
+    return LinearAct.apply(x, w, b, int(act))
+
+
+class LevelLoss(torch.autograd.Function):
+    """(cross entropy of logits vs target, mean sigmoid(logp[neg] - logp[pos])) of one CAFE level (cafe.py:541-553)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, pos, neg):
+        lib = _lib.load()
+        logits = _dev(logits, torch.float32, "logits").contiguous()
+        n, v = logits.shape
+        target = _idx(target, "target").contiguous()
+        pos = None if pos is None else _idx(pos, "pos").contiguous()
+        neg = None if neg is None else _idx(neg, "neg").contiguous()
+        lse = torch.empty(n, dtype=torch.float32, device=logits.device)
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)
+        ws = torch.empty(2 * n, dtype=torch.float32, device=logits.device)
+        check(lib.hw_cafe_level_loss(_ptr(logits), logits.stride(0), n, v, _ptr(target), _ptr(pos), _ptr(neg), _ptr(lse),
+                                     _ptr(out), _ptr(ws), _stream()), "hw_cafe_level_loss")
+        ctx.has_rank = pos is not None
+        ctx.save_for_backward(logits, lse, target, *([pos, neg] if pos is not None else []))
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_ce, g_rank):
+        lib = _lib.load()
+        logits, lse, target = ctx.saved_tensors[:3]
+        pos, neg = (ctx.saved_tensors[3], ctx.saved_tensors[4]) if ctx.has_rank else (None, None)
+        d = torch.empty_like(logits)
+        n, v = logits.shape
+        check(lib.hw_cafe_level_loss_grad(_ptr(logits), logits.stride(0), n, v, _ptr(lse), _ptr(target), _ptr(pos),
+                                          _ptr(neg), float(g_ce), float(g_rank) if ctx.has_rank else 0.0, _ptr(d),
+                                          d.stride(0), _stream()), "hw_cafe_level_loss_grad")
+        return d, None, None, None
+
+
+def level_loss(logits, target, pos=None, neg=None):
+    return LevelLoss.apply(logits, target, pos, neg)
+
+
 class GatherRows(torch.autograd.Function):
     """table[idx] with a dense scatter-add backward (nn.Embedding forward/backward on the HIP row kernels)."""
 

@@ -43,6 +43,7 @@ class DeviceCKG:
         self.max_degree = int(np.diff(ptr).max()) if n > 0 else 0
         self.nnz = len(src)
         self.device = torch.device(device)
+        self.h_ptr, self.h_rel, self.h_dst = ptr, rel.astype(np.int32), dst.astype(np.int32)  # host copies (path samplers)
         self.ptr = torch.from_numpy(ptr).to(self.device)
         self.rel = torch.from_numpy(rel.astype(np.int32)).to(self.device)
         self.dst = torch.from_numpy(dst.astype(np.int32)).to(self.device)
@@ -51,6 +52,15 @@ class DeviceCKG:
         g.n_users, g.n_entities, g.n_items, g.ui_relation = self.n_users, self.n_entities, self.n_items, self.ui_relation
         g.max_degree = self.max_degree
         self.c = g
+
+
+def host_neighbours(graph, ntype, nid, rel):
+    """graph_dict[type][id][rel] of the reference as a slice of the host CSR (ids ascending, multiplicity kept)."""
+    gid = int(nid) if ntype == "user" else graph.n_users + int(nid)
+    lo, hi = graph.h_ptr[gid], graph.h_ptr[gid + 1]
+    r = graph.h_rel[lo:hi]
+    a, b = np.searchsorted(r, rel, "left"), np.searchsorted(r, rel, "right")
+    return graph.h_dst[lo + a : lo + b]
 
 
 def init_paths(users, paths, probs, n_rows):

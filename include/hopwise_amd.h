@@ -385,6 +385,17 @@ typedef struct {
     int32_t slot_off;      /* first output slot of this node, relative to the task's slot_ptr */
 } hw_cafe_node;
 
+/* One level of SymbolicNetwork.forward's loss (cafe.py:541-553): nn.CrossEntropyLoss(logits, target) (mean) and, when
+ * pos / neg are given, mean sigmoid(log_softmax[neg] - log_softmax[pos]).  loss_out[0] = cross entropy, [1] = ranking term;
+ * lse_out [n_rows] feeds the gradient call; row_ws: 2 * n_rows floats. */
+int hw_cafe_level_loss(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const int64_t* target,
+                       const int64_t* pos, const int64_t* neg, float* lse_out, float* loss_out, float* row_ws,
+                       void* stream);
+/* dlogits for upstream gradients (g_ce, g_rank) of the two losses. */
+int hw_cafe_level_loss_grad(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const float* lse,
+                            const int64_t* target, const int64_t* pos, const int64_t* neg, float g_ce, float g_rank,
+                            float* dlogits, int64_t ldd, void* stream);
+
 /* Interpret every task's program: for each node in order and each parent path in order, candidates = distinct
  * neighbours of the path's tail under node.rel, minus ids already picked at this node, minus (leaves) the excluded
  * set; keep the top-k by logprobs[node.lp_row] (value desc, id asc); append.  Outputs per slot: 3 ids (after the

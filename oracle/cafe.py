@@ -36,6 +36,42 @@ def module_forward(p, rel, eh_vec, user_vec, deep=True):
     return (x @ p[pre + ".fc2.weight"].T + p[pre + ".fc2.bias"] + eh_vec).astype(F32)
 
 
+def _bn_train(x, p, pre, eps=1e-5):
+    """BatchNorm1d in training mode: batch mean / biased variance."""
+    mu, var = x.mean(0, dtype=np.float64), x.var(0, dtype=np.float64)
+    return (((x - mu) / np.sqrt(var + eps)) * p[pre + ".weight"] + p[pre + ".bias"]).astype(F32)
+
+
+def module_forward_train(p, rel, eh_vec, user_vec, masks, deep=True):
+    """Train-mode forward (cafe.py:656-667, :686-699): ``masks`` = the multiplicative dropout masks in call order."""
+    pre = f"model.{rel}"
+    feat = np.concatenate([eh_vec, user_vec], axis=-1).astype(F32)
+    x = np.maximum(feat @ p[pre + ".fc1.weight"].T + p[pre + ".fc1.bias"], 0).astype(F32)
+    x = _bn_train(x * masks[0], p, pre + ".bn1")
+    if not deep:
+        return (x @ p[pre + ".fc2.weight"].T + p[pre + ".fc2.bias"] + eh_vec).astype(F32)
+    x = np.maximum(x @ p[pre + ".fc2.weight"].T + p[pre + ".fc2.bias"] + feat, 0).astype(F32)
+    x = _bn_train(x * masks[1], p, pre + ".bn2")
+    return (x @ p[pre + ".fc3.weight"].T + p[pre + ".fc3.bias"]).astype(F32)
+
+
+def symbolic_forward_loss(p, metapath, pos_paths, neg_pids, tables, masks, deep=True):
+    """(reg_loss, rank_loss) of SymbolicNetwork.forward (cafe.py:526-555); tables = {"user": U, "entity": E}."""
+    user_vec = tables["user"][pos_paths[:, 0]]
+    x, reg, rank = user_vec, 0.0, None
+    per = 2 if deep else 1
+    for i, (rel, et) in enumerate(metapath[1:]):
+        x = module_forward_train(p, rel, x, user_vec, masks[per * i : per * (i + 1)], deep)
+        scores = (x @ tables[et].T).astype(np.float64)
+        lse = np.log(np.exp(scores - scores.max(1, keepdims=True)).sum(1)) + scores.max(1)
+        rows = np.arange(len(scores))
+        reg += float(np.mean(lse - scores[rows, pos_paths[:, i + 1]]))
+        if i == len(metapath) - 2:
+            z = scores[rows, neg_pids] - scores[rows, pos_paths[:, -1]]
+            rank = float(np.mean(1.0 / (1.0 + np.exp(-z))))
+    return reg, rank
+
+
 def log_softmax(x):
     x = x.astype(F32)
     m = x.max()

@@ -391,8 +391,39 @@ def gen_cafe(out_dir):
     out["run.score"] = np.array([c[2] for c in collected], np.float32)
     out["run.path_ids"] = np.array([[n[2] for n in c[3]] for c in collected], np.int64).reshape(-1, 4)
     out["run.path_rels"] = np.array([[str(n[0]) for n in c[3][1:]] for c in collected]).reshape(-1, 3)
+    # training: one batch through the reference's sampler and SymbolicNetwork.forward in train mode (batch-statistics
+    # BatchNorm, recorded dropout masks), losses + gradients of the modules on the sampled metapath
+    import random
+
+    import torch.nn.functional as F
+    from make_golden_pgpr import RecordingDropout
+
+    model.train()
+    model.rng = np.random.default_rng(5)
+    random.seed(5)
+    tr_users = torch.from_numpy(active[:24].astype(np.int64))
+    mpid, pos_paths, neg_pids = model._get_batch_by_user(tr_users)
+    out["train.mpid"], out["train.pos_paths"], out["train.neg_pids"] = np.int64(mpid), pos_paths.astype(np.int64), neg_pids.astype(np.int64)
+    real = F.dropout
+    rec = RecordingDropout(31)
+    F.dropout = rec
+    model.zero_grad()
+    reg_loss, rank_loss = model.model.forward(model.metapaths[mpid], torch.from_numpy(pos_paths), torch.from_numpy(neg_pids))
+    (reg_loss + rank_loss * model.rank_weight).backward()
+    F.dropout = real
+    out["train.reg_loss"], out["train.rank_loss"] = reg_loss.detach().numpy(), rank_loss.detach().numpy()
+    out["train.rank_weight"] = np.float64(model.rank_weight)
+    for i, m in enumerate(rec.masks):
+        out[f"train.mask{i}"] = m
+    for k, prm in model.named_parameters():
+        if prm.grad is not None:
+            out[f"train.grad.{k}"] = prm.grad.numpy().copy()
+    for k, v in model.state_dict().items():
+        if "running" in k and any(k.startswith(f"model.{r}.") for r, _ in model.metapaths[mpid][1:]):
+            out[f"train.after.{k}"] = v.numpy().copy()
     np.savez_compressed(os.path.join(out_dir, "cafe_default.npz"), **out)
-    print("cafe", len(infer), out["infer.paths"].shape, scores.shape, len(collected))
+    print("cafe", len(infer), out["infer.paths"].shape, scores.shape, len(collected), "train", mpid, pos_paths.shape,
+          float(reg_loss), float(rank_loss), len(rec.masks))
 
 
 if __name__ == "__main__":

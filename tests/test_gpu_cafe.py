@@ -96,3 +96,105 @@ def test_run_program_vs_reference():
     check_collected(col, z)
     fs, paths = m.full_sort_predict({"user_id": torch.from_numpy(z["users"])})
     assert all(isinstance(p[3][1][0], (int, np.integer)) for p in paths)  # relation ids after convert_path_relations
+
+
+class ReplayDropout:
+    """F.dropout stand-in that multiplies by recorded masks in call order."""
+
+    def __init__(self, masks):
+        self.masks, self.i = masks, 0
+
+    def __call__(self, x, p=0.5, training=True, inplace=False):
+        m = self.masks[self.i]
+        self.i += 1
+        return x * m
+
+
+def test_training_forward_backward_vs_reference(monkeypatch):
+    """SymbolicNetwork.forward in train mode on the reference's sampled batch: both losses, every module gradient, the
+    BatchNorm running statistics afterwards."""
+    import torch.nn.functional as F
+
+    z, orc, m = build()
+    m.train()
+    mpid = int(z["train.mpid"])
+    masks = [torch.from_numpy(z[f"train.mask{i}"]).to(dev()) for i in range(6)]
+    monkeypatch.setattr(F, "dropout", ReplayDropout(masks))
+    m.zero_grad()
+    reg, rank = m.model(m.metapaths[mpid], torch.from_numpy(z["train.pos_paths"]).to(dev()),
+                        torch.from_numpy(z["train.neg_pids"]).to(dev()), m.embeddings)
+    np.testing.assert_allclose(reg.item(), float(z["train.reg_loss"]), rtol=2e-5)
+    np.testing.assert_allclose(rank.item(), float(z["train.rank_loss"]), rtol=2e-5)
+    (reg + rank * float(z["train.rank_weight"])).backward()
+    rels = sorted(m.relation_info, key=len, reverse=True)
+    n_checked = 0
+    for k in z.files:
+        if not k.startswith("train.grad.model.") and not k.startswith("train.after.model."):
+            continue
+        kind = "grad" if k.startswith("train.grad.") else "after"
+        rest = k[len(f"train.{kind}.model."):]
+        rel = next(r for r in rels if rest.startswith(r + "."))
+        obj = m._module(rel)
+        for a in rest[len(rel) + 1:].split("."):
+            obj = getattr(obj, a)
+        got = (obj.grad if kind == "grad" else obj).cpu().numpy()
+        scale = np.abs(z[k]).max() + 1e-12
+        np.testing.assert_allclose(got, z[k], rtol=3e-4, atol=3e-6 * scale + 1e-9, err_msg=k)
+        n_checked += 1
+    assert n_checked >= 30
+
+
+def test_level_loss_kernels_vs_numpy():
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(0)
+    for n, v in ((1, 5), (37, 301), (24, 6238), (300, 70000)):
+        x = torch.from_numpy((rng.standard_normal((n, v)) * 3).astype(np.float32)).to(dev()).requires_grad_(True)
+        t, a, b = (torch.from_numpy(rng.integers(0, v, n)).to(dev()) for _ in range(3))
+        b[0] = a[0]  # neg == pos: the two ranking gradients cancel
+        ce, rk = ops.level_loss(x, t, a, b)
+        (ce * 0.7 + rk * 1.9).backward()
+        xr = x.detach().double().cpu().requires_grad_(True)
+        lp = torch.log_softmax(xr, 1)
+        rows = torch.arange(n)
+        ce_r = -lp[rows, t.cpu()].mean()
+        rk_r = torch.sigmoid(lp[rows, b.cpu()] - lp[rows, a.cpu()]).mean()
+        (ce_r * 0.7 + rk_r * 1.9).backward()
+        np.testing.assert_allclose(ce.item(), ce_r.item(), rtol=1e-5)
+        np.testing.assert_allclose(rk.item(), rk_r.item(), rtol=1e-5)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-8)
+        ce2, _ = ops.level_loss(x, t)  # without the ranking term
+        np.testing.assert_allclose(ce2.item(), ce_r.item(), rtol=1e-5)
+
+
+def test_calculate_loss_samples_valid_paths_and_trains():
+    z, orc, m = build()
+    m.train()
+    m.rng = np.random.default_rng(3)
+    users = torch.from_numpy(np.unique(z["inter_users"])[:32]).to(dev())
+    mpid, pos, neg = m._get_batch_by_user(users.cpu().numpy())
+    assert pos.shape[1] == 4 and len(pos) == len(neg) and len(pos) > 0
+    rid = m.relation2rid
+    for path in pos:  # walks of the batch metapath... of SOME metapath: replayed paths keep their own (cafe.py:172-175)
+        ok = False
+        for mp in m.metapaths:
+            typ, cur, good = 0, int(path[0]), True
+            for (rel, _), nxt in zip(mp[1:], path[1:]):
+                rels, dsts = orc.g.neighbours(typ, cur)
+                good = good and any(r == rid[rel] and d == nxt for r, d in zip(rels, dsts))
+                typ, cur = 1, int(nxt)
+            ok = ok or good
+        assert ok, path
+    top = m._compute_top_items()
+    assert all(int(p[-1]) in top[int(p[0])] for p in pos)
+    opt = torch.optim.Adam(m.model.parameters(), lr=1e-3)
+    first = last = None
+    for step in range(12):
+        opt.zero_grad()
+        reg, rank = m.calculate_loss({m.USER_ID: users})
+        (reg + rank).backward()
+        opt.step()
+        val = float(reg.detach())
+        first = val if first is None else first
+        last = val
+    assert np.isfinite(last) and last < first

@@ -70,3 +70,26 @@ def check_collected(col, z):
                    for j in (k - 1, k + 1))
         if not near:
             assert got_order[k] == ref_order[k], k
+
+
+def test_training_forward_loss():
+    """SymbolicNetwork.forward in train mode on the reference's sampled batch (recorded dropout masks)."""
+    z, orc, rid, ui = load()
+    mp = orc.metapaths[int(z["train.mpid"])]
+    masks = [z[f"train.mask{i}"] for i in range(6)]
+    reg, rank = oc.symbolic_forward_loss(orc.p, mp, z["train.pos_paths"], z["train.neg_pids"],
+                                         {"user": orc.U, "entity": orc.E}, masks)
+    np.testing.assert_allclose(reg, float(z["train.reg_loss"]), rtol=2e-5)
+    np.testing.assert_allclose(rank, float(z["train.rank_loss"]), rtol=2e-5)
+    # every sampled path is a walk of SOME metapath (the reference draws a metapath per user and scores the whole batch
+    # with the last one drawn, cafe.py:161,198)
+    for path in z["train.pos_paths"]:
+        ok = False
+        for cand in orc.metapaths:
+            typ, cur, good = 0, int(path[0]), True
+            for (rel, _), nxt in zip(cand[1:], path[1:]):
+                rels, dsts = orc.g.neighbours(typ, cur)
+                good = good and any(r == rid[rel] and d == nxt for r, d in zip(rels, dsts))
+                typ, cur = 1, int(nxt)
+            ok = ok or good
+        assert ok, path
