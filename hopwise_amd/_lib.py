@@ -133,6 +133,11 @@ SIGNATURES = {
         [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p, C.c_void_p,
          C.c_void_p, C.c_void_p],
     ),
+    "hw_pgpr_user_scores_tp": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "hw_pgpr_actions": (
         C.c_int,
         [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, c_i32p, c_i32p, C.c_int64, C.c_int32,

@@ -287,8 +287,10 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
 
 // ---- float64 score tables for the trim --------------------------------------------------------------------
 // src[s, :] rows: 0 = U[user_s] (mode 0), U[user_s] + R[ui] (mode 1)
-__global__ void pgpr_user_src_kernel(const double* __restrict__ U64, const double* __restrict__ R64, int d,
-                                     int ui_relation, const int64_t* __restrict__ users, int n, int n_users_table,
+// V64 (nullable): per-user replacement of the R[ui] row (TPRec's temporal vector sum_c w[u][c] C[c], tprec.py:454-460)
+__global__ void pgpr_user_src_kernel(const double* __restrict__ U64, const double* __restrict__ R64,
+                                     const double* __restrict__ V64, int d, int ui_relation,
+                                     const int64_t* __restrict__ users, int n, int n_users_table,
                                      double* __restrict__ src0, double* __restrict__ src1) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * d) return;
@@ -297,7 +299,7 @@ __global__ void pgpr_user_src_kernel(const double* __restrict__ U64, const doubl
     u = u < 0 ? 0 : (u >= n_users_table ? n_users_table - 1 : u);
     const double v = U64[(size_t)u * d + k];
     src0[i] = v;
-    src1[i] = v + R64[(size_t)ui_relation * d + k];
+    src1[i] = v + (V64 ? V64[(size_t)u * d + k] : R64[(size_t)ui_relation * d + k]);
 }
 
 // out[s, n] = sum_k src[s, k] * T[n, k]   (float64, k ascending: one fixed summation order)
@@ -674,9 +676,10 @@ extern "C" int hw_pgpr_rel_entity_scores(const double* relation_emb64, const dou
     return HW_LAUNCH_RC();
 }
 
-extern "C" int hw_pgpr_user_scores(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
-                                   const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
-                                   double* src_workspace, double* score_user, double* score_entity, void* stream) {
+static int user_scores_impl(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                            const double* relation_emb64, const double* user_vec64, int32_t dim, const int64_t* users,
+                            int64_t n_batch, double* src_workspace, double* score_user, double* score_entity,
+                            void* stream) {
     int rc = check_graph(graph);
     if (rc) return rc;
     if (!user_emb64 || !entity_emb64 || !relation_emb64 || !users || !src_workspace || !score_user || !score_entity)
@@ -688,11 +691,27 @@ extern "C" int hw_pgpr_user_scores(const hw_pgpr_graph* graph, const double* use
     double* src0 = src_workspace;
     double* src1 = src_workspace + (size_t)n_batch * dim;
     const int total = (int)(n_batch * dim);
-    hipLaunchKernelGGL(pgpr_user_src_kernel, dim3((total + 255) / 256), dim3(256), 0, st, user_emb64, relation_emb64, dim,
+    hipLaunchKernelGGL(pgpr_user_src_kernel, dim3((total + 255) / 256), dim3(256), 0, st, user_emb64, relation_emb64, user_vec64, dim,
                        graph->ui_relation, users, (int)n_batch, graph->n_users, src0, src1);
     launch_dot64(src0, n_batch, user_emb64, graph->n_users, dim, score_user, st);
     launch_dot64(src1, n_batch, entity_emb64, graph->n_entities, dim, score_entity, st);
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_user_scores(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                                   const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                                   double* src_workspace, double* score_user, double* score_entity, void* stream) {
+    return user_scores_impl(graph, user_emb64, entity_emb64, relation_emb64, nullptr, dim, users, n_batch, src_workspace,
+                            score_user, score_entity, stream);
+}
+
+extern "C" int hw_pgpr_user_scores_tp(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                                      const double* relation_emb64, const double* user_vec64, int32_t dim,
+                                      const int64_t* users, int64_t n_batch, double* src_workspace, double* score_user,
+                                      double* score_entity, void* stream) {
+    if (!user_vec64) return HW_ERR_INVALID_ARG;
+    return user_scores_impl(graph, user_emb64, entity_emb64, relation_emb64, user_vec64, dim, users, n_batch,
+                            src_workspace, score_user, score_entity, stream);
 }
 
 extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_user, const double* score_entity,

@@ -4,3 +4,4 @@ from .knowledge_graph_embedding_recommender import (  # noqa: F401
 )
 from .cafe import CAFE  # noqa: F401,E402
 from .knowledge_aware_recommender import PGPR  # noqa: F401,E402
+from .tprec import TPRec  # noqa: F401,E402

@@ -189,7 +189,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         U32, E32, R32 = self._t32
         nr = buf["n_rows"]
         P.init_paths(users, buf["paths"][0], buf["probs"][0], nr[0:1])
-        score_user, score_entity = P.user_scores(g, U64, E64, R64, users)  # float64 trim tables of this batch
+        score_user, score_entity = P.user_scores(g, U64, E64, R64, users, self._user_vec())  # float64 trim tables
         trace = []
         for hop, k in enumerate(hops):
             rmax = buf["rows"][hop]
@@ -214,6 +214,14 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         res.n_rows_per_hop = nr
         res.trace = trace
         return res
+
+    def _user_vec(self):
+        """Per-user replacement of the [UI-Relation] row in the trimming / reward scores (None: PGPR; TPRec overrides)."""
+        return None
+
+    def _collect_tables(self):
+        """(U, E, R) float64 tables collect_scores reads; TPRec swaps the [UI-Relation] row."""
+        return self._t64
 
     # -- training: one REINFORCE episode per batch (pgpr.py:120-203, 335-396) ---------------------------------------
     def _head_params(self):
@@ -249,8 +257,12 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             scratch = torch.empty((min(2048, B), g.max_degree), dtype=torch.int64, device=dev)
         head_w, head_b = self._head_params()
         P.init_paths(users, ep["paths"][0], probs3[0], nr[0:1])
-        score_user, score_entity = P.user_scores(g, U64, E64, R64, users)
+        score_user, score_entity = P.user_scores(g, U64, E64, R64, users, self._user_vec())
         scales = torch.empty(B, dtype=torch.float64, device=dev)
+        own_scales = self._user_vec() is None  # u_p_scales always come from the plain (U + R_ui) tables (tprec.py:146-149)
+        if not own_scales:
+            _, plain = P.user_scores(g, U64, E64, R64, users)
+            P.reward(ep["paths"][0], B, None, plain, self.n_items, scales, True, ep["rewards"][:B])
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
             paths, n_rows = ep["paths"][t], nr[t : t + 1]
@@ -282,7 +294,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                             None if forced_acts is None else forced_acts[t].contiguous())
             P.expand(g, paths, probs3[t % 2], acts_buf, A, n_acts, n_rows, B, ep["acts"][sl].view(B, 1),
                      ep["logp"][sl].view(B, 1), 1, offsets, ep["paths"][t + 1], probs3[(t + 1) % 2], nr[t + 1 : t + 2], B)
-            P.reward(ep["paths"][t + 1], B, self._patterns, score_entity, self.n_items, scales, t == 0, ep["rewards"][sl])
+            P.reward(ep["paths"][t + 1], B, self._patterns, score_entity, self.n_items, scales, own_scales and t == 0,
+                     ep["rewards"][sl])
         ep["raw_rewards"] = ep["rewards"].clone()
         ep["loss"] = torch.empty(4, dtype=torch.float64, device=dev)
         ep["coef_actor"], ep["dvalue"] = f32(T * B), f32(T * B)
@@ -363,7 +376,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         """scores [len(users), n_items] on the device + the selection arrays (pgpr.py:486-552)."""
         users = users.to(self._t64[0].device, torch.int64).contiguous()
         n_nodes = len(self.beam_search_hop) + 1 if n_nodes is None else n_nodes
-        return P.collect(self.graph, *self._t64, users, self._pos_bits, res.paths, res.probs, res._n,
+        return P.collect(self.graph, *self._collect_tables(), users, self._pos_bits, res.paths, res.probs, res._n,
                          res.paths.shape[0], n_nodes, max(self.topk))
 
     def explanations(self, users, res, sel):

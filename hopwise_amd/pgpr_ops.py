@@ -79,14 +79,21 @@ def rel_entity_scores(R64, E64):
     return out
 
 
-def user_scores(graph, U64, E64, R64, users):
-    """(score_user [B, n_users], score_entity [B, n_entities]) float64 for the root users of a search batch."""
+def user_scores(graph, U64, E64, R64, users, user_vec=None):
+    """(score_user [B, n_users], score_entity [B, n_entities]) float64 for the root users of a search batch.
+    ``user_vec`` [n_users, d] float64 replaces the [UI-Relation] row per user (TPRec)."""
     lib = _lib.load()
     users = _dev(users, torch.int64, "users").contiguous()
     B, d = users.numel(), U64.shape[1]
     ws = torch.empty(2 * B * d, dtype=torch.float64, device=users.device)
     su = torch.empty((B, graph.n_users), dtype=torch.float64, device=users.device)
     se = torch.empty((B, graph.n_entities), dtype=torch.float64, device=users.device)
+    if user_vec is not None:
+        if user_vec.dtype != torch.float64 or tuple(user_vec.shape) != (graph.n_users, d) or not user_vec.is_contiguous():
+            raise ValueError("user_vec must be contiguous float64 [n_users, d]")
+        check(lib.hw_pgpr_user_scores_tp(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), _ptr(user_vec), d, _ptr(users),
+                                         B, _ptr(ws), _ptr(su), _ptr(se), _stream()), "hw_pgpr_user_scores_tp")
+        return su, se
     check(lib.hw_pgpr_user_scores(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), d, _ptr(users), B, _ptr(ws),
                                   _ptr(su), _ptr(se), _stream()), "hw_pgpr_user_scores")
     return su, se

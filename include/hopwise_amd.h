@@ -218,6 +218,12 @@ int hw_pgpr_rel_entity_scores(const double* relation_emb64, const double* entity
 int hw_pgpr_user_scores(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
                         const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
                         double* src_workspace, double* score_user, double* score_entity, void* stream);
+/* TPRec (tprec.py:454-471): the same tables with the [UI-Relation] row replaced per user by user_vec64[u]
+ * ([n_users, dim] float64: sum_c uc_weight[u][c] * ui_clust_relation_embedding[c]). */
+int hw_pgpr_user_scores_tp(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                           const double* relation_emb64, const double* user_vec64, int32_t dim, const int64_t* users,
+                           int64_t n_batch, double* src_workspace, double* score_user, double* score_entity,
+                           void* stream);
 
 /* _get_actions (pgpr.py:226-290): acts[row] = [(self, cur)] + unvisited neighbours in (rel, dst) order; when
  * more than max_acts remain, the max_acts with the largest float64 score (ties: later CSR position wins),

@@ -442,6 +442,10 @@ if __name__ == "__main__":
         from make_golden_pgpr import gen_pgpr
 
         gen_pgpr(HERE)
+    if what in ("tprec", "all"):
+        from make_golden_tprec import gen_tprec
+
+        gen_tprec(HERE)
     if what in ("pgpr_train", "all"):
         from make_golden_pgpr_train import gen_pgpr_train
 
