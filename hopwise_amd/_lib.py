@@ -111,6 +111,16 @@ SIGNATURES = {
         [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_i64p, c_i64p, c_i64p, C.c_float, C.c_float, c_f32p, C.c_int64,
          C.c_void_p],
     ),
+    "hw_conv2d_1ch_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "hw_conv2d_1ch_forward": (
+        C.c_int,
+        [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_void_p],
+    ),
+    "hw_conv2d_1ch_backward": (
+        C.c_int,
+        [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
+         c_f32p, C.c_void_p],
+    ),
     "hw_loss_margin_ranking_sigmoid": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],

@@ -531,3 +531,122 @@ class TuckER(KnowledgeRecommender):
         user = interaction[self.USER_ID]
         score = self.forward(user, self._ui(user), self.user_embedding.weight, "rec")
         return score[:, self.n_users :]
+
+
+class _PadEmbedding(torch.autograd.Function):
+    """table[idx] whose backward skips ``padding_idx`` (nn.Embedding(padding_idx=0) semantics, conve.py:52-55)."""
+
+    @staticmethod
+    def forward(ctx, table, idx, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.pad = table.shape, padding_idx
+        return ops.gather_rows(table, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gt = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        keep = idx != ctx.pad
+        ops.scatter_add_rows_(gt, idx[keep].contiguous(), g[keep].contiguous())
+        return gt, None, None
+
+
+class ConvE(KnowledgeRecommender):
+    """ConvE 1-vs-all scorer (conve.py:21-190): the head and relation rows are reshaped to [d1, d2] images, stacked,
+    convolved with 32 3x3 filters, projected back to d and multiplied with every row of the entity table.
+
+    Same parameters / state_dict keys as the reference (``user_embedding`` has n_users + n_items rows, ``relations_embeddings``,
+    ``conv1``, ``bn0/bn1/bn2``, ``b_users``, ``b_entities``, ``fc``), config keys (embedding_shape, hidden_size, use_bias,
+    input_dropout, hidden_dropout, feature_dropout, label_smoothing) and quirks: union-of-the-batch targets
+    (conve.py:124-128), label smoothing with 1 / n_items and 1 / n_entities (:131-132), predict_kg returns
+    ``score[:, tail]`` -- a [B, B] matrix (:162), full_sort_predict_kg reads attributes that do not exist (:183-186) and
+    therefore raises AttributeError, lookups skip the gradient of id 0 (padding_idx) while the 1-vs-all product does not.
+    The convolution (csrc/conv.hip), the two dense products and sigmoid + BCE are HIP; BatchNorm / dropout modules are
+    torch (a few MB next to the [B, N] logits), as for TuckER."""
+
+    input_type = InputType.PAIRWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        d = self.embedding_size = config["embedding_size"]
+        self.label_smoothing = config["label_smoothing"]
+        self.embedding_dim1 = config["embedding_shape"]
+        self.embedding_dim2 = d // self.embedding_dim1
+        self.hidden_size = config["hidden_size"]
+        self.use_bias = config["use_bias"]
+        self.ui_relation = dataset.field2token_id["relation_id"][dataset.ui_relation]
+        self.user_embedding = nn.Embedding(self.n_users + self.n_items, d, padding_idx=0)
+        self.entity_embedding = nn.Embedding(self.n_entities, d, padding_idx=0)
+        self.relations_embeddings = nn.Embedding(self.n_relations, d, padding_idx=0)
+        self.inp_drop = nn.Dropout(config["input_dropout"])
+        self.hidden_drop = nn.Dropout(config["hidden_dropout"])
+        self.feature_map_drop = nn.Dropout2d(config["feature_dropout"])
+        self.conv1 = nn.Conv2d(1, 32, (3, 3), 1, 0, bias=self.use_bias)
+        self.bn0 = nn.BatchNorm2d(1)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.bn2 = nn.BatchNorm1d(d)
+        self.register_parameter("b_users", nn.Parameter(torch.zeros(self.n_users + self.n_items)))
+        self.register_parameter("b_entities", nn.Parameter(torch.zeros(self.n_entities)))
+        self.fc = nn.Linear(self.hidden_size, d)
+        self.apply(xavier_normal_initialization)
+        self.forced_masks = None  # tests: {"rec": (m_inp, m_feature, m_hidden), "kg": (...)} multiplicative masks
+
+    def _drop(self, module, x, forced):
+        return x * forced if forced is not None else module(x)
+
+    def logits(self, h_idx, r_idx, head_table, out_table, bias, side):
+        """Pre-sigmoid scores [B, rows(out_table)] of forward() (conve.py:75-93)."""
+        fm = self.forced_masks[side] if self.forced_masks is not None else (None, None, None)
+        shape = (-1, 1, self.embedding_dim1, self.embedding_dim2)
+        h = _PadEmbedding.apply(head_table, h_idx, 0).view(shape)
+        r = _PadEmbedding.apply(self.relations_embeddings.weight, r_idx, 0).view(shape)
+        x = self.bn0(torch.cat([h, r], 2))
+        x = self._drop(self.inp_drop, x, fm[0])
+        x = ops.conv2d_1ch(x, self.conv1.weight, self.conv1.bias)
+        x = torch.relu(self.bn1(x))
+        x = self._drop(self.feature_map_drop, x, fm[1])
+        x = ops.linear_act(x.reshape(x.shape[0], -1), self.fc.weight, self.fc.bias)
+        x = self._drop(self.hidden_drop, x, fm[2])
+        x = torch.relu(self.bn2(x))
+        return ops.linear_act(x, out_table, bias)
+
+    def forward(self, h_idx, r_idx, head_table, out_table, bias, side):
+        return ops.sigmoid(self.logits(h_idx, r_idx, head_table, out_table, bias, side))
+
+    def _rec(self, user):
+        return (user, torch.full_like(user, self.ui_relation), self.user_embedding.weight, self.user_embedding.weight,
+                self.b_users, "rec")
+
+    def _kg(self, head, rel):
+        return head, rel, self.entity_embedding.weight, self.entity_embedding.weight, self.b_entities, "kg"
+
+    def calculate_loss(self, interaction):  # conve.py:110-137
+        user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
+        head, rel, tail = interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], interaction[self.TAIL_ENTITY_ID]
+        dev = user.device
+        item_flag = torch.zeros(self.n_users + self.n_items, dtype=torch.uint8, device=dev)
+        item_flag[item + self.n_users] = 1
+        tail_flag = torch.zeros(self.n_entities, dtype=torch.uint8, device=dev)
+        tail_flag[tail] = 1
+        if self.label_smoothing:
+            s, a_rec, a_kg = 1.0 - self.label_smoothing, 1.0 / self.n_items, 1.0 / self.n_entities
+        else:
+            s, a_rec, a_kg = 1.0, 0.0, 0.0
+        lu = self.logits(*self._rec(user))
+        lk = self.logits(*self._kg(head, rel))
+        return ops.sigmoid_bce_mean(lu, item_flag, s, a_rec) + ops.sigmoid_bce_mean(lk, tail_flag, s, a_kg)
+
+    def predict(self, interaction):  # conve.py:139-151
+        user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
+        score = self.forward(*self._rec(user))[:, self.n_users :]
+        return score[torch.arange(user.size(0), device=user.device), item]
+
+    def predict_kg(self, interaction):  # conve.py:153-164: ``score[:, tail]`` -> [B, len(tail)]
+        score = self.forward(*self._kg(interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID]))
+        return score[:, interaction[self.TAIL_ENTITY_ID]]
+
+    def full_sort_predict(self, interaction):  # conve.py:166-176
+        return self.forward(*self._rec(interaction[self.USER_ID]))[:, self.n_users :]
+
+    def full_sort_predict_kg(self, interaction):  # conve.py:178-190 touches self.entities_embeddings, which is never set
+        raise AttributeError("'ConvE' object has no attribute 'entities_embeddings'")

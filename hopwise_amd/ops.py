@@ -613,6 +613,48 @@ def level_loss(logits, target, pos=None, neg=None):
     return LevelLoss.apply(logits, target, pos, neg)
 
 
+class Conv2d1ch(torch.autograd.Function):
+    """nn.Conv2d(1, C, (kh, kw)) on an input [B, 1, H, W] (stride 1, no padding) -- csrc/conv.hip."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "x").contiguous()
+        w = _dev(w, torch.float32, "w").contiguous()
+        B, one, H, W = x.shape
+        C_, one2, kh, kw = w.shape
+        if one != 1 or one2 != 1:
+            raise ValueError("Conv2d1ch: one input channel only")
+        out = torch.empty((B, C_, H - kh + 1, W - kw + 1), dtype=torch.float32, device=x.device)
+        check(lib.hw_conv2d_1ch_forward(_ptr(x), _ptr(w), _ptr(bias), B, C_, H, W, kh, kw, _ptr(out), _stream()),
+              "hw_conv2d_1ch_forward")
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        B, _, H, W = x.shape
+        C_, _, kh, kw = w.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(C_, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        need_w = dw is not None or db is not None
+        if need_w and dw is None:
+            dw = torch.empty_like(w)
+        ws = torch.empty(int(lib.hw_conv2d_1ch_workspace_floats(C_, kh, kw)), dtype=torch.float32, device=x.device) if need_w else None
+        check(lib.hw_conv2d_1ch_backward(_ptr(x), _ptr(w), _ptr(gy), B, C_, H, W, kh, kw, _ptr(dx), _ptr(dw), _ptr(db),
+                                         _ptr(ws), _stream()), "hw_conv2d_1ch_backward")
+        return dx, (dw if ctx.needs_input_grad[1] else None), db
+
+
+def conv2d_1ch(x, w, bias=None):
+    return Conv2d1ch.apply(x, w, bias)
+
+
 class GatherRows(torch.autograd.Function):
     """table[idx] with a dense scatter-add backward (nn.Embedding forward/backward on the HIP row kernels)."""
 

@@ -135,6 +135,17 @@ int hw_kge_project_rows_grad(const float* mats, int64_t n_rel, const float* tabl
                              const int64_t* r_idx, int64_t r_fixed, const int64_t* e_idx, int64_t n, const float* g_out,
                              float* g_table, float* g_mats, void* stream);
 
+/* ---- single-input-channel 2-D convolution (ConvE conve.py:63, ConvKB convkb.py:52) --------------------------------
+ * out[b, c, i, j] = bias[c] + sum_{u, v} w[c, u, v] x[b, i + u, j + v]; stride 1, no padding, kh * kw <= 32.
+ * x [batch, height, width], w [channels, kh, kw], out / dy [batch, channels, height - kh + 1, width - kw + 1].
+ * backward: dx / dw / dbias nullable; workspace of hw_conv2d_1ch_workspace_floats() floats is needed for dw. */
+int64_t hw_conv2d_1ch_workspace_floats(int32_t channels, int32_t kh, int32_t kw);
+int hw_conv2d_1ch_forward(const float* x, const float* w, const float* bias, int64_t batch, int32_t channels,
+                          int32_t height, int32_t width, int32_t kh, int32_t kw, float* out, void* stream);
+int hw_conv2d_1ch_backward(const float* x, const float* w, const float* dy, int64_t batch, int32_t channels,
+                           int32_t height, int32_t width, int32_t kh, int32_t kw, float* dx, float* dw, float* dbias,
+                           float* workspace, void* stream);
+
 /* ---- losses on score vectors (deterministic two-stage reductions) ---------------------------------
  * `workspace` must hold at least hw_loss_workspace_floats() floats. */
 int64_t hw_loss_workspace_floats(void);

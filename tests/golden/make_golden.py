@@ -310,6 +310,76 @@ def gen_tucker(out_dir):
         print("tucker", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks))
 
 
+def gen_conve(out_dir):
+    """ConvE: eval-mode outputs + loss + grads, and a train-mode step with recorded dropout / dropout2d masks."""
+    import torch.nn.functional as F
+    from hopwise.model.knowledge_graph_embedding_recommender.conve import ConvE
+
+    from make_golden_pgpr import RecordingDropout
+
+    class RecordingDropout2d(RecordingDropout):
+        def __call__(self, x, p=0.5, training=True, inplace=False):
+            keep = (torch.rand(x.shape[:2], generator=self.gen) >= p).float().view(*x.shape[:2], 1, 1) / (1.0 - p)
+            self.masks.append(keep.numpy().copy())
+            return x * keep
+
+    nU, nI, nE, nR = 20, 16, 48, 5
+    real, real2 = F.dropout, F.dropout2d
+    for d, shape in ((32, 4), (64, 8)):  # d = 200 would store 3 x 7.8 MB of fc weights and gradients
+        torch.manual_seed(900 + d)
+        d2 = d // shape
+        config = dict(FIELDS, embedding_size=d, device=torch.device("cpu"), label_smoothing=0.1, input_dropout=0.2,
+                      hidden_dropout=0.3, feature_dropout=0.2, embedding_shape=shape, hidden_size=32 * (2 * shape - 2) * (d2 - 2),
+                      use_bias=True)
+        model = ConvE(config, FakeDataset(nU, nI, nE, nR))
+        with torch.no_grad():  # non-trivial BatchNorm state and biases
+            for bn in (model.bn0, model.bn1, model.bn2):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.2)
+                bn.running_mean.normal_(0, 0.1)
+                bn.running_var.uniform_(0.5, 2.0)
+            model.b_users.normal_(0, 0.1)
+            model.b_entities.normal_(0, 0.1)
+        rng = np.random.default_rng(60 + d)
+        inter_np = make_batch(rng, nU, nI, nE, nR, 12, 14)
+        inter = {k: torch.from_numpy(v) for k, v in inter_np.items()}
+        out = {f"p.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        out.update({f"inter.{k}": v for k, v in inter_np.items()})
+        out["embedding_shape"], out["hidden_size"] = np.int64(shape), np.int64(config["hidden_size"])
+        model.eval()
+        with torch.no_grad():
+            out["eval.predict"] = model.predict(inter).numpy()
+            out["eval.predict_kg"] = model.predict_kg(inter).numpy()
+            users = torch.tensor([1, 5, 0, 19])
+            out["eval.fs_users"] = users.numpy()
+            out["eval.fs"] = model.full_sort_predict({"user_id": users}).numpy()
+        model.zero_grad()
+        loss = model.calculate_loss(inter)
+        loss.backward()
+        out["eval.loss"] = loss.detach().numpy()
+        for k, prm in model.named_parameters():
+            out[f"eval.grad.{k}"] = prm.grad.numpy().copy()
+        model.train()
+        rec, rec2 = RecordingDropout(7 + d), RecordingDropout2d(17 + d)
+        F.dropout, F.dropout2d = rec, rec2
+        model.zero_grad()
+        loss = model.calculate_loss(inter)
+        loss.backward()
+        F.dropout, F.dropout2d = real, real2
+        out["train.loss"] = loss.detach().numpy()
+        for i, m in enumerate(rec.masks):
+            out[f"train.mask{i}"] = m
+        for i, m in enumerate(rec2.masks):
+            out[f"train.mask2d{i}"] = m
+        for k, prm in model.named_parameters():
+            out[f"train.grad.{k}"] = prm.grad.numpy().copy()
+        for k, v in model.state_dict().items():
+            if "running" in k:
+                out[f"train.after.{k}"] = v.numpy().copy()
+        np.savez_compressed(os.path.join(out_dir, f"conve_d{d}.npz"), **out)
+        print("conve", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks), len(rec2.masks))
+
+
 def gen_cafe(out_dir):
     """CAFE inference on the reference fixture: module outputs, infer_with_path for every (user, metapath), executor +
     run_program with the child permutation patched to the identity, eval mode."""
@@ -436,6 +506,8 @@ if __name__ == "__main__":
         gen_sampler(HERE)
     if what in ("cafe", "all"):
         gen_cafe(HERE)
+    if what in ("conve", "all"):
+        gen_conve(HERE)
     if what in ("tucker", "all"):
         gen_tucker(HERE)
     if what in ("pgpr", "all"):
