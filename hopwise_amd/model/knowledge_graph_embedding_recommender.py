@@ -650,3 +650,94 @@ class ConvE(KnowledgeRecommender):
 
     def full_sort_predict_kg(self, interaction):  # conve.py:178-190 touches self.entities_embeddings, which is never set
         raise AttributeError("'ConvE' object has no attribute 'entities_embeddings'")
+
+
+class ConvKB(KnowledgeRecommender):
+    """ConvKB (convkb.py:24-160): the (h, r, t) rows form a [d, 3] matrix that goes through BatchNorm2d(1), T filters of
+    shape (kernel_size, 3), BatchNorm2d(T), ReLU, dropout and a bias-free Linear to one score.
+
+    Same parameters / state_dict keys (``conv1_bn``, ``conv_layer``, ``conv2_bn``, ``fc_layer``), config keys
+    (out_channels, kernel_size, dropout_prob, lambda) and loss: LogisticLoss on the negated scores with the
+    regulariser lambda * (mean h^2 + mean t^2 + mean r^2 + ||conv W|| + ||conv b|| + ||fc W||) added to both terms,
+    rec + kg; four forward passes per step (pos / neg x rec / kg), each with its own BatchNorm batch statistics, in the
+    reference's order (convkb.py:131-134).  The convolution and the Linear run on csrc/conv.hip and the MFMA GEMM, the
+    softplus means on the BCE kernel; BatchNorm / dropout / the tiny norms are torch.  No full-sort methods exist in
+    the reference."""
+
+    input_type = InputType.PAIRWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        d = self.embedding_size = config["embedding_size"]
+        self.out_channels = config["out_channels"]
+        self.kernel_size = config["kernel_size"]
+        self.drop_prob = config["dropout_prob"]
+        self.lmbda = config["lambda"]
+        self.ui_relation = dataset.field2token_id["relation_id"][dataset.ui_relation]
+        self.user_embedding = nn.Embedding(self.n_users, d)
+        self.entity_embedding = nn.Embedding(self.n_entities, d)
+        self.relation_embedding = nn.Embedding(self.n_relations, d)
+        self.conv1_bn = nn.BatchNorm2d(1)
+        self.conv_layer = nn.Conv2d(1, self.out_channels, (self.kernel_size, 3))
+        self.conv2_bn = nn.BatchNorm2d(self.out_channels)
+        self.dropout = nn.Dropout(self.drop_prob)
+        self.fc_layer = nn.Linear((d - self.kernel_size + 1) * self.out_channels, 1, bias=False)
+        self.apply(xavier_normal_initialization)
+        self.forced_masks = None  # tests: list of multiplicative dropout masks, one per forward call
+
+    def forward(self, head, relation, tail):
+        """Scores of gathered rows [B, d] x 3 (convkb.py:65-82)."""
+        x = torch.stack([head, relation, tail], dim=2).unsqueeze(1)  # [B, 1, d, 3]
+        x = self.conv1_bn(x)
+        x = ops.conv2d_1ch(x, self.conv_layer.weight, self.conv_layer.bias)
+        x = torch.relu(self.conv2_bn(x))
+        x = x.reshape(x.shape[0], -1)
+        if self.forced_masks is not None:
+            x = x * self.forced_masks.pop(0)
+        else:
+            x = self.dropout(x)
+        return ops.linear_act(x, self.fc_layer.weight, None).view(-1)
+
+    def _reg(self, h, r, t):  # convkb.py:84-88
+        l2 = torch.mean(h**2) + torch.mean(t**2) + torch.mean(r**2)
+        for w in (*self.conv_layer.parameters(), *self.fc_layer.parameters()):
+            l2 = l2 + w.norm(2)
+        return self.lmbda * l2
+
+    def _rows(self, table, idx):
+        return ops.embedding(table.weight, idx)
+
+    def _logistic(self, pos, neg, pos_reg, neg_reg):
+        # LogisticLoss(-pos, -neg, regs) (loss.py:172-190): mean softplus(-pos) + mean softplus(neg) (+ regs when both are
+        # non-zero) = twice the BCE-with-logits mean over cat(pos, neg) with labels (1, 0)
+        loss = 2.0 * ops.bce_logits_mean(torch.stack([pos, neg]), pos.shape[0])
+        if bool(pos_reg) and bool(neg_reg):
+            loss = loss + pos_reg + neg_reg
+        return loss
+
+    def calculate_loss(self, interaction):  # convkb.py:106-141
+        ui = torch.full_like(interaction[self.USER_ID], self.ui_relation)
+        u = self._rows(self.user_embedding, interaction[self.USER_ID])
+        ur = self._rows(self.relation_embedding, ui)
+        ip = self._rows(self.entity_embedding, interaction[self.ITEM_ID])
+        ineg = self._rows(self.entity_embedding, interaction[self.NEG_ITEM_ID])
+        h = self._rows(self.entity_embedding, interaction[self.HEAD_ENTITY_ID])
+        r = self._rows(self.relation_embedding, interaction[self.RELATION_ID])
+        tp = self._rows(self.entity_embedding, interaction[self.TAIL_ENTITY_ID])
+        tn = self._rows(self.entity_embedding, interaction[self.NEG_TAIL_ENTITY_ID])
+        s_pu, s_nu = self.forward(u, ur, ip), self.forward(u, ur, ineg)
+        s_pk, s_nk = self.forward(h, r, tp), self.forward(h, r, tn)
+        rec = self._logistic(s_pu, s_nu, self._reg(u, ur, ip), self._reg(u, ur, ineg))
+        kg = self._logistic(s_pk, s_nk, self._reg(h, r, tp), self._reg(h, r, tn))
+        return rec + kg
+
+    def predict(self, interaction):
+        users = interaction[self.USER_ID]
+        return self.forward(self._rows(self.user_embedding, users),
+                            self._rows(self.relation_embedding, torch.full_like(users, self.ui_relation)),
+                            self._rows(self.entity_embedding, interaction[self.ITEM_ID]))
+
+    def predict_kg(self, interaction):
+        return self.forward(self._rows(self.entity_embedding, interaction[self.HEAD_ENTITY_ID]),
+                            self._rows(self.relation_embedding, interaction[self.RELATION_ID]),
+                            self._rows(self.entity_embedding, interaction[self.TAIL_ENTITY_ID]))

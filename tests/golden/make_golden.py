@@ -380,6 +380,61 @@ def gen_conve(out_dir):
         print("conve", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks), len(rec2.masks))
 
 
+def gen_convkb(out_dir):
+    """ConvKB: eval-mode predict / predict_kg / loss / grads, and a train-mode step with recorded dropout masks."""
+    import torch.nn.functional as F
+    from hopwise.model.knowledge_graph_embedding_recommender.convkb import ConvKB
+
+    from make_golden_pgpr import RecordingDropout
+
+    nU, nI, nE, nR = 20, 16, 48, 5
+    real = F.dropout
+    for d, ks, T in ((16, 1, 8), (50, 1, 64), (24, 3, 5)):
+        torch.manual_seed(1300 + d)
+        config = {**FIELDS, "embedding_size": d, "device": torch.device("cpu"), "out_channels": T, "kernel_size": ks,
+                  "dropout_prob": 0.3, "lambda": 0.2}
+        model = ConvKB(config, FakeDataset(nU, nI, nE, nR))
+        with torch.no_grad():
+            for bn in (model.conv1_bn, model.conv2_bn):
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_(0, 0.2)
+                bn.running_mean.normal_(0, 0.1)
+                bn.running_var.uniform_(0.5, 2.0)
+        rng = np.random.default_rng(70 + d)
+        inter_np = make_batch(rng, nU, nI, nE, nR, 12, 14)
+        inter = {k: torch.from_numpy(v) for k, v in inter_np.items()}
+        out = {f"p.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items()}
+        out.update({f"inter.{k}": v for k, v in inter_np.items()})
+        out["kernel_size"], out["out_channels"] = np.int64(ks), np.int64(T)
+        model.eval()
+        with torch.no_grad():
+            out["eval.predict"] = model.predict(inter).numpy()
+            out["eval.predict_kg"] = model.predict_kg(inter).numpy()
+        model.zero_grad()
+        loss = model.calculate_loss(inter)
+        loss.backward()
+        out["eval.loss"] = loss.detach().numpy()
+        for k, prm in model.named_parameters():
+            out[f"eval.grad.{k}"] = prm.grad.numpy().copy()
+        model.train()
+        rec = RecordingDropout(3 + d)
+        F.dropout = rec
+        model.zero_grad()
+        loss = model.calculate_loss(inter)
+        loss.backward()
+        F.dropout = real
+        out["train.loss"] = loss.detach().numpy()
+        for i, m in enumerate(rec.masks):
+            out[f"train.mask{i}"] = m
+        for k, prm in model.named_parameters():
+            out[f"train.grad.{k}"] = prm.grad.numpy().copy()
+        for k, v in model.state_dict().items():
+            if "running" in k:
+                out[f"train.after.{k}"] = v.numpy().copy()
+        np.savez_compressed(os.path.join(out_dir, f"convkb_d{d}.npz"), **out)
+        print("convkb", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks))
+
+
 def gen_cafe(out_dir):
     """CAFE inference on the reference fixture: module outputs, infer_with_path for every (user, metapath), executor +
     run_program with the child permutation patched to the identity, eval mode."""
@@ -506,6 +561,8 @@ if __name__ == "__main__":
         gen_sampler(HERE)
     if what in ("cafe", "all"):
         gen_cafe(HERE)
+    if what in ("convkb", "all"):
+        gen_convkb(HERE)
     if what in ("conve", "all"):
         gen_conve(HERE)
     if what in ("tucker", "all"):

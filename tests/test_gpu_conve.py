@@ -33,6 +33,9 @@ def check_grads(m, z, prefix):
     for k, prm in m.named_parameters():
         ref = z[f"{prefix}.{k}"]
         scale = np.abs(ref).max() + 1e-12
+        if scale < 1e-7:  # a bias in front of a batch-statistics BatchNorm: the gradient is rounding noise on both sides
+            assert np.abs(prm.grad.cpu().numpy()).max() < 1e-6, k
+            continue
         np.testing.assert_allclose(prm.grad.cpu().numpy(), ref, rtol=3e-4, atol=3e-6 * scale + 1e-9, err_msg=k)
 
 
