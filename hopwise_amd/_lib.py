@@ -121,6 +121,14 @@ SIGNATURES = {
         [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p,
          c_f32p, C.c_void_p],
     ),
+    "hw_tucker_contract_dropout": (
+        C.c_int,
+        [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, c_f32p, C.c_void_p],
+    ),
+    "hw_tucker_contract_dropout_grad": (
+        C.c_int,
+        [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, C.c_void_p],
+    ),
     "hw_loss_margin_ranking_sigmoid": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],

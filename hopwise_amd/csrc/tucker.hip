@@ -8,18 +8,53 @@
 
 namespace hw {
 
-// out[b, j] = sum_i x[b, i] * w[b, i, j] * mask[b, i, j]        (mask nullable; mask holds 0 or 1/(1-p))
+// Dropout mask of element (b, i, j) in Philox mode: word (i & 3) of block (b * ceil(d / 4) + (i >> 2)) * d + j of the
+// (seed, offset) stream, so that a thread walking i for a fixed j (forward) or a wave handling four consecutive rows
+// (backward) pays for one Philox block per four elements.
+__device__ __forceinline__ void philox_block(uint64_t seed, uint64_t offset, uint64_t blk, uint32_t (&w)[4]) {
+    uint32_t c0 = (uint32_t)blk, c1 = (uint32_t)(blk >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    w[0] = c0, w[1] = c1, w[2] = c2, w[3] = c3;
+}
+__device__ __forceinline__ float keep_scale(uint32_t word, float p, float inv_keep) {
+    return (float)(word >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
+}
+
+// out[b, j] = sum_i x[b, i] * w[b, i, j] * m[b, i, j]; MODE 0: no mask, 1: mask tensor (0 or 1/(1-p)), 2: Philox
+template <int MODE>
 __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ w,
-                                                                  const float* __restrict__ mask, int d,
+                                                                  const float* __restrict__ mask, int d, float drop_p,
+                                                                  uint64_t seed, uint64_t offset,
                                                                   float* __restrict__ out) {
     const int b = blockIdx.x;
     const float* __restrict__ wb = w + (size_t)b * d * d;
-    const float* __restrict__ mb = mask ? mask + (size_t)b * d * d : nullptr;
+    const float* __restrict__ mb = MODE == 1 ? mask + (size_t)b * d * d : nullptr;
     const float* __restrict__ xb = x + (size_t)b * d;
+    const int nq = (d + 3) >> 2;
+    const float inv_keep = 1.f / (1.f - drop_p);
     for (int j = threadIdx.x; j < d; j += 256) {
         float acc = 0.f;
-        if (mb) {
+        if constexpr (MODE == 2) {
+            for (int q = 0; q < nq; ++q) {
+                uint32_t rw[4];
+                philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = 4 * q + k;
+                    if (i < d) acc = fmaf(xb[i], wb[(size_t)i * d + j] * keep_scale(rw[k], drop_p, inv_keep), acc);
+                }
+            }
+        } else if constexpr (MODE == 1) {
 #pragma unroll 4
             for (int i = 0; i < d; ++i) acc = fmaf(xb[i], wb[(size_t)i * d + j] * mb[(size_t)i * d + j], acc);
         } else {
@@ -31,27 +66,46 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
 }
 
 // gx[b, i] = sum_j go[b, j] w[b, i, j] m[b, i, j];   gw[b, i, j] = x[b, i] go[b, j] m[b, i, j]
+template <int MODE>
 __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ w,
                                                                   const float* __restrict__ mask,
-                                                                  const float* __restrict__ go, int d,
+                                                                  const float* __restrict__ go, int d, float drop_p,
+                                                                  uint64_t seed, uint64_t offset,
                                                                   float* __restrict__ gx, float* __restrict__ gw) {
     const int b = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* __restrict__ wb = w + (size_t)b * d * d;
-    const float* __restrict__ mb = mask ? mask + (size_t)b * d * d : nullptr;
+    const float* __restrict__ mb = MODE == 1 ? mask + (size_t)b * d * d : nullptr;
     const float* __restrict__ gob = go + (size_t)b * d;
-    for (int i = wave; i < d; i += 4) {
-        const float xi = x[(size_t)b * d + i];
-        float acc = 0.f;
+    const int nq = (d + 3) >> 2;
+    const float inv_keep = 1.f / (1.f - drop_p);
+    for (int q = wave; q < nq; q += 4) {  // four consecutive rows i = 4q .. 4q + 3 per wave pass
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float xi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xi[k] = 4 * q + k < d ? x[(size_t)b * d + 4 * q + k] : 0.f;
         for (int j = lane; j < d; j += 64) {
-            const float m = mb ? mb[(size_t)i * d + j] : 1.f;
-            const float g = gob[j] * m;
-            acc = fmaf(g, wb[(size_t)i * d + j], acc);
-            if (gw) gw[(size_t)b * d * d + (size_t)i * d + j] = xi * g;
+            uint32_t rw[4] = {0u, 0u, 0u, 0u};
+            if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+            const float gj = gob[j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 4 * q + k;
+                if (i >= d) continue;
+                float m = 1.f;
+                if constexpr (MODE == 1) m = mb[(size_t)i * d + j];
+                if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
+                const float g = gj * m;
+                acc[k] = fmaf(g, wb[(size_t)i * d + j], acc[k]);
+                if (gw) gw[(size_t)b * d * d + (size_t)i * d + j] = xi[k] * g;
+            }
         }
-        acc = group_sum<64>(acc);
-        if (gx && lane == 0) gx[(size_t)b * d + i] = acc;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v = group_sum<64>(acc[k]);
+            if (gx && lane == 0 && 4 * q + k < d) gx[(size_t)b * d + 4 * q + k] = v;
+        }
     }
 }
 
@@ -59,27 +113,57 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
 // Arithmetic order of the reference: p = sigmoid(x) in fp32, loss terms max(log(p), -100) and max(log(1 - p), -100)
 // (torch BCELoss), gradient (p - t) / max((1 - p) p, 1e-12) * p (1 - p) / numel (binary_cross_entropy_backward
 // followed by sigmoid_backward).  pred (nullable) receives p; glogits (nullable) the gradient.
-constexpr int TB_BLOCKS = 1024;
+constexpr int TB_BLOCKS = 4096;
 
+// One element of the loss / gradient.  Hardware exp / log (v_exp_f32, v_log_f32): the kernel is transcendental-bound
+// (one exp, two logs, one divide per element over ~3e8 elements), not bandwidth-bound, with the libm sequences.
+__device__ __forceinline__ float bce_elem(float x, float t, float inv_numel, float* p_out, float* g_out) {
+    const float p = __fdividef(1.f, 1.f + __expf(-x));
+    const float lp = fmaxf(__logf(p), -100.f), l1p = fmaxf(__logf(1.f - p), -100.f);
+    const float pq = (1.f - p) * p;
+    *p_out = p;
+    *g_out = __fdividef(p - t, fmaxf(pq, 1e-12f)) * pq * inv_numel;
+    return -(t * lp + (1.f - t) * l1p);
+}
+
+// Flat float4 sweep over the [n_rows, n_cols] matrix (rows are not 16-byte aligned when n_cols is odd, the flat buffer
+// is); the column of the first lane element is carried incrementally -- no 64-bit modulo in the loop.
 __global__ __launch_bounds__(256) void tucker_bce_kernel(const float* __restrict__ logits, int64_t n_rows, int64_t n_cols,
                                                          const uint8_t* __restrict__ flag, float scale, float add,
                                                          float inv_numel, float* __restrict__ pred,
                                                          float* __restrict__ glogits, float* __restrict__ partial) {
     __shared__ float red[4];
     const int64_t total = n_rows * n_cols;
+    const int64_t n4 = total >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t stride_mod = (stride * 4) % n_cols;
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t c = i % n_cols;
-        const float x = logits[i];
-        const float p = 1.f / (1.f + expf(-x));
-        const float t = flag ? fmaf(scale, (float)flag[c], add) : add;
-        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
-        acc -= t * lp + (1.f - t) * l1p;
-        if (pred) pred[i] = p;
-        if (glogits) {
-            const float pq = (1.f - p) * p;
-            glogits[i] = (p - t) / fmaxf(pq, 1e-12f) * pq * inv_numel;
+    int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t c = (i4 * 4) % n_cols;
+    const f32x4* __restrict__ in4 = reinterpret_cast<const f32x4*>(logits);
+    for (; i4 < n4; i4 += stride) {
+        const f32x4 x = in4[i4];
+        const float xs[4] = {x.x, x.y, x.z, x.w};
+        float ps[4], gs[4];
+        int64_t cc = c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = flag ? fmaf(scale, (float)flag[cc], add) : add;
+            acc += bce_elem(xs[k], t, inv_numel, &ps[k], &gs[k]);
+            cc = cc + 1 == n_cols ? 0 : cc + 1;
         }
+        if (pred) reinterpret_cast<f32x4*>(pred)[i4] = f32x4{ps[0], ps[1], ps[2], ps[3]};
+        if (glogits) reinterpret_cast<f32x4*>(glogits)[i4] = f32x4{gs[0], gs[1], gs[2], gs[3]};
+        c += stride_mod;
+        c = c >= n_cols ? c - n_cols : c;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {  // up to three tail elements
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float t = flag ? fmaf(scale, (float)flag[i % n_cols], add) : add;
+        float pv, gv;
+        acc += bce_elem(logits[i], t, inv_numel, &pv, &gv);
+        if (pred) pred[i] = pv;
+        if (glogits) glogits[i] = gv;
     }
     acc = group_sum<64>(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -107,24 +191,50 @@ __global__ void sigmoid_kernel(const float* __restrict__ x, int64_t n, float* __
 
 using namespace hw;
 
-extern "C" int hw_tucker_contract(const float* x, const float* w, const float* mask, int64_t batch, int32_t dim,
-                                  float* out, void* stream) {
-    if (!x || !w || !out || batch < 0 || dim < 1 || batch > INT32_MAX) return HW_ERR_INVALID_ARG;
+static int contract_launch(int mode, const float* x, const float* w, const float* mask, const float* gout, int64_t batch,
+                           int32_t dim, float drop_p, uint64_t seed, uint64_t offset, float* out, float* gx, float* gw,
+                           bool backward, void* stream) {
+    if (!x || !w || batch < 0 || dim < 1 || batch > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (mode == 2 && !(drop_p >= 0.f && drop_p < 1.f)) return HW_ERR_INVALID_ARG;
+    if (backward ? !gout : !out) return HW_ERR_INVALID_ARG;
     if (batch == 0) return HW_OK;
     HW_CLEAR_ERR();
-    hipLaunchKernelGGL(tucker_contract_fwd_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, x, w, mask,
-                       dim, out);
+    hipStream_t st = (hipStream_t)stream;
+#define FWD(M) hipLaunchKernelGGL((tucker_contract_fwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, dim, drop_p, seed, offset, out)
+#define BWD(M) hipLaunchKernelGGL((tucker_contract_bwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, gout, dim, drop_p, seed, offset, gx, gw)
+    if (!backward) {
+        if (mode == 2) FWD(2);
+        else if (mode == 1) FWD(1);
+        else FWD(0);
+    } else {
+        if (mode == 2) BWD(2);
+        else if (mode == 1) BWD(1);
+        else BWD(0);
+    }
+#undef FWD
+#undef BWD
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_tucker_contract(const float* x, const float* w, const float* mask, int64_t batch, int32_t dim,
+                                  float* out, void* stream) {
+    return contract_launch(mask ? 1 : 0, x, w, mask, nullptr, batch, dim, 0.f, 0, 0, out, nullptr, nullptr, false, stream);
 }
 
 extern "C" int hw_tucker_contract_grad(const float* x, const float* w, const float* mask, const float* gout,
                                        int64_t batch, int32_t dim, float* gx, float* gw, void* stream) {
-    if (!x || !w || !gout || batch < 0 || dim < 1 || batch > INT32_MAX) return HW_ERR_INVALID_ARG;
-    if (batch == 0) return HW_OK;
-    HW_CLEAR_ERR();
-    hipLaunchKernelGGL(tucker_contract_bwd_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, x, w, mask,
-                       gout, dim, gx, gw);
-    return HW_LAUNCH_RC();
+    return contract_launch(mask ? 1 : 0, x, w, mask, gout, batch, dim, 0.f, 0, 0, nullptr, gx, gw, true, stream);
+}
+
+extern "C" int hw_tucker_contract_dropout(const float* x, const float* w, int64_t batch, int32_t dim, float drop_p,
+                                          uint64_t seed, uint64_t offset, float* out, void* stream) {
+    return contract_launch(2, x, w, nullptr, nullptr, batch, dim, drop_p, seed, offset, out, nullptr, nullptr, false, stream);
+}
+
+extern "C" int hw_tucker_contract_dropout_grad(const float* x, const float* w, const float* gout, int64_t batch,
+                                               int32_t dim, float drop_p, uint64_t seed, uint64_t offset, float* gx,
+                                               float* gw, void* stream) {
+    return contract_launch(2, x, w, nullptr, gout, batch, dim, drop_p, seed, offset, nullptr, gx, gw, true, stream);
 }
 
 extern "C" int64_t hw_tucker_bce_workspace_floats(void) { return TB_BLOCKS; }
@@ -136,8 +246,10 @@ extern "C" int hw_tucker_sigmoid_bce(const float* logits, int64_t n_rows, int64_
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int64_t total = n_rows * n_cols;
-    int64_t grid = (total + 255) / 256;
+    int64_t grid = (total / 4 + 255) / 256;
     if (grid > TB_BLOCKS) grid = TB_BLOCKS;
+    if (grid < 1) grid = 1;
+    if ((((uintptr_t)logits | (uintptr_t)pred | (uintptr_t)glogits) & 15) != 0) return HW_ERR_INVALID_ARG;  // float4 sweep
     const float inv = 1.0f / (float)total;
     hipLaunchKernelGGL(tucker_bce_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, n_rows, n_cols, pos_flag,
                        target_scale, target_add, inv, pred, glogits, workspace);

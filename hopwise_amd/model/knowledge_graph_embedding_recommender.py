@@ -466,6 +466,7 @@ class TuckER(KnowledgeRecommender):
         self.bn1 = nn.BatchNorm1d(d)
         self.apply(xavier_normal_initialization)
         self.forced_masks = None  # tests: {"rec": (m0 [B,d], m1 [B,d,d], m2 [B,d]), "kg": (...)} multiplicative masks
+        self._seed, self._drop_calls = int(_cfg(config, "seed", 2020)), 0
 
     def _drop(self, module, x, forced):
         if forced is not None:
@@ -480,14 +481,12 @@ class TuckER(KnowledgeRecommender):
         r = ops.embedding(self.relation_embedding.weight, r_idx)
         x = self._drop(self.input_dropout, self.bn0(h), fm[0])
         w_mat = ops.matmul_nn(r, self.weights.view(d, d * d)).view(-1, d, d)
-        if fm[1] is not None:
-            mask1 = fm[1]
-        elif self.training and self.hidden_dropout1.p > 0:
-            keep = 1.0 - self.hidden_dropout1.p
-            mask1 = (torch.rand_like(w_mat) < keep).to(torch.float32) / keep
+        if fm[1] is None and self.training and self.hidden_dropout1.p > 0:
+            # hidden_dropout1 over the [B, d, d] tensor is drawn inside the contraction (Philox), never materialised
+            self._drop_calls += 1
+            x = ops.tucker_contract_dropout(x, w_mat, self.hidden_dropout1.p, self._seed, self._drop_calls)
         else:
-            mask1 = None
-        x = ops.tucker_contract(x, w_mat, mask1)
+            x = ops.tucker_contract(x, w_mat, fm[1])
         x = self._drop(self.hidden_dropout2, self.bn1(x), fm[2])
         return ops.matmul_nt(x, table)
 

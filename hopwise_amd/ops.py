@@ -709,8 +709,45 @@ class TuckerContract(torch.autograd.Function):
         return gx, gw, None
 
 
+class TuckerContractDropout(torch.autograd.Function):
+    """TuckerContract with the dropout mask drawn inside the kernel (Philox), regenerated in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, p, seed, offset):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "x").contiguous()
+        w = _dev(w, torch.float32, "w").contiguous()
+        B, d = x.shape
+        if tuple(w.shape) != (B, d, d):
+            raise ValueError("w must be [B, d, d]")
+        out = torch.empty((B, d), dtype=torch.float32, device=x.device)
+        check(lib.hw_tucker_contract_dropout(_ptr(x), _ptr(w), B, d, float(p), C.c_uint64(seed), C.c_uint64(offset),
+                                             _ptr(out), _stream()), "hw_tucker_contract_dropout")
+        ctx.args = (float(p), int(seed), int(offset))
+        ctx.save_for_backward(x, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        p, seed, offset = ctx.args
+        B, d = x.shape
+        go = go.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        check(lib.hw_tucker_contract_dropout_grad(_ptr(x), _ptr(w), _ptr(go), B, d, p, C.c_uint64(seed),
+                                                  C.c_uint64(offset), _ptr(gx), _ptr(gw), _stream()),
+              "hw_tucker_contract_dropout_grad")
+        return gx, gw, None, None, None
+
+
 def tucker_contract(x, w, mask=None):
     return TuckerContract.apply(x, w, mask)
+
+
+def tucker_contract_dropout(x, w, p, seed, offset):
+    return TuckerContractDropout.apply(x, w, float(p), int(seed), int(offset))
 
 
 class SigmoidBceMean(torch.autograd.Function):

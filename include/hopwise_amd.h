@@ -287,6 +287,13 @@ int hw_tucker_contract(const float* x, const float* w, const float* mask, int64_
                        float* out, void* stream);
 int hw_tucker_contract_grad(const float* x, const float* w, const float* mask, const float* gout,
                             int64_t batch, int32_t dim, float* gx, float* gw, void* stream);
+/* The same with hidden_dropout1 drawn on the fly (no [B, d, d] mask tensor): element (b, i, j) is kept with probability
+ * 1 - drop_p (scaled by 1 / (1 - drop_p)) from word (i & 3) of Philox block (b * ceil(d / 4) + (i >> 2)) * d + j of the
+ * (seed, offset) stream; the gradient call regenerates the mask from the same (seed, offset). */
+int hw_tucker_contract_dropout(const float* x, const float* w, int64_t batch, int32_t dim, float drop_p, uint64_t seed,
+                               uint64_t offset, float* out, void* stream);
+int hw_tucker_contract_dropout_grad(const float* x, const float* w, const float* gout, int64_t batch, int32_t dim,
+                                    float drop_p, uint64_t seed, uint64_t offset, float* gx, float* gw, void* stream);
 
 /* sigmoid + nn.BCELoss(mean) against target[b, c] = target_scale * pos_flag[c] + target_add (tucker.py:111-125:
  * the union-of-the-batch multi-hot with label smoothing).  pred / glogits nullable.  workspace:

@@ -95,3 +95,36 @@ def test_tucker_vs_oracle_larger():
     m.zero_grad()
     m.calculate_loss(it).backward()
     assert all(torch.isfinite(q.grad).all() for q in m.parameters())
+
+
+def test_contract_with_in_kernel_dropout():
+    """Philox mode of the contraction: the mask is recovered with one-hot probes, then forward and both gradients must
+    equal the explicit-mask path; keep rate and scale as configured."""
+    from hopwise_amd import ops
+
+    dev = torch.device("cuda", 0)
+    for B, d, p in ((3, 8, 0.4), (5, 50, 0.25), (2, 200, 0.5)):
+        torch.manual_seed(d)
+        w1 = torch.ones(B, d, d, device=dev)
+        mask = torch.empty(B, d, d, device=dev)
+        for i in range(d):
+            e = torch.zeros(B, d, device=dev)
+            e[:, i] = 1
+            mask[:, i, :] = ops.tucker_contract_dropout(e, w1, p, 77, 5)
+        vals = torch.unique(mask).cpu().numpy()
+        assert set(np.round(vals, 5)).issubset({0.0, np.float32(round(1 / (1 - p), 5))}), vals
+        assert abs((mask > 0).float().mean().item() - (1 - p)) < 0.05
+        x = torch.randn(B, d, device=dev, requires_grad=True)
+        w = torch.randn(B, d, d, device=dev, requires_grad=True)
+        go = torch.randn(B, d, device=dev)
+        out = ops.tucker_contract_dropout(x, w, p, 77, 5)
+        out.backward(go)
+        gx, gw = x.grad.clone(), w.grad.clone()
+        x.grad = w.grad = None
+        ref = ops.tucker_contract(x, w, mask)
+        ref.backward(go)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(gx.cpu().numpy(), x.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(gw.cpu().numpy(), w.grad.cpu().numpy())
+        other = ops.tucker_contract_dropout(x, w, p, 77, 6)  # another offset, another mask
+        assert not torch.equal(other, out)
