@@ -15,6 +15,11 @@ shapes = [
     ("pgpr act  [131072,256]x[251,256]^T", 131072, 256, 251, True, True),
     ("tucker rW [2048,200]x[200,40000]", 2048, 200, 40000, True, False),
     ("tucker xE [2048,200]x[144779,200]^T", 2048, 200, 144779, True, True),
+    ("tucker xE kg [2048,200]x[59157,200]^T", 2048, 200, 59157, True, True),
+    ("tucker dX [2048,144779]x[144779,200]", 2048, 144779, 200, True, False),
+    ("tucker dE [2048,144779]^T x [2048,200]", 144779, 2048, 200, False, False),
+    ("tucker dW [2048,200]^T x [2048,40000]", 200, 2048, 40000, False, False),
+    ("tucker dr [2048,40000]x[200,40000]^T", 2048, 40000, 200, True, True),
     ("square 4096", 4096, 4096, 4096, True, True),
 ]
 for name, M, K, N, akc, bkc in shapes:
