@@ -6,6 +6,8 @@
 // positions round by round on the host; here each output position owns a Philox4x32-10 counter
 // stream and redraws in registers until accepted, so the result is distribution-equal (not
 // numpy-stream-equal) and independent of launch geometry.
+#include <stdlib.h>
+
 #include "hw_common.h"
 
 namespace hw {
@@ -98,6 +100,58 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(
     out[o] = v;
 }
 
+// Fast path for the grouped layout (a block of 256 consecutive draws belongs to ONE key, uniform distribution): the
+// key's used set becomes an LDS bitmap once per block, membership is one LDS read instead of a dependent binary
+// search through global memory.  Same Philox counters as neg_sample_kernel -> bit-identical output.
+constexpr int SAMPLER_BITMAP_WORDS = 8192;  // value_num <= 262 144
+
+__global__ __launch_bounds__(256) void neg_sample_bitmap_kernel(
+    const int64_t* __restrict__ used_ptr, const int64_t* __restrict__ used_idx, int64_t n_key_space,
+    const int64_t* __restrict__ keys, int64_t n_keys, int num, int64_t value_num, uint64_t seed, uint64_t offset,
+    int64_t* __restrict__ out, int64_t out_stride_key, int64_t out_stride_draw, int32_t* oob) {
+    __shared__ uint32_t bits[SAMPLER_BITMAP_WORDS];
+    const int chunks = (num + 255) / 256;
+    const int64_t i = blockIdx.x / chunks;
+    const int j = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
+    const int64_t key = keys[i];
+    const bool bad_key = key < 0 || key >= n_key_space;
+    const int words = (int)((value_num + 31) >> 5);
+    for (int w = threadIdx.x; w < words; w += 256) bits[w] = 0u;
+    __syncthreads();
+    if (!bad_key) {
+        const int64_t lo = used_ptr[key], hi = used_ptr[key + 1];
+        for (int64_t q = lo + threadIdx.x; q < hi; q += 256) {
+            const int64_t u = used_idx[q];
+            if (u >= 0 && u < value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
+        }
+    }
+    __syncthreads();
+    if (j >= num) return;
+    const int64_t o = i * out_stride_key + (int64_t)j * out_stride_draw;
+    if (bad_key) {
+        if (oob && threadIdx.x == 0) atomicAdd(oob, 1);
+        out[o] = 0;
+        return;
+    }
+    const int64_t e = (int64_t)j * n_keys + i;
+    Philox rng{(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const uint32_t span = (uint32_t)(value_num - 1);
+    int64_t v = 0;
+    bool ok = false;
+    for (uint32_t attempt = 0; attempt < SAMPLER_MAX_ATTEMPTS && !ok; ++attempt) {
+        uint32_t c[4] = {(uint32_t)e, (uint32_t)((uint64_t)e >> 32) ^ (attempt << 8), (uint32_t)offset,
+                         (uint32_t)(offset >> 32)};
+        rng(c);
+#pragma unroll
+        for (int t = 0; t < 4 && !ok; ++t) {
+            v = 1 + (int64_t)(((uint64_t)c[t] * (uint64_t)span) >> 32);
+            ok = !((bits[v >> 5] >> (v & 31)) & 1u);
+        }
+    }
+    if (!ok && oob) atomicAdd(oob, 1);
+    out[o] = v;
+}
+
 }  // namespace hw
 
 using namespace hw;
@@ -114,6 +168,15 @@ extern "C" int hw_neg_sample(const int64_t* used_ptr, const int64_t* used_idx, i
     if (total == 0) return HW_OK;
     if ((total + 255) / 256 > INT32_MAX) return HW_ERR_INVALID_ARG;
     HW_CLEAR_ERR();
+    const int64_t chunks = ((int64_t)num + 255) / 256;
+    const char* knob = getenv("HW_SAMPLER_BITMAP");  // "0" forces the generic kernel (tests compare the two)
+    if (!(knob && knob[0] == '0') && !alias_prob && used_idx && num >= 128 && out_stride_draw <= out_stride_key &&
+        value_num <= (int64_t)SAMPLER_BITMAP_WORDS * 32 && n_keys * chunks <= INT32_MAX) {
+        hipLaunchKernelGGL(neg_sample_bitmap_kernel, dim3((unsigned)(n_keys * chunks)), dim3(256), 0, (hipStream_t)stream,
+                           used_ptr, used_idx, n_key_space, keys, n_keys, (int)num, value_num, seed, offset, out,
+                           out_stride_key, out_stride_draw, oob_counter);
+        return HW_LAUNCH_RC();
+    }
     hipLaunchKernelGGL(neg_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        used_ptr, used_idx, n_key_space, keys, n_keys, total, value_num, alias_prob, alias_keys,
                        alias_alias, n_alias, seed, offset, out, out_stride_key, out_stride_draw, oob_counter);

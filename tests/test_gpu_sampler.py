@@ -123,3 +123,29 @@ def test_sampler_rejects_saturated_key():
     tails = np.array([1, 2, 3, 4, 5, 1])
     with pytest.raises(ValueError):
         KGSampler(types.SimpleNamespace(head_entities=heads, tail_entities=tails, entity_num=n), device=dev())
+
+
+def test_bitmap_fast_path_equals_generic_kernel(monkeypatch):
+    from hopwise_amd.data import synthetic
+
+    """Grouped layout, many draws per key: the LDS-bitmap kernel and the binary-search kernel draw the same ids."""
+    from hopwise_amd import ops
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1)
+    n_users, n_items = 300, 2985
+    iu, ii = rng.integers(1, n_users, 40000), rng.integers(1, n_items, 40000)
+    ptr, idx = synthetic.used_csr(iu, ii, n_users)
+    ptr, idx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+    keys = torch.from_numpy(rng.integers(1, n_users, 77)).to(dev)
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("HW_SAMPLER_BITMAP", knob)
+        buf = torch.zeros((77, 1 + 300), dtype=torch.int64, device=dev)
+        ops.neg_sample(ptr, idx, keys, 300, n_items, seed=9, offset=4, out=buf[:, 1:])
+        outs.append(buf.cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
+    used = {(int(u), int(i)) for u, i in zip(iu, ii)}
+    k = keys.cpu().numpy()
+    assert all((int(k[r]), int(v)) not in used for r in range(77) for v in outs[0][r, 1:])
+    assert outs[0][:, 1:].min() >= 1 and outs[0][:, 1:].max() < n_items
