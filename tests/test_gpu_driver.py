@@ -78,3 +78,45 @@ def test_train_from_atomic_files():
     users = torch.arange(1, ds.user_num, device=dev)
     scores = model.full_sort_predict({"user_id": users}).view(len(users), -1)
     assert scores.shape[1] == ds.item_num and torch.isfinite(scores).all()
+
+
+@pytest.mark.parametrize("model_name", ["RotatE", "TransE", "TransD"])
+def test_graphed_train_step_equals_eager(model_name):
+    """The HIP-graph replay of zero_grad / calculate_loss / backward / Adam gives the eager run's losses and weights."""
+    import copy
+
+    import hopwise_amd.model as M
+    from hopwise_amd.driver import GraphedTrainStep
+
+    dev = torch.device("cuda", 0)
+    nU, nI, nE, nR, nb = 300, 200, 900, 7, 512
+    torch.manual_seed(3)
+    eager = getattr(M, model_name)(make_config(dev, 64, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
+    graphed = copy.deepcopy(eager)
+    rng = np.random.default_rng(0)
+
+    def batch():
+        return {k: torch.from_numpy(rng.integers(1, hi, nb)).to(dev) for k, hi in (
+            ("user_id", nU), ("item_id", nI), ("neg_item_id", nI), ("head_id", nE), ("relation_id", nR - 1),
+            ("tail_id", nE), ("neg_tail_id", nE))}
+
+    batches = [batch() for _ in range(6)]
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-3, capturable=True)
+    opt_g = torch.optim.Adam(graphed.parameters(), lr=1e-3, capturable=True)
+    step = GraphedTrainStep(graphed, opt_g, batches[0])
+    # the constructor ran warm-up + capture steps on batches[0] (the capture itself does not execute): mirror them
+    for _ in range(2):
+        opt_e.zero_grad()
+        eager.calculate_loss(batches[0]).backward()
+        opt_e.step()
+    for b in batches:
+        opt_e.zero_grad()
+        le = eager.calculate_loss(b)
+        le.backward()
+        opt_e.step()
+        lg = step(b)
+        np.testing.assert_allclose(float(lg), float(le.detach()), rtol=2e-4, atol=1e-6)
+    for (k, a), (_, c) in zip(eager.state_dict().items(), graphed.state_dict().items()):
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=5e-4, err_msg=k)
+    with pytest.raises(ValueError):
+        GraphedTrainStep(graphed, torch.optim.Adam(graphed.parameters()), batches[0])
