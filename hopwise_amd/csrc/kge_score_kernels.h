@@ -243,12 +243,25 @@ __global__ __launch_bounds__(256) void kge_full_sort_kernel(
         for (int u = 0; u < U; ++u) {
             float aux = 0.f;  // tail-only pre-reduction (TransD: t . t_vec), shared by the HB queries
             if constexpr (MT::TWO_PASS) aux = group_sum<G>(sc[0].template pre<true>(t[u], d.dim, gl));
+            if constexpr (HB == 4) {
+                // the four heads' partial sums of this tail share one reduce-scatter butterfly (4 + 4 cross-lane steps
+                // instead of 4 x 6); four lanes of the group end up owning one head each
+                float p[4];
 #pragma unroll
-            for (int q = 0; q < HB; ++q) {
-                float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
-                p = group_sum<G>(p);
-                const int bi = hb * HB + q;
-                if (gl == 0 && n[u] < n1 && bi < n_heads) out[(int64_t)bi * ld + (n[u] - lo)] = SC::finalize(p, d.margin);
+                for (int q = 0; q < 4; ++q) p[q] = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
+                int which;
+                const float tot = group_reduce_multi<G, 4>(p, gl, which);
+                const int bi = hb * HB + which;
+                if ((gl & (G / 4 - 1)) == 0 && n[u] < n1 && bi < n_heads)
+                    out[(int64_t)bi * ld + (n[u] - lo)] = SC::finalize(tot, d.margin);
+            } else {
+#pragma unroll
+                for (int q = 0; q < HB; ++q) {
+                    float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
+                    p = group_sum<G>(p);
+                    const int bi = hb * HB + q;
+                    if (gl == 0 && n[u] < n1 && bi < n_heads) out[(int64_t)bi * ld + (n[u] - lo)] = SC::finalize(p, d.margin);
+                }
             }
         }
     }
@@ -315,11 +328,20 @@ __global__ __launch_bounds__(256) void kge_full_sort_topk_kernel(
         for (int u = 0; u < U; ++u) {
             float aux = 0.f;  // tail-only pre-reduction (TransD: t . t_vec), shared by the HB queries
             if constexpr (MT::TWO_PASS) aux = group_sum<G>(sc[0].template pre<true>(t[u], d.dim, gl));
+            if constexpr (HB == 4) {
+                float p[4];
 #pragma unroll
-            for (int q = 0; q < HB; ++q) {
-                float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
-                p = group_sum<G>(p);
-                if (gl == 0 && n[u] < n1) my[q][n[u] - n0] = SC::finalize(p, d.margin);
+                for (int q = 0; q < 4; ++q) p[q] = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
+                int which;
+                const float tot = group_reduce_multi<G, 4>(p, gl, which);
+                if ((gl & (G / 4 - 1)) == 0 && n[u] < n1) my[which][n[u] - n0] = SC::finalize(tot, d.margin);
+            } else {
+#pragma unroll
+                for (int q = 0; q < HB; ++q) {
+                    float p = sc[q].template partial<true>(t[u], d.eps, d.dim, gl, aux);
+                    p = group_sum<G>(p);
+                    if (gl == 0 && n[u] < n1) my[q][n[u] - n0] = SC::finalize(p, d.margin);
+                }
             }
         }
     }
