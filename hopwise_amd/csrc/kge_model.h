@@ -174,7 +174,7 @@ struct Scorer {
                 q[0].v[i] = hh[0].v[i] * rr[0].v[i];
             } else if constexpr (MODEL == HW_ROTATE) {
                 float sn, cs;
-                sincosf(rr[0].v[i], &sn, &cs);
+                __sincosf(rr[0].v[i], &sn, &cs);  // v_sin_f32 / v_cos_f32: abs error ~5e-7 on a unit-modulus factor
                 q[0].v[i] = cs * hh[0].v[i] - sn * hh[1].v[i];
                 q[1].v[i] = cs * hh[1].v[i] + sn * hh[0].v[i];
                 if constexpr (KEEP) {  // hand back (cos, sin) instead of theta: what the backward consumes
