@@ -73,6 +73,20 @@ __device__ __forceinline__ float group_sum(float v) {
 template <int G, int U>
 __device__ __forceinline__ float group_reduce_multi(float (&p)[U], int gl, int& which) {
     static_assert((G & (G - 1)) == 0 && (U & (U - 1)) == 0 && U <= G, "shape");
+    if constexpr (G == 64 && U == 4) {
+        // gfx950 lane-half / row swaps do a butterfly stage of the reduce-scatter in ONE instruction and without
+        // selects: v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of its second, so
+        // (p0, p2) -> a pair whose sum holds p0's two-lane sums in the lower half and p2's in the upper half;
+        // v_permlane16_swap does the same between odd and even 16-lane rows.  After the two stages row r of the wave
+        // holds the four-row sums of p[r]; a DPP row reduction finishes.  10 instructions for four tails.
+        const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[0]), __float_as_uint(p[2]), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(p[1]), __float_as_uint(p[3]), false, false);
+        const float s02 = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+        const float s13 = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+        const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
+        which = gl >> 4;  // rows 0..3 own p[0], p[1], p[2], p[3]
+        return dpp_group_sum<16>(__uint_as_float(c[0]) + __uint_as_float(c[1]));
+    }
     constexpr int REM = G / U;  // lanes that share one value after the scatter phase
     which = 0;
     int live = U;

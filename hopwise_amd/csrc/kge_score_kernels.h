@@ -53,12 +53,10 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
 #pragma unroll 1
         for (int k = 0; k < HW_WAVE / NS; k += U) {  // k counts rows of NS tails inside the chunk
             if (j_of(q0 + k * NS) >= ntail) break;   // wave-uniform
-            int jj[U];
             R t[U][MT::NT];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ql = (k + u) * NS + sub;  // position inside the 64-tail chunk
-                jj[u] = j_of(q0 + ql);
                 int tj;
                 if constexpr (NS == 1) tj = __builtin_amdgcn_readlane(tpre, ql);  // wave-uniform -> scalar row base
                 else tj = __shfl(tpre, ql, HW_WAVE);
@@ -75,9 +73,7 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
             int which;
             const float tot = group_reduce_multi<G, U>(p, gl, which);
             // one writer lane per tail: the first lane of the sub-block that ended up owning it
-            int jw = jj[0];
-#pragma unroll
-            for (int u = 1; u < U; ++u) jw = which == u ? jj[u] : jw;
+            const int jw = j_of(q0 + (k + which) * NS + sub);
             if ((gl & (G / U - 1)) == 0 && jw < ntail) ob[(int64_t)jw * osj] = SC::finalize(tot, d.margin);
         }
     }
