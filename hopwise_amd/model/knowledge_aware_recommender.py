@@ -28,7 +28,7 @@ from torch import nn
 from .. import pgpr_ops as P
 from ..utils import InputType
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
-from .knowledge_graph_embedding_recommender import _cfg, xavier_normal_initialization
+from .knowledge_graph_embedding_recommender import _cfg
 
 
 class BeamResult:

@@ -31,7 +31,6 @@ import torch
 from torch import nn
 
 from .. import ops
-from .. import pgpr_ops as P
 from .knowledge_aware_recommender import PGPR
 from .knowledge_graph_embedding_recommender import _cfg
 

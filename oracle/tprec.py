@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .pgpr import ENTITY, USER
+from .pgpr import USER
 from .pgpr_train import PGPRTrainOracle
 
 F32 = np.float32
