@@ -116,7 +116,7 @@ class GraphedTrainStep:
             if not grp.get("capturable", False):
                 raise ValueError("the optimizer must be constructed with capturable=True (e.g. torch.optim.Adam)")
         self.model, self.opt, self.clip = model, optimizer, clip_grad_norm
-        self.keys = sorted(k for k in example.keys() if torch.is_tensor(example[k]))
+        self.keys = sorted(k for k in example if torch.is_tensor(example[k]))  # dict or Interaction: iterate field names
         self.static = {k: example[k].clone() for k in self.keys}
         self.shapes = {k: tuple(v.shape) for k, v in self.static.items()}
         side = torch.cuda.Stream()
