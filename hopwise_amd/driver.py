@@ -32,15 +32,16 @@ class KGBatcher:
 
     def __init__(self, inter_users, inter_items, heads, rels, tails, sampler, kg_sampler, train_batch_size=2048,
                  sample_num=1, shuffle=True, seed=2020, device="cpu"):
-        self.u, self.i = torch.as_tensor(np.asarray(inter_users)), torch.as_tensor(np.asarray(inter_items))
-        self.h, self.r, self.t = (torch.as_tensor(np.asarray(x)) for x in (heads, rels, tails))
+        self.device = torch.device(device)
+        # the id arrays live where the batches are consumed: index selection, sampling and tiling then stay on the device
+        self.u, self.i = (torch.as_tensor(np.asarray(x)).to(self.device) for x in (inter_users, inter_items))
+        self.h, self.r, self.t = (torch.as_tensor(np.asarray(x)).to(self.device) for x in (heads, rels, tails))
         self.sampler, self.kg_sampler = sampler, kg_sampler
         self.times = int(sample_num)
         self.rec_step = max(int(train_batch_size) // self.times, 1)  # positives per batch (general_dataloader.py:46-55)
         self.kg_step = int(train_batch_size)  # knowledge_dataloader.py:64-67
         self.shuffle = shuffle
         self.gen = torch.Generator().manual_seed(seed)
-        self.device = torch.device(device)
         self._kg_perm, self._kg_pos = None, 0
 
     def __len__(self):
@@ -48,7 +49,7 @@ class KGBatcher:
 
     def _next_kg(self):
         if self._kg_perm is None or self._kg_pos >= len(self.h):  # restart when exhausted (:138-142)
-            self._kg_perm = torch.randperm(len(self.h), generator=self.gen)  # the kg loader always shuffles (:44-47)
+            self._kg_perm = torch.randperm(len(self.h), generator=self.gen).to(self.device)  # always shuffles (:44-47)
             self._kg_pos = 0
         idx = self._kg_perm[self._kg_pos : self._kg_pos + self.kg_step]
         self._kg_pos += self.kg_step
@@ -56,7 +57,7 @@ class KGBatcher:
 
     def __iter__(self):
         n = len(self.u)
-        perm = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        perm = (torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)).to(self.device)
         for s in range(0, n, self.rec_step):
             idx = perm[s : s + self.rec_step]
             users, items = self.u[idx], self.i[idx]
