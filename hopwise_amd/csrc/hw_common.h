@@ -87,6 +87,29 @@ __device__ __forceinline__ float group_reduce_multi(float (&p)[U], int gl, int& 
         which = gl >> 4;  // rows 0..3 own p[0], p[1], p[2], p[3]
         return dpp_group_sum<16>(__uint_as_float(c[0]) + __uint_as_float(c[1]));
     }
+    if constexpr (G == 32 && U == 4) {
+        // two 32-lane groups per wave, each reducing its own four values: the row stage is one v_permlane16_swap per pair
+        // (odd rows of the first operand <-> even rows of the second), the half-row stage two selects and a DPP rotate
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[0]), __float_as_uint(p[1]), false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(p[2]), __float_as_uint(p[3]), false, false);
+        const float s01 = __uint_as_float(a[0]) + __uint_as_float(a[1]);  // even row: p0, odd row: p1
+        const float s23 = __uint_as_float(b[0]) + __uint_as_float(b[1]);  // even row: p2, odd row: p3
+        const bool hi8 = (gl & 8) != 0;
+        const float keep = hi8 ? s23 : s01, send = hi8 ? s01 : s23;
+        which = ((gl >> 4) & 1) + (hi8 ? 2 : 0);
+        return dpp_group_sum<8>(keep + dpp_mov<0x128>(send));  // row_ror:8 pairs the two halves of a row
+    }
+    if constexpr (G == 16 && U == 4) {
+        // four 16-lane groups per wave (one DPP row each): halves of the row, then quads of each half -- DPP only
+        const bool hi8 = (gl & 8) != 0, hi4 = (gl & 4) != 0;
+        const float k0 = hi8 ? p[2] : p[0], s0 = hi8 ? p[0] : p[2];
+        const float k1 = hi8 ? p[3] : p[1], s1 = hi8 ? p[1] : p[3];
+        const float r0 = k0 + dpp_mov<0x128>(s0), r1 = k1 + dpp_mov<0x128>(s1);
+        const float k = hi4 ? r1 : r0, sd = hi4 ? r0 : r1;
+        which = (hi8 ? 2 : 0) + (hi4 ? 1 : 0);
+        // row_half_mirror (i -> 7 - i) is a bijection between the two quads of a half row: enough, the quad is summed next
+        return dpp_group_sum<4>(k + dpp_mov<0x141>(sd));
+    }
     constexpr int REM = G / U;  // lanes that share one value after the scatter phase
     which = 0;
     int live = U;
