@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-variant", action="store_true")
     ap.add_argument("--no-pgpr", action="store_true")
+    ap.add_argument("--unfused-sampler", action="store_true", help="run hw_neg_sample as its own launch before the scorer")
     ap.add_argument("--pgpr-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--entities", type=int, default=0, help="override n_entities (HBM-resident variant, e.g. 2600000)")
@@ -117,11 +118,24 @@ def main():
                   1 + K_NEG, P(scores), scores.stride(0), scores.stride(1), P(oob), stream)
     loss_args = (P(scores), B_POS, 1 + K_NEG, C.c_float(1.0), P(loss), None, P(ws), stream)
 
+    # Negatives are drawn inside the scorer when the item space fits its per-wave LDS bitmap (hw_kge_score_grouped_sampled:
+    # the same ids hw_neg_sample would write, one launch less, the id matrix written but never re-read); otherwise the
+    # sampler runs as its own launch first.
+    fused = n_items <= 65536 and not args.unfused_sampler
+    fused_args = (C.byref(desc), P(users), None, kg.ui_relation, P(t_idx), t_idx.stride(0), t_idx.stride(1), B_POS,
+                  1 + K_NEG, P(uptr), P(uidx), uptr.numel() - 1, P(users), n_items, C.c_uint64(2024 + rank))
+    fused_tail = (P(scores), scores.stride(0), scores.stride(1), P(oob), stream)
+
     def step(i, timed=False):
-        rc = lib.hw_neg_sample(*samp_head, C.c_uint64(i), *samp_tail)
+        rc = 0
+        if not fused:
+            rc = lib.hw_neg_sample(*samp_head, C.c_uint64(i), *samp_tail)
         if timed:
             ev_a[i].record()
-        rc |= lib.hw_kge_score_grouped(*score_args)
+        if fused:
+            rc |= lib.hw_kge_score_grouped_sampled(*fused_args, C.c_uint64(i), *fused_tail)
+        else:
+            rc |= lib.hw_kge_score_grouped(*score_args)
         if timed:
             ev_b[i].record()
         rc |= lib.hw_loss_self_adversarial(*loss_args)
@@ -181,7 +195,7 @@ def main():
             "triples_per_step": triples_per_step, "parallelism": f"replicas x{world}",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "kge_score_grouped_kernel<RotatE>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "kge_score_grouped_kernel<RotatE" + (", SAMPLE>" if fused else ">"), "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": abytes,
             "scorer_only_triples_per_s": triples_per_step / (kern_ms * 1e-3),

@@ -129,6 +129,11 @@ SIGNATURES = {
         C.c_int,
         [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, C.c_void_p],
     ),
+    "hw_kge_score_grouped_sampled": (
+        C.c_int,
+        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p,
+         C.c_int64, c_i64p, C.c_int64, C.c_uint64, C.c_uint64, c_f32p, C.c_int64, C.c_int64, c_i32p, C.c_void_p],
+    ),
     "hw_loss_margin_ranking_sigmoid": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],

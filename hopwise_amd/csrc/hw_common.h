@@ -36,6 +36,32 @@ __device__ __forceinline__ uint32_t philox_bits(uint64_t seed, uint64_t offset, 
 
 
 
+// Philox4x32-10 on a caller-built counter block (the negative sampler's convention: c = {position lo, position hi ^
+// (attempt << 8), offset lo, offset hi}, key = seed); all four output words are used.
+__device__ __forceinline__ void philox4(uint64_t seed, uint32_t (&c)[4]) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0, c[1] = n1, c[2] = n2, c[3] = n3;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+}
+
+// Arguments of the in-scorer uniform negative sampler (hw_kge_score_grouped_sampled): same draws as hw_neg_sample.
+struct SamplerArgs {
+    const int64_t* used_ptr;
+    const int64_t* used_idx;
+    const int64_t* keys;
+    int64_t n_key_space, value_num;
+    uint64_t seed, offset;
+    int words;  // bitmap words per wave = ceil(value_num / 32)
+};
+constexpr int SAMPLER_MAX_ATTEMPTS_FUSED = 1 << 16;
+
 // ---- DPP helpers ------------------------------------------------------------------------------------
 // Cross-lane adds inside a 16-lane row cost one VALU op with a DPP modifier (no LDS-crossbar round trip):
 // quad_perm for xor 1 / xor 2, row_half_mirror / row_mirror to finish the row.  Crossing rows (xor 16 / 32)

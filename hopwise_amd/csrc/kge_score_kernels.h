@@ -17,15 +17,20 @@ namespace hw {
 // grouped scorer.  wave task = (group b, split s of S); the NS = 64/G sub-groups of the wave and the
 // S splits interleave over the group's tails:  j = (k*S + s)*NS + sub,  k = 0, 1, ...
 // ------------------------------------------------------------------------------------------------
-template <int MODEL, int G, int NE, bool VEC, int U>
+// SAMPLE = true: columns 1.. of the tail-id matrix are DRAWN here (uniform over [1, value_num) minus the key's used set,
+// the Philox counters and the rejection rule of neg_sample_kernel, so the ids equal hw_neg_sample's bit for bit) and
+// written back to t_idx for the gradient pass; column 0 (the positive) is read.  The key's used set is an LDS bitmap per
+// wave, built once per task.  Saves the sampler launch and the read of the id matrix.
+template <int MODEL, int G, int NE, bool VEC, int U, bool SAMPLE = false>
 __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
-    const int64_t* __restrict__ t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
-    float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob) {
+    int64_t* t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
+    float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob, SamplerArgs sa) {
     using SC = Scorer<MODEL, G, NE, VEC>;
     using MT = ModelTraits<MODEL>;
     using R = Row<G, NE, VEC>;
     constexpr int NS = HW_WAVE / G;
+    extern __shared__ uint32_t used_bits_all[];
 
     const int lane = threadIdx.x & (HW_WAVE - 1);
     const int sub = lane / G, gl = lane % G;
@@ -33,6 +38,25 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     if (task >= n_groups * S) return;  // wave-uniform
     const int64_t b = task / S;
     const int s = (int)(task % S);
+    uint32_t* bits = nullptr;
+    bool bad_key = false;
+    if constexpr (SAMPLE) {
+        bits = used_bits_all + (threadIdx.x / HW_WAVE) * sa.words;
+        for (int w = lane; w < sa.words; w += HW_WAVE) bits[w] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t key = sa.keys[b];
+        bad_key = key < 0 || key >= sa.n_key_space;
+        if (!bad_key) {
+            const int64_t lo = sa.used_ptr[key], hi = sa.used_ptr[key + 1];
+            for (int64_t q = lo + lane; q < hi; q += HW_WAVE) {
+                const int64_t u = sa.used_idx[q];
+                if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     bool bad = false;
     const int h = clamp_row_flag(h_idx[b], d.n_head, bad);
@@ -49,7 +73,35 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     auto j_of = [&](int q) { return ((q / NS) * S + s) * NS + (q % NS); };
     for (int q0 = 0; j_of(q0) < ntail; q0 += HW_WAVE) {  // wave-uniform: j_of is monotone in q for q % NS == 0
         const int jq = j_of(q0 + lane);
-        const int tpre = jq < ntail ? clamp_row_flag(tb[(int64_t)jq * tsj], d.n_tail, bad) : 0;
+        int tpre = 0;
+        if (jq < ntail) {
+            int64_t id;
+            if (SAMPLE && jq > 0) {
+                id = 0;
+                if (!bad_key) {
+                    const int64_t e = (int64_t)(jq - 1) * n_groups + b;  // hw_neg_sample's position: draw * n_keys + key
+                    const uint32_t span = (uint32_t)(sa.value_num - 1);
+                    bool ok = false;
+                    for (uint32_t attempt = 0; attempt < (uint32_t)SAMPLER_MAX_ATTEMPTS_FUSED && !ok; ++attempt) {
+                        uint32_t c[4] = {(uint32_t)e, (uint32_t)((uint64_t)e >> 32) ^ (attempt << 8), (uint32_t)sa.offset,
+                                         (uint32_t)(sa.offset >> 32)};
+                        philox4(sa.seed, c);
+#pragma unroll
+                        for (int t = 0; t < 4 && !ok; ++t) {
+                            id = 1 + (int64_t)(((uint64_t)c[t] * (uint64_t)span) >> 32);
+                            ok = !((bits[id >> 5] >> (id & 31)) & 1u);
+                        }
+                    }
+                    bad |= !ok;
+                } else {
+                    bad = true;
+                }
+                t_idx[b * tsb + (int64_t)jq * tsj] = id;
+            } else {
+                id = tb[(int64_t)jq * tsj];
+            }
+            tpre = clamp_row_flag(id, d.n_tail, bad);
+        }
 #pragma unroll 1
         for (int k = 0; k < HW_WAVE / NS; k += U) {  // k counts rows of NS tails inside the chunk
             if (j_of(q0 + k * NS) >= ntail) break;   // wave-uniform
@@ -534,12 +586,14 @@ template <int FAMILY>
 static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx,
                                     int64_t r_fixed, const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
                                     int64_t n_groups, int64_t n_tail_per_group, float* out, int64_t o_stride_b,
-                                    int64_t o_stride_j, int32_t* oob_counter, void* stream) {
+                                    int64_t o_stride_j, int32_t* oob_counter, void* stream,
+                                    const SamplerArgs* sampler = nullptr) {
     int rc = check_desc(desc);
     if (rc) return rc;
     if (!h_idx || !t_idx || !out || n_groups < 0 || n_tail_per_group < 0) return HW_ERR_INVALID_ARG;
     if (n_tail_per_group > INT32_MAX / 2) return HW_ERR_INVALID_ARG;
     if (n_groups == 0 || n_tail_per_group == 0) return HW_OK;
+    if (sampler && FAMILY != 0) return HW_ERR_UNSUPPORTED;
     const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
     const int ntail = (int)n_tail_per_group;
     const int NS = HW_WAVE / shape.G;
@@ -547,7 +601,7 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
     HW_CLEAR_ERR();
     // Variant: groups with many tails are routed by tail id to XCD-local L2 slices; short groups (predict,
     // pos/neg pairs) use the plain kernel.  HW_GROUPED_VARIANT = 0 (plain) / 1 (xcd) overrides for experiments.
-    int variant = env_int("HW_GROUPED_VARIANT", -1);
+    int variant = sampler ? 0 : env_int("HW_GROUPED_VARIANT", -1);  // the in-kernel sampler lives in the plain kernel
     if (variant < 0) {
         // tail rows the launch can touch: up to 4 MiB they sit in every XCD's L2 anyway; beyond the 256 MiB
         // Infinity Cache nothing is resident and the plain kernel's lower overhead wins (measured, profiles/r1)
@@ -567,7 +621,7 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
 #undef CALLX
         return HW_LAUNCH_RC();
     }
-    const bool u8 = env_int("HW_GROUPED_U", 4) == 8;
+    const bool u8 = !sampler && env_int("HW_GROUPED_U", 4) == 8;
     constexpr int U = 4;
     // splits per group: enough waves to fill 256 CUs x 32 wave slots, but keep >= U*NS tails per wave
     // so the (h, r) query build is amortised.
@@ -585,13 +639,25 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
     const int64_t n_blocks = (n_tasks + 3) / 4;
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
 #define CALL(MODEL, G_, NE_, VEC_)                                                                              \
-    hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U>), dim3((unsigned)n_blocks), dim3(256), 0, \
-                       st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, out,  \
-                       o_stride_b, o_stride_j, oob_counter)
+    do {                                                                                                        \
+        if constexpr (FAMILY == 0) {                                                                            \
+            if (sampler) {                                                                                      \
+                hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U, true>),                   \
+                                   dim3((unsigned)n_blocks), dim3(256), (size_t)sampler->words * 16, st, *desc,  \
+                                   h_idx, r_idx, r_fixed, const_cast<int64_t*>(t_idx), t_stride_b, t_stride_j,   \
+                                   n_groups, ntail, S, out, o_stride_b, o_stride_j, oob_counter, *sampler);      \
+                break;                                                                                          \
+            }                                                                                                   \
+        }                                                                                                       \
+            hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U>), dim3((unsigned)n_blocks),    \
+                               dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, const_cast<int64_t*>(t_idx),      \
+                               t_stride_b, t_stride_j, n_groups, ntail, S, out, o_stride_b, o_stride_j,          \
+                               oob_counter, SamplerArgs{});                                                      \
+    } while (0)
     if (u8 && desc->model == HW_ROTATE && shape.vec && shape.G == 64 && shape.NE == 4) {  // experiment hook
         hipLaunchKernelGGL((kge_score_grouped_kernel<HW_ROTATE, 64, 4, true, 8>), dim3((unsigned)n_blocks), dim3(256), 0,
-                           st, *desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, out,
-                           o_stride_b, o_stride_j, oob_counter);
+                           st, *desc, h_idx, r_idx, r_fixed, const_cast<int64_t*>(t_idx), t_stride_b, t_stride_j, n_groups,
+                           ntail, S, out, o_stride_b, o_stride_j, oob_counter, SamplerArgs{});
         return HW_LAUNCH_RC();
     }
     HW_DISPATCH_MODEL(desc->model, shape, CALL);

@@ -118,6 +118,30 @@ def kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, t_idx, j_major_out=False)
     return out
 
 
+def kge_score_grouped_sampled_raw(desc, h_idx, r_idx, r_fixed, t_idx, used_ptr, used_idx, keys, value_num, seed, offset,
+                                 out=None):
+    """Scores [B, 1 + K] with the K negatives of every group drawn inside the scorer (column 0 of ``t_idx`` is the
+    positive; columns 1.. are overwritten with the ids hw_neg_sample would draw for ``keys`` under (seed, offset))."""
+    lib = _lib.load()
+    h_idx = _idx(h_idx, "h_idx").contiguous()
+    t_idx = _idx(t_idx, "t_idx")
+    keys = _idx(keys, "keys").contiguous()
+    if t_idx.dim() != 2 or t_idx.shape[0] != h_idx.shape[0] or keys.shape != h_idx.shape:
+        raise ValueError("t_idx must be [n_groups, 1 + K]; keys one per group")
+    if r_idx is not None:
+        r_idx = _idx(r_idx, "r_idx").contiguous()
+    B, G = t_idx.shape
+    if out is None:
+        out = torch.empty((B, G), dtype=torch.float32, device=h_idx.device)
+    used_ptr, used_idx = _idx(used_ptr, "used_ptr").contiguous(), _idx(used_idx, "used_idx").contiguous()
+    rc = lib.hw_kge_score_grouped_sampled(
+        C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), _ptr(t_idx), t_idx.stride(0), t_idx.stride(1), B, G,
+        _ptr(used_ptr), _ptr(used_idx), used_ptr.numel() - 1, _ptr(keys), int(value_num), C.c_uint64(seed),
+        C.c_uint64(offset), _ptr(out), out.stride(0), out.stride(1), _ptr(_OobCounter.get(h_idx.device)), _stream())
+    check(rc, "hw_kge_score_grouped_sampled")
+    return out
+
+
 def kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi):
     lib = _lib.load()
     h_idx = _idx(h_idx, "h_idx").contiguous()

@@ -91,6 +91,18 @@ int hw_kge_score_grouped(const hw_kge_desc* desc,
                          float* out, int64_t o_stride_b, int64_t o_stride_j,
                          int32_t* oob_counter, void* stream);
 
+/* The same with the negatives drawn inside the scorer: column 0 of t_idx (the positive) is read, columns
+ * 1 .. n_tail_per_group-1 are DRAWN -- uniform over [1, value_num) minus used(keys[b]), the counters and rejection rule of
+ * hw_neg_sample with num = n_tail_per_group - 1, so the ids are the ones that call would write -- scored, and written
+ * back to t_idx for the gradient pass.  One launch instead of sampler + scorer.  HW_ERR_UNSUPPORTED for the widened
+ * scorer set and for value_num > 65536 (the used set is an LDS bitmap per wave): sample and score separately then. */
+int hw_kge_score_grouped_sampled(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                                 int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j, int64_t n_groups,
+                                 int64_t n_tail_per_group, const int64_t* used_ptr, const int64_t* used_idx,
+                                 int64_t n_key_space, const int64_t* keys, int64_t value_num, uint64_t seed,
+                                 uint64_t offset, float* out, int64_t o_stride_b, int64_t o_stride_j,
+                                 int32_t* oob_counter, void* stream);
+
 /* Full sort: out[b, n - tail_lo] = score(h_idx[b], r, n) for every tail row n in [tail_lo, tail_hi).
  * Replaces full_sort_predict / full_sort_predict_kg (rotate.py:161-220, transe.py:112-154,
  * complex.py:162-219, distmult.py:119-146) without the [B, N, d] temporaries. */

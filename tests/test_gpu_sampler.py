@@ -149,3 +149,36 @@ def test_bitmap_fast_path_equals_generic_kernel(monkeypatch):
     k = keys.cpu().numpy()
     assert all((int(k[r]), int(v)) not in used for r in range(77) for v in outs[0][r, 1:])
     assert outs[0][:, 1:].min() >= 1 and outs[0][:, 1:].max() < n_items
+
+
+@pytest.mark.parametrize("model,dim", [("RotatE", 200), ("TransE", 64), ("ComplEx", 100), ("DistMult", 24)])
+def test_scorer_with_in_kernel_sampler_equals_sampler_then_scorer(model, dim):
+    """hw_kge_score_grouped_sampled == hw_neg_sample followed by hw_kge_score_grouped: ids and scores, bit for bit."""
+    from hopwise_amd import ops
+    from hopwise_amd.data import synthetic
+    from tests.helpers import random_tables
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    nU, nI, nE, nR, B, K = 200, 2985, 4000, 7, 93, 130
+    iu, ii = rng.integers(1, nU, 30000), rng.integers(1, nI, 30000)
+    ptr, idx = synthetic.used_csr(iu, ii, nU)
+    ptr, idx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+    tabs = {k: torch.from_numpy(v).to(dev) for k, v in random_tables(model, nU, nE, nR, dim, seed=1).items()}
+    from oracle import kge as okge
+
+    hn, rn, tn = okge.slots(model, "rec")
+    desc = ops.make_desc(model, tuple(tabs[n] for n in hn), tuple(tabs[n] for n in rn), tuple(tabs[n] for n in tn),
+                         margin=1.0, tail_rows=nI)
+    users = torch.from_numpy(rng.integers(1, nU, B)).to(dev)
+    pos = torch.from_numpy(rng.integers(1, nI, B)).to(dev)
+    a = torch.zeros((B, 1 + K), dtype=torch.int64, device=dev)
+    a[:, 0] = pos
+    b = a.clone()
+    oob_before = ops.oob_count(dev)  # cumulative per device: other tests provoke it on purpose
+    ops.neg_sample(ptr, idx, users, K, nI, seed=11, offset=5, out=a[:, 1:])
+    ref = ops.kge_score_grouped_raw(desc, users, None, nR - 1, a)
+    got = ops.kge_score_grouped_sampled_raw(desc, users, None, nR - 1, b, ptr, idx, users, nI, 11, 5)
+    np.testing.assert_array_equal(b.cpu().numpy(), a.cpu().numpy())
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    assert ops.oob_count(dev) == oob_before
