@@ -53,12 +53,17 @@ if fetch and write:
         rows.append(dict(kernel=k, launches=len(fv), fetch_kib_raw_median=sorted(fv)[len(fv) // 2],
                          fetch_kib_raw_max=max(fv), write_kib_median=sorted(wv)[len(wv) // 2], write_kib_max=max(wv)))
     json.dump(rows, open(os.path.join(dst, f"pmc_traffic_{tag}.json"), "w"), indent=1)
-    for r in rows:
-        if "kge_score_grouped" in r["kernel"]:
-            out["kge_score_grouped_bytes_per_launch"] = (2.0 * r["fetch_kib_raw_median"] + r["write_kib_median"]) * 1024.0
-            out["kge_score_grouped_hbm_variant_bytes_per_launch"] = (2.0 * r["fetch_kib_raw_max"] + r["write_kib_max"]) * 1024.0
-            out["note"] = ("median over launches = ml-1m-small tables (L2 / Infinity Cache resident: fabric-side requests "
-                           "that reach HBM or hit the Infinity Cache); max = the 4.2 GB-table variant. FETCH_SIZE doubled per the gfx950 note.")
+    grouped = [r for r in rows if "kge_score_grouped" in r["kernel"]]
+    if grouped:
+        # the bench's timed step runs the most-launched grouped kernel (with the in-kernel sampler when it applies); the
+        # 4.2 GB-table variant is the largest launch of any of them
+        main = max(grouped, key=lambda r: r["launches"])
+        out["kge_score_grouped_bytes_per_launch"] = (2.0 * main["fetch_kib_raw_median"] + main["write_kib_median"]) * 1024.0
+        out["kge_score_grouped_hbm_variant_bytes_per_launch"] = max(
+            (2.0 * r["fetch_kib_raw_max"] + r["write_kib_max"]) * 1024.0 for r in grouped)
+        out["note"] = ("median over launches of the bench step's kernel = ml-1m-small tables (L2 / Infinity Cache resident: "
+                       "fabric-side requests that reach HBM or hit the Infinity Cache); max over all grouped launches = the "
+                       "4.2 GB-table variant. FETCH_SIZE doubled per the gfx950 note.")
     out["source"] = f"profiles/{rnd}/pmc_traffic_{tag}.json"
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
