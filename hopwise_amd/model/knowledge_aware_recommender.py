@@ -78,6 +78,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.beam_search_hop = list(config["beam_search_hop"])
         self.fix_scores_sorting_bug = bool(config["fix_scores_sorting_bug"])
         self.policy_dropout = _cfg(config, "policy_dropout", "reference")
+        self.l1_lookup = bool(_cfg(config, "l1_lookup", True))  # beam search: first policy layer from slot tables
         self.user_chunk = int(_cfg(config, "beam_user_chunk", 64))
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         dev = torch.device(self.device)
@@ -155,8 +156,17 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             buf["scratch"] = torch.empty((min(2048, rmax), self.graph.max_degree), dtype=torch.int64, device=dev)
         return buf
 
-    def _policy_logits(self, buf, n_rows, rmax, drops, hop):
-        """l1 -> ELU -> dropout -> l2 -> ELU -> dropout -> actor (pgpr.py:175-187), logits into buf['logits']."""
+    def _l1_slot_tables(self):
+        """Slot tables of the first layer for the current l1 weights (rebuilt when the parameter version changes)."""
+        key = (self.l1.weight._version, self.l1.weight.data_ptr())
+        if getattr(self, "_l1_cache_key", None) != key:
+            self._l1_cache = P.layer1_tables(self._t32, self.l1.weight.detach(), self.state_history)
+            self._l1_cache_key = key
+        return self._l1_cache
+
+    def _policy_logits(self, buf, n_rows, rmax, drops, hop, paths=None):
+        """l1 -> ELU -> dropout -> l2 -> ELU -> dropout -> actor (pgpr.py:175-187), logits into buf['logits'].
+        With ``paths`` the first layer is the table-lookup form (no state tensor, no first GEMM)."""
         modes = []
         for li in range(2):
             if drops is not None:
@@ -166,8 +176,12 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             else:
                 modes.append((None, 0))
         self._drop_calls += 1
-        P.mlp_layer(buf["state"], self.l1.weight, self.l1.bias, buf["x1"], n_rows, rmax, True, modes[0][0], modes[0][1],
-                    self._seed, 2 * self._drop_calls)
+        if paths is not None:
+            P.layer1_lookup(self._l1_slot_tables(), self.l1.bias.detach(), self.state_history, paths, n_rows, rmax,
+                            buf["x1"], modes[0][0], modes[0][1], self._seed, 2 * self._drop_calls)
+        else:
+            P.mlp_layer(buf["state"], self.l1.weight, self.l1.bias, buf["x1"], n_rows, rmax, True, modes[0][0],
+                        modes[0][1], self._seed, 2 * self._drop_calls)
         P.mlp_layer(buf["x1"], self.l2.weight, self.l2.bias, buf["x2"], n_rows, rmax, True, modes[1][0], modes[1][1],
                     self._seed, 2 * self._drop_calls + 1)
         P.mlp_layer(buf["x2"], self.actor.weight, self.actor.bias, buf["logits"], n_rows, rmax, False)
@@ -194,13 +208,14 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         for hop, k in enumerate(hops):
             rmax = buf["rows"][hop]
             paths, probs, n_rows = buf["paths"][hop], buf["probs"][hop], nr[hop : hop + 1]
-            if hop <= 2:
+            lookup = self.l1_lookup and self.hidden_sizes[0] % 4 == 0
+            if hop <= 2 and (keep_trace or not lookup):
                 # the reference refreshes state_pool at the end of hops 0 and 1 only (pgpr.py:481); with at most
                 # three hops every hop sees a fresh state, which is the same thing.
                 P.state(g, U32, E32, R32, self.state_history, paths, n_rows, rmax, buf["state"])
             P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, rmax, self.max_acts,
                       self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"])
-            self._policy_logits(buf, n_rows, rmax, drops, hop)
+            self._policy_logits(buf, n_rows, rmax, drops, hop, paths if lookup else None)
             P.policy_topk(buf["logits"], self.act_dim, buf["n_acts"], n_rows, rmax, k, buf["tk_idx"], buf["tk_val"])
             P.expand(g, paths, probs, buf["acts"], self.act_dim, buf["n_acts"], n_rows, rmax, buf["tk_idx"],
                      buf["tk_val"], k, buf["offsets"], buf["paths"][hop + 1], buf["probs"][hop + 1],

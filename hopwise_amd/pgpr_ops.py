@@ -134,6 +134,34 @@ def mlp_layer(a, w, bias, out, m_rows, m_max, elu, drop_mask=None, drop_mode=0, 
     )
 
 
+def layer1_tables(tables32, w1, state_history):
+    """The slot tables of hw_pgpr_layer1_lookup for first-layer weights ``w1`` [hidden, (2 + 2 h) * d]: (U, E, R) float32
+    tables times the matching column block of w1, on the MFMA GEMM."""
+    from .ops import gemm
+
+    U, E, R = tables32
+    d = U.shape[1]
+    blk = lambda s: w1[:, s * d : (s + 1) * d]
+    out = [gemm(U, blk(0)), gemm(U, blk(1)), gemm(E, blk(1))]
+    if state_history >= 1:
+        out += [gemm(U, blk(2)), gemm(E, blk(2)), gemm(R, blk(3))]
+    if state_history >= 2:
+        out += [gemm(U, blk(4)), gemm(E, blk(4)), gemm(R, blk(5))]
+    return out
+
+
+def layer1_lookup(slot_tables, bias, state_history, paths, n_rows, max_rows, out, drop_mask=None, drop_mode=0, seed=0,
+                  offset=0):
+    lib = _lib.load()
+    arr = (C.c_void_p * len(slot_tables))(*[t.data_ptr() for t in slot_tables])
+    check(
+        lib.hw_pgpr_layer1_lookup(arr, _ptr(bias), bias.numel(), int(state_history), _ptr(paths), _ptr(n_rows),
+                                  int(max_rows), _ptr(drop_mask), int(drop_mode), C.c_uint64(seed), C.c_uint64(offset),
+                                  _ptr(out), out.stride(0), _stream()),
+        "hw_pgpr_layer1_lookup",
+    )
+
+
 def policy_topk(logits, act_dim, n_acts, n_rows, max_rows, k, out_idx, out_val, probs_out=None):
     lib = _lib.load()
     check(

@@ -279,6 +279,16 @@ int hw_mlp_layer(const float* a, int64_t lda, const float* w, const float* bias,
                  const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, int32_t elu,
                  const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream);
 
+/* First policy layer by table lookup (beam search, fixed weights): out[row, :] = dropout(ELU(bias + sum over the state's
+ * slots of T_slot[node or relation of that slot, :])) with T_slot = table . W1[:, slot * dim : (slot + 1) * dim]^T
+ * precomputed by the caller ([rows, hidden] each, 16-byte aligned).  slot_tables (HOST array of device pointers):
+ * {user slot over users, current node over users, over entities, last node over users, over entities, last relation over
+ * relations, older node over users, over entities, older relation}: 3 / 6 / 9 entries for state_history 0 / 1 / 2.
+ * Slot semantics = hw_pgpr_state (pgpr.py:296-333); dropout modes / Philox words = hw_mlp_layer. */
+int hw_pgpr_layer1_lookup(const float* const* slot_tables, const float* bias, int32_t hidden, int32_t state_history,
+                          const int32_t* paths, const int32_t* n_rows, int64_t max_rows, const float* drop_mask,
+                          int32_t drop_mode, uint64_t seed, uint64_t offset, float* out, int64_t ld, void* stream);
+
 /* General fp32 MFMA GEMM: c[m, n] = f(op(a)[m, :] . op(b)[:, n] + bias[n]).  a is [m, k] row-major when
  * a_k_contiguous, else stored transposed [k, m]; b is [n, k] row-major (nn.Linear weight) when b_k_contiguous, else
  * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187).
