@@ -70,6 +70,72 @@ __global__ void pgpr_init_paths_kernel(const int64_t* __restrict__ users, int n,
 // ---- A10: actions ------------------------------------------------------------------------------------
 constexpr int ACT_LDS_KEYS = 4096;  // candidates whose select keys fit in LDS (32 KiB); larger rows use scratch
 
+// First pass, one WAVE per row and no block barrier: rows whose unvisited neighbours fit max_acts -- 98 % of the rows of
+// a 64/64/64 beam on the ml-1m-shaped graph, median degree 99 -- are finished here with ballot / popcount compaction in
+// CSR (= relation, dst) order; rows that need the float64 trim get n_acts = -1 and are left to the block kernel below.
+__global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g, const int32_t* __restrict__ paths,
+                                                                 const int32_t* __restrict__ n_rows_ptr, int max_acts,
+                                                                 int flags, int32_t* __restrict__ acts,
+                                                                 int32_t* __restrict__ n_acts) {
+    const int n_rows = n_rows_ptr[0];
+    const int act_dim = max_acts + 1;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+        const int32_t* p = paths + (size_t)row * PATH_INTS;
+        const int uid = p[0], len = p[1];
+        int cur_t = T_USER, cur_n = uid;
+        if (len > 1) cur_t = p[2 + 3 * (len - 2) + 1], cur_n = p[2 + 3 * (len - 2) + 2];
+        int vt[4], vn[4];  // visited (type, id); wave-uniform
+        bool lead = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int t = -1, n = -1;
+            if (k == 0) t = T_USER, n = uid;
+            else if (k < len) t = p[2 + 3 * (k - 1) + 1], n = p[2 + 3 * (k - 1) + 2];
+            if (k >= 1 && k < len) lead = lead && p[2 + 3 * (k - 1)] == SELF_LOOP;
+            if ((flags & 2) && k < len && lead) t = -1;  // training: the start user and its self-loop copies (see below)
+            vt[k] = t, vn[k] = n;
+        }
+        const int64_t gid = cur_t == T_USER ? cur_n : (int64_t)g.n_users + cur_n;
+        const int64_t lo = g.ptr[gid];
+        const int deg = (int)(g.ptr[gid + 1] - lo);
+        const int32_t* __restrict__ erel = g.rel + lo;
+        const int32_t* __restrict__ edst = g.dst + lo;
+        auto is_cand = [&](int e) -> bool {
+            const int r = erel[e], n = edst[e];
+            const int nt = next_type(g, cur_t, r);
+            bool seen = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) seen |= (vt[k] == nt && vn[k] == n);
+            return !seen;
+        };
+        int cnt = 0;
+        for (int base = 0; base < deg; base += 64) {
+            const int e = base + lane;
+            cnt += __popcll(__ballot(e < deg && is_cand(e)));
+        }
+        if (cnt > max_acts) {
+            if (lane == 0) n_acts[row] = -1;  // the block kernel scores and trims this row
+            continue;
+        }
+        int32_t* arow = acts + (size_t)row * act_dim * 2;
+        if (lane == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + cnt;
+        int running = 0;
+        for (int base = 0; base < deg; base += 64) {
+            const int e = base + lane;
+            const bool f = e < deg && is_cand(e);
+            const unsigned long long m = __ballot(f);
+            if (f) {
+                const int pos = 1 + running + __popcll(m & lt_mask);
+                arow[2 * pos] = erel[e];
+                arow[2 * pos + 1] = edst[e];
+            }
+            running += __popcll(m);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pgpr_actions_kernel(
     hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
     const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
@@ -86,6 +152,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
     const int tid = threadIdx.x;
 
     for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        if (n_acts[row] >= 0) continue;  // finished by pgpr_actions_small_kernel (block-uniform: one value per row)
         const int32_t* p = paths + (size_t)row * PATH_INTS;
         const int uid = p[0], len = p[1];
         int cur_t, cur_n;
@@ -804,6 +871,12 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_u
         scratch_stride = 0;
     }
     HW_CLEAR_ERR();
+    {
+        int64_t g1 = (max_rows + 3) / 4;
+        if (g1 > 8192) g1 = 8192;
+        hipLaunchKernelGGL(pgpr_actions_small_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, *graph, paths,
+                           n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts);
+    }
     hipLaunchKernelGGL(pgpr_actions_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph, score_user,
                        score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
                        scratch, scratch_stride);
