@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The C-ABI tests need hopwise_amd/csrc/libhopwise_amd.so; build it (hipcc cross-compiles gfx950 without a GPU) when a
+    fresh checkout runs the tests before __graft_entry__.build()."""
+    from hopwise_amd import build as hb
+
+    if not os.path.exists(hb.LIB) and os.path.exists(hb.HIPCC):
+        hb.build(verbose=False)
