@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
     __shared__ uint64_t lds_keys[ACT_LDS_KEYS];
     __shared__ unsigned hist[256];
     __shared__ int wsum[4];
-    __shared__ int sh_bin, sh_need;
+    __shared__ int sh_bin, sh_need, sh_done;
     __shared__ int vis_t[4], vis_n[4];
 
     const int n_rows = n_rows_ptr[0];
@@ -286,13 +286,21 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
                     }
                     sh_bin = bin;
                     sh_need = need - run;
+                    // every key of the selected bin is wanted: nothing below this digit needs resolving
+                    sh_done = (int)hh[bin & 3] == need - run ? 1 : 0;
                 }
             }
             __syncthreads();
             prefix |= (uint64_t)sh_bin << shift;
             mask |= 0xFFull << shift;
             need = sh_need;
+            const int done = sh_done;
             __syncthreads();
+            if (done) {  // block-uniform: keep every key >= prefix (remaining digits 0), no ties to break
+                prefix -= 1;
+                need = 0;
+                break;
+            }
         }
         const uint64_t T = prefix;
         int c_eq_local = 0;
@@ -307,8 +315,8 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
                 const int e = base + tid;
                 const uint64_t k = e < deg ? keys[e] : 0ull;
                 const int tie = (e < deg && k == T) ? 1 : 0;
-                int tot_tie;
-                const int tpos = block_excl_scan(tie, wsum, tot_tie);
+                int tot_tie = 0, tpos = 0;
+                if (c_eq > 0) tpos = block_excl_scan(tie, wsum, tot_tie);  // block-uniform: most rows have no key == T
                 const int keep = (e < deg && (k > T || (tie && run_tie + tpos >= tie_skip))) ? 1 : 0;
                 int tot_keep;
                 const int kpos = block_excl_scan(keep, wsum, tot_keep);
