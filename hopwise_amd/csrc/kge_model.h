@@ -117,6 +117,43 @@ struct Scorer {
             // relation row a gather inside one L1-resident row
             const float* __restrict__ hrow = d.head[0] + (size_t)h * d.dim;
             const float* __restrict__ rrow = d.rel[0] + (size_t)r * d.dim;
+            if constexpr (VEC) {
+                // 4 x 4 tiles: the lane's columns j0..j0+3 against h[i0..i0+3] need r[(j0 - i0) - 3 .. (j0 - i0) + 3],
+                // i.e. two aligned 16-byte chunks of the relation row (dim % 4 == 0, so the wrap is chunk-aligned too);
+                // 16 FMAs per 2 vector loads.  The head row address is wave-uniform (every caller builds one query per wave):
+                // say so, and it becomes scalar loads.
+                const f32x4* __restrict__ h4 =
+                    reinterpret_cast<const f32x4*>(d.head[0] + (size_t)__builtin_amdgcn_readfirstlane(h) * d.dim);
+                const f32x4* __restrict__ r4 = reinterpret_cast<const f32x4*>(rrow);
+                const int d4 = d.dim >> 2;
+#pragma unroll
+                for (int c = 0; c < NE / 4; ++c) {
+                    const int jc = gl + c * G;
+                    const bool valid = jc < d4;
+                    int a = valid ? jc : 0;  // chunk index of (j0 - i0) mod dim, walks down as i0 walks up
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                    for (int m = 0; m < d4; ++m) {
+                        const f32x4 hv = h4[m];
+                        const f32x4 hi_ = r4[a];
+                        const f32x4 lo_ = r4[a == 0 ? d4 - 1 : a - 1];
+                        const float hh_[4] = {hv.x, hv.y, hv.z, hv.w};
+                        const float win[8] = {lo_.x, lo_.y, lo_.z, lo_.w, hi_.x, hi_.y, hi_.z, hi_.w};  // r[(j0-i0) - 4 + t]
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int ii = 0; ii < 4; ++ii) acc[jj] = fmaf(hh_[ii], win[4 + jj - ii], acc[jj]);
+                        a = a == 0 ? d4 - 1 : a - 1;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) q[0].v[4 * c + jj] = valid ? acc[jj] : 0.f;
+                }
+                if constexpr (KEEP) {
+                    hraw[0].load(hrow, d.dim, gl);
+                    rraw[0].load(rrow, d.dim, gl);
+                }
+                return;
+            }
             int cc[NE];
 #pragma unroll
             for (int k = 0; k < NE; ++k) {

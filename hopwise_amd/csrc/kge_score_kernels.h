@@ -609,6 +609,8 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
                        : desc->model == HW_ANALOGY ? 3 : 1;
         const double footprint = (double)desc->n_tail * desc->dim * 4.0 * nt;
         variant = (ntail >= 64 && footprint > 6.0e6 && footprint <= 256.0e6) ? 1 : 0;
+        // the XCD kernel rebuilds the query in each of its 8 partitions: too dear for the d^2 builds
+        if (desc->model == HW_HOLE || desc->model == HW_RESCAL) variant = 0;
     }
     if (variant == 1) {
         const int64_t n_blocks = ((n_groups + 3) / 4) * 8;
@@ -633,7 +635,9 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
         S = (int)(want < 1 ? 1 : (want > s_max ? s_max : want));
         // HolE / RESCAL pay d^2 per query build: every extra split repeats it, so only split when the launch would
         // otherwise leave most of the chip idle
-        if ((desc->model == HW_HOLE || desc->model == HW_RESCAL) && n_groups >= 1024) S = 1;
+        // (measured at B = 2048, K = 256: RESCAL d = 64 16.6 / 20.3 / 29.5 us and HolE d = 200 37 / 33 / 40 us at S = 1 / 2 / 4)
+        if ((desc->model == HW_HOLE || desc->model == HW_RESCAL) && n_groups >= 1024)
+            S = desc->model == HW_HOLE && s_max >= 2 ? 2 : 1;
     }
     const int64_t n_tasks = n_groups * S;
     const int64_t n_blocks = (n_tasks + 3) / 4;

@@ -19,6 +19,8 @@ from tests.helpers import FakeDataset, make_config
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--models", default="TransE,RotatE,TorusE,TransH,TransD,Analogy,HolE,RESCAL,TransR")
+ap.add_argument("--forward-only", action="store_true", help="grouped forward timings only (kernel tuning)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 
@@ -40,7 +42,7 @@ import hopwise_amd.model as M
 
 nU, nI, nE, nR = 6041, 2985, 13805, 13
 B, K = 2048, 256
-for name in ("TransE", "RotatE", "TorusE", "TransH", "TransD", "Analogy", "HolE", "RESCAL", "TransR"):
+for name in a.models.split(","):
     d = 64 if name in ("RESCAL", "TransR") else 200
     torch.manual_seed(0)
     m = getattr(M, name)(make_config(dev, d, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
@@ -55,6 +57,8 @@ for name in ("TransE", "RotatE", "TorusE", "TransH", "TransD", "Analogy", "HolE"
         abytes = (nt * d * 4 + 12) * B * (K + 1)
         print(json.dumps({"what": "grouped_forward", "model": name, "dim": d, "B": B, "K": K, "ms": ms,
                           "triples_per_s": B * (K + 1) / ms * 1e3, "alg_TB_per_s": abytes / ms / 1e9}), flush=True)
+    if a.forward_only:
+        continue
     nb = 4096
     inter = {k: torch.randint(1, hi, (nb,), device=dev) for k, hi in (
         ("user_id", nU), ("item_id", nI), ("neg_item_id", nI), ("head_id", nE), ("relation_id", nR - 1), ("tail_id", nE),
@@ -71,6 +75,8 @@ for name in ("TransE", "RotatE", "TorusE", "TransH", "TransD", "Analogy", "HolE"
     print(json.dumps({"what": "train_step(loss+backward+adam)", "model": name, "dim": d, "rec": nb, "kg": nb, "ms": ms,
                       "triples_per_s": 4 * nb / ms * 1e3}), flush=True)
 
+if a.forward_only:
+    sys.exit(0)
 # PGPR REINFORCE episode
 kg, ds, pm = bench_pgpr.make_model(dev)
 pm.action_dropout = 0.5
