@@ -87,6 +87,7 @@ SIGNATURES = {
         [C.POINTER(KgeDesc), C.POINTER(KgeGrads), c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int64,
          C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_void_p],
     ),
+    "hw_kge_grad_grouped_workspace_floats": (C.c_int64, [C.POINTER(KgeDesc), C.c_int64, C.c_int64, C.c_int32]),
     "hw_loss_workspace_floats": (C.c_int64, []),
     "hw_loss_bce_logits": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hw_loss_margin_ranking": (

@@ -27,6 +27,7 @@
 //   HolE     gQ = g t, gt = g Q;  gh_i = sum_j gQ_j r[(j - i) mod d], gr_m = sum_j gQ_j h[(j - m) mod d]
 //   TorusE   not differentiated by the reference (its calculate_loss is TransE's) -> HW_ERR_UNSUPPORTED
 #include "kge_model.h"
+#include "rel_matrix.h"
 
 namespace hw {
 
@@ -50,7 +51,8 @@ template <int MODEL, int NE>
 __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
     hw_kge_desc d, hw_kge_grads gr, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx,
     int64_t r_fixed, const int64_t* __restrict__ t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
-    const float* __restrict__ g, int64_t gsb, int64_t gsj, float* __restrict__ rel_replicas) {
+    const float* __restrict__ g, int64_t gsb, int64_t gsj, float* __restrict__ rel_replicas,
+    float* __restrict__ gq_out) {
     constexpr int G = 64;
     using SC = Scorer<MODEL, G, NE, false>;
     using MT = ModelTraits<MODEL>;
@@ -159,6 +161,14 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
 
     const size_t ho = (size_t)h * d.dim, ro = (size_t)r * d.dim;
     if constexpr (MODEL == HW_RESCAL) {
+        if (gq_out) {  // dL/dQ of this task goes to scratch; the two d^2 products follow as their own launches
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                const int c = R::col(k, d.dim, gl);
+                if (c >= 0) gq_out[(size_t)task * d.dim + c] = GQ[0][k];
+            }
+            return;
+        }
         // Q = h^T M:  gh[i] = sum_j GQ[j] M[i][j]  (one wave reduction per matrix row),  gM[i][j] += h[i] GQ[j]
         const float* __restrict__ hrow = d.head[0] + ho;
         const float* __restrict__ mat = d.rel[0] + (size_t)r * d.dim * d.dim;
@@ -305,6 +315,27 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
 
 using namespace hw;
 
+// splits: the head/relation rows are flushed once per wave task, so prefer few, long tasks; split
+// only as far as needed to put ~8k waves on the chip.
+static int grad_splits(int64_t n_groups, int ntail) {
+    const int s_max = (ntail + 7) / 8;
+    const int64_t want = (8192 + n_groups - 1) / n_groups;
+    const int S = (int)(want < 1 ? 1 : (want > s_max ? s_max : want));
+    return S < 1 ? 1 : S;
+}
+
+static int n_rel_tables(int model) {
+    return model == HW_ANALOGY ? 3 : (model == HW_COMPLEX || model == HW_TRANSH || model == HW_TRANSD) ? 2 : 1;
+}
+
+extern "C" int64_t hw_kge_grad_grouped_workspace_floats(const hw_kge_desc* desc, int64_t n_groups,
+                                                        int64_t n_tail_per_group, int32_t relation_is_fixed) {
+    if (!desc || desc->dim < 1 || n_groups < 0 || n_tail_per_group < 0 || n_tail_per_group > INT32_MAX / 2) return 0;
+    if (desc->model == HW_RESCAL)  // dL/dQ rows, one per (group, split) task
+        return n_groups * grad_splits(n_groups > 0 ? n_groups : 1, (int)n_tail_per_group) * desc->dim;
+    return relation_is_fixed ? (int64_t)REL_REPLICAS * n_rel_tables(desc->model) * desc->dim : 0;
+}
+
 extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* grads, const int64_t* h_idx,
                                    const int64_t* r_idx, int64_t r_fixed, const int64_t* t_idx, int64_t t_stride_b,
                                    int64_t t_stride_j, int64_t n_groups, int64_t n_tail_per_group, const float* g,
@@ -315,15 +346,7 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     if (n_tail_per_group > INT32_MAX / 2) return HW_ERR_INVALID_ARG;
     if (n_groups == 0 || n_tail_per_group == 0) return HW_OK;
     const int ntail = (int)n_tail_per_group;
-    // splits: the head/relation rows are flushed once per wave task, so prefer few, long tasks; split
-    // only as far as needed to put ~8k waves on the chip.
-    int S = 1;
-    {
-        const int s_max = (ntail + 7) / 8;
-        const int64_t want = (8192 + n_groups - 1) / n_groups;
-        S = (int)(want < 1 ? 1 : (want > s_max ? s_max : want));
-        if (S < 1) S = 1;
-    }
+    const int S = grad_splits(n_groups, ntail);
     const int64_t n_tasks = n_groups * S;
     const int64_t n_blocks = (n_tasks + 3) / 4;
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
@@ -331,15 +354,19 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     // replica scratch only when the relation is fixed, has a gradient, and enough tasks collide on it
-    const int n_rel_tab = desc->model == HW_ANALOGY ? 3
-                          : (desc->model == HW_COMPLEX || desc->model == HW_TRANSH || desc->model == HW_TRANSD) ? 2 : 1;
-    const int64_t rel_row_len = desc->model == HW_RESCAL ? (int64_t)desc->dim * desc->dim : desc->dim;
-    float* replicas = (!r_idx && rel_workspace && grads->rel[0] && n_tasks >= 256) ? rel_workspace : nullptr;
+    const int n_rel_tab = n_rel_tables(desc->model);
+    const int64_t rel_row_len = desc->dim;
+    // RESCAL with scratch: the kernel only leaves dL/dQ per task; the head and matrix gradients are two small
+    // matrix kernels over those rows (rel_matrix.h) instead of d^2 atomics per task
+    float* gq = desc->model == HW_RESCAL ? rel_workspace : nullptr;
+    float* replicas =
+        (!gq && desc->model != HW_RESCAL && !r_idx && rel_workspace && grads->rel[0] && n_tasks >= 256) ? rel_workspace
+                                                                                                          : nullptr;
     if (replicas) (void)hipMemsetAsync(replicas, 0, sizeof(float) * REL_REPLICAS * n_rel_tab * rel_row_len, st);
 #define CALL(MODEL, NE_)                                                                                           \
     hipLaunchKernelGGL((kge_grad_grouped_kernel<MODEL, NE_>), dim3((unsigned)n_blocks), dim3(256), 0, st, *desc,     \
                        *grads, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, g,          \
-                       g_stride_b, g_stride_j, replicas)
+                       g_stride_b, g_stride_j, replicas, gq)
 #define BYNE(MODEL)                        \
     do {                                   \
         if (NE == 1) CALL(MODEL, 1);       \
@@ -360,6 +387,24 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     }
 #undef BYNE
 #undef CALL
+    if (gq) {
+        const int dim = desc->dim;
+        if (grads->head[0]) {  // gh[h_b] += M[r_b] gQ
+            const unsigned grid = (unsigned)((n_tasks + 3) / 4);
+#define PCALL(NE_)                                                                                                    \
+    hipLaunchKernelGGL((project_rows_kernel<NE_, true>), dim3(grid), dim3(256), 0, st, desc->rel[0], desc->n_rel, gq, \
+                       n_tasks, dim, r_idx, r_fixed, nullptr, n_tasks, grads->head[0], h_idx, desc->n_head, S)
+            if (NE == 1) PCALL(1);
+            else if (NE == 4) PCALL(4);
+            else PCALL(16);
+#undef PCALL
+        }
+        if (grads->rel[0]) {  // gM[r][i][j] += h[i] gQ[j]
+            const OuterSide A{desc->head[0], dim, h_idx, desc->n_head, dim};
+            const OuterSide B{gq, dim, nullptr, n_tasks, dim};
+            launch_outer_by_relation(A, B, r_idx, desc->n_rel, r_fixed, S, n_tasks, grads->rel[0], st);
+        }
+    }
     if (replicas) {
         const int64_t n = rel_row_len * n_rel_tab;
         const int64_t rf = r_fixed < 0 ? 0 : (r_fixed >= desc->n_rel ? desc->n_rel - 1 : r_fixed);

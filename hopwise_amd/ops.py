@@ -215,8 +215,9 @@ class KgeScoreGrouped(torch.autograd.Function):
         h_idx = h_idx.contiguous()
         B, G = t_idx.shape
         rel_ws = None
-        if r_idx is None and gs.rel[0]:
-            rel_ws = torch.empty(64 * sum(t.shape[1] for t in rel), dtype=torch.float32, device=g.device)
+        n_ws = int(lib.hw_kge_grad_grouped_workspace_floats(C.byref(desc), B, G, 1 if r_idx is None else 0))
+        if n_ws > 0:
+            rel_ws = torch.empty(n_ws, dtype=torch.float32, device=g.device)
         rc = lib.hw_kge_grad_grouped(
             C.byref(desc), C.byref(gs), _ptr(h_idx), _ptr(r_idx), int(ctx.r_fixed), _ptr(t_idx), t_idx.stride(0),
             t_idx.stride(1), B, G, _ptr(g), g.stride(0), g.stride(1), _ptr(rel_ws), _stream(),

@@ -126,8 +126,12 @@ int hw_kge_full_sort_topk(const hw_kge_desc* desc, const int64_t* h_idx, const i
 /* Backward of hw_kge_score_grouped: given g[b, j] = dLoss/dscore[b, j] (same strides as `out`),
  * atomically accumulates the row gradients into `grads`.  Replaces autograd through
  * nn.Embedding + <Model>.forward (dense embedding_dense_backward in the reference).
- * rel_workspace (nullable): 64 * (relation tables) * (relation row length) floats; used when r_idx == NULL so that
- * the fixed relation row is not hammered by every wave (the adds go to 64 replica rows, summed afterwards). */
+ * rel_workspace (nullable): hw_kge_grad_grouped_workspace_floats(...) floats of scratch.  With r_idx == NULL it keeps
+ * the fixed relation row from being hammered by every wave (the adds go to 64 replica rows, summed afterwards); for
+ * HW_RESCAL it holds dL/dQ per task so that the head and d x d matrix gradients are formed by two matrix kernels
+ * instead of d^2 atomics per group.  NULL selects the plain atomic paths (same results up to float add order). */
+int64_t hw_kge_grad_grouped_workspace_floats(const hw_kge_desc* desc, int64_t n_groups, int64_t n_tail_per_group,
+                                             int32_t relation_is_fixed);
 int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* grads,
                         const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
                         const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,

@@ -401,6 +401,36 @@ def test_rescal_grouped_loss_and_grads_vs_oracle(dim):
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
 
 
+@pytest.mark.parametrize("fixed_rel", [False, True])
+@pytest.mark.parametrize("dim", [24, 72])
+def test_rescal_grouped_grads_with_split_tasks(dim, fixed_rel):
+    """Few groups with many tails: the backward splits every group over several wave tasks, whose dL/dQ rows feed the
+    head-gradient and relation-matrix kernels (rel_matrix.h); checked against float64 autograd of h^T M_r t."""
+    from hopwise_amd import ops
+
+    nE, nR, B, J = 50, 4, 6, 70
+    g = torch.Generator().manual_seed(dim)
+    E = torch.randn(nE, dim, generator=g)
+    M = torch.randn(nR, dim * dim, generator=g) / dim
+    h, t = torch.randint(0, nE, (B,), generator=g), torch.randint(0, nE, (B, J), generator=g)
+    r = torch.randint(0, nR, (B,), generator=g)
+    w = torch.randn(B, J, generator=g)
+    w[1] = 0.0  # a group whose tails all carry zero gradient
+    E64, M64 = E.double().requires_grad_(), M.double().requires_grad_()
+    rr = torch.full((B,), nR - 1) if fixed_rel else r
+    q = torch.einsum("bi,bij->bj", E64[h], M64[rr].view(B, dim, dim))
+    ref = torch.einsum("bj,bkj->bk", q, E64[t])
+    (ref * w.double()).sum().backward()
+    Ed, Md = E.to(dev()).requires_grad_(), M.to(dev()).requires_grad_()
+    got = ops.kge_score_grouped("RESCAL", [Ed], [Md], [Ed], h.to(dev()), None if fixed_rel else r.to(dev()), nR - 1,
+                                t.to(dev()), 0.0)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    (got * w.to(dev())).sum().backward()
+    for name, a, b in (("entity", Ed.grad, E64.grad), ("relation", Md.grad, M64.grad)):
+        scale = b.abs().max().item()
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=2e-4, atol=2e-6 * scale, err_msg=name)
+
+
 @pytest.mark.parametrize("model", ALL_MODELS)
 def test_fused_full_sort_topk_equals_unfused(model):
     """hw_kge_full_sort_topk == full sort -> mask -> top-k, values and indices, rec and kg side."""

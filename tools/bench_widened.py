@@ -20,6 +20,7 @@ from tests.helpers import FakeDataset, make_config
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--models", default="TransE,RotatE,TorusE,TransH,TransD,Analogy,HolE,RESCAL,TransR")
+ap.add_argument("--no-pgpr", action="store_true")
 ap.add_argument("--forward-only", action="store_true", help="grouped forward timings only (kernel tuning)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -75,7 +76,7 @@ for name in a.models.split(","):
     print(json.dumps({"what": "train_step(loss+backward+adam)", "model": name, "dim": d, "rec": nb, "kg": nb, "ms": ms,
                       "triples_per_s": 4 * nb / ms * 1e3}), flush=True)
 
-if a.forward_only:
+if a.forward_only or a.no_pgpr:
     sys.exit(0)
 # PGPR REINFORCE episode
 kg, ds, pm = bench_pgpr.make_model(dev)
