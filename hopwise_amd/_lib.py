@@ -63,6 +63,17 @@ class KgeGrads(C.Structure):
     _fields_ = [("head", C.c_void_p * MAX_TABLES), ("rel", C.c_void_p * MAX_TABLES), ("tail", C.c_void_p * MAX_TABLES)]
 
 
+ADAM_MAX_SEGS = 16
+
+
+class AdamSeg(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("seg", AdamSeg * ADAM_MAX_SEGS), ("n_segs", C.c_int32)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check that every symbol declared in
 # include/hopwise_amd.h is exported.
 SIGNATURES = {
@@ -88,6 +99,11 @@ SIGNATURES = {
          C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_void_p],
     ),
     "hw_kge_grad_grouped_workspace_floats": (C.c_int64, [C.POINTER(KgeDesc), C.c_int64, C.c_int64, C.c_int32]),
+    "hw_adam_step": (
+        C.c_int,
+        [C.POINTER(AdamArgs), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64p, C.c_int32,
+         C.c_void_p],
+    ),
     "hw_loss_workspace_floats": (C.c_int64, []),
     "hw_loss_bce_logits": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hw_loss_margin_ranking": (

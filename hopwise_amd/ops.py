@@ -157,6 +157,31 @@ def kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi):
     return out
 
 
+# ---- gradient sinks: persistent p.grad buffers the gradient kernels accumulate into directly (optim.FusedAdam) ----
+_GRAD_SINKS = {}  # parameter data_ptr -> (weakref to the parameter, owner state with a .dirty flag)
+
+
+def register_grad_sink(param, state):
+    import weakref
+
+    _GRAD_SINKS[param.data_ptr()] = (weakref.ref(param), state)
+
+
+def _live_sink(t):
+    """(grad buffer, state) when table ``t`` is a registered parameter whose .grad is in place, else None."""
+    hit = _GRAD_SINKS.get(t.data_ptr())
+    if hit is None:
+        return None
+    p = hit[0]()
+    if p is None:
+        del _GRAD_SINKS[t.data_ptr()]
+        return None
+    g = p.grad
+    if g is None or g.shape != t.shape or g.dtype != torch.float32 or not g.is_contiguous() or p.shape != t.shape:
+        return None
+    return g, hit[1]
+
+
 class KgeScoreGrouped(torch.autograd.Function):
     """Differentiable grouped scorer.  Inputs after the fixed arguments are the head, relation and
     tail tables in slot order; the same Parameter may appear in several slots (kg side: entity tables
@@ -205,6 +230,10 @@ class KgeScoreGrouped(torch.autograd.Function):
                     key = t.data_ptr()
                     if key in bufs:
                         grads_out.append(None)  # shared buffer already returned for an earlier slot
+                    elif (sink := _live_sink(t)) is not None and torch.is_grad_enabled() is False:
+                        bufs[key] = sink[0]  # accumulate straight into p.grad; autograd gets nothing to add
+                        sink[1].dirty = True
+                        grads_out.append(None)
                     else:
                         bufs[key] = torch.zeros_like(t)
                         grads_out.append(bufs[key])

@@ -456,6 +456,25 @@ int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const
                     int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
                     int32_t* out_count, const int64_t* slot_ptr, void* stream);
 
+/* ---- dense Adam over all tables of a model in one launch (trainer/trainer.py:189-190: optim.Adam(params, lr,
+ * weight_decay), the reference's default learner; torch/optim/adam.py update rule, no amsgrad / maximize).
+ * *step is a DEVICE counter, incremented by the call (so the launch replays inside a HIP graph); every segment is
+ * updated with the incremented value.  zero_grads != 0 also clears each g (stands in for the next zero_grad). */
+#define HW_ADAM_MAX_SEGS 16
+typedef struct {
+    float* p;  /* parameter */
+    float* g;  /* gradient */
+    float* m;  /* exp_avg */
+    float* v;  /* exp_avg_sq */
+    int64_t n; /* elements */
+} hw_adam_seg;
+typedef struct {
+    hw_adam_seg seg[HW_ADAM_MAX_SEGS];
+    int32_t n_segs;
+} hw_adam_args;
+int hw_adam_step(const hw_adam_args* args, double lr, double beta1, double beta2, double eps, double weight_decay,
+                 int64_t* step, int32_t zero_grads, void* stream);
+
 const char* hw_version(void);
 
 #ifdef __cplusplus
