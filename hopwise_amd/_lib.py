@@ -106,6 +106,8 @@ SIGNATURES = {
     ),
     "hw_loss_workspace_floats": (C.c_int64, []),
     "hw_loss_bce_logits": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "hw_loss_bce_logits_weighted": (
+        C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "hw_loss_margin_ranking": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],

@@ -32,18 +32,20 @@ __global__ __launch_bounds__(LOSS_THREADS) void finish_mean_kernel(const float* 
 }
 
 // BCEWithLogits: l = max(x,0) - x*y + log1p(exp(-|x|)); dl/dx = sigmoid(x) - y
+// pos_weight: every positive stands for pos_weight identical rows of the reference's tiled batch (1 = plain mean)
 __global__ __launch_bounds__(LOSS_THREADS) void bce_logits_kernel(const float* __restrict__ x, int64_t n, int64_t n_pos,
-                                                                  float inv_n, float* __restrict__ gx,
+                                                                  float pos_weight, float inv_n, float* __restrict__ gx,
                                                                   float* __restrict__ partial) {
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * LOSS_THREADS) {
         const float xi = x[i];
         const float y = i < n_pos ? 1.f : 0.f;
+        const float w = i < n_pos ? pos_weight : 1.f;
         const float e = expf(-fabsf(xi));
-        acc += fmaxf(xi, 0.f) - xi * y + log1pf(e);
+        acc = fmaf(w, fmaxf(xi, 0.f) - xi * y + log1pf(e), acc);
         if (gx) {
             const float sg = xi >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-            gx[i] = (sg - y) * inv_n;
+            gx[i] = (sg - y) * (w * inv_n);
         }
     }
     acc = block_sum_256(acc);
@@ -195,16 +197,23 @@ static int loss_grid(int64_t n) {
     return (int)(b < 1 ? 1 : (b > LOSS_BLOCKS ? LOSS_BLOCKS : b));
 }
 
-extern "C" int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, float* loss_out, float* gx,
-                                  float* workspace, void* stream) {
-    if (!x || !loss_out || !workspace || n <= 0 || n_pos < 0) return HW_ERR_INVALID_ARG;
+extern "C" int hw_loss_bce_logits_weighted(const float* x, int64_t n, int64_t n_pos, float pos_weight, float* loss_out,
+                                           float* gx, float* workspace, void* stream) {
+    if (!x || !loss_out || !workspace || n <= 0 || n_pos < 0 || n_pos > n || !(pos_weight > 0.f))
+        return HW_ERR_INVALID_ARG;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int grid = loss_grid(n);
-    const float inv_n = 1.0f / (float)n;
-    hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, x, n, n_pos, inv_n, gx, workspace);
+    const float inv_n = (float)(1.0 / ((double)pos_weight * (double)n_pos + (double)(n - n_pos)));
+    hipLaunchKernelGGL(bce_logits_kernel, dim3(grid), dim3(LOSS_THREADS), 0, st, x, n, n_pos, pos_weight, inv_n, gx,
+                       workspace);
     hipLaunchKernelGGL(finish_mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, st, workspace, grid, inv_n, loss_out);
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, float* loss_out, float* gx,
+                                  float* workspace, void* stream) {
+    return hw_loss_bce_logits_weighted(x, n, n_pos, 1.0f, loss_out, gx, workspace, stream);
 }
 
 static int margin_ranking_launch(bool sig, const float* pos, const float* neg, int64_t n, float margin, float* loss_out,

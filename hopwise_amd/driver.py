@@ -145,8 +145,8 @@ class GraphedTrainStep:
         return all(k in interaction and tuple(interaction[k].shape) == self.shapes[k] for k in self.keys)
 
     def __call__(self, interaction):
-        for k in self.keys:
-            self.static[k].copy_(interaction[k], non_blocking=True)
+        # one multi-tensor launch instead of a copy per field (7 of ~25 launches of a RotatE step otherwise)
+        torch._foreach_copy_([self.static[k] for k in self.keys], [interaction[k] for k in self.keys], non_blocking=True)
         self.graph.replay()
         return self.loss
 

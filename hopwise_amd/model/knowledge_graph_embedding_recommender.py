@@ -74,6 +74,9 @@ class _GatherKGE(KnowledgeRecommender):
         self.self_adversarial = bool(_cfg(config, "self_adversarial", False))
         self.adversarial_temperature = float(_cfg(config, "adversarial_temperature", 1.0))
         self.sample_num = int(_cfg(_cfg(config, "train_neg_sample_args", {}) or {}, "sample_num", 1))
+        # sample_num > 1: trust the dataloader's tile order (row j*P + i = j-th negative of positive i); set False for
+        # hand-made batches that repeat positives in another order
+        self.rec_tiled_layout = bool(_cfg(config, "rec_tiled_layout", True))
         self.apply(xavier_normal_initialization)
 
     def REL_ROW_FACTOR(self):
@@ -229,6 +232,19 @@ class _BceKGE(_GatherKGE):
             users, tails = self._rec_grouped_from_tiled(interaction)
             rec_scores = self.score_grouped("rec", users, None, tails)
             rec_loss = ops.self_adversarial_mean(rec_scores, self.adversarial_temperature)
+            kg = self._score("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
+                             self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]),
+                             0.0, True).t()
+            return rec_loss + ops.bce_logits_mean(kg, kg.shape[1])
+        K = self.sample_num
+        if K > 1 and self.rec_tiled_layout and interaction[self.USER_ID].shape[0] % K == 0:
+            # The batch tiles each of its P positives K times (abstract_dataloader.py:192-198), so 2 P K rows hold only
+            # P distinct positive scores: score every (user, positive) once in a [P, 1+K] group and give it weight K in
+            # the mean.  Same loss value; the gradient kernel sees P groups instead of K-fold repeated rows hammering the
+            # same user / item rows with atomics.
+            users, tails = self._rec_grouped_from_tiled(interaction)
+            rec = self._score("rec", users, None, self._rec_rel_loss(), tails, 0.0, True).t()  # [1 + K, P]: positives first
+            rec_loss = ops.bce_logits_mean(rec, rec.shape[1], pos_weight=K)
             kg = self._score("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
                              self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]),
                              0.0, True).t()

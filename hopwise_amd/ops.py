@@ -343,22 +343,22 @@ class BceLogitsMean(torch.autograd.Function):
     """BCEWithLogitsLoss(mean) over a flat score vector whose first ``n_pos`` entries are positives."""
 
     @staticmethod
-    def forward(ctx, x, n_pos):
+    def forward(ctx, x, n_pos, pos_weight=1.0):
         lib = _lib.load()
         ctx.in_shape = x.shape
         x = _dev(x, torch.float32, "scores").contiguous().view(-1)
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         gx = torch.empty_like(x) if x.requires_grad or ctx.needs_input_grad[0] else None
         ws = _workspace(x.device)
-        check(lib.hw_loss_bce_logits(_ptr(x), x.numel(), int(n_pos), _ptr(loss), _ptr(gx), _ptr(ws), _stream()),
-              "hw_loss_bce_logits")
+        check(lib.hw_loss_bce_logits_weighted(_ptr(x), x.numel(), int(n_pos), float(pos_weight), _ptr(loss), _ptr(gx),
+                                              _ptr(ws), _stream()), "hw_loss_bce_logits_weighted")
         ctx.save_for_backward(gx)
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
         (gx,) = ctx.saved_tensors
-        return (gx * g).view(ctx.in_shape), None
+        return (gx * g).view(ctx.in_shape), None, None
 
 
 class MarginRankingMean(torch.autograd.Function):
@@ -407,8 +407,9 @@ class SelfAdversarialMean(torch.autograd.Function):
         return gs * g, None
 
 
-def bce_logits_mean(x, n_pos):
-    return BceLogitsMean.apply(x, n_pos)
+def bce_logits_mean(x, n_pos, pos_weight=1.0):
+    """``pos_weight``: each of the first ``n_pos`` scores stands for that many identical positive rows."""
+    return BceLogitsMean.apply(x, n_pos, pos_weight)
 
 
 def margin_ranking_mean(pos, neg, margin, sigmoid=False):

@@ -170,6 +170,11 @@ int64_t hw_loss_workspace_floats(void);
  * complex.py:115-128).  loss_out[0] = loss * loss_scale...; gx (nullable) receives dLoss/dx. */
 int hw_loss_bce_logits(const float* x, int64_t n, int64_t n_pos, float* loss_out, float* gx,
                        float* workspace, void* stream);
+/* Same with every positive counted pos_weight times: loss = (pos_weight * sum_pos + sum_neg) / (pos_weight * n_pos +
+ * n - n_pos).  The reference's rec batch tiles each positive sample_num times next to its negatives
+ * (abstract_dataloader.py:192-198); scoring each positive once with pos_weight = sample_num gives the same mean. */
+int hw_loss_bce_logits_weighted(const float* x, int64_t n, int64_t n_pos, float pos_weight, float* loss_out, float* gx,
+                                float* workspace, void* stream);
 
 /* mean(max(0, -(pos - neg) + margin)): torch MarginRankingLoss(target=+1) (distmult.py:86-93) and,
  * on scores = -distance, TripletMarginLoss (transe.py:48,96).  gpos/gneg nullable. */

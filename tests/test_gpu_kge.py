@@ -401,6 +401,38 @@ def test_rescal_grouped_loss_and_grads_vs_oracle(dim):
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * scale + 1e-9, err_msg=k)
 
 
+@pytest.mark.parametrize("model", ["RotatE", "ComplEx"])
+def test_tiled_rec_batch_scored_as_groups_equals_row_by_row(model):
+    """sample_num = K > 1: the dataloader tiles each positive K times (abstract_dataloader.py:192-198).  The BCE models
+    score each positive once per group with weight K; loss and every gradient must equal the row-by-row evaluation of
+    the same batch (what the reference computes)."""
+    import copy
+
+    import hopwise_amd.model as M
+    from tests.helpers import FakeDataset, make_config
+
+    nU, nI, nE, nR, d, K, P = 50, 30, 80, 5, 20, 6, 7
+    torch.manual_seed(11)
+    cfg = make_config(dev(), d, 3.0, train_neg_sample_args={"sample_num": K})
+    m1 = getattr(M, model)(cfg, FakeDataset(nU, nI, nE, nR)).to(dev())
+    m2 = copy.deepcopy(m1)
+    m2.rec_tiled_layout = False
+    rng = np.random.default_rng(3)
+    users, pos = rng.integers(1, nU, P), rng.integers(1, nI, P)
+    B = P * K
+    inter = to_dev(dict(
+        user_id=np.tile(users, K), item_id=np.tile(pos, K), neg_item_id=rng.integers(1, nI, B),
+        head_id=rng.integers(1, nE, B), relation_id=rng.integers(1, nR - 1, B), tail_id=rng.integers(1, nE, B),
+        neg_tail_id=rng.integers(1, nE, B)))
+    l1, l2 = m1.calculate_loss(inter), m2.calculate_loss(inter)
+    l1.backward()
+    l2.backward()
+    np.testing.assert_allclose(l1.item(), l2.item(), rtol=2e-6)
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        scale = p2.grad.abs().max().item()
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale, err_msg=k)
+
+
 @pytest.mark.parametrize("fixed_rel", [False, True])
 @pytest.mark.parametrize("dim", [24, 72])
 def test_rescal_grouped_grads_with_split_tasks(dim, fixed_rel):
