@@ -17,6 +17,7 @@ import torch
 import hopwise_amd.model as M
 from hopwise_amd.data import synthetic
 from hopwise_amd.driver import KGBatcher, train_epoch_graphed
+from hopwise_amd.optim import FusedAdam
 from hopwise_amd.sampler import KGSampler, Sampler
 from tests.helpers import FakeDataset, make_config
 
@@ -51,7 +52,7 @@ rec = Sampler("train", train_ds, device=dev).set_phase("train")
 kgs = KGSampler(train_ds, device=dev)
 torch.manual_seed(0)
 model = getattr(M, a.model)(make_config(dev, a.dim, 2.0), FakeDataset(nU, nI, nE, nR)).to(dev)
-opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=True)
+opt = FusedAdam(model.parameters(), lr=5e-3)  # torch.optim.Adam(..., capturable=True) works too, ~2x the step time
 batches = KGBatcher(iu[~test], ii[~test], heads, rels, tails, rec, kgs, train_batch_size=a.batch, device=dev)
 step = None
 for ep in range(a.epochs):
