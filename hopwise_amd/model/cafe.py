@@ -340,28 +340,47 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
         ks = [[manual_topk] * len(o) for o in orders]
         res = self._run_programs(users, programs, ks, grow_excluded=True, exclude=True)
         leaves = self._leaf_chains()
-        results = torch.full((len(users_np), self.n_items), -torch.inf)
+        results = np.full((len(users_np), self.n_items), -np.inf, np.float32)
         collected = []
+        # collect_results + the ranking loop of run_program (cafe.py:417-441), array-wise per user.  In the reference every
+        # path is appended to tmp in leaf order, inst[item] keeps the LAST path to an item, tmp is sorted by score
+        # (stable, descending) and an entry is emitted when it beats results[item] -- i.e. the first valid entry per item
+        # in sorted order, carrying inst[item]'s path (not necessarily its own).
         for b, (u, order, per) in enumerate(zip(users_np, orders, res)):
             u = int(u)
             index_of_chain = {_chain_of(order, i): i for i in range(len(order))}
-            tmp, inst = [], {}
+            blocks, items, scores, blk, row = [], [], [], [], []
             for chain in leaves:
                 c, ids, vals = per[index_of_chain[chain]]
-                for j in range(c):
-                    score = np.float32(vals[j][0])
-                    for x in vals[j][1:]:
-                        score = np.float32(score * np.float32(x))  # reduce(mul) over np.float32 (cafe.py:425)
-                    item = int(ids[j][-1])
-                    tmp.append((item, score))
-                    path = [("self_loop", "user", u)]
-                    for jj, rel in enumerate(chain):
-                        path.append((rel, self._module(rel).et_name, int(ids[j][jj])))
-                    inst[item] = path  # a later path to the same item replaces the earlier one (cafe.py:433)
-            for item, score in sorted(tmp, key=lambda x: x[1], reverse=True):
-                if item < self.n_items and results[b, item] < score:
-                    results[b, item] = float(score)
-                    collected.append([u, item, score, inst[item]])
+                if c == 0:
+                    continue
+                sc = vals[:, 0].astype(np.float32)
+                for d in range(1, vals.shape[1]):
+                    sc = sc * vals[:, d].astype(np.float32)  # reduce(mul) over np.float32, left to right (cafe.py:425)
+                items.append(ids[:, -1].astype(np.int64))
+                scores.append(sc)
+                blk.append(np.full(c, len(blocks), np.int64))
+                row.append(np.arange(c, dtype=np.int64))
+                blocks.append((chain, ids))
+            if not blocks:
+                continue
+            items, scores, blk, row = (np.concatenate(x) for x in (items, scores, blk, row))
+            n = len(items)
+            uniq, first_rev = np.unique(items[::-1], return_index=True)
+            last_of = dict(zip(uniq.tolist(), (n - 1 - first_rev).tolist()))  # item -> its last entry: inst[item]
+            srt = np.argsort(-scores, kind="stable")
+            srt = srt[(scores[srt] > -np.inf) & (items[srt] < self.n_items)]  # entries that can beat the -inf fill
+            _, first = np.unique(items[srt], return_index=True)
+            for k in srt[np.sort(first)].tolist():
+                item, score = int(items[k]), scores[k]
+                results[b, item] = score
+                chain, ids = blocks[int(blk[last_of[item]])]
+                r = int(row[last_of[item]])
+                path = [("self_loop", "user", u)]
+                for jj, rel in enumerate(chain):
+                    path.append((rel, self._module(rel).et_name, int(ids[r][jj])))
+                collected.append([u, item, score, path])
+        results = torch.from_numpy(results)
         return results, collected
 
     def full_sort_predict(self, interaction):
