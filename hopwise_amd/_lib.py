@@ -208,6 +208,11 @@ SIGNATURES = {
         C.c_int,
         [c_f32p, C.c_int64, C.c_int64, C.c_void_p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],
     ),
+    "hw_tucker_sigmoid_bce_ld": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
+         C.c_void_p],
+    ),
     "hw_sigmoid": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "hw_pgpr_layer1_lookup": (
         C.c_int,

@@ -128,12 +128,14 @@ __device__ __forceinline__ float bce_elem(float x, float t, float inv_numel, flo
 
 // Flat float4 sweep over the [n_rows, n_cols] matrix (rows are not 16-byte aligned when n_cols is odd, the flat buffer
 // is); the column of the first lane element is carried incrementally -- no 64-bit modulo in the loop.
-__global__ __launch_bounds__(256) void tucker_bce_kernel(const float* __restrict__ logits, int64_t n_rows, int64_t n_cols,
-                                                         const uint8_t* __restrict__ flag, float scale, float add,
-                                                         float inv_numel, float* __restrict__ pred,
+// ld > n_cols (padded rows, see hw_tucker_sigmoid_bce_ld): the sweep runs over the flat [n_rows, ld] buffer and the
+// ld - n_cols trailing entries of each row count for nothing (no loss, gradient 0; their content is never interpreted).
+__global__ __launch_bounds__(256) void tucker_bce_kernel(const float* __restrict__ logits, int64_t n_rows, int64_t n_valid,
+                                                         int64_t n_cols, const uint8_t* __restrict__ flag, float scale,
+                                                         float add, float inv_numel, float* __restrict__ pred,
                                                          float* __restrict__ glogits, float* __restrict__ partial) {
     __shared__ float red[4];
-    const int64_t total = n_rows * n_cols;
+    const int64_t total = n_rows * n_cols;  // n_cols = leading dimension, n_valid = real columns
     const int64_t n4 = total >> 2;
     const int64_t stride = (int64_t)gridDim.x * 256;
     const int64_t stride_mod = (stride * 4) % n_cols;
@@ -148,8 +150,11 @@ __global__ __launch_bounds__(256) void tucker_bce_kernel(const float* __restrict
         int64_t cc = c;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float t = flag ? fmaf(scale, (float)flag[cc], add) : add;
-            acc += bce_elem(xs[k], t, inv_numel, &ps[k], &gs[k]);
+            const bool live = cc < n_valid;
+            const float t = (flag && live) ? fmaf(scale, (float)flag[cc], add) : add;
+            const float l = bce_elem(live ? xs[k] : 0.f, t, inv_numel, &ps[k], &gs[k]);
+            acc += live ? l : 0.f;
+            gs[k] = live ? gs[k] : 0.f;
             cc = cc + 1 == n_cols ? 0 : cc + 1;
         }
         if (pred) reinterpret_cast<f32x4*>(pred)[i4] = f32x4{ps[0], ps[1], ps[2], ps[3]};
@@ -159,11 +164,13 @@ __global__ __launch_bounds__(256) void tucker_bce_kernel(const float* __restrict
     }
     if (blockIdx.x == 0 && threadIdx.x < (total & 3)) {  // up to three tail elements
         const int64_t i = (n4 << 2) + threadIdx.x;
-        const float t = flag ? fmaf(scale, (float)flag[i % n_cols], add) : add;
+        const bool live = i % n_cols < n_valid;
+        const float t = (flag && live) ? fmaf(scale, (float)flag[i % n_cols], add) : add;
         float pv, gv;
-        acc += bce_elem(logits[i], t, inv_numel, &pv, &gv);
+        const float l = bce_elem(live ? logits[i] : 0.f, t, inv_numel, &pv, &gv);
+        acc += live ? l : 0.f;
         if (pred) pred[i] = pv;
-        if (glogits) glogits[i] = gv;
+        if (glogits) glogits[i] = live ? gv : 0.f;
     }
     acc = group_sum<64>(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -239,22 +246,29 @@ extern "C" int hw_tucker_contract_dropout_grad(const float* x, const float* w, c
 
 extern "C" int64_t hw_tucker_bce_workspace_floats(void) { return TB_BLOCKS; }
 
-extern "C" int hw_tucker_sigmoid_bce(const float* logits, int64_t n_rows, int64_t n_cols, const uint8_t* pos_flag,
-                                     float target_scale, float target_add, float* loss_out, float* pred,
-                                     float* glogits, float* workspace, void* stream) {
-    if (!logits || !loss_out || !workspace || n_rows < 1 || n_cols < 1) return HW_ERR_INVALID_ARG;
+extern "C" int hw_tucker_sigmoid_bce_ld(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols,
+                                        const uint8_t* pos_flag, float target_scale, float target_add, float* loss_out,
+                                        float* pred, float* glogits, float* workspace, void* stream) {
+    if (!logits || !loss_out || !workspace || n_rows < 1 || n_cols < 1 || ld < n_cols) return HW_ERR_INVALID_ARG;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
-    const int64_t total = n_rows * n_cols;
+    const int64_t total = n_rows * ld;
     int64_t grid = (total / 4 + 255) / 256;
     if (grid > TB_BLOCKS) grid = TB_BLOCKS;
     if (grid < 1) grid = 1;
     if ((((uintptr_t)logits | (uintptr_t)pred | (uintptr_t)glogits) & 15) != 0) return HW_ERR_INVALID_ARG;  // float4 sweep
-    const float inv = 1.0f / (float)total;
-    hipLaunchKernelGGL(tucker_bce_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, n_rows, n_cols, pos_flag,
+    const float inv = (float)(1.0 / ((double)n_rows * (double)n_cols));
+    hipLaunchKernelGGL(tucker_bce_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, n_rows, n_cols, ld, pos_flag,
                        target_scale, target_add, inv, pred, glogits, workspace);
     hipLaunchKernelGGL(tucker_bce_finish_kernel, dim3(1), dim3(256), 0, st, workspace, (int)grid, inv, loss_out);
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_tucker_sigmoid_bce(const float* logits, int64_t n_rows, int64_t n_cols, const uint8_t* pos_flag,
+                                     float target_scale, float target_add, float* loss_out, float* pred,
+                                     float* glogits, float* workspace, void* stream) {
+    return hw_tucker_sigmoid_bce_ld(logits, n_cols, n_rows, n_cols, pos_flag, target_scale, target_add, loss_out, pred,
+                                    glogits, workspace, stream);
 }
 
 extern "C" int hw_sigmoid(const float* x, int64_t n, float* y, void* stream) {

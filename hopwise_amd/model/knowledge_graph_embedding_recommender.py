@@ -491,6 +491,10 @@ class TuckER(KnowledgeRecommender):
 
     def logits(self, h_idx, r_idx, table, side):
         """Pre-sigmoid scores [B, rows(table)] of forward() (tucker.py:69-84)."""
+        return ops.matmul_nt(self._features(h_idx, r_idx, side), table)
+
+    def _features(self, h_idx, r_idx, side):
+        """forward() up to the product with the candidate table (tucker.py:69-82)."""
         d = self.embedding_size
         fm = self.forced_masks[side] if self.forced_masks is not None else (None, None, None)
         h = ops.embedding(self.user_embedding.weight if side == "rec" else self.entity_embedding.weight, h_idx)
@@ -503,8 +507,7 @@ class TuckER(KnowledgeRecommender):
             x = ops.tucker_contract_dropout(x, w_mat, self.hidden_dropout1.p, self._seed, self._drop_calls)
         else:
             x = ops.tucker_contract(x, w_mat, fm[1])
-        x = self._drop(self.hidden_dropout2, self.bn1(x), fm[2])
-        return ops.matmul_nt(x, table)
+        return self._drop(self.hidden_dropout2, self.bn1(x), fm[2])
 
     def forward(self, h_idx, r_idx, table, side):
         return ops.sigmoid(self.logits(h_idx, r_idx, table, side))
@@ -528,9 +531,10 @@ class TuckER(KnowledgeRecommender):
             a_rec = a_kg = 0.0
         # the kg forward runs first in the reference (tucker.py:108-109 gather order does not matter; BN running
         # statistics are updated by score_users first, then score_kg -- tucker.py:121-122)
-        lu = self.logits(user, self._ui(user), self.user_embedding.weight, "rec")
-        lk = self.logits(head, rel, self.entity_embedding.weight, "kg")
-        return ops.sigmoid_bce_mean(lu, item_flag, s_rec, a_rec) + ops.sigmoid_bce_mean(lk, tail_flag, s_kg, a_kg)
+        xu = self._features(user, self._ui(user), "rec")
+        xk = self._features(head, rel, "kg")
+        return (ops.score_all_bce_mean(xu, self.user_embedding.weight, item_flag, s_rec, a_rec)
+                + ops.score_all_bce_mean(xk, self.entity_embedding.weight, tail_flag, s_kg, a_kg))
 
     def predict(self, interaction):
         user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
@@ -611,6 +615,10 @@ class ConvE(KnowledgeRecommender):
 
     def logits(self, h_idx, r_idx, head_table, out_table, bias, side):
         """Pre-sigmoid scores [B, rows(out_table)] of forward() (conve.py:75-93)."""
+        return ops.linear_act(self._features(h_idx, r_idx, head_table, side), out_table, bias)
+
+    def _features(self, h_idx, r_idx, head_table, side):
+        """forward() up to the product with the candidate table (conve.py:75-90)."""
         fm = self.forced_masks[side] if self.forced_masks is not None else (None, None, None)
         shape = (-1, 1, self.embedding_dim1, self.embedding_dim2)
         h = _PadEmbedding.apply(head_table, h_idx, 0).view(shape)
@@ -622,8 +630,7 @@ class ConvE(KnowledgeRecommender):
         x = self._drop(self.feature_map_drop, x, fm[1])
         x = ops.linear_act(x.reshape(x.shape[0], -1), self.fc.weight, self.fc.bias)
         x = self._drop(self.hidden_drop, x, fm[2])
-        x = torch.relu(self.bn2(x))
-        return ops.linear_act(x, out_table, bias)
+        return torch.relu(self.bn2(x))
 
     def forward(self, h_idx, r_idx, head_table, out_table, bias, side):
         return ops.sigmoid(self.logits(h_idx, r_idx, head_table, out_table, bias, side))
@@ -647,9 +654,12 @@ class ConvE(KnowledgeRecommender):
             s, a_rec, a_kg = 1.0 - self.label_smoothing, 1.0 / self.n_items, 1.0 / self.n_entities
         else:
             s, a_rec, a_kg = 1.0, 0.0, 0.0
-        lu = self.logits(*self._rec(user))
-        lk = self.logits(*self._kg(head, rel))
-        return ops.sigmoid_bce_mean(lu, item_flag, s, a_rec) + ops.sigmoid_bce_mean(lk, tail_flag, s, a_kg)
+        uh, ur, utab, uout, ub, _ = self._rec(user)
+        kh, kr, ktab, kout, kb, _ = self._kg(head, rel)
+        xu = self._features(uh, ur, utab, "rec")
+        xk = self._features(kh, kr, ktab, "kg")
+        return (ops.score_all_bce_mean(xu, uout, item_flag, s, a_rec, bias=ub)
+                + ops.score_all_bce_mean(xk, kout, tail_flag, s, a_kg, bias=kb))
 
     def predict(self, interaction):  # conve.py:139-151
         user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]

@@ -834,6 +834,54 @@ def sigmoid_bce_mean(logits, flag, scale, add):
     return SigmoidBceMean.apply(logits, flag, scale, add)
 
 
+class ScoreAllBceMean(torch.autograd.Function):
+    """BCELoss(sigmoid(x @ table^T), scale * flag[col] + add), mean over the [B, N] score matrix (tucker.py:83-84,
+    111-125), as one unit: the scores live in a buffer whose rows are padded to 32 floats (aligned tile stores and
+    16-byte operand loads for the MFMA GEMM whatever N is), the loss kernel overwrites them with dLoss/dscore in place,
+    and the backward scales the two small products instead of the [B, N] matrix."""
+
+    @staticmethod
+    def forward(ctx, x, table, bias, flag, scale, add):
+        lib = _lib.load()
+        x, table = x.contiguous(), table.contiguous()
+        B, N = x.shape[0], table.shape[0]
+        ld = (N + 31) // 32 * 32
+        buf = torch.empty((B, ld), dtype=torch.float32, device=x.device)
+        s = buf[:, :N]
+        gemm(x, table, True, True, bias=bias, out=s)
+        if flag is not None:
+            flag = _dev(flag, torch.uint8, "flag").contiguous()
+            if flag.numel() != N:
+                raise ValueError("flag must have one entry per column")
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        need = any(ctx.needs_input_grad[:3])
+        ws = torch.empty(int(lib.hw_tucker_bce_workspace_floats()), dtype=torch.float32, device=x.device)
+        check(lib.hw_tucker_sigmoid_bce_ld(_ptr(buf), ld, B, N, _ptr(flag), float(scale), float(add), _ptr(loss), None,
+                                           _ptr(buf) if need else None, _ptr(ws), _stream()), "hw_tucker_sigmoid_bce_ld")
+        ctx.n = N
+        ctx.save_for_backward(x, table, buf if need else None)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        x, table, buf = ctx.saved_tensors
+        from . import pgpr_ops as P
+
+        g = buf[:, : ctx.n]  # dLoss/dscore for gl = 1
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm(g, table, True, False) * gl  # [B, N] @ [N, d]
+        if ctx.needs_input_grad[1]:
+            gw = gemm(g, x, False, False) * gl  # g^T [N, B] @ x [B, d]
+        if ctx.needs_input_grad[2]:
+            gb = P.colsum(g) * gl
+        return gx, gw, gb, None, None, None
+
+
+def score_all_bce_mean(x, table, flag, scale, add, bias=None):
+    return ScoreAllBceMean.apply(x, table, bias, flag, scale, add)
+
+
 def sigmoid(x):
     lib = _lib.load()
     x = _dev(x, torch.float32, "x").contiguous()

@@ -333,6 +333,13 @@ int64_t hw_tucker_bce_workspace_floats(void);
 int hw_tucker_sigmoid_bce(const float* logits, int64_t n_rows, int64_t n_cols, const uint8_t* pos_flag,
                           float target_scale, float target_add, float* loss_out, float* pred,
                           float* glogits, float* workspace, void* stream);
+/* Same over a score matrix stored with leading dimension ld >= n_cols (pred / glogits share the layout; glogits may alias
+ * logits).  The engine keeps the [B, N] 1-vs-all scores with ld rounded up to 32 floats: with N = 144 779 the unpadded
+ * rows start at arbitrary 4-byte offsets, the GEMM's tile stores straddle cache lines and its K-contiguous reads of
+ * the backward fall back to dword loads (75 -> 90, 59 -> 72, 66 -> 74 TFLOP/s on the three products, tools/gemm_ld_pad.py). */
+int hw_tucker_sigmoid_bce_ld(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const uint8_t* pos_flag,
+                             float target_scale, float target_add, float* loss_out, float* pred, float* glogits,
+                             float* workspace, void* stream);
 int hw_sigmoid(const float* x, int64_t n, float* y, void* stream);
 
 /* logits -> masked softmax -> (+1 on valid actions, pgpr.py:453) -> top-k (value desc, index asc).
