@@ -68,6 +68,53 @@ __device__ __forceinline__ void stage_tile(const float* __restrict__ X, int64_t 
     }
 }
 
+// ---- software-pipelined tile movement (16-byte aligned operands) -------------------------------------------------------
+// fetch_tile brings this thread's 2 x 16 bytes of the NEXT k-tile into registers while the current one is multiplied,
+// put_tile writes them to LDS afterwards.  The fetch is straight-line code: hipcc waits for a load at the end of the
+// basic block that issued it when its value leaves the block through a phi, so any edge test around the loads would put
+// s_waitcnt vmcnt(0) in front of the MFMAs and undo the overlap.  Edges are handled by clamping addresses instead (a
+// 16-byte aligned operand has ld % 4 == 0 >= its inner extent, so the last partial float4 of a row stays inside the row's
+// allocation) and by zeroing k >= K when the registers are stored; rows / columns past M / N only feed outputs that are
+// never written.
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ X, int64_t ld, int rows, int K, int r0, int k0,
+                                           f32x4 (&v)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        if constexpr (KC) {
+            const int r = f >> 2, kq = (f & 3) * 4;
+            const int gr = min(r0 + r, rows - 1), gk = min(k0 + kq, ((K + 3) & ~3) - 4);
+            v[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ld + gk);
+        } else {
+            const int k = f >> 5, rq = (f & 31) * 4;
+            const int gk = min(k0 + k, K - 1), gr = min(r0 + rq, ((rows + 3) & ~3) - 4);
+            v[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gk * ld + gr);
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void put_tile(const f32x4 (&v)[2], int K, int k0, float (*T)[LDT]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        const float x[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        if constexpr (KC) {
+            const int r = f >> 2, kq = (f & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[kq + j][r] = k0 + kq + j < K ? x[j] : 0.f;
+        } else {
+            const int k = f >> 5, rq = (f & 31) * 4;
+            const bool live = k0 + k < K;
+            *reinterpret_cast<f32x4*>(&T[k][rq]) =
+                f32x4{live ? x[0] : 0.f, live ? x[1] : 0.f, live ? x[2] : 0.f, live ? x[3] : 0.f};
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
@@ -76,9 +123,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ drop_mask, int drop_mode,
                                                           uint64_t seed, uint64_t offset, int vec_a, int vec_b,
-                                                          int k_len, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float As[BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][LDT];
+                                                          int k_len, float* __restrict__ partial, int pipe) {
+    // two LDS stages: the pipelined loop writes tile k+1 into the stage nobody reads while tile k is multiplied, which
+    // leaves one barrier per k-step (the unpipelined fallback uses stage 0 only)
+    __shared__ __attribute__((aligned(16))) float As2[2][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LDT];
+    float (*As)[LDT] = As2[0];
+    float (*Bs)[LDT] = Bs2[0];
     const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     if (m0 >= M) return;
@@ -93,6 +144,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
     // split-K: blockIdx.z owns k in [z * k_len, min(K, (z + 1) * k_len)); partial sums go to `partial[z]`
     const int k_begin = blockIdx.z * k_len;
     const int k_end = min(K, k_begin + k_len);
+    if (pipe) {
+        f32x4 ra[2], rb[2];
+        fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra);
+        fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin, rb);
+        put_tile<A_KC>(ra, k_end, k_begin, As2[0]);
+        put_tile<B_KC>(rb, k_end, k_begin, Bs2[0]);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
+            // unconditional: past the last tile the clamped addresses re-read valid memory and put_tile stores zeros
+            fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + BK, ra);
+            fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + BK, rb);
+            __builtin_amdgcn_sched_barrier(0);  // or the scheduler sinks the loads below the MFMAs to shorten live ranges
+            float (*Ac)[LDT] = As2[cur];
+            float (*Bc)[LDT] = Bs2[cur];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const int kr = kk + (lane >> 5);
+                const float a0 = Ac[kr][wm + (lane & 31)];
+                const float a1 = Ac[kr][wm + 32 + (lane & 31)];
+                const float b0 = Bc[kr][wn + (lane & 31)];
+                const float b1 = Bc[kr][wn + 32 + (lane & 31)];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // ... and hoists put_tile's selects (first use of the loads) above them
+            // the other stage was last read one k-step ago, and every wave has passed the barrier that ended that step
+            put_tile<A_KC>(ra, k_end, k0 + BK, As2[cur ^ 1]);
+            put_tile<B_KC>(rb, k_end, k0 + BK, Bs2[cur ^ 1]);
+            __syncthreads();
+        }
+    } else
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         stage_tile<A_KC>(A, lda, M, k_end, m0, k0, vec_a != 0, As);
         stage_tile<B_KC>(B, ldb, N, k_end, n0, k0, vec_b != 0, Bs);
@@ -183,9 +268,13 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     float* partial = splits > 1 ? workspace : nullptr;
     dim3 grid((unsigned)gm, (unsigned)gn, (unsigned)splits);
     const int va = aligned16(a, lda), vb = aligned16(b, ldb);
+    const char* pe = getenv("HW_GEMM_PIPE");
+    // the pipelined loop needs 16-byte loads on both operands and at least one float4 along each inner extent
+    const int pipe = (pe ? atoi(pe) : 1) && va && vb && k >= 4 && m_max >= 4 && n >= 4;
 #define GO(AK, BK_, EL)                                                                                              \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows,       \
-                       (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial)
+                       (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial,   \
+                       pipe)
 #define GO3(AK, BK_)              \
     do {                          \
         if (act == 1) GO(AK, BK_, 1);      \
