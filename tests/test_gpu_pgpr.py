@@ -267,6 +267,35 @@ def test_gemm_all_layouts_vs_fp64():
     np.testing.assert_allclose(w.grad.cpu().numpy(), (g.double().t() @ x.detach().double()).cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
+def test_gemm_pipelined_loop_on_padded_operands():
+    """Operands with 16-byte aligned rows take the software-pipelined loop, whose fetch clamps addresses instead of
+    testing edges: inner extents that are not multiples of 4 (views into padded buffers), K below / not a multiple of
+    the 16-deep tile, ragged M and N, and the split-K form (long K, small output), all four layouts, against float64."""
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(5)
+
+    def padded(x):  # [r, c] -> view [r, c] of a buffer with ld = c rounded up to 4 (+4 when already a multiple)
+        r, c = x.shape
+        ld = (c + 3) // 4 * 4 + (4 if c % 4 == 0 else 0)
+        buf = torch.full((r, ld), float("nan"), device=dev())
+        buf[:, :c] = torch.from_numpy(x).to(dev())
+        return buf[:, :c]
+
+    for M, K, N in ((5, 3, 7), (37, 201, 129), (300, 18, 259), (129, 130, 131), (1000, 403, 70), (130, 5003, 41),
+                    (2048, 6001, 200), (4, 4, 4)):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = rng.standard_normal((N, K)).astype(np.float32)
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        At, Bt = padded(A), padded(B)
+        AT, BT = padded(np.ascontiguousarray(A.T)), padded(np.ascontiguousarray(B.T))
+        tol = dict(rtol=2e-5, atol=2e-5 * np.sqrt(K))
+        for a, b, akc, bkc in ((At, Bt, True, True), (At, BT, True, False), (AT, BT, False, False), (AT, Bt, False, True)):
+            out = padded(np.zeros((M, N), np.float32))
+            ops.gemm(a, b, akc, bkc, out=out)
+            np.testing.assert_allclose(out.cpu().numpy(), ref, err_msg=f"{M}x{K}x{N} {akc} {bkc}", **tol)
+
+
 def test_policy_topk_sort_edge_cases():
     """Saturated rows (one probability rounds p + 1 to 2.0), equal logits (index-ascending ties), single action."""
     from hopwise_amd import pgpr_ops as P
