@@ -183,8 +183,9 @@ SIGNATURES = {
     "hw_pgpr_actions": (
         C.c_int,
         [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, c_i32p, c_i32p, C.c_int64, C.c_int32,
-         C.c_int32, c_i32p, c_i32p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p],
+         C.c_int32, c_i32p, c_i32p, C.c_void_p, C.c_int64, C.c_int64, c_i32p, C.c_int64, C.c_void_p],
     ),
+    "hw_pgpr_actions_workspace_ints": (C.c_int64, [C.c_int64]),
     "hw_pgpr_state": (
         C.c_int,
         [C.POINTER(PgprGraph), c_f32p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int64, c_f32p,

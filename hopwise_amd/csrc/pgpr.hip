@@ -69,6 +69,8 @@ __global__ void pgpr_init_paths_kernel(const int64_t* __restrict__ users, int n,
 
 // ---- A10: actions ------------------------------------------------------------------------------------
 constexpr int ACT_LDS_KEYS = 4096;  // candidates whose select keys fit in LDS (32 KiB); larger rows use scratch
+constexpr int TRIM_WAVE_MAX_DEG = 2048;   // rows trimmed by one wave with the keys in registers
+constexpr int TRIM_BLOCK_MAX_DEG = 8192;  // ... by one block, same scheme; beyond: radix select over LDS / scratch keys
 
 // First pass, one WAVE per row and no block barrier: rows whose unvisited neighbours fit max_acts -- 98 % of the rows of
 // a 64/64/64 beam on the ml-1m-shaped graph, median degree 99 -- are finished here with ballot / popcount compaction in
@@ -76,7 +78,8 @@ constexpr int ACT_LDS_KEYS = 4096;  // candidates whose select keys fit in LDS (
 __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g, const int32_t* __restrict__ paths,
                                                                  const int32_t* __restrict__ n_rows_ptr, int max_acts,
                                                                  int flags, int32_t* __restrict__ acts,
-                                                                 int32_t* __restrict__ n_acts) {
+                                                                 int32_t* __restrict__ n_acts,
+                                                                 int32_t* __restrict__ work, int64_t list_cap) {
     const int n_rows = n_rows_ptr[0];
     const int act_dim = max_acts + 1;
     const int lane = threadIdx.x & 63;
@@ -116,7 +119,16 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
             cnt += __popcll(__ballot(e < deg && is_cand(e)));
         }
         if (cnt > max_acts) {
-            if (lane == 0) n_acts[row] = -1;  // the block kernel scores and trims this row
+            // the trim kernels score and cut this row; with a work buffer it is queued by degree class so that they
+            // walk short lists instead of scanning every row for n_acts < 0
+            if (lane == 0) {
+                n_acts[row] = -1;
+                if (work) {
+                    const int cls = (flags & 1) ? 2 : (deg <= TRIM_WAVE_MAX_DEG ? 0 : (deg <= TRIM_BLOCK_MAX_DEG ? 1 : 2));
+                    const int at = atomicAdd(&work[cls], 1);
+                    work[4 + (int64_t)cls * list_cap + at] = row;
+                }
+            }
             continue;
         }
         int32_t* arow = acts + (size_t)row * act_dim * 2;
@@ -136,23 +148,300 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
     }
 }
 
+// Select keys of the edges e = i * STRIDE + t (i < KPL) of one row: orderable float64 score of an unvisited neighbour,
+// 0 for visited ones and past the end.  Straight-line loads (clamped edge index, clamped table indices, selects
+// afterwards), eight edges per lane in flight at a time.
+template <int KPL, int STRIDE>
+__device__ __forceinline__ void load_select_keys(const hw_pgpr_graph& g, const double* __restrict__ su,
+                                                 const double* __restrict__ se,
+                                                 const double* __restrict__ score_rel_entity, int cur_t,
+                                                 const int (&vt)[4], const int (&vn)[4],
+                                                 const int32_t* __restrict__ erel, const int32_t* __restrict__ edst,
+                                                 int deg, int t, uint64_t (&key)[KPL]) {
+#pragma unroll
+    for (int i0 = 0; i0 < KPL; i0 += 8) {
+#pragma unroll
+        for (int i = i0; i < i0 + 8; ++i) {
+            const int e = i * STRIDE + t;
+            const int ec = e < deg ? e : deg - 1;
+            const int r = erel[ec], n = edst[ec];
+            const int nt = next_type(g, cur_t, r);
+            bool seen = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) seen |= (vt[k] == nt && vn[k] == n);
+            const bool to_user = nt == T_USER;
+            const double s1 = (to_user ? su : se)[n];
+            const double s2 = score_rel_entity[(size_t)r * g.n_entities + (to_user ? 0 : n)];
+            const double sc = (to_user || n < g.n_items) ? s1 : s1 + s2;  // pgpr.py:268-276 via the per-search tables
+            key[i] = (e < deg && !seen) ? orderable(sc) : 0ull;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Second pass, still one WAVE per row: rows that need the float64 trim but have at most 64 * KPL neighbours keep their
+// select keys in registers (KPL per lane) and find the max_acts-th largest key by a bitwise binary search whose counts are
+// ballots + scalar popcounts -- no LDS, no block barrier.  The block-per-row radix select below costs 40-80 us per row in
+// barriers and LDS atomics (8 digit passes x 5 syncs); a hop over item nodes (every row trimmed, degree ~10^3) spent
+// 160-180 us there, this pass needs under 10.  Same keys, same threshold, same tie rule (ties kept from the END of the
+// row) and the same CSR output order as the block kernel; the descending order of fix_scores_sorting_bug stays there.
+template <int KPL>
+__device__ __forceinline__ void trim_row_in_registers(const hw_pgpr_graph& g, const double* __restrict__ su,
+                                                      const double* __restrict__ se,
+                                                      const double* __restrict__ score_rel_entity, int cur_t,
+                                                      const int (&vt)[4], const int (&vn)[4],
+                                                      const int32_t* __restrict__ erel,
+                                                      const int32_t* __restrict__ edst, int deg, int max_acts,
+                                                      int32_t* __restrict__ arow, int lane,
+                                                      unsigned long long lt_mask) {
+    uint64_t key[KPL];
+    load_select_keys<KPL, 64>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, lane, key);
+    // T = max_acts-th largest key: the largest v with count(key >= v) >= max_acts, built bit by bit
+    // ... and abandoned as soon as a prefix is met by exactly max_acts keys: keeping every key >= that prefix is then the
+    // answer with no tie to break (distinct float64 scores separate after ~log2(deg) bits below their common exponent)
+    uint64_t T = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+        const uint64_t c = T | (1ull << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) cnt += __popcll(__ballot(key[i] >= c));
+        if (cnt >= max_acts) T = c;  // wave-uniform
+        if (cnt == max_acts) break;
+    }
+    int c_gt = 0, c_eq = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        c_gt += __popcll(__ballot(key[i] > T));
+        c_eq += __popcll(__ballot(key[i] == T));
+    }
+    const int tie_skip = c_eq - (max_acts - c_gt);  // ties are kept from the END of the row (stable argsort, [-max_acts:])
+    int run_keep = 0, run_tie = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int e = i * 64 + lane;
+        const int ec = e < deg ? e : deg - 1;
+        const int r = erel[ec], n = edst[ec];  // L1 hits; unconditional so that they are issued together
+        const bool tie = key[i] == T;
+        const unsigned long long tb = __ballot(tie);
+        const bool keep = key[i] > T || (tie && run_tie + __popcll(tb & lt_mask) >= tie_skip);
+        const unsigned long long kb = __ballot(keep);
+        if (keep) {
+            const int pos = 1 + run_keep + __popcll(kb & lt_mask);
+            arow[2 * pos] = r;
+            arow[2 * pos + 1] = n;
+        }
+        run_keep += __popcll(kb);
+        run_tie += __popcll(tb);
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
+    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+    const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
+    const int32_t* __restrict__ n_rows_ptr, int max_acts, int flags, int32_t* __restrict__ acts,
+    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len) {
+    const int n_rows = list ? list_len[0] : n_rows_ptr[0];
+    const int act_dim = max_acts + 1;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_rows; it += gridDim.x * 4) {
+        const int row = list ? list[it] : it;
+        if (n_acts[row] >= 0) continue;  // wave-uniform: finished by the first pass
+        const int32_t* p = paths + (size_t)row * PATH_INTS;
+        const int uid = p[0], len = p[1];
+        int cur_t = T_USER, cur_n = uid;
+        if (len > 1) cur_t = p[2 + 3 * (len - 2) + 1], cur_n = p[2 + 3 * (len - 2) + 2];
+        const int64_t gid = cur_t == T_USER ? cur_n : (int64_t)g.n_users + cur_n;
+        const int64_t lo = g.ptr[gid];
+        const int deg = (int)(g.ptr[gid + 1] - lo);
+        if (deg > TRIM_WAVE_MAX_DEG) continue;  // left to the block kernel
+        int vt[4], vn[4];  // visited (type, id), as in the first pass
+        bool lead = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int t = -1, n = -1;
+            if (k == 0) t = T_USER, n = uid;
+            else if (k < len) t = p[2 + 3 * (k - 1) + 1], n = p[2 + 3 * (k - 1) + 2];
+            if (k >= 1 && k < len) lead = lead && p[2 + 3 * (k - 1)] == SELF_LOOP;
+            if ((flags & 2) && k < len && lead) t = -1;
+            vt[k] = t, vn[k] = n;
+        }
+        const int b = p[PATH_INTS - 1];
+        const double* __restrict__ su = score_user + (size_t)b * g.n_users;
+        const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
+        const int32_t* __restrict__ erel = g.rel + lo;
+        const int32_t* __restrict__ edst = g.dst + lo;
+        int32_t* arow = acts + (size_t)row * act_dim * 2;
+        if (deg <= 512) trim_row_in_registers<8>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
+        else if (deg <= 1024) trim_row_in_registers<16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
+        else trim_row_in_registers<32>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
+        if (lane == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + max_acts;
+    }
+}
+
+// Third pass, one BLOCK per row for 2048 < neighbours <= 8192: the same register-resident search with the counts of the
+// four waves summed through LDS -- one barrier per search step and three for the output, against the ~150 barriers and the
+// same-bin LDS atomics of the radix select below (a 6 000-neighbour item row took ~120 us there).
+template <int KPL>
+__device__ __forceinline__ void trim_row_in_block(const hw_pgpr_graph& g, const double* __restrict__ su,
+                                                  const double* __restrict__ se,
+                                                  const double* __restrict__ score_rel_entity, int cur_t,
+                                                  const int (&vt)[4], const int (&vn)[4],
+                                                  const int32_t* __restrict__ erel, const int32_t* __restrict__ edst,
+                                                  int deg, int max_acts, int32_t* __restrict__ arow,
+                                                  unsigned long long lt_mask, int (*sh_cnt)[2][4], int (*sh_slot)[32][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint64_t key[KPL];
+    load_select_keys<KPL, 256>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, tid, key);
+    // block-wide count of a predicate over all keys: per-wave ballots, one LDS exchange, one barrier (stage `par`)
+    int par = 0;
+    auto block_sum2 = [&](int a, int b, int& sa, int& sb) {
+        if (lane == 0) sh_cnt[par][0][w] = a, sh_cnt[par][1][w] = b;
+        __syncthreads();
+        sa = sh_cnt[par][0][0] + sh_cnt[par][0][1] + sh_cnt[par][0][2] + sh_cnt[par][0][3];
+        sb = sh_cnt[par][1][0] + sh_cnt[par][1][1] + sh_cnt[par][1][2] + sh_cnt[par][1][3];
+        par ^= 1;  // the other stage is only rewritten after the next barrier, when everyone has read this one
+    };
+    uint64_t T = 0;
+    for (int bit = 63; bit >= 0; --bit) {
+        const uint64_t c = T | (1ull << bit);
+        int mine = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) mine += __popcll(__ballot(key[i] >= c));
+        int cnt, unused;
+        block_sum2(mine, 0, cnt, unused);
+        if (cnt >= max_acts) T = c;  // block-uniform
+        if (cnt == max_acts) break;
+    }
+    int gt_w = 0, eq_w = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        gt_w += __popcll(__ballot(key[i] > T));
+        eq_w += __popcll(__ballot(key[i] == T));
+    }
+    int c_gt, c_eq;
+    block_sum2(gt_w, eq_w, c_gt, c_eq);
+    const int tie_skip = c_eq - (max_acts - c_gt);  // ties are kept from the END of the row
+    // edge order = (slot i, wave w, lane).  Per-(slot, wave) tie and keep counts go through LDS once each; the exclusive
+    // prefixes over that order are then rebuilt on the fly where they are used (no per-slot arrays in registers).
+    const bool ties = tie_skip > 0;  // block-uniform; rare: several keys equal to the threshold, not all of them wanted
+    if (ties) {
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int c = __popcll(__ballot(key[i] == T));
+            if (lane == 0) sh_slot[0][i][w] = c;
+        }
+    }
+    __syncthreads();
+    auto keep_of = [&](int i, int tie_before) -> bool {
+        const bool tie = key[i] == T;
+        const unsigned long long tb = __ballot(tie);
+        return key[i] > T || (tie && tie_before + __popcll(tb & lt_mask) >= tie_skip);
+    };
+    auto step_prefix = [&](int (*tab)[4], int i, int& run) -> int {  // exclusive prefix of (slot i, this wave); run += slot
+        int here = run;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int x = tab[i][v];
+            here += v < w ? x : 0;
+            run += x;
+        }
+        return here;
+    };
+    {
+        int run_t = 0;
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int tb4 = ties ? step_prefix(sh_slot[0], i, run_t) : 0;
+            const int c = __popcll(__ballot(keep_of(i, tb4)));
+            if (lane == 0) sh_slot[1][i][w] = c;
+        }
+    }
+    __syncthreads();
+    int run_t = 0, run_k = 0;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) {
+        const int e = i * 256 + tid;
+        const int ec = e < deg ? e : deg - 1;
+        const int r = erel[ec], n = edst[ec];
+        const int tb4 = ties ? step_prefix(sh_slot[0], i, run_t) : 0;
+        const bool keep = keep_of(i, tb4);
+        const unsigned long long kb = __ballot(keep);
+        const int before = step_prefix(sh_slot[1], i, run_k);
+        if (keep) {
+            const int pos = 1 + before + __popcll(kb & lt_mask);
+            arow[2 * pos] = r;
+            arow[2 * pos + 1] = n;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
+    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+    const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
+    const int32_t* __restrict__ n_rows_ptr, int max_acts, int flags, int32_t* __restrict__ acts,
+    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len) {
+    __shared__ int sh_cnt[2][2][4];
+    __shared__ int sh_slot[2][32][4];
+    const int n_rows = list ? list_len[0] : n_rows_ptr[0];
+    const int act_dim = max_acts + 1;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
+        const int row = list ? list[it] : it;
+        if (n_acts[row] >= 0) continue;  // block-uniform
+        const int32_t* p = paths + (size_t)row * PATH_INTS;
+        const int uid = p[0], len = p[1];
+        int cur_t = T_USER, cur_n = uid;
+        if (len > 1) cur_t = p[2 + 3 * (len - 2) + 1], cur_n = p[2 + 3 * (len - 2) + 2];
+        const int64_t gid = cur_t == T_USER ? cur_n : (int64_t)g.n_users + cur_n;
+        const int64_t lo = g.ptr[gid];
+        const int deg = (int)(g.ptr[gid + 1] - lo);
+        if (deg > TRIM_BLOCK_MAX_DEG) continue;  // left to the radix-select kernel
+        int vt[4], vn[4];
+        bool lead = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int t = -1, n = -1;
+            if (k == 0) t = T_USER, n = uid;
+            else if (k < len) t = p[2 + 3 * (k - 1) + 1], n = p[2 + 3 * (k - 1) + 2];
+            if (k >= 1 && k < len) lead = lead && p[2 + 3 * (k - 1)] == SELF_LOOP;
+            if ((flags & 2) && k < len && lead) t = -1;
+            vt[k] = t, vn[k] = n;
+        }
+        const int b = p[PATH_INTS - 1];
+        const double* __restrict__ su = score_user + (size_t)b * g.n_users;
+        const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
+        const int32_t* __restrict__ erel = g.rel + lo;
+        const int32_t* __restrict__ edst = g.dst + lo;
+        int32_t* arow = acts + (size_t)row * act_dim * 2;
+        __syncthreads();  // LDS of the previous row is free
+        if (deg <= 4096) trim_row_in_block<16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lt_mask, sh_cnt, sh_slot);
+        else trim_row_in_block<32>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lt_mask, sh_cnt, sh_slot);
+        __syncthreads();  // every wave has finished the row before it is marked done
+        if (threadIdx.x == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + max_acts;
+    }
+}
+
 __global__ __launch_bounds__(256) void pgpr_actions_kernel(
     hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
     const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
     const int32_t* __restrict__ n_rows_ptr, int max_acts, int fix_bug, int32_t* __restrict__ acts,
-    int32_t* __restrict__ n_acts, uint64_t* __restrict__ scratch, int64_t scratch_stride) {
+    int32_t* __restrict__ n_acts, uint64_t* __restrict__ scratch, int64_t scratch_stride,
+    const int32_t* __restrict__ list, const int32_t* __restrict__ list_len) {
     __shared__ uint64_t lds_keys[ACT_LDS_KEYS];
     __shared__ unsigned hist[256];
     __shared__ int wsum[4];
     __shared__ int sh_bin, sh_need, sh_done;
     __shared__ int vis_t[4], vis_n[4];
 
-    const int n_rows = n_rows_ptr[0];
+    const int n_rows = list ? list_len[0] : n_rows_ptr[0];
     const int act_dim = max_acts + 1;
     const int tid = threadIdx.x;
 
-    for (int row = blockIdx.x; row < n_rows; row += gridDim.x) {
-        if (n_acts[row] >= 0) continue;  // finished by pgpr_actions_small_kernel (block-uniform: one value per row)
+    for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
+        const int row = list ? list[it] : it;
+        if (n_acts[row] >= 0) continue;  // finished by an earlier pass (block-uniform: one value per row)
         const int32_t* p = paths + (size_t)row * PATH_INTS;
         const int uid = p[0], len = p[1];
         int cur_t, cur_n;
@@ -185,40 +474,9 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
         const int32_t* __restrict__ erel = g.rel + lo;
         const int32_t* __restrict__ edst = g.dst + lo;
 
-        auto is_cand = [&](int e) -> bool {
-            const int r = erel[e], n = edst[e];
-            const int nt = next_type(g, cur_t, r);
-            bool seen = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) seen |= (vis_t[k] == nt && vis_n[k] == n);
-            return !seen;
-        };
 
-        // (2)-(4): count the unvisited neighbours
-        int cnt = 0;
-        for (int e = tid; e < deg; e += 256) cnt += is_cand(e) ? 1 : 0;
-        int n_cand;
-        (void)block_excl_scan(cnt, wsum, n_cand);
-
-        if (n_cand <= max_acts) {
-            // keep all, already in (relation, dst) order
-            int running = 0;
-            for (int base = 0; base < deg; base += 256) {
-                const int e = base + tid;
-                const int f = (e < deg && is_cand(e)) ? 1 : 0;
-                int tot;
-                const int pos = block_excl_scan(f, wsum, tot);
-                if (f) {
-                    arow[2 * (1 + running + pos)] = erel[e];
-                    arow[2 * (1 + running + pos) + 1] = edst[e];
-                }
-                running += tot;
-            }
-            if (tid == 0) n_acts[row] = 1 + n_cand;
-            continue;
-        }
-
-        // (5): too many -> float64 scores, keep the top max_acts by (score, position)
+        // Only rows the first pass marked n_acts = -1 arrive here: more than max_acts unvisited neighbours, so
+        // (pgpr.py:258-288) float64 scores, keep the top max_acts by (score, position)
         if (deg > ACT_LDS_KEYS && (!scratch || scratch_stride < deg)) {  // host validation makes this unreachable
             if (tid == 0) n_acts[row] = 1;
             continue;
@@ -234,18 +492,28 @@ __global__ __launch_bounds__(256) void pgpr_actions_kernel(
             const int b = p[PATH_INTS - 1];
             const double* __restrict__ su = score_user + (size_t)b * g.n_users;
             const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
-            for (int e = tid; e < deg; e += 256) {
-                uint64_t key = 0ull;
-                if (is_cand(e)) {
-                    const int r = erel[e], n = edst[e];
+            // four edges per thread per trip, loads on clamped indices with the selects afterwards: the trip count of this
+            // loop (deg / 1024) times two dependent load latencies is most of what a long row costs
+            for (int e0 = tid; e0 < deg; e0 += 1024) {
+                uint64_t k4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + 256 * u;
+                    const int ec = e < deg ? e : deg - 1;
+                    const int r = erel[ec], n = edst[ec];
                     const int nt = next_type(g, cur_t, r);
-                    double sc;
-                    if (nt == T_USER) sc = su[n];
-                    else if (n < g.n_items) sc = se[n];
-                    else sc = se[n] + score_rel_entity[(size_t)r * g.n_entities + n];
-                    key = orderable(sc);
+                    bool seen = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) seen |= (vis_t[k] == nt && vis_n[k] == n);
+                    const bool to_user = nt == T_USER;
+                    const double s1 = (to_user ? su : se)[n];
+                    const double s2 = score_rel_entity[(size_t)r * g.n_entities + (to_user ? 0 : n)];
+                    const double sc = (to_user || n < g.n_items) ? s1 : s1 + s2;
+                    k4[u] = seen ? 0ull : orderable(sc);
                 }
-                keys[e] = key;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (e0 + 256 * u < deg) keys[e0 + 256 * u] = k4[u];
             }
         }
         __syncthreads();
@@ -858,17 +1126,20 @@ extern "C" int hw_pgpr_user_scores_tp(const hw_pgpr_graph* graph, const double* 
                             src_workspace, score_user, score_entity, stream);
 }
 
+extern "C" int64_t hw_pgpr_actions_workspace_ints(int64_t max_rows) { return max_rows < 0 ? 0 : 4 + 3 * max_rows; }
+
 extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_user, const double* score_entity,
                                const double* score_rel_entity, const int32_t* paths, const int32_t* n_rows,
                                int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug, int32_t* acts,
                                int32_t* n_acts, uint64_t* scratch, int64_t scratch_blocks, int64_t scratch_stride,
-                               void* stream) {
+                               int32_t* work, int64_t work_ints, void* stream) {
     int rc = check_graph(graph);
     if (rc) return rc;
     if (!score_user || !score_entity || !score_rel_entity || !paths || !n_rows || !acts || !n_acts)
         return HW_ERR_INVALID_ARG;
-    if (max_acts < 1 || max_acts > 1023 || max_rows < 0) return HW_ERR_INVALID_ARG;
+    if (max_acts < 1 || max_acts > 1023 || max_rows < 0 || max_rows > INT32_MAX) return HW_ERR_INVALID_ARG;
     if (max_rows == 0) return HW_OK;
+    if (work && work_ints < 4 + 3 * max_rows) return HW_ERR_WORKSPACE;
     // every block that may meet a row with more than ACT_LDS_KEYS neighbours needs a private scratch slice
     int64_t grid = max_rows < 2048 ? max_rows : 2048;
     if (graph->max_degree > ACT_LDS_KEYS) {
@@ -879,15 +1150,38 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_u
         scratch_stride = 0;
     }
     HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    // work: three queues of rows that need the trim (by degree class) + their lengths; without it the trim kernels scan
+    // all rows for n_acts < 0
+    const int32_t* lists[3] = {nullptr, nullptr, nullptr};
+    const int32_t* lens[3] = {nullptr, nullptr, nullptr};
+    if (work) {
+        (void)hipMemsetAsync(work, 0, 4 * sizeof(int32_t), st);
+        for (int c = 0; c < 3; ++c) lists[c] = work + 4 + (int64_t)c * max_rows, lens[c] = work + c;
+    }
     {
         int64_t g1 = (max_rows + 3) / 4;
         if (g1 > 8192) g1 = 8192;
-        hipLaunchKernelGGL(pgpr_actions_small_kernel, dim3((unsigned)g1), dim3(256), 0, (hipStream_t)stream, *graph, paths,
-                           n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts);
+        hipLaunchKernelGGL(pgpr_actions_small_kernel, dim3((unsigned)g1), dim3(256), 0, st, *graph, paths, n_rows, max_acts,
+                           fix_scores_sorting_bug, acts, n_acts, work, max_rows);
     }
-    hipLaunchKernelGGL(pgpr_actions_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph, score_user,
-                       score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
-                       scratch, scratch_stride);
+    if (!(fix_scores_sorting_bug & 1)) {
+        int64_t g2 = (max_rows + 3) / 4;
+        if (g2 > 4096) g2 = 4096;
+        hipLaunchKernelGGL(pgpr_actions_trim_wave_kernel, dim3((unsigned)g2), dim3(256), 0, st, *graph, score_user,
+                           score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
+                           lists[0], lens[0]);
+        if (graph->max_degree > TRIM_WAVE_MAX_DEG) {
+            const int64_t g3 = max_rows < 2048 ? max_rows : 2048;
+            hipLaunchKernelGGL(pgpr_actions_trim_block_kernel, dim3((unsigned)g3), dim3(256), 0, st, *graph, score_user,
+                               score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts,
+                               n_acts, lists[1], lens[1]);
+        }
+    }
+    if ((fix_scores_sorting_bug & 1) || graph->max_degree > TRIM_BLOCK_MAX_DEG)
+        hipLaunchKernelGGL(pgpr_actions_kernel, dim3((unsigned)grid), dim3(256), 0, st, *graph, score_user, score_entity,
+                           score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts, scratch,
+                           scratch_stride, lists[2], lens[2]);
     return HW_LAUNCH_RC();
 }
 

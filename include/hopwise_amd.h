@@ -270,11 +270,14 @@ int hw_pgpr_user_scores_tp(const hw_pgpr_graph* graph, const double* user_emb64,
  * a path return to its own user. */
 #define HW_PGPR_FIX_SORTING 1
 #define HW_PGPR_START_USER_REVISITABLE 2
+/* work (nullable): hw_pgpr_actions_workspace_ints(max_rows) int32 of scratch in which the first pass queues the rows
+ * that need the trim, by degree class, for the trim kernels; without it they scan every row. */
+int64_t hw_pgpr_actions_workspace_ints(int64_t max_rows);
 int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_user, const double* score_entity,
                     const double* score_rel_entity, const int32_t* paths, const int32_t* n_rows,
                     int64_t max_rows, int32_t max_acts, int32_t fix_scores_sorting_bug,
                     int32_t* acts, int32_t* n_acts, uint64_t* scratch, int64_t scratch_blocks,
-                    int64_t scratch_stride, void* stream);
+                    int64_t scratch_stride, int32_t* work, int64_t work_ints, void* stream);
 
 /* _get_state (pgpr.py:296-333): state [max_rows, (2 + 2*state_history) * dim] float32. */
 int hw_pgpr_state(const hw_pgpr_graph* graph, const float* user_emb32, const float* entity_emb32,
