@@ -73,8 +73,9 @@ constexpr int TRIM_WAVE_MAX_DEG = 2048;   // rows trimmed by one wave with the k
 constexpr int TRIM_BLOCK_MAX_DEG = 8192;  // ... by one block, same scheme; beyond: radix select over LDS / scratch keys
 
 // First pass, one WAVE per row and no block barrier: rows whose unvisited neighbours fit max_acts -- 98 % of the rows of
-// a 64/64/64 beam on the ml-1m-shaped graph, median degree 99 -- are finished here with ballot / popcount compaction in
-// CSR (= relation, dst) order; rows that need the float64 trim get n_acts = -1 and are left to the block kernel below.
+// a 64/64/64 beam on the ml-1m-shaped graph, median degree 99 -- are finished here in ONE sweep over their edges with
+// ballot / popcount compaction in CSR (= relation, dst) order; rows that overflow max_acts get n_acts = -1 and are queued
+// for the trim kernels below.
 __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g, const int32_t* __restrict__ paths,
                                                                  const int32_t* __restrict__ n_rows_ptr, int max_acts,
                                                                  int flags, int32_t* __restrict__ acts,
@@ -105,20 +106,37 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
         const int deg = (int)(g.ptr[gid + 1] - lo);
         const int32_t* __restrict__ erel = g.rel + lo;
         const int32_t* __restrict__ edst = g.dst + lo;
-        auto is_cand = [&](int e) -> bool {
-            const int r = erel[e], n = edst[e];
-            const int nt = next_type(g, cur_t, r);
-            bool seen = false;
+        // One sweep: entries are written as they are found (CSR = (relation, dst) order) and the row is handed to the trim
+        // kernels as soon as more than max_acts have been seen -- what was written so far is overwritten there.  Four
+        // 64-edge chunks per trip with their loads issued together (clamped index, selects afterwards).
+        int32_t* arow = acts + (size_t)row * act_dim * 2;
+        int running = 0;
+        for (int base = 0; base < deg && running <= max_acts; base += 256) {
+            int rr[4], nn[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) seen |= (vt[k] == nt && vn[k] == n);
-            return !seen;
-        };
-        int cnt = 0;
-        for (int base = 0; base < deg; base += 64) {
-            const int e = base + lane;
-            cnt += __popcll(__ballot(e < deg && is_cand(e)));
+            for (int u = 0; u < 4; ++u) {
+                const int e = base + 64 * u + lane;
+                const int ec = e < deg ? e : deg - 1;
+                rr[u] = erel[ec], nn[u] = edst[ec];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = base + 64 * u + lane;
+                const int nt = next_type(g, cur_t, rr[u]);
+                bool seen = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) seen |= (vt[k] == nt && vn[k] == nn[u]);
+                const bool f = e < deg && !seen;
+                const unsigned long long m = __ballot(f);
+                const int pos = 1 + running + __popcll(m & lt_mask);
+                if (f && pos <= max_acts) {
+                    arow[2 * pos] = rr[u];
+                    arow[2 * pos + 1] = nn[u];
+                }
+                running += __popcll(m);
+            }
         }
-        if (cnt > max_acts) {
+        if (running > max_acts) {
             // the trim kernels score and cut this row; with a work buffer it is queued by degree class so that they
             // walk short lists instead of scanning every row for n_acts < 0
             if (lane == 0) {
@@ -131,20 +149,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
             }
             continue;
         }
-        int32_t* arow = acts + (size_t)row * act_dim * 2;
-        if (lane == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + cnt;
-        int running = 0;
-        for (int base = 0; base < deg; base += 64) {
-            const int e = base + lane;
-            const bool f = e < deg && is_cand(e);
-            const unsigned long long m = __ballot(f);
-            if (f) {
-                const int pos = 1 + running + __popcll(m & lt_mask);
-                arow[2 * pos] = erel[e];
-                arow[2 * pos + 1] = edst[e];
-            }
-            running += __popcll(m);
-        }
+        if (lane == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + running;
     }
 }
 
