@@ -90,7 +90,7 @@ def test_model_steps_with_gradient_sinks_match_torch_adam(model_name):
             loss = sum(loss) if isinstance(loss, tuple) else loss
             loss.backward()
             o.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         np.testing.assert_allclose(losses[1], losses[0], rtol=1e-5)
     for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         np.testing.assert_allclose(p2.detach().cpu().numpy(), p1.detach().cpu().numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
