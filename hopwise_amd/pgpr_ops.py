@@ -100,6 +100,7 @@ def user_scores(graph, U64, E64, R64, users, user_vec=None):
 
 
 _ACTION_WORK = {}
+QUEUE_TRIM_ROWS = True  # False: hw_pgpr_actions without its work buffer (the trim kernels scan every row)
 
 
 def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, max_rows, max_acts, fix_bug, acts, n_acts,
@@ -108,15 +109,18 @@ def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, ma
     sb = ss = 0
     if scratch is not None:
         sb, ss = scratch.shape
-    key = (paths.device, int(max_rows))
-    work = _ACTION_WORK.get(key)
-    if work is None:  # queues of the rows that need the trim; one buffer per (device, row capacity)
-        work = torch.empty(int(lib.hw_pgpr_actions_workspace_ints(int(max_rows))), dtype=torch.int32, device=paths.device)
-        _ACTION_WORK[key] = work
+    work = None
+    if QUEUE_TRIM_ROWS:  # queues of the rows that need the trim; one buffer per (device, row capacity)
+        key = (paths.device, int(max_rows))
+        work = _ACTION_WORK.get(key)
+        if work is None:
+            work = torch.empty(int(lib.hw_pgpr_actions_workspace_ints(int(max_rows))), dtype=torch.int32,
+                               device=paths.device)
+            _ACTION_WORK[key] = work
     check(
         lib.hw_pgpr_actions(C.byref(graph.c), _ptr(score_user), _ptr(score_entity), _ptr(score_rel_entity), _ptr(paths),
                             _ptr(n_rows), int(max_rows), int(max_acts), int(bool(fix_bug)) | (2 if start_user_revisitable else 0), _ptr(acts), _ptr(n_acts),
-                            _ptr(scratch), sb, ss, _ptr(work), work.numel(), _stream()),
+                            _ptr(scratch), sb, ss, _ptr(work), 0 if work is None else work.numel(), _stream()),
         "hw_pgpr_actions",
     )
 

@@ -83,6 +83,60 @@ def test_actions_and_state_kernels(tag):
     np.testing.assert_array_equal(st, z["prim.states"].astype(np.float32))
 
 
+@pytest.mark.parametrize("queue", [True, False])
+def test_actions_trim_on_high_degree_rows(queue, monkeypatch):
+    """Rows of every degree class of hw_pgpr_actions -- wave-resident trim (8 / 16 / 32 keys per lane), block-resident
+    trim (16 / 32 keys per thread) and the radix-select fallback past 8 192 neighbours -- against the oracle's
+    get_actions, with duplicate edges so that equal float64 scores meet the threshold; with and without the work queues."""
+    from hopwise_amd import pgpr_ops as P
+    from hopwise_amd.model.knowledge_aware_recommender import PGPR
+    from oracle.pgpr import CKG, ENTITY, SELF_LOOP, USER, PGPROracle
+
+    monkeypatch.setattr(P, "QUEUE_TRIM_ROWS", queue)
+    rng = np.random.default_rng(12)
+    n_users, n_items, n_ent, n_rel, d = 9500, 12, 40, 4, 8
+    ui = n_rel - 1
+    degs = {1: 9100, 2: 5000, 3: 3000, 4: 1500, 5: 700, 6: 300, 7: 251, 8: 90}
+    iu, ii = [], []
+    for item, k in degs.items():
+        us = rng.choice(np.arange(1, n_users), size=k, replace=False)
+        us[: k // 50] = us[k // 50 : 2 * (k // 50)]  # some users interact twice: duplicate edges, equal scores
+        iu.append(us), ii.append(np.full(k, item))
+    iu, ii = np.concatenate(iu), np.concatenate(ii)
+    heads = rng.integers(1, n_ent, 60)
+    rels = rng.integers(1, ui, 60)
+    tails = rng.integers(1, n_ent, 60)
+    U = rng.standard_normal((n_users, d))
+    E = rng.standard_normal((n_ent, d))
+    R = rng.standard_normal((n_rel, d))
+    positives = np.zeros((n_users, 1), np.int64)
+    ds = FakeKGDataset(n_users, n_items, n_ent, n_rel, ui, iu, ii, heads, rels, tails, positives, U, E, R)
+    m = PGPR(pgpr_config(dev(), 250, 1, (25, 5, 1), False, (10,), "identity"), ds).to(dev())
+    g = CKG(n_users, n_ent, ui, iu, ii, heads, rels, tails)
+    orc = PGPROracle(g, n_items, U, E, R, positives, {}, max_acts=250, tie_rule="stable")
+    u0 = int(iu[0])
+    paths = [[(SELF_LOOP, USER, u0), (ui, ENTITY, item)] for item in degs] + [[(SELF_LOOP, USER, u0)]]
+    n = len(paths)
+    recs = paths_to_records(paths)
+    rec = torch.from_numpy(recs).to(dev())  # batch index 0: one root user
+    n_rows = torch.tensor([n], dtype=torch.int32, device=dev())
+    acts = torch.full((n, m.act_dim, 2), -7, dtype=torch.int32, device=dev())
+    n_acts = torch.zeros(n, dtype=torch.int32, device=dev())
+    su, se = P.user_scores(m.graph, *m._t64, torch.tensor([u0], device=dev()))
+    scratch = torch.empty((n, int(m.graph.max_degree)), dtype=torch.int64, device=dev())
+    P.actions(m.graph, su, se, m._score_rel_entity, rec, n_rows, n, m.max_acts, False, acts, n_acts, scratch)
+    acts, n_acts = acts.cpu().numpy(), n_acts.cpu().numpy()
+    for i, path in enumerate(paths):
+        want = orc.get_actions(path)
+        got = [tuple(int(x) for x in a) for a in acts[i, : n_acts[i]]]
+        if got != want:  # the score tables add two dot products where the oracle dots a summed vector: last-ulp ties only
+            cand, sc = orc.action_scores(path)
+            kth = np.sort(sc)[-orc.max_acts]
+            diff = set(got) ^ set(want)
+            assert len(got) == len(want) and all(abs(sc[cand.index(a)] - kth) <= 1e-12 * abs(kth) for a in diff), i
+        assert len(got) == min(251, 1 + len(orc._candidates(path, "sorted")))
+
+
 @pytest.mark.parametrize("tag", ["default", "trim20"])
 def test_policy_forward_kernels(tag):
     from hopwise_amd import pgpr_ops as P
