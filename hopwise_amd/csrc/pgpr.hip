@@ -1025,32 +1025,60 @@ __global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const
                                                           int64_t cap) {
     const int n_rows = n_rows_ptr[0];
     const int64_t total = (int64_t)n_rows * k;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / k), j = (int)(i % k);
-        const int nc = min(k, n_acts[row]);
-        if (j >= nc) continue;
-        const int64_t o = (int64_t)offsets[row] + j;
-        if (o >= cap) continue;
-        const int idx = topk_idx[(size_t)row * k + j];
-        // 48-byte record: three 16-byte loads / stores (records are 16-byte aligned: 48 = 3 x 16)
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const i32x4* __restrict__ pv = reinterpret_cast<const i32x4*>(paths + (size_t)row * PATH_INTS);
-        i32x4 rec[3] = {pv[0], pv[1], pv[2]};
-        int* f = reinterpret_cast<int*>(rec);
-        const int len = f[1];
-        const int cur_t = len == 1 ? T_USER : f[2 + 3 * (len - 2) + 1];
-        const int rel = acts[((size_t)row * act_dim + idx) * 2], node = acts[((size_t)row * act_dim + idx) * 2 + 1];
-        const int nt = rel == SELF_LOOP ? cur_t : next_type(g, cur_t, rel);
-        f[1] = len + 1;
-        f[2 + 3 * (len - 1)] = rel;
-        f[2 + 3 * (len - 1) + 1] = nt;
-        f[2 + 3 * (len - 1) + 2] = node;
-        i32x4* __restrict__ qv = reinterpret_cast<i32x4*>(paths_out + (size_t)o * PATH_INTS);
-        qv[0] = rec[0], qv[1] = rec[1], qv[2] = rec[2];
-        float* pq = probs_out + (size_t)o * 3;
-        const float* pp = probs + (size_t)row * 3;
-        pq[0] = pp[0], pq[1] = pp[1], pq[2] = pp[2];
-        pq[len - 1] = topk_val[(size_t)row * k + j];
+    // Children of consecutive (row, j) land on consecutive output slots (offsets is the exclusive scan of the child
+    // counts), so the records a wave produces form one contiguous run.  Each lane builds its 48-byte record + 12-byte
+    // probability triple in LDS and the wave then streams the run out as consecutive 16-byte / 4-byte pieces: full cache
+    // lines per store instruction instead of 64 lanes each touching a third of a line three times.
+    __shared__ __attribute__((aligned(16))) int rec_lds[4][64 * PATH_INTS];
+    __shared__ float prob_lds[4][64 * 3];
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int64_t n_iter = (total + 63) / 64;
+    for (int64_t it = (int64_t)blockIdx.x * 4 + w; it < n_iter; it += (int64_t)gridDim.x * 4) {  // wave-uniform trips
+        const int64_t i = it * 64 + lane;
+        bool live = i < total;
+        const int row = live ? (int)(i / k) : 0, j = live ? (int)(i % k) : 0;
+        live = live && j < min(k, n_acts[row]);
+        const int64_t o = live ? (int64_t)offsets[row] + j : 0;
+        live = live && o < cap;
+        const unsigned long long m = __ballot(live);
+        if (m == 0ull) continue;
+        const int slot = __popcll(m & lt_mask);  // position inside the wave's run
+        const int first = __ffsll((long long)m) - 1;
+        const int64_t o0 = __shfl(o, first, 64);  // the run starts at the first live lane's slot
+        const int n_live = __popcll(m);
+        if (live) {
+            const int idx = topk_idx[(size_t)row * k + j];
+            const i32x4* __restrict__ pv = reinterpret_cast<const i32x4*>(paths + (size_t)row * PATH_INTS);
+            i32x4 rec[3] = {pv[0], pv[1], pv[2]};
+            int* f = reinterpret_cast<int*>(rec);
+            const int len = f[1];
+            const int cur_t = len == 1 ? T_USER : f[2 + 3 * (len - 2) + 1];
+            const int rel = acts[((size_t)row * act_dim + idx) * 2], node = acts[((size_t)row * act_dim + idx) * 2 + 1];
+            const int nt = rel == SELF_LOOP ? cur_t : next_type(g, cur_t, rel);
+            f[1] = len + 1;
+            f[2 + 3 * (len - 1)] = rel;
+            f[2 + 3 * (len - 1) + 1] = nt;
+            f[2 + 3 * (len - 1) + 2] = node;
+            i32x4* q = reinterpret_cast<i32x4*>(&rec_lds[w][slot * PATH_INTS]);
+            q[0] = rec[0], q[1] = rec[1], q[2] = rec[2];
+            const float* pp = probs + (size_t)row * 3;
+            float pr[3] = {pp[0], pp[1], pp[2]};
+            pr[len - 1] = topk_val[(size_t)row * k + j];
+            prob_lds[w][slot * 3 + 0] = pr[0], prob_lds[w][slot * 3 + 1] = pr[1], prob_lds[w][slot * 3 + 2] = pr[2];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // live lanes of one trip are consecutive children, but a trip may span two rows whose runs are adjacent as well:
+        // slots o0 .. o0 + n_live - 1
+        i32x4* __restrict__ qo = reinterpret_cast<i32x4*>(paths_out + (size_t)o0 * PATH_INTS);
+        const i32x4* ql = reinterpret_cast<const i32x4*>(&rec_lds[w][0]);
+        for (int c = lane; c < n_live * 3; c += 64) qo[c] = ql[c];
+        float* __restrict__ po = probs_out + (size_t)o0 * 3;
+        for (int c = lane; c < n_live * 3; c += 64) po[c] = prob_lds[w][c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
