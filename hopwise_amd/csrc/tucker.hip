@@ -48,10 +48,19 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
             for (int q = 0; q < nq; ++q) {
                 uint32_t rw[4];
                 philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+                if (4 * q + 3 < d) {  // full quad: the four row loads are issued together (no test between load and use)
+                    float wv[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = 4 * q + k;
-                    if (i < d) acc = fmaf(xb[i], wb[(size_t)i * d + j] * keep_scale(rw[k], drop_p, inv_keep), acc);
+                    for (int k = 0; k < 4; ++k) wv[k] = wb[(size_t)(4 * q + k) * d + j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        acc = fmaf(xb[4 * q + k], wv[k] * keep_scale(rw[k], drop_p, inv_keep), acc);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int i = 4 * q + k;
+                        if (i < d) acc = fmaf(xb[i], wb[(size_t)i * d + j] * keep_scale(rw[k], drop_p, inv_keep), acc);
+                    }
                 }
             }
         } else if constexpr (MODE == 1) {
@@ -89,6 +98,23 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
             uint32_t rw[4] = {0u, 0u, 0u, 0u};
             if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
             const float gj = gob[j];
+            if (4 * q + 3 < d) {  // full quad: loads first, no test between a load and its use
+                float wv[4], mv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    wv[k] = wb[(size_t)(4 * q + k) * d + j];
+                    mv[k] = 1.f;
+                    if constexpr (MODE == 1) mv[k] = mb[(size_t)(4 * q + k) * d + j];
+                    if constexpr (MODE == 2) mv[k] = keep_scale(rw[k], drop_p, inv_keep);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float g = gj * mv[k];
+                    acc[k] = fmaf(g, wv[k], acc[k]);
+                    if (gw) gw[(size_t)b * d * d + (size_t)(4 * q + k) * d + j] = xi[k] * g;
+                }
+                continue;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * q + k;
