@@ -148,7 +148,8 @@ __device__ __forceinline__ float bce_elem(float x, float t, float inv_numel, flo
     const float lp = fmaxf(__logf(p), -100.f), l1p = fmaxf(__logf(1.f - p), -100.f);
     const float pq = (1.f - p) * p;
     *p_out = p;
-    *g_out = __fdividef(p - t, fmaxf(pq, 1e-12f)) * pq * inv_numel;
+    // (p - t) / max(pq, 1e-12) * pq: the quotient and the product cancel unless pq was clamped -- one reciprocal fewer
+    *g_out = (pq >= 1e-12f ? p - t : (p - t) * (pq * 1e12f)) * inv_numel;
     return -(t * lp + (1.f - t) * l1p);
 }
 
