@@ -181,7 +181,13 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
 
     # ------------------------------------------------------------------------------------------------
     def _module(self, relation):
-        return getattr(self.model, relation)
+        # nn.Module.__getattr__ walks three dicts per call and this is asked per program node and per returned path
+        # (~10^5 times per 256-user batch): keep a plain name -> module table
+        tab = self.__dict__.get("_module_table")
+        if tab is None:
+            tab = {name: getattr(self.model, name) for name in self.relation_info}
+            self.__dict__["_module_table"] = tab
+        return tab[relation]
 
     def _excluded_bits(self, users_np, exclude):
         """Bitset [B, words] of the ids excluded at leaves: the user's train positives without the 0 padding for the
@@ -304,7 +310,9 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
     def _bfs_program(self):
         """Nodes of the layout tree in the executor's BFS order (children of a node visited in self.rng.permutation
         order, cafe.py:807-808) as (parent index, relation), plus per-node relation / entity chains for the output."""
-        root = build_layout(self.metapaths)
+        root = self.__dict__.get("_layout_root")  # the tree only depends on the metapaths; the visiting order is drawn per call
+        if root is None:
+            root = self.__dict__["_layout_root"] = build_layout(self.metapaths)
         order, index = [], {}
         queue = [(c, -1) for c in root.get_children()]
         while queue:
