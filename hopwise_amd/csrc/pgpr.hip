@@ -872,9 +872,14 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
         float x[4];
         float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {  // clamped index, select afterwards: the four loads are issued together
             const int j = lane * 4 + i;  // blocked layout: element j of the row
-            x[i] = (j < na && j < act_dim) ? lr[j] : -INFINITY;
+            x[i] = lr[j < act_dim ? j : act_dim - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = lane * 4 + i;
+            x[i] = (j < na && j < act_dim) ? x[i] : -INFINITY;
             mx = fmaxf(mx, x[i]);
         }
 #pragma unroll
