@@ -39,8 +39,10 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(hw_adam_args a, double 
     const float step_size = bias[0], inv_sqrt_bc2 = bias[1];
     // 1 - beta in double first: (float)(1 - 0.999) is what torch's python-side scalars give, 1.f - 0.999f is 5e-5 off
     const float b2 = (float)beta2, omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    const float decay = 1.f - (float)lr * wd;  // AdamW: p *= 1 - lr wd before the step (torch/optim/adamw.py)
     auto upd = [&](float& p, float& g, float& m, float& v) {
-        if (wd != 0.f) g = fmaf(wd, p, g);
+        if (zero_grads & 2) p *= decay;
+        else if (wd != 0.f) g = fmaf(wd, p, g);
         m = fmaf(omb1, g - m, m);
         v = fmaf(omb2 * g, g, b2 * v);
         const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_sqrt_bc2, eps);
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(hw_adam_args a, double 
             P[i] = f32x4{pp[0], pp[1], pp[2], pp[3]};
             M[i] = f32x4{mm[0], mm[1], mm[2], mm[3]};
             V[i] = f32x4{vv[0], vv[1], vv[2], vv[3]};
-            if (zero_grads) G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (zero_grads & 1) G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         return;
     }
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(hw_adam_args a, double 
         sg.p[i] = p;
         sg.m[i] = m;
         sg.v[i] = v;
-        if (zero_grads) sg.g[i] = 0.f;
+        if (zero_grads & 1) sg.g[i] = 0.f;
     }
 }
 
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(hw_adam_args a, double 
 using namespace hw;
 
 extern "C" int hw_adam_step(const hw_adam_args* args, double lr, double beta1, double beta2, double eps,
-                            double weight_decay, int64_t* step, int32_t zero_grads, void* stream) {
+                            double weight_decay, int64_t* step, int32_t flags, void* stream) {
+    const int32_t zero_grads = flags;  // bit 0: clear the gradients; bit 1: decoupled weight decay (AdamW)
     if (!args || !step || args->n_segs < 0 || args->n_segs > HW_ADAM_MAX_SEGS) return HW_ERR_INVALID_ARG;
     if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0)) return HW_ERR_INVALID_ARG;
     int64_t blocks = 0;

@@ -29,12 +29,16 @@ class _SinkState:
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_sinks=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_sinks=True,
+                 decoupled_weight_decay=False):
+        """``decoupled_weight_decay=True`` is torch.optim.AdamW's rule (the reference's ``learner: adamw``,
+        trainer.py:191-192); its default weight_decay there is 1e-2, pass it explicitly."""
         if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
             raise ValueError("FusedAdam: invalid hyper-parameter")
         # capturable: the step counter is a device tensor (what driver.GraphedTrainStep asks of an optimizer)
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, capturable=True))
         self._sinks = _SinkState() if grad_sinks else None
+        self._decoupled = bool(decoupled_weight_decay)
         self._launch_cache = {}
         for group in self.param_groups:
             for p in group["params"]:
@@ -129,7 +133,7 @@ class FusedAdam(torch.optim.Optimizer):
             for args, step in self._launches(group):
                 rc = lib.hw_adam_step(C.byref(args), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                       float(group["weight_decay"]), C.c_void_p(step.data_ptr()),
-                                      1 if self._sinks is not None else 0,
+                                      (1 if self._sinks is not None else 0) | (2 if self._decoupled else 0),
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
                 _lib.check(rc, "hw_adam_step")
         if self._sinks is not None:

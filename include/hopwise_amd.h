@@ -474,7 +474,10 @@ int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const
 /* ---- dense Adam over all tables of a model in one launch (trainer/trainer.py:189-190: optim.Adam(params, lr,
  * weight_decay), the reference's default learner; torch/optim/adam.py update rule, no amsgrad / maximize).
  * *step is a DEVICE counter, incremented by the call (so the launch replays inside a HIP graph); every segment is
- * updated with the incremented value.  zero_grads != 0 also clears each g (stands in for the next zero_grad). */
+ * updated with the incremented value.  flags: HW_ADAM_ZERO_GRADS also clears each g (stands in for the next zero_grad);
+ * HW_ADAM_DECOUPLED_WD applies the weight decay to p directly (optim.AdamW, trainer.py:191-192) instead of to g. */
+#define HW_ADAM_ZERO_GRADS 1
+#define HW_ADAM_DECOUPLED_WD 2
 #define HW_ADAM_MAX_SEGS 16
 typedef struct {
     float* p;  /* parameter */
@@ -488,7 +491,7 @@ typedef struct {
     int32_t n_segs;
 } hw_adam_args;
 int hw_adam_step(const hw_adam_args* args, double lr, double beta1, double beta2, double eps, double weight_decay,
-                 int64_t* step, int32_t zero_grads, void* stream);
+                 int64_t* step, int32_t flags, void* stream);
 
 const char* hw_version(void);
 

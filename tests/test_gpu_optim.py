@@ -41,6 +41,24 @@ def test_fused_adam_matches_torch_adam_on_raw_tensors(wd):
         np.testing.assert_allclose(so["exp_avg_sq"].cpu().numpy(), sr["exp_avg_sq"].cpu().numpy(), rtol=2e-6, atol=3e-7)
 
 
+def test_decoupled_weight_decay_matches_torch_adamw():
+    from hopwise_amd.optim import FusedAdam
+
+    g = torch.Generator().manual_seed(6)
+    a = [torch.randn(s, generator=g).to(dev()).requires_grad_() for s in ((700, 64), (33,))]
+    b = [x.detach().clone().requires_grad_() for x in a]
+    ref = torch.optim.AdamW(a, lr=2e-3, weight_decay=0.05)
+    opt = FusedAdam(b, lr=2e-3, weight_decay=0.05, decoupled_weight_decay=True, grad_sinks=False)
+    for _ in range(4):
+        for x, y in zip(a, b):
+            gr = torch.randn(x.shape, generator=g).to(dev())
+            x.grad, y.grad = gr.clone(), gr.clone()
+        ref.step()
+        opt.step()
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(y.detach().cpu().numpy(), x.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
 def test_more_than_sixteen_tensors_and_gradient_clear():
     from hopwise_amd.optim import FusedAdam
 
