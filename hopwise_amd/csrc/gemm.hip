@@ -252,9 +252,11 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     const int64_t gm = (m_max + BM - 1) / BM, gn = (n + BN - 1) / BN;
     // split-K when the output grid cannot fill the chip and K is long (e.g. dX = dY [2048, 144779] . E [144779, 200])
     int splits = 1;
-    if (workspace && gm * gn < 256 && k >= 64 * BK) {
+    if (workspace && gm * gn < 256 && k >= 16 * BK) {
+        // also the short-K, few-row products of a beam search's first hops: a lone tile walks its K / 16 steps at one
+        // load latency each (75 us for [64, 512] x [256, 512]^T), so the chain is cut into splits of >= 4 steps
         int64_t want = (768 + gm * gn - 1) / (gm * gn);
-        const int64_t kmax = k / (8 * BK);
+        const int64_t kmax = k >= 64 * BK ? k / (8 * BK) : k / (4 * BK);
         if (want > kmax) want = kmax;
         const int64_t fit = workspace_floats / (m_max * n);
         if (want > fit) want = fit;

@@ -134,10 +134,29 @@ def state(graph, U32, E32, R32, state_history, paths, n_rows, max_rows, out):
     )
 
 
+_GEMM_WS = {}
+
+
 def mlp_layer(a, w, bias, out, m_rows, m_max, elu, drop_mask=None, drop_mode=0, seed=0, offset=0):
     """out[:m, :n] = f(a[:m, :k] @ w.T + bias); a / out may be wider than k / n (leading dimension = stride(0))."""
     lib = _lib.load()
     n, k = w.shape
+    tiles = ((int(m_max) + 127) // 128) * ((n + 127) // 128)
+    if tiles < 256 and k >= 256:
+        # few rows (the first hops of a beam search): give the GEMM split-K room, or a lone tile walks K at one load
+        # latency per 16-deep step
+        splits = min(max(768 // tiles, 2), k // 64)
+        key = (a.device, splits * int(m_max) * n)
+        ws = _GEMM_WS.get(key)
+        if ws is None:
+            ws = _GEMM_WS[key] = torch.empty(key[1], dtype=torch.float32, device=a.device)
+        check(
+            lib.hw_gemm_f32(_ptr(a), a.stride(0), 1, _ptr(w), k, 1, _ptr(out), out.stride(0), _ptr(m_rows), int(m_max), n, k,
+                            _ptr(bias), int(bool(elu)), _ptr(drop_mask), int(drop_mode), C.c_uint64(seed),
+                            C.c_uint64(offset), _ptr(ws), ws.numel(), _stream()),
+            "hw_gemm_f32",
+        )
+        return
     check(
         lib.hw_mlp_layer(_ptr(a), a.stride(0), _ptr(w), _ptr(bias), _ptr(out), out.stride(0), _ptr(m_rows), int(m_max),
                          n, k, int(bool(elu)), _ptr(drop_mask), int(drop_mode), C.c_uint64(seed), C.c_uint64(offset),
