@@ -767,13 +767,17 @@ __global__ __launch_bounds__(256) void pgpr_layer1_lookup_kernel(L1Tables t, con
             for (int q = 0; q < 6; ++q)
                 if (src[q]) acc += *reinterpret_cast<const f32x4*>(src[q] + c);
             float v[4] = {acc.x, acc.y, acc.z, acc.w};
+            // row * H + c is a multiple of 4 (H % 4 == 0, c = 4 * lane + 256 * trip): the four dropout bits of this chunk
+            // are the four words of ONE Philox block (the compiler cannot see that and would evaluate it four times)
+            uint32_t pw[4] = {0u, 0u, 0u, 0u};
+            if (drop_mode == 2) philox_bits4(seed, offset, ((uint64_t)row * H + c) >> 2, pw);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float x = v[k];
                 x = x > 0.f ? x : expm1f(x);
                 const uint64_t idx = (uint64_t)row * H + c + k;
                 if (drop_mode == 1) x *= drop_mask[idx];
-                else if (drop_mode == 2) x = (philox_bits(seed, offset, idx) & 1u) ? x * 2.f : 0.f;
+                else if (drop_mode == 2) x = (pw[k] & 1u) ? x * 2.f : 0.f;
                 v[k] = x;
             }
             *reinterpret_cast<f32x4*>(out + (size_t)row * ld + c) = f32x4{v[0], v[1], v[2], v[3]};
