@@ -203,6 +203,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
         for (int tj = 0; tj < 2; ++tj) {
             const int gn = n0 + wn + tj * 32 + (lane & 31);
             const float bv = (bias && gn < N) ? bias[gn] : 0.f;
+            // Philox dropout: the four lanes of a quad hold four consecutive columns of one row, i.e. the four words of ONE
+            // Philox block when N % 4 == 0.  Quad lane q evaluates the block of row (rg & 3) == q once and the keep bits
+            // travel by DPP quad broadcast: one evaluation per four elements instead of four.
+            const bool quad_drop = drop_mode == 2 && !partial && (N & 3) == 0;
+            unsigned keep16 = 0u;  // bit rg: keep element rg of this lane
+            if (quad_drop) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int gmq = m0 + wm + ti * 32 + (lane & 3) + 8 * r4 + 4 * (lane >> 5);
+                    uint32_t w[4];
+                    philox_bits4(seed, offset, ((uint64_t)gmq * N + (gn & ~3)) >> 2, w);
+                    const int nib = (int)((w[0] & 1u) | ((w[1] & 1u) << 1) | ((w[2] & 1u) << 2) | ((w[3] & 1u) << 3));
+                    const int b0 = __builtin_amdgcn_update_dpp(0, nib, 0x00, 0xF, 0xF, true);  // quad_perm: lane 0's
+                    const int b1 = __builtin_amdgcn_update_dpp(0, nib, 0x55, 0xF, 0xF, true);  // lane 1's
+                    const int b2 = __builtin_amdgcn_update_dpp(0, nib, 0xAA, 0xF, 0xF, true);
+                    const int b3 = __builtin_amdgcn_update_dpp(0, nib, 0xFF, 0xF, 0xF, true);
+                    const int sh = lane & 3;
+                    keep16 |= (unsigned)((b0 >> sh) & 1) << (4 * r4 + 0);
+                    keep16 |= (unsigned)((b1 >> sh) & 1) << (4 * r4 + 1);
+                    keep16 |= (unsigned)((b2 >> sh) & 1) << (4 * r4 + 2);
+                    keep16 |= (unsigned)((b3 >> sh) & 1) << (4 * r4 + 3);
+                }
+            }
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
                 const int gm = m0 + wm + ti * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
@@ -213,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                     if (ACT == 1) v = v > 0.f ? v : expm1f(v);
                     if (ACT == 2) v = fmaxf(v, 0.f);
                     if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
+                    else if (quad_drop) v = ((keep16 >> rg) & 1u) ? v * 2.f : 0.f;
                     else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
                     C[(size_t)gm * ldc + gn] = v;
                 }

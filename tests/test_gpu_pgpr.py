@@ -350,6 +350,27 @@ def test_gemm_pipelined_loop_on_padded_operands():
             np.testing.assert_allclose(out.cpu().numpy(), ref, err_msg=f"{M}x{K}x{N} {akc} {bkc}", **tol)
 
 
+@pytest.mark.parametrize("N", [256, 252, 251, 40])
+def test_philox_dropout_masks_of_the_policy_layers(N):
+    """The keep-1/2 masks drawn inside the GEMM epilogue (quad-shared Philox blocks when N % 4 == 0, one evaluation per
+    element otherwise), the split-K reduction and the first-layer lookup follow hw_common.h:philox_bits word for word."""
+    from hopwise_amd import pgpr_ops as P
+    from oracle.philox import philox_words
+
+    rng = np.random.default_rng(N)
+    seed, offset = 0x1234567890ABCDEF, 77
+    for M, K in ((300, 64), (130, 512)):  # the second shape takes the split-K path
+        a = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev())
+        w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(dev())
+        b = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(dev())
+        plain = torch.empty((M, N), device=dev())
+        drop = torch.empty((M, N), device=dev())
+        P.mlp_layer(a, w, b, plain, None, M, True)
+        P.mlp_layer(a, w, b, drop, None, M, True, None, 2, seed, offset)
+        keep = (philox_words(seed, offset, np.arange(M * N, dtype=np.uint64)) & 1).reshape(M, N).astype(np.float32)
+        np.testing.assert_array_equal(drop.cpu().numpy(), plain.cpu().numpy() * (2.0 * keep))
+
+
 def test_policy_topk_sort_edge_cases():
     """Saturated rows (one probability rounds p + 1 to 2.0), equal logits (index-ascending ties), single action."""
     from hopwise_amd import pgpr_ops as P
