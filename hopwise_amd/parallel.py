@@ -111,6 +111,12 @@ class _ShardedLookup(torch.autograd.Function):
             recv = g_sorted
         outs = []
         for s, part in zip(shards, recv.split(ctx.d_each, dim=1)):
+            sink = ops._live_sink(s) if not torch.is_grad_enabled() else None
+            if sink is not None:  # optim.FusedAdam's persistent .grad: add the rows there, nothing for autograd to add
+                _scatter_add_(sink[0], plan.recv_local, part.contiguous())
+                sink[1].dirty = True
+                outs.append(None)
+                continue
             gs = torch.zeros_like(s)
             _scatter_add_(gs, plan.recv_local, part.contiguous())
             outs.append(gs)

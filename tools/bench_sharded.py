@@ -41,7 +41,13 @@ D = 256
 torch.manual_seed(0)  # same full tables on every rank before sharding
 model = ComplEx(make_config(dev, D, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
 sharded = parallel.RowShardedKGE(model).to(dev)
-opt = torch.optim.Adam(sharded.parameters(), lr=1e-3, fused=bool(int(os.environ.get("HW_FUSED_ADAM", "1"))))
+if os.environ.get("HW_OPTIM", "hw") == "hw":  # hopwise_amd.optim.FusedAdam: one launch, gradient clear folded in
+    from hopwise_amd.optim import FusedAdam
+
+    # the sharded lookup scatters the returned row gradients straight into the persistent .grad shards
+    opt = FusedAdam(sharded.parameters(), lr=1e-3, grad_sinks=bool(int(os.environ.get("HW_SINKS", "1"))))
+else:
+    opt = torch.optim.Adam(sharded.parameters(), lr=1e-3, fused=bool(int(os.environ.get("HW_FUSED_ADAM", "1"))))
 rng = np.random.default_rng(100 + rank)
 B = a.batch
 
