@@ -175,3 +175,36 @@ def test_cpu_parameters_are_refused():
 
     with pytest.raises(_lib.HopwiseAmdError):
         FusedAdam([torch.zeros(4, requires_grad=True)])
+
+
+def test_entry_points_reject_bad_arguments():
+    """Status codes instead of launches for malformed calls of the entry points added with the optimizer work
+    (include/hopwise_amd.h: returns 0 or a negative hw_status, never throws)."""
+    import ctypes as C
+
+    from hopwise_amd import _lib
+
+    lib = _lib.load()
+    x = torch.zeros(64, device=dev())
+    step = torch.zeros((), dtype=torch.int64, device=dev())
+    args = _lib.AdamArgs()
+    args.n_segs = _lib.ADAM_MAX_SEGS + 1
+    null = C.c_void_p(0)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.hw_adam_step(C.byref(args), 1e-3, 0.9, 0.999, 1e-8, 0.0, C.c_void_p(step.data_ptr()), 1, stream) == -1
+    args.n_segs = 1
+    args.seg[0].p, args.seg[0].n = x.data_ptr(), 64  # g / m / v missing
+    assert lib.hw_adam_step(C.byref(args), 1e-3, 0.9, 0.999, 1e-8, 0.0, C.c_void_p(step.data_ptr()), 1, stream) == -1
+    args.seg[0].g = args.seg[0].m = args.seg[0].v = x.data_ptr()
+    assert lib.hw_adam_step(C.byref(args), 1e-3, 1.0, 0.999, 1e-8, 0.0, C.c_void_p(step.data_ptr()), 1, stream) == -1  # beta1
+    assert lib.hw_adam_step(C.byref(args), 1e-3, 0.9, 0.999, 1e-8, 0.0, null, 1, stream) == -1  # no step counter
+    assert int(step) == 0
+    ws = torch.zeros(int(lib.hw_loss_workspace_floats()), device=dev())
+    loss = torch.zeros(1, device=dev())
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.hw_loss_bce_logits_weighted(p(x), 64, 65, 2.0, p(loss), null, p(ws), stream) == -1  # n_pos > n
+    assert lib.hw_loss_bce_logits_weighted(p(x), 64, 8, 0.0, p(loss), null, p(ws), stream) == -1  # weight <= 0
+    tws = torch.zeros(int(lib.hw_tucker_bce_workspace_floats()), device=dev())
+    assert lib.hw_tucker_sigmoid_bce_ld(p(x), 4, 8, 8, null, 1.0, 0.0, p(loss), null, null, p(tws), stream) == -1  # ld < cols
+    assert lib.hw_pgpr_actions_workspace_ints(10) == 34 and lib.hw_pgpr_actions_workspace_ints(-1) == 0
+    torch.cuda.synchronize()
