@@ -133,7 +133,7 @@ def test_graphed_step_with_fused_adam_matches_eager_torch_adam():
         loss = sum(loss) if isinstance(loss, tuple) else loss
         loss.backward()
         o1.step()
-        ref_losses.append(float(loss))
+        ref_losses.append(float(loss.detach()))
     o2 = FusedAdam(m2.parameters(), lr=1e-2)
     step = GraphedTrainStep(m2, o2, bs[0])
     # the capture itself executes nothing; replays follow
