@@ -130,8 +130,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
                 const unsigned long long m = __ballot(f);
                 const int pos = 1 + running + __popcll(m & lt_mask);
                 if (f && pos <= max_acts) {
-                    arow[2 * pos] = rr[u];
-                    arow[2 * pos + 1] = nn[u];
+                    *reinterpret_cast<int2*>(&arow[2 * pos]) = make_int2(rr[u], nn[u]);  // (relation, dst): one 8-byte store
                 }
                 running += __popcll(m);
             }
@@ -232,8 +231,7 @@ __device__ __forceinline__ void trim_row_in_registers(const hw_pgpr_graph& g, co
         const unsigned long long kb = __ballot(keep);
         if (keep) {
             const int pos = 1 + run_keep + __popcll(kb & lt_mask);
-            arow[2 * pos] = r;
-            arow[2 * pos + 1] = n;
+            *reinterpret_cast<int2*>(&arow[2 * pos]) = make_int2(r, n);
         }
         run_keep += __popcll(kb);
         run_tie += __popcll(tb);
@@ -375,8 +373,7 @@ __device__ __forceinline__ void trim_row_in_block(const hw_pgpr_graph& g, const 
         const int before = step_prefix(sh_slot[1], i, run_k);
         if (keep) {
             const int pos = 1 + before + __popcll(kb & lt_mask);
-            arow[2 * pos] = r;
-            arow[2 * pos + 1] = n;
+            *reinterpret_cast<int2*>(&arow[2 * pos]) = make_int2(r, n);
         }
     }
 }
@@ -1064,7 +1061,8 @@ __global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const
             int* f = reinterpret_cast<int*>(rec);
             const int len = f[1];
             const int cur_t = len == 1 ? T_USER : f[2 + 3 * (len - 2) + 1];
-            const int rel = acts[((size_t)row * act_dim + idx) * 2], node = acts[((size_t)row * act_dim + idx) * 2 + 1];
+            const int2 act = *reinterpret_cast<const int2*>(&acts[((size_t)row * act_dim + idx) * 2]);
+            const int rel = act.x, node = act.y;
             const int nt = rel == SELF_LOOP ? cur_t : next_type(g, cur_t, rel);
             f[1] = len + 1;
             f[2 + 3 * (len - 1)] = rel;
