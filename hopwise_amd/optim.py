@@ -134,7 +134,7 @@ class FusedAdam(torch.optim.Optimizer):
                 rc = lib.hw_adam_step(C.byref(args), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                       float(group["weight_decay"]), C.c_void_p(step.data_ptr()),
                                       (1 if self._sinks is not None else 0) | (2 if self._decoupled else 0),
-                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                      ops._stream())
                 _lib.check(rc, "hw_adam_step")
         if self._sinks is not None:
             self._sinks.dirty = False

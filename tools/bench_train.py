@@ -26,7 +26,12 @@ for name, d, K, big in (("TransE", 64, 1, 1), ("RotatE", 200, 256, 1), ("DistMul
     cfg = make_config(dev, d, 1.0, train_neg_sample_args={"sample_num": K})
     torch.manual_seed(0)
     m = getattr(M, name)(cfg, FakeDataset(nU, nI, nE, nR)).to(dev)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    if os.environ.get("HW_OPTIM", "hw") == "hw":  # the engine's one-launch Adam with gradient sinks; "torch": torch.optim.Adam
+        from hopwise_amd.optim import FusedAdam
+
+        opt = FusedAdam(m.parameters(), lr=1e-3)
+    else:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
     B = 2048 * big
     P = B // K
     users, pos = rng.integers(1, nU, P), rng.integers(1, nI, P)
