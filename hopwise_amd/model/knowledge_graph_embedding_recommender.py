@@ -77,6 +77,8 @@ class _GatherKGE(KnowledgeRecommender):
         # sample_num > 1: trust the dataloader's tile order (row j*P + i = j-th negative of positive i); set False for
         # hand-made batches that repeat positives in another order
         self.rec_tiled_layout = bool(_cfg(config, "rec_tiled_layout", True))
+        # calculate_loss as one autograd node (ops.FusedPairLoss); False keeps the per-op graph (scorer nodes + loss nodes)
+        self.fused_loss = bool(_cfg(config, "fused_loss", True))
         self.apply(xavier_normal_initialization)
 
     def REL_ROW_FACTOR(self):
@@ -120,6 +122,34 @@ class _GatherKGE(KnowledgeRecommender):
         kg = self._score("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
                          self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]), eps, True, m)
         return rec.t(), kg.t()
+
+    def _fused_pair_loss(self, interaction, kind, eps=0.0, scale=1.0, group_rec=False):
+        """The reference's calculate_loss as one autograd node (ops.FusedPairLoss): rec side (user, [UI-Relation], item /
+        neg item) + kg side (head, relation, tail / neg tail).  ``group_rec``: the rec batch tiles each positive
+        sample_num times (abstract_dataloader.py:192-198); score it as [P, 1 + K] groups, positives weighted K."""
+        params, pos = [], {}
+
+        def at(t):
+            if id(t) not in pos:
+                pos[id(t)] = len(params)
+                params.append(t)
+            return pos[id(t)]
+
+        def side(name, h_idx, r_idx, r_fixed, t_idx, pos_weight=1.0):
+            head, rel, tail = self._tables(name)
+            tail_rows = self.n_items if (name == "rec" and self._narrow_rec_tails) else None
+            return ops.PairSide([at(t) for t in head], [at(t) for t in rel], [at(t) for t in tail], h_idx, r_idx, r_fixed,
+                                t_idx, tail_rows, pos_weight)
+
+        if group_rec:
+            users, tails = self._rec_grouped_from_tiled(interaction)
+            rec = side("rec", users, None, self._rec_rel_loss(), tails, float(self.sample_num))
+        else:
+            rec = side("rec", interaction[self.USER_ID], None, self._rec_rel_loss(),
+                       self._pair(interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]))
+        kg = side("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
+                  self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]))
+        return ops.fused_pair_loss(self.LOSS_MODEL or self.MODEL, kind, self.margin, eps, scale, [rec, kg], params)
 
     # -- reference API ------------------------------------------------------------------------------
     def forward(self, *rows):
@@ -190,6 +220,8 @@ class TransE(_GatherKGE):
     def calculate_loss(self, interaction):
         # TripletMarginLoss(margin, p=2) on (h + r, t+, t-) over cat(rec, kg) (transe.py:86-96); its
         # distance is ||a - b + 1e-6||, so the loss path scores with eps = 1e-6.
+        if self.fused_loss:
+            return self._fused_pair_loss(interaction, "margin", eps=ops.PAIRWISE_EPS)
         rec, kg = self._pair_scores(interaction, eps=ops.PAIRWISE_EPS)
         pos = torch.cat([rec[0], kg[0]])
         neg = torch.cat([rec[1], kg[1]])
@@ -208,6 +240,8 @@ class DistMult(_GatherKGE):
     _rec_rel_full_sort = _rec_rel_loss
 
     def calculate_loss(self, interaction):  # distmult.py:69-95
+        if self.fused_loss:
+            return self._fused_pair_loss(interaction, "margin")
         rec, kg = self._pair_scores(interaction)
         pos = torch.cat([rec[0], kg[0]])
         neg = torch.cat([rec[1], kg[1]])
@@ -237,7 +271,10 @@ class _BceKGE(_GatherKGE):
                              0.0, True).t()
             return rec_loss + ops.bce_logits_mean(kg, kg.shape[1])
         K = self.sample_num
-        if K > 1 and self.rec_tiled_layout and interaction[self.USER_ID].shape[0] % K == 0:
+        grouped = K > 1 and self.rec_tiled_layout and interaction[self.USER_ID].shape[0] % K == 0
+        if self.fused_loss:
+            return self._fused_pair_loss(interaction, "bce", group_rec=grouped)
+        if grouped:
             # The batch tiles each of its P positives K times (abstract_dataloader.py:192-198), so 2 P K rows hold only
             # P distinct positive scores: score every (user, positive) once in a [P, 1+K] group and give it weight K in
             # the mean.  Same loss value; the gradient kernel sees P groups instead of K-fold repeated rows hammering the
@@ -355,6 +392,8 @@ class Analogy(_GatherKGE):
     def calculate_loss(self, interaction):
         # LogisticLoss(-pos, -neg) = mean softplus(-pos) + mean softplus(neg) (loss.py:172-190): twice the BCE-with-logits
         # mean over cat(pos, neg) with labels (1, 0); rec and kg separately (analogy.py:196-198)
+        if self.fused_loss:
+            return self._fused_pair_loss(interaction, "bce", scale=2.0)
         rec, kg = self._pair_scores(interaction)
         return 2.0 * (ops.bce_logits_mean(rec, rec.shape[1]) + ops.bce_logits_mean(kg, kg.shape[1]))
 
@@ -366,6 +405,8 @@ class HolE(TransE):
     MODEL = "HolE"
 
     def calculate_loss(self, interaction):
+        if self.fused_loss:
+            return self._fused_pair_loss(interaction, "margin_sigmoid")
         rec, kg = self._pair_scores(interaction)
         pos = torch.cat([rec[0], kg[0]])
         neg = torch.cat([rec[1], kg[1]])

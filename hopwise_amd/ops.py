@@ -262,6 +262,151 @@ class KgeScoreGrouped(torch.autograd.Function):
         return (None,) * 9 + tuple(grads_out)
 
 
+class PairSide:
+    """One side (rec or kg) of a pairwise training loss: positions of its head / relation / tail tables in the parameter
+    list handed to :class:`FusedPairLoss`, and its ids (``t_idx`` [B, G], column 0 the positive)."""
+
+    __slots__ = ("head", "rel", "tail", "h_idx", "r_idx", "r_fixed", "t_idx", "tail_rows", "pos_weight")
+
+    def __init__(self, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, tail_rows=None, pos_weight=1.0):
+        self.head, self.rel, self.tail = tuple(head), tuple(rel), tuple(tail)
+        self.h_idx, self.r_idx, self.r_fixed, self.t_idx = h_idx, r_idx, int(r_fixed), t_idx
+        self.tail_rows, self.pos_weight = tail_rows, float(pos_weight)
+
+
+def _grad_slots(desc_tables, needs, bufs, grads_out_by_pos, positions):
+    """Fill a KgeGrads for one launch: every table that needs a gradient gets a buffer -- the parameter's own .grad when
+    optim.FusedAdam registered it as a sink, a zero-filled temporary otherwise -- shared between slots and sides that
+    use the same parameter (``bufs`` is keyed by storage pointer, ``grads_out_by_pos`` by parameter position)."""
+    gs = KgeGrads()
+    for slot, tabs, pos in zip(("head", "rel", "tail"), desc_tables, positions):
+        arr = getattr(gs, slot)
+        for i in range(_lib.MAX_TABLES):
+            arr[i] = None
+        for i, (t, p) in enumerate(zip(tabs, pos)):
+            if not needs[p]:
+                continue
+            key = t.data_ptr()
+            if key not in bufs:
+                sink = _live_sink(t) if not torch.is_grad_enabled() else None
+                if sink is not None:
+                    bufs[key] = sink[0]
+                    sink[1].dirty = True
+                else:
+                    bufs[key] = torch.zeros_like(t)
+                    grads_out_by_pos[p] = bufs[key]
+            arr[i] = bufs[key].data_ptr()
+    return gs
+
+
+class FusedPairLoss(torch.autograd.Function):
+    """calculate_loss of the pairwise gather models as ONE autograd node: both sides' scorers write into the loss
+    kernel's input buffer (no cat / stack), the loss kernel leaves dLoss/dscore next to the loss, and the backward is the
+    two gradient launches.  The per-op graph (two scorer nodes, views, one or two loss nodes, an add) costs ~0.25 ms of
+    host time per step under an eager trainer loop, several times the device time of the step.
+
+    kind: "bce" -- sum over the sides of BCEWithLogits(mean) over [positives; negatives] (rotate.py:118-131,
+    complex.py:115-128, analogy.py:196-198 with scale = 2), a side's positives weighted ``pos_weight`` (tiled batches
+    scored as groups); "margin" / "margin_sigmoid" -- MarginRankingLoss over the concatenated sides (transe.py:86-96
+    with eps, distmult.py:86-93, rescal.py:73-99, hole.py:100-104), pairs only."""
+
+    @staticmethod
+    def forward(ctx, model, kind, margin, eps, scale, sides, *params):
+        lib = _lib.load()
+        dev = params[0].device
+        st = _stream()
+        oob = _ptr(_OobCounter.get(dev))
+        ctx.model, ctx.kind, ctx.margin, ctx.eps, ctx.scale, ctx.sides = model, kind, margin, eps, scale, sides
+        need_g = any(ctx.needs_input_grad[6:])
+        idx = []
+        for s in sides:
+            h = _idx(s.h_idx, "h_idx").contiguous()
+            r = None if s.r_idx is None else _idx(s.r_idx, "r_idx").contiguous()
+            t = _idx(s.t_idx, "t_idx")
+            if t.dim() != 2 or t.shape[0] != h.shape[0]:
+                raise ValueError("t_idx must be [n_groups, n_tail_per_group]")
+            idx.append((h, r, t))
+        descs = [make_desc(model, [params[i] for i in s.head], [params[i] for i in s.rel], [params[i] for i in s.tail],
+                           margin, eps, s.tail_rows) for s in sides]
+        ws = _workspace(dev)
+        gbufs = []
+        if kind == "bce":
+            losses = torch.empty(len(sides), dtype=torch.float32, device=dev)
+            for k, (s, d, (h, r, t)) in enumerate(zip(sides, descs, idx)):
+                B, G = t.shape
+                buf = torch.empty((G, B), dtype=torch.float32, device=dev)  # j-major: the B positives first
+                check(lib.hw_kge_score_grouped(C.byref(d), _ptr(h), _ptr(r), s.r_fixed, _ptr(t), t.stride(0), t.stride(1),
+                                               B, G, _ptr(buf), 1, B, oob, st), "hw_kge_score_grouped")
+                g = torch.empty_like(buf) if need_g else None
+                check(lib.hw_loss_bce_logits_weighted(_ptr(buf), G * B, B, s.pos_weight,
+                                                      C.c_void_p(losses.data_ptr() + 4 * k), _ptr(g), _ptr(ws), st),
+                      "hw_loss_bce_logits_weighted")
+                gbufs.append(g)
+            loss = losses.sum() if len(sides) > 1 else losses[0]
+        else:
+            if any(t.shape[1] != 2 for _, _, t in idx):
+                raise ValueError("margin losses take (positive, negative) pairs")
+            n_tot = sum(t.shape[0] for _, _, t in idx)
+            buf = torch.empty((2, n_tot), dtype=torch.float32, device=dev)
+            off = 0
+            for s, d, (h, r, t) in zip(sides, descs, idx):
+                B = t.shape[0]
+                check(lib.hw_kge_score_grouped(C.byref(d), _ptr(h), _ptr(r), s.r_fixed, _ptr(t), t.stride(0), t.stride(1),
+                                               B, 2, C.c_void_p(buf.data_ptr() + 4 * off), 1, n_tot, oob, st),
+                      "hw_kge_score_grouped")
+                off += B
+            g = torch.empty_like(buf) if need_g else None
+            losses = torch.empty(1, dtype=torch.float32, device=dev)
+            fn = lib.hw_loss_margin_ranking_sigmoid if kind == "margin_sigmoid" else lib.hw_loss_margin_ranking
+            check(fn(_ptr(buf[0]), _ptr(buf[1]), n_tot, float(margin), _ptr(losses), _ptr(g[0]) if need_g else None,
+                     _ptr(g[1]) if need_g else None, _ptr(ws), st), "hw_loss_margin_ranking")
+            gbufs.append(g)
+            loss = losses[0]
+        ctx.n_idx = [(h, r, t) for h, r, t in idx]
+        ctx.save_for_backward(*params, *[x for x in gbufs if x is not None])
+        ctx.n_params = len(params)
+        if scale != 1.0:
+            loss = loss * scale
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_up):
+        lib = _lib.load()
+        saved = ctx.saved_tensors
+        params, gbufs = saved[: ctx.n_params], saved[ctx.n_params :]
+        needs = ctx.needs_input_grad[6:]
+        st = _stream()
+        coef = g_up * ctx.scale if ctx.scale != 1.0 else g_up
+        bufs, out_by_pos = {}, {}
+        off = 0
+        n_tot = gbufs[0].shape[1] if ctx.kind != "bce" else 0
+        for k, (s, (h, r, t)) in enumerate(zip(ctx.sides, ctx.n_idx)):
+            head, rel, tail = [params[i] for i in s.head], [params[i] for i in s.rel], [params[i] for i in s.tail]
+            desc = make_desc(ctx.model, head, rel, tail, ctx.margin, ctx.eps, s.tail_rows)
+            gs = _grad_slots((head, rel, tail), needs, bufs, out_by_pos, (s.head, s.rel, s.tail))
+            B, G = t.shape
+            if ctx.kind == "bce":
+                gk = gbufs[k] * coef  # [G, B]
+                gptr, gsb, gsj = gk.data_ptr(), 1, B
+            else:
+                if k == 0:
+                    gall = gbufs[0] * coef  # [2, n_tot]
+                gptr, gsb, gsj = gall.data_ptr() + 4 * off, 1, n_tot
+                off += B
+            rel_ws = None
+            n_ws = int(lib.hw_kge_grad_grouped_workspace_floats(C.byref(desc), B, G, 1 if r is None else 0))
+            if n_ws > 0:
+                rel_ws = torch.empty(n_ws, dtype=torch.float32, device=t.device)
+            check(lib.hw_kge_grad_grouped(C.byref(desc), C.byref(gs), _ptr(h), _ptr(r), s.r_fixed, _ptr(t), t.stride(0),
+                                          t.stride(1), B, G, C.c_void_p(gptr), gsb, gsj, _ptr(rel_ws), st),
+                  "hw_kge_grad_grouped")
+        return (None,) * 6 + tuple(out_by_pos.get(p) for p in range(ctx.n_params))
+
+
+def fused_pair_loss(model, kind, margin, eps, scale, sides, params):
+    return FusedPairLoss.apply(model, kind, float(margin), float(eps), float(scale), sides, *params)
+
+
 def kge_score_grouped(model, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, margin=0.0, eps=0.0, j_major_out=False,
                       tail_rows=None):
     return KgeScoreGrouped.apply(model, float(margin), float(eps), h_idx, r_idx, int(r_fixed), t_idx, j_major_out,

@@ -433,6 +433,46 @@ def test_tiled_rec_batch_scored_as_groups_equals_row_by_row(model):
         np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale, err_msg=k)
 
 
+@pytest.mark.parametrize("model", ["TransE", "DistMult", "RESCAL", "RotatE", "ComplEx", "TorusE", "TransH", "TransD",
+                                   "Analogy", "HolE"])
+@pytest.mark.parametrize("K", [1, 4])
+def test_fused_loss_node_equals_the_per_op_graph(model, K):
+    """calculate_loss as one autograd node (ops.FusedPairLoss, the default) against the per-op graph it replaces (scorer
+    nodes, stack / cat, loss nodes): same loss, same gradients, for every pairwise gather model, pair and tiled batches."""
+    import copy
+
+    import hopwise_amd.model as M
+    from tests.helpers import FakeDataset, make_config
+
+    if K > 1 and model not in ("RotatE", "ComplEx"):
+        pytest.skip("only the BCE models regroup tiled batches")
+    nU, nI, nE, nR, d, P = 50, 30, 80, 5, 16, 9
+    torch.manual_seed(21)
+    cfg = make_config(dev(), d, 2.0, train_neg_sample_args={"sample_num": K})
+    m1 = getattr(M, model)(cfg, FakeDataset(nU, nI, nE, nR)).to(dev())
+    m2 = copy.deepcopy(m1)
+    m2.fused_loss = False
+    assert m1.fused_loss
+    rng = np.random.default_rng(4)
+    B = P * K
+    users, pos = rng.integers(1, nU, P), rng.integers(1, nI, P)
+    inter = to_dev(dict(
+        user_id=np.tile(users, K), item_id=np.tile(pos, K), neg_item_id=rng.integers(1, nI, B),
+        head_id=rng.integers(1, nE, B), relation_id=rng.integers(1, nR - 1, B), tail_id=rng.integers(1, nE, B),
+        neg_tail_id=rng.integers(1, nE, B)))
+    l1, l2 = m1.calculate_loss(inter), m2.calculate_loss(inter)
+    (3.0 * l1).backward()  # an upstream factor other than 1
+    (3.0 * l2).backward()
+    np.testing.assert_allclose(l1.item(), l2.item(), rtol=2e-6)
+    for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p2.grad is None:
+            assert p1.grad is None or float(p1.grad.abs().max()) == 0.0, k
+            continue
+        scale = p2.grad.abs().max().item()
+        np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=2e-4, atol=2e-6 * scale + 1e-12,
+                                   err_msg=k)
+
+
 @pytest.mark.parametrize("fixed_rel", [False, True])
 @pytest.mark.parametrize("dim", [24, 72])
 def test_rescal_grouped_grads_with_split_tasks(dim, fixed_rel):
