@@ -262,6 +262,9 @@ class KgeScoreGrouped(torch.autograd.Function):
         return (None,) * 9 + tuple(grads_out)
 
 
+_GRAD_WS_FLOATS = {}  # (model, dim, groups, tails, fixed relation) -> hw_kge_grad_grouped_workspace_floats
+
+
 class PairSide:
     """One side (rec or kg) of a pairwise training loss: positions of its head / relation / tail tables in the parameter
     list handed to :class:`FusedPairLoss`, and its ids (``t_idx`` [B, G], column 0 the positive)."""
@@ -363,6 +366,7 @@ class FusedPairLoss(torch.autograd.Function):
             gbufs.append(g)
             loss = losses[0]
         ctx.n_idx = [(h, r, t) for h, r, t in idx]
+        ctx.descs = descs  # raw table pointers: valid as long as the saved parameters are
         ctx.save_for_backward(*params, *[x for x in gbufs if x is not None])
         ctx.n_params = len(params)
         if scale != 1.0:
@@ -382,7 +386,7 @@ class FusedPairLoss(torch.autograd.Function):
         n_tot = gbufs[0].shape[1] if ctx.kind != "bce" else 0
         for k, (s, (h, r, t)) in enumerate(zip(ctx.sides, ctx.n_idx)):
             head, rel, tail = [params[i] for i in s.head], [params[i] for i in s.rel], [params[i] for i in s.tail]
-            desc = make_desc(ctx.model, head, rel, tail, ctx.margin, ctx.eps, s.tail_rows)
+            desc = ctx.descs[k]
             gs = _grad_slots((head, rel, tail), needs, bufs, out_by_pos, (s.head, s.rel, s.tail))
             B, G = t.shape
             if ctx.kind == "bce":
@@ -394,7 +398,11 @@ class FusedPairLoss(torch.autograd.Function):
                 gptr, gsb, gsj = gall.data_ptr() + 4 * off, 1, n_tot
                 off += B
             rel_ws = None
-            n_ws = int(lib.hw_kge_grad_grouped_workspace_floats(C.byref(desc), B, G, 1 if r is None else 0))
+            wkey = (ctx.model, desc.dim, B, G, r is None)
+            n_ws = _GRAD_WS_FLOATS.get(wkey)
+            if n_ws is None:
+                n_ws = _GRAD_WS_FLOATS[wkey] = int(
+                    lib.hw_kge_grad_grouped_workspace_floats(C.byref(desc), B, G, 1 if r is None else 0))
             if n_ws > 0:
                 rel_ws = torch.empty(n_ws, dtype=torch.float32, device=t.device)
             check(lib.hw_kge_grad_grouped(C.byref(desc), C.byref(gs), _ptr(h), _ptr(r), s.r_fixed, _ptr(t), t.stride(0),
@@ -486,9 +494,14 @@ def project_rows(mats, table, r_idx, r_fixed, e_idx):
 # ------------------------------------------------------------------------------------------------
 # losses
 # ------------------------------------------------------------------------------------------------
+_LOSS_WS_FLOATS = None
+
+
 def _workspace(device, extra=0):
-    n = int(_lib.load().hw_loss_workspace_floats()) + int(extra)
-    return torch.empty(n, dtype=torch.float32, device=device)
+    global _LOSS_WS_FLOATS
+    if _LOSS_WS_FLOATS is None:  # a constant of the library: one ctypes call, not one per loss
+        _LOSS_WS_FLOATS = int(_lib.load().hw_loss_workspace_floats())
+    return torch.empty(_LOSS_WS_FLOATS + int(extra), dtype=torch.float32, device=device)
 
 
 class BceLogitsMean(torch.autograd.Function):
