@@ -335,16 +335,22 @@ class FusedPairLoss(torch.autograd.Function):
         gbufs = []
         if kind == "bce":
             losses = torch.empty(len(sides), dtype=torch.float32, device=dev)
+            sizes = [t.shape[0] * t.shape[1] for _, _, t in idx]
+            # one buffer for every side's scores and one for their gradients (a single scaling launch in the backward)
+            buf_all = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            g_all = torch.empty_like(buf_all) if need_g else None
+            off = 0
             for k, (s, d, (h, r, t)) in enumerate(zip(sides, descs, idx)):
                 B, G = t.shape
-                buf = torch.empty((G, B), dtype=torch.float32, device=dev)  # j-major: the B positives first
+                bptr = buf_all.data_ptr() + 4 * off  # [G, B] j-major: the B positives first
                 check(lib.hw_kge_score_grouped(C.byref(d), _ptr(h), _ptr(r), s.r_fixed, _ptr(t), t.stride(0), t.stride(1),
-                                               B, G, _ptr(buf), 1, B, oob, st), "hw_kge_score_grouped")
-                g = torch.empty_like(buf) if need_g else None
-                check(lib.hw_loss_bce_logits_weighted(_ptr(buf), G * B, B, s.pos_weight,
-                                                      C.c_void_p(losses.data_ptr() + 4 * k), _ptr(g), _ptr(ws), st),
+                                               B, G, C.c_void_p(bptr), 1, B, oob, st), "hw_kge_score_grouped")
+                gptr = C.c_void_p(g_all.data_ptr() + 4 * off) if need_g else None
+                check(lib.hw_loss_bce_logits_weighted(C.c_void_p(bptr), G * B, B, s.pos_weight,
+                                                      C.c_void_p(losses.data_ptr() + 4 * k), gptr, _ptr(ws), st),
                       "hw_loss_bce_logits_weighted")
-                gbufs.append(g)
+                off += sizes[k]
+            gbufs.append(g_all)
             loss = losses.sum() if len(sides) > 1 else losses[0]
         else:
             if any(t.shape[1] != 2 for _, _, t in idx):
@@ -384,18 +390,17 @@ class FusedPairLoss(torch.autograd.Function):
         bufs, out_by_pos = {}, {}
         off = 0
         n_tot = gbufs[0].shape[1] if ctx.kind != "bce" else 0
+        gall = gbufs[0] * coef  # every side's dLoss/dscore, scaled by the upstream gradient in one launch
         for k, (s, (h, r, t)) in enumerate(zip(ctx.sides, ctx.n_idx)):
             head, rel, tail = [params[i] for i in s.head], [params[i] for i in s.rel], [params[i] for i in s.tail]
             desc = ctx.descs[k]
             gs = _grad_slots((head, rel, tail), needs, bufs, out_by_pos, (s.head, s.rel, s.tail))
             B, G = t.shape
             if ctx.kind == "bce":
-                gk = gbufs[k] * coef  # [G, B]
-                gptr, gsb, gsj = gk.data_ptr(), 1, B
+                gptr, gsb, gsj = gall.data_ptr() + 4 * off, 1, B  # this side's [G, B] block
+                off += B * G
             else:
-                if k == 0:
-                    gall = gbufs[0] * coef  # [2, n_tot]
-                gptr, gsb, gsj = gall.data_ptr() + 4 * off, 1, n_tot
+                gptr, gsb, gsj = gall.data_ptr() + 4 * off, 1, n_tot  # columns of the shared [2, n_tot] matrix
                 off += B
             rel_ws = None
             wkey = (ctx.model, desc.dim, B, G, r is None)
