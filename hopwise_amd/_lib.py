@@ -214,6 +214,12 @@ SIGNATURES = {
         [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
          C.c_void_p],
     ),
+    "hw_gemm_bce_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64]),
+    "hw_gemm_f32_bce": (
+        C.c_int,
+        [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+         C.c_float, C.c_float, c_f32p, c_f32p, C.c_int64, C.c_void_p],
+    ),
     "hw_sigmoid": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "hw_pgpr_layer1_lookup": (
         C.c_int,

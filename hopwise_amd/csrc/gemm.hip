@@ -115,6 +115,15 @@ __device__ __forceinline__ void put_tile(const f32x4 (&v)[2], int K, int k0, flo
     }
 }
 
+// ACT == 3: sigmoid + BCELoss epilogue (TuckER / ConvE 1-vs-all scores, tucker.py:83,124-125): the tile never leaves as
+// scores -- each element becomes dLoss/dscore (what the backward GEMMs consume) and the block's loss terms are summed into
+// loss_partial[linear block id]; target[c] = scale * flag[c] + add.
+struct GemmBce {
+    const uint8_t* flag;
+    float scale, add, inv_numel;
+    float* loss_partial;
+};
+
 template <bool A_KC, bool B_KC, int ACT>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
@@ -123,7 +132,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ drop_mask, int drop_mode,
                                                           uint64_t seed, uint64_t offset, int vec_a, int vec_b,
-                                                          int k_len, float* __restrict__ partial, int pipe) {
+                                                          int k_len, float* __restrict__ partial, int pipe,
+                                                          GemmBce bce) {
     // two LDS stages: the pipelined loop writes tile k+1 into the stage nobody reads while tile k is multiplied, which
     // leaves one barrier per k-step (the unpipelined fallback uses stage 0 only)
     __shared__ __attribute__((aligned(16))) float As2[2][BK][LDT];
@@ -197,6 +207,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
         __syncthreads();
     }
     // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (ACT == 3) {
+        float loss = 0.f;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int gn = n0 + wn + tj * 32 + (lane & 31);
+                const bool col_ok = gn < N;
+                const float bv = (bias && col_ok) ? bias[gn] : 0.f;
+                const float t = (bce.flag && col_ok) ? fmaf(bce.scale, (float)bce.flag[gn], bce.add) : bce.add;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int gm = m0 + wm + ti * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+                    float pv, gv;
+                    const float l = bce_elem(acc[ti][tj][rg] + bv, t, bce.inv_numel, &pv, &gv);
+                    if (gm < M && col_ok) {
+                        loss += l;
+                        C[(size_t)gm * ldc + gn] = gv;
+                    }
+                }
+            }
+        loss = group_sum<64>(loss);
+        __shared__ float red[4];
+        if (lane == 0) red[wave] = loss;
+        __syncthreads();
+        if (tid == 0) bce.loss_partial[blockIdx.x + gridDim.x * blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+        return;
+    }
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -267,16 +305,27 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     }
 }
 
+__global__ __launch_bounds__(256) void gemm_bce_finish_kernel(const float* __restrict__ partial, int n, float inv_numel,
+                                                              float* __restrict__ loss) {
+    __shared__ float red[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];  // fixed order: deterministic
+    v = group_sum<64>(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_numel;
+}
+
 static bool aligned16(const void* p, int64_t ld) { return (((uintptr_t)p) & 15) == 0 && (ld % 4) == 0; }
 
 static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, int64_t ldb, bool b_kc, float* c,
                        int64_t ldc, const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, const float* bias,
                        int act, const float* drop_mask, int drop_mode, uint64_t seed, uint64_t offset,
-                       float* workspace, int64_t workspace_floats, hipStream_t st) {
+                       float* workspace, int64_t workspace_floats, hipStream_t st, GemmBce bce = GemmBce{}) {
     const int64_t gm = (m_max + BM - 1) / BM, gn = (n + BN - 1) / BN;
     // split-K when the output grid cannot fill the chip and K is long (e.g. dX = dY [2048, 144779] . E [144779, 200])
     int splits = 1;
-    if (workspace && gm * gn < 256 && k >= 16 * BK) {
+    if (act != 3 && workspace && gm * gn < 256 && k >= 16 * BK) {
         // also the short-K, few-row products of a beam search's first hops: a lone tile walks its K / 16 steps at one
         // load latency each (75 us for [64, 512] x [256, 512]^T), so the chain is cut into splits of >= 4 steps
         int64_t want = (768 + gm * gn - 1) / (gm * gn);
@@ -300,14 +349,17 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
 #define GO(AK, BK_, EL)                                                                                              \
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows,       \
                        (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial,   \
-                       pipe)
+                       pipe, bce)
 #define GO3(AK, BK_)              \
     do {                          \
         if (act == 1) GO(AK, BK_, 1);      \
         else if (act == 2) GO(AK, BK_, 2); \
         else GO(AK, BK_, 0);               \
     } while (0)
-    if (a_kc && b_kc) GO3(true, true);
+    if (act == 3) {  // fused BCE epilogue: x . E^T only, never split
+        if (!(a_kc && b_kc) || splits != 1) return HW_ERR_UNSUPPORTED;
+        GO(true, true, 3);
+    } else if (a_kc && b_kc) GO3(true, true);
     else if (a_kc && !b_kc) GO3(true, false);
     else if (!a_kc && !b_kc) GO3(false, false);
     else GO3(false, true);
@@ -352,4 +404,27 @@ extern "C" int hw_mlp_layer(const float* a, int64_t lda, const float* w, const f
                             const float* drop_mask, int32_t drop_mode, uint64_t seed, uint64_t offset, void* stream) {
     return hw_gemm_f32(a, lda, 1, w, k, 1, c, ldc, m_rows, m_max, n, k, bias, elu, drop_mask, drop_mode, seed, offset,
                        nullptr, 0, stream);
+}
+
+extern "C" int64_t hw_gemm_bce_workspace_floats(int64_t m, int64_t n) {
+    return m < 0 || n < 0 ? 0 : ((m + BM - 1) / BM) * ((n + BN - 1) / BN);
+}
+
+extern "C" int hw_gemm_f32_bce(const float* x, int64_t ldx, const float* table, int64_t ldt, const float* bias, float* g_out,
+                               int64_t ldg, int64_t m, int64_t n, int64_t k, const uint8_t* pos_flag, float target_scale,
+                               float target_add, float* loss_out, float* workspace, int64_t workspace_floats,
+                               void* stream) {
+    if (!x || !table || !g_out || !loss_out || !workspace || m < 1 || n < 1 || k < 1 || ldg < n || ldx < k || ldt < k)
+        return HW_ERR_INVALID_ARG;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    const int64_t blocks = hw_gemm_bce_workspace_floats(m, n);
+    if (workspace_floats < blocks || blocks > INT32_MAX) return HW_ERR_WORKSPACE;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    GemmBce bce{pos_flag, target_scale, target_add, (float)(1.0 / ((double)m * (double)n)), workspace};
+    const int rc = launch_gemm(x, ldx, true, table, ldt, true, g_out, ldg, nullptr, m, n, k, bias, 3, nullptr, 0, 0, 0, nullptr,
+                               0, st, bce);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gemm_bce_finish_kernel, dim3(1), dim3(256), 0, st, workspace, (int)blocks, bce.inv_numel, loss_out);
+    return HW_LAUNCH_RC();
 }

@@ -190,6 +190,21 @@ __device__ __forceinline__ int clamp_row(int64_t id, int64_t n, int32_t* oob) {
     return (int)id;
 }
 
+// ---- sigmoid + BCELoss element (tucker.py:83,124-125), shared by tucker.hip and the GEMM's fused epilogue ------------
+// One element of the loss / gradient.  Hardware exp / log (v_exp_f32, v_log_f32): the kernel is transcendental-bound
+// (one exp, two logs, one divide per element over ~3e8 elements), not bandwidth-bound, with the libm sequences.
+__device__ __forceinline__ float bce_elem(float x, float t, float inv_numel, float* p_out, float* g_out) {
+    const float p = __fdividef(1.f, 1.f + __expf(-x));
+    const float lp = fmaxf(__logf(p), -100.f), l1p = fmaxf(__logf(1.f - p), -100.f);
+    const float pq = (1.f - p) * p;
+    *p_out = p;
+    // (p - t) / max(pq, 1e-12) * pq: the quotient and the product cancel unless pq was clamped -- one reciprocal fewer
+    *g_out = (pq >= 1e-12f ? p - t : (p - t) * (pq * 1e12f)) * inv_numel;
+    return -(t * lp + (1.f - t) * l1p);
+}
+
+// Flat float4 sweep over the [n_rows, n_cols] matrix (rows are not 16-byte aligned when n_cols is odd, the flat buffer
+// is); the column of the first lane element is carried incrementally -- no 64-bit modulo in the loop.
 // ---- one embedding row spread over the G lanes of a sub-wave group -----------------------------
 // VEC = true : dim % 4 == 0; lane gl owns float4 chunks gl, gl+G, ...  (NE/4 chunks)  -> 16-B loads
 // VEC = false: any dim;      lane gl owns elements   gl, gl+G, ...     (NE elements)  -> 4-B loads

@@ -141,20 +141,6 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
 // followed by sigmoid_backward).  pred (nullable) receives p; glogits (nullable) the gradient.
 constexpr int TB_BLOCKS = 4096;
 
-// One element of the loss / gradient.  Hardware exp / log (v_exp_f32, v_log_f32): the kernel is transcendental-bound
-// (one exp, two logs, one divide per element over ~3e8 elements), not bandwidth-bound, with the libm sequences.
-__device__ __forceinline__ float bce_elem(float x, float t, float inv_numel, float* p_out, float* g_out) {
-    const float p = __fdividef(1.f, 1.f + __expf(-x));
-    const float lp = fmaxf(__logf(p), -100.f), l1p = fmaxf(__logf(1.f - p), -100.f);
-    const float pq = (1.f - p) * p;
-    *p_out = p;
-    // (p - t) / max(pq, 1e-12) * pq: the quotient and the product cancel unless pq was clamped -- one reciprocal fewer
-    *g_out = (pq >= 1e-12f ? p - t : (p - t) * (pq * 1e12f)) * inv_numel;
-    return -(t * lp + (1.f - t) * l1p);
-}
-
-// Flat float4 sweep over the [n_rows, n_cols] matrix (rows are not 16-byte aligned when n_cols is odd, the flat buffer
-// is); the column of the first lane element is carried incrementally -- no 64-bit modulo in the loop.
 // ld > n_cols (padded rows, see hw_tucker_sigmoid_bce_ld): the sweep runs over the flat [n_rows, ld] buffer and the
 // ld - n_cols trailing entries of each row count for nothing (no loss, gradient 0; their content is never interpreted).
 __global__ __launch_bounds__(256) void tucker_bce_kernel(const float* __restrict__ logits, int64_t n_rows, int64_t n_valid,

@@ -1004,6 +1004,9 @@ def sigmoid_bce_mean(logits, flag, scale, add):
     return SigmoidBceMean.apply(logits, flag, scale, add)
 
 
+FUSED_SCORE_BCE = True  # False: GEMM, then the separate sigmoid + BCE sweep over the stored scores
+
+
 class ScoreAllBceMean(torch.autograd.Function):
     """BCELoss(sigmoid(x @ table^T), scale * flag[col] + add), mean over the [B, N] score matrix (tucker.py:83-84,
     111-125), as one unit: the scores live in a buffer whose rows are padded to 32 floats (aligned tile stores and
@@ -1017,17 +1020,26 @@ class ScoreAllBceMean(torch.autograd.Function):
         B, N = x.shape[0], table.shape[0]
         ld = (N + 31) // 32 * 32
         buf = torch.empty((B, ld), dtype=torch.float32, device=x.device)
-        s = buf[:, :N]
-        gemm(x, table, True, True, bias=bias, out=s)
         if flag is not None:
             flag = _dev(flag, torch.uint8, "flag").contiguous()
             if flag.numel() != N:
                 raise ValueError("flag must have one entry per column")
         loss = torch.empty(1, dtype=torch.float32, device=x.device)
         need = any(ctx.needs_input_grad[:3])
-        ws = torch.empty(int(lib.hw_tucker_bce_workspace_floats()), dtype=torch.float32, device=x.device)
-        check(lib.hw_tucker_sigmoid_bce_ld(_ptr(buf), ld, B, N, _ptr(flag), float(scale), float(add), _ptr(loss), None,
-                                           _ptr(buf) if need else None, _ptr(ws), _stream()), "hw_tucker_sigmoid_bce_ld")
+        K = x.shape[1]
+        if FUSED_SCORE_BCE and x.stride(0) % 4 == 0 and table.stride(0) % 4 == 0:
+            # scores never written: the GEMM epilogue turns each tile into dLoss/dscore and sums its loss terms
+            n_ws = int(lib.hw_gemm_bce_workspace_floats(B, N))
+            ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
+            check(lib.hw_gemm_f32_bce(_ptr(x), x.stride(0), _ptr(table), table.stride(0), _ptr(bias), _ptr(buf), ld, B, N, K,
+                                      _ptr(flag), float(scale), float(add), _ptr(loss), _ptr(ws), n_ws, _stream()),
+                  "hw_gemm_f32_bce")
+        else:
+            gemm(x, table, True, True, bias=bias, out=buf[:, :N])
+            ws = torch.empty(int(lib.hw_tucker_bce_workspace_floats()), dtype=torch.float32, device=x.device)
+            check(lib.hw_tucker_sigmoid_bce_ld(_ptr(buf), ld, B, N, _ptr(flag), float(scale), float(add), _ptr(loss), None,
+                                               _ptr(buf) if need else None, _ptr(ws), _stream()),
+                  "hw_tucker_sigmoid_bce_ld")
         ctx.n = N
         ctx.save_for_backward(x, table, buf if need else None)
         return loss.view(())

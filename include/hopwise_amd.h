@@ -343,6 +343,14 @@ int hw_tucker_sigmoid_bce(const float* logits, int64_t n_rows, int64_t n_cols, c
 int hw_tucker_sigmoid_bce_ld(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const uint8_t* pos_flag,
                              float target_scale, float target_add, float* loss_out, float* pred, float* glogits,
                              float* workspace, void* stream);
+/* The same loss with the score product itself: g_out[b, c] = dLoss/dscore of score[b, c] = x[b, :] . table[c, :] + bias[c]
+ * (x [m, k] and table [n, k] K-contiguous, bias nullable), loss_out[0] = the mean BCE.  The scores are never written: the
+ * MFMA GEMM's epilogue turns each tile into its gradient and sums the tile's loss terms (deterministic two-stage sum).
+ * workspace: hw_gemm_bce_workspace_floats(m, n) floats.  ldg >= n (the engine pads it to 32 floats). */
+int64_t hw_gemm_bce_workspace_floats(int64_t m, int64_t n);
+int hw_gemm_f32_bce(const float* x, int64_t ldx, const float* table, int64_t ldt, const float* bias, float* g_out,
+                    int64_t ldg, int64_t m, int64_t n, int64_t k, const uint8_t* pos_flag, float target_scale,
+                    float target_add, float* loss_out, float* workspace, int64_t workspace_floats, void* stream);
 int hw_sigmoid(const float* x, int64_t n, float* y, void* stream);
 
 /* logits -> masked softmax -> (+1 on valid actions, pgpr.py:453) -> top-k (value desc, index asc).

@@ -128,3 +128,30 @@ def test_contract_with_in_kernel_dropout():
         np.testing.assert_array_equal(gw.cpu().numpy(), w.grad.cpu().numpy())
         other = ops.tucker_contract_dropout(x, w, p, 77, 6)  # another offset, another mask
         assert not torch.equal(other, out)
+
+
+@pytest.mark.parametrize("shape", [(5, 37, 16), (300, 1001, 200), (129, 144, 36)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_score_loss_in_gemm_epilogue_equals_gemm_then_bce(shape, with_bias, monkeypatch):
+    """hw_gemm_f32_bce (scores never stored: the GEMM epilogue writes dLoss/dscore and sums the loss) against the GEMM
+    followed by the separate sigmoid + BCE sweep: same loss, same gradients of x / table / bias, ragged M and N."""
+    from hopwise_amd import ops
+
+    B, N, d = shape
+    g = torch.Generator().manual_seed(B + N)
+    x0 = torch.randn(B, d, generator=g)
+    t0 = torch.randn(N, d, generator=g) * 0.3
+    b0 = torch.randn(N, generator=g) * 0.1
+    flag = (torch.rand(N, generator=g) < 0.05).to(torch.uint8).to(dev())
+    out = []
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_SCORE_BCE", fused)
+        x, t = x0.to(dev()).requires_grad_(), t0.to(dev()).requires_grad_()
+        b = b0.to(dev()).requires_grad_() if with_bias else None
+        loss = ops.score_all_bce_mean(x, t, flag, 0.9, 1.0 / N, bias=b)
+        (2.0 * loss).backward()
+        out.append((loss.item(), x.grad.cpu().numpy(), t.grad.cpu().numpy(), None if b is None else b.grad.cpu().numpy()))
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6)
+    for a, c in zip(out[0][1:], out[1][1:]):
+        if a is not None:
+            np.testing.assert_allclose(a, c, rtol=2e-4, atol=1e-7 * max(1.0, float(np.abs(c).max())))
