@@ -40,10 +40,14 @@ class FusedAdam(torch.optim.Optimizer):
         self._sinks = _SinkState() if grad_sinks else None
         self._decoupled = bool(decoupled_weight_decay)
         self._launch_cache = {}
+        devices = set()
         for group in self.param_groups:
             for p in group["params"]:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise _lib.HopwiseAmdError("FusedAdam: parameters must be contiguous fp32 HIP tensors (no CPU path)")
+                devices.add(p.device)
+                if len(devices) > 1:  # one launch updates a whole group: one process per GPU, as everywhere in this engine
+                    raise _lib.HopwiseAmdError("FusedAdam: all parameters must live on one device")
                 if self._sinks is not None and p.requires_grad:
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
