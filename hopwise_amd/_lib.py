@@ -99,6 +99,17 @@ SIGNATURES = {
          C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_void_p],
     ),
     "hw_kge_grad_grouped_workspace_floats": (C.c_int64, [C.POINTER(KgeDesc), C.c_int64, C.c_int64, C.c_int32]),
+    "hw_batchnorm2d_workspace_doubles": (C.c_int64, [C.c_int32]),
+    "hw_batchnorm2d_forward": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
+         c_f32p, C.c_void_p, C.c_void_p],
+    ),
+    "hw_batchnorm2d_backward": (
+        C.c_int,
+        [c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p,
+         C.c_void_p],
+    ),
     "hw_adam_step": (
         C.c_int,
         [C.POINTER(AdamArgs), C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_i64p, C.c_int32,

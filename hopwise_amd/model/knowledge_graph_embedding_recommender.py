@@ -642,8 +642,8 @@ class ConvE(KnowledgeRecommender):
         self.hidden_drop = nn.Dropout(config["hidden_dropout"])
         self.feature_map_drop = nn.Dropout2d(config["feature_dropout"])
         self.conv1 = nn.Conv2d(1, 32, (3, 3), 1, 0, bias=self.use_bias)
-        self.bn0 = nn.BatchNorm2d(1)
-        self.bn1 = nn.BatchNorm2d(32)
+        self.bn0 = ops.BatchNorm2d(1)
+        self.bn1 = ops.BatchNorm2d(32)
         self.bn2 = nn.BatchNorm1d(d)
         self.register_parameter("b_users", nn.Parameter(torch.zeros(self.n_users + self.n_items)))
         self.register_parameter("b_entities", nn.Parameter(torch.zeros(self.n_entities)))
@@ -743,9 +743,9 @@ class ConvKB(KnowledgeRecommender):
         self.user_embedding = nn.Embedding(self.n_users, d)
         self.entity_embedding = nn.Embedding(self.n_entities, d)
         self.relation_embedding = nn.Embedding(self.n_relations, d)
-        self.conv1_bn = nn.BatchNorm2d(1)
+        self.conv1_bn = ops.BatchNorm2d(1)
         self.conv_layer = nn.Conv2d(1, self.out_channels, (self.kernel_size, 3))
-        self.conv2_bn = nn.BatchNorm2d(self.out_channels)
+        self.conv2_bn = ops.BatchNorm2d(self.out_channels)
         self.dropout = nn.Dropout(self.drop_prob)
         self.fc_layer = nn.Linear((d - self.kernel_size + 1) * self.out_channels, 1, bias=False)
         self.apply(xavier_normal_initialization)

@@ -771,6 +771,52 @@ def matmul_nn(x, w):
     return MatMulNN.apply(x, w)
 
 
+class _BatchNorm2dTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "x").contiguous()
+        N, Cc, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(int(lib.hw_batchnorm2d_workspace_doubles(Cc)), dtype=torch.float64, device=x.device)
+        check(lib.hw_batchnorm2d_forward(_ptr(x), N, Cc, H * W, _ptr(weight), _ptr(bias), float(eps), float(momentum),
+                                         _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), _ptr(y), _ptr(ws),
+                                         _stream()), "hw_batchnorm2d_forward")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Cc, H, W = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dg = torch.empty(Cc, dtype=torch.float32, device=x.device) if weight is not None and ctx.needs_input_grad[1] else None
+        db = torch.empty(Cc, dtype=torch.float32, device=x.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        ws = torch.empty(int(lib.hw_batchnorm2d_workspace_doubles(Cc)), dtype=torch.float64, device=x.device)
+        check(lib.hw_batchnorm2d_backward(_ptr(x), _ptr(dy), N, Cc, H * W, _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                          _ptr(dg), _ptr(db), _ptr(ws), _stream()), "hw_batchnorm2d_backward")
+        return dx, dg, db, None, None, None, None
+
+
+class BatchNorm2d(torch.nn.BatchNorm2d):
+    """nn.BatchNorm2d whose training-mode forward / backward are the two-pass HIP kernels of csrc/batchnorm.hip (same
+    parameters, buffers and state_dict keys; eval mode and anything but fp32 HIP NCHW input go to torch)."""
+
+    def forward(self, x):
+        if (self.training and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and self.track_running_stats
+                and self.momentum is not None):
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return _BatchNorm2dTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                           self.momentum)
+        return super().forward(x)
+
+
 class LinearAct(torch.autograd.Function):
     """y = act(x @ w^T + b) (nn.Linear + optional ReLU / ELU) with the backward on the HIP kernels: the activation's
     derivative is recovered from y, the three gradients are two GEMMs and a column sum."""

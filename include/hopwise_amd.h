@@ -479,6 +479,18 @@ int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const
                     int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
                     int32_t* out_count, const int64_t* slot_ptr, void* stream);
 
+/* ---- nn.BatchNorm2d, training mode, NCHW with few channels (conve.py:62-66, convkb.py:51-56) ------------------------
+ * y = (x - mean_c) rstd_c gamma_c + beta_c with the batch statistics over N x HW (biased variance), running_mean / _var
+ * updated in place with `momentum` (running_var from the unbiased variance, as torch does); save_mean / save_rstd [C] feed
+ * the backward.  gamma / beta / running_* nullable.  workspace: hw_batchnorm2d_workspace_doubles(C) float64. */
+int64_t hw_batchnorm2d_workspace_doubles(int32_t channels);
+int hw_batchnorm2d_forward(const float* x, int64_t batch, int32_t channels, int32_t hw, const float* gamma,
+                           const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                           float* save_mean, float* save_rstd, float* y, double* workspace, void* stream);
+int hw_batchnorm2d_backward(const float* x, const float* dy, int64_t batch, int32_t channels, int32_t hw,
+                            const float* gamma, const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
+                            float* dbeta, double* workspace, void* stream);
+
 /* ---- dense Adam over all tables of a model in one launch (trainer/trainer.py:189-190: optim.Adam(params, lr,
  * weight_decay), the reference's default learner; torch/optim/adam.py update rule, no amsgrad / maximize).
  * *step is a DEVICE counter, incremented by the call (so the launch replays inside a HIP graph); every segment is

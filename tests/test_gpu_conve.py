@@ -112,3 +112,44 @@ def test_default_shape_forward_vs_oracle():
         fs = m.full_sort_predict({"user_id": torch.from_numpy(users).to(dev())}).cpu().numpy()
     ref = oc.forward(p, users, np.full_like(users, NR - 1), "user_embedding.weight", "user_embedding.weight", "b_users", 20)
     np.testing.assert_allclose(fs, ref[:, NU:], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(7, 1, 20, 20), (130, 32, 18, 18), (2048, 5, 3, 7), (1, 3, 4, 4)])
+def test_batchnorm2d_kernels_match_torch_in_training_mode(shape):
+    """ops.BatchNorm2d (csrc/batchnorm.hip) against nn.BatchNorm2d evaluated in float64: output, the three gradients,
+    running statistics (unbiased variance) and num_batches_tracked after two steps."""
+    from hopwise_amd import ops
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(sum(shape))
+    ref = torch.nn.BatchNorm2d(shape[1]).double()
+    mine = ops.BatchNorm2d(shape[1]).to(dev)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(shape[1], generator=g).double())
+        ref.bias.copy_(torch.randn(shape[1], generator=g).double())
+        mine.weight.copy_(ref.weight.float())
+        mine.bias.copy_(ref.bias.float())
+    for step in range(2):
+        x = torch.randn(shape, generator=g) * 2 + 0.5
+        w = torch.randn(shape, generator=g)
+        if shape[0] * shape[2] * shape[3] == 1:
+            continue
+        xr = x.double().requires_grad_()
+        xm = x.to(dev).requires_grad_()
+        yr, ym = ref(xr), mine(xm)
+        (yr * w.double()).sum().backward()
+        (ym * w.to(dev)).sum().backward()
+        np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-5, atol=2e-5)
+        scale = float(xr.grad.abs().max())
+        np.testing.assert_allclose(xm.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5 * scale)
+        np.testing.assert_allclose(mine.weight.grad.cpu().numpy(), ref.weight.grad.numpy(), rtol=2e-4, atol=1e-3)
+        np.testing.assert_allclose(mine.bias.grad.cpu().numpy(), ref.bias.grad.numpy(), rtol=2e-4, atol=1e-3)
+        mine.zero_grad()
+        ref.zero_grad()
+    np.testing.assert_allclose(mine.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mine.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
+    mine.eval()
+    ref.eval()
+    x = torch.randn(shape, generator=g)
+    np.testing.assert_allclose(mine(x.to(dev)).detach().cpu().numpy(), ref(x.double()).detach().numpy(), rtol=2e-5, atol=2e-5)
