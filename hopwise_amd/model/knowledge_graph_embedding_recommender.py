@@ -621,8 +621,8 @@ class ConvE(KnowledgeRecommender):
     (conve.py:124-128), label smoothing with 1 / n_items and 1 / n_entities (:131-132), predict_kg returns
     ``score[:, tail]`` -- a [B, B] matrix (:162), full_sort_predict_kg reads attributes that do not exist (:183-186) and
     therefore raises AttributeError, lookups skip the gradient of id 0 (padding_idx) while the 1-vs-all product does not.
-    The convolution (csrc/conv.hip), the two dense products and sigmoid + BCE are HIP; BatchNorm / dropout modules are
-    torch (a few MB next to the [B, N] logits), as for TuckER."""
+    The convolution (csrc/conv.hip), the two BatchNorm2d layers (csrc/batchnorm.hip), the two dense products and sigmoid +
+    BCE are HIP; BatchNorm1d / dropout modules are torch (a few MB next to the [B, N] logits), as for TuckER."""
 
     input_type = InputType.PAIRWISE
 
@@ -727,7 +727,7 @@ class ConvKB(KnowledgeRecommender):
     regulariser lambda * (mean h^2 + mean t^2 + mean r^2 + ||conv W|| + ||conv b|| + ||fc W||) added to both terms,
     rec + kg; four forward passes per step (pos / neg x rec / kg), each with its own BatchNorm batch statistics, in the
     reference's order (convkb.py:131-134).  The convolution and the Linear run on csrc/conv.hip and the MFMA GEMM, the
-    softplus means on the BCE kernel; BatchNorm / dropout / the tiny norms are torch.  No full-sort methods exist in
+    softplus means on the BCE kernel, the BatchNorm2d layers on csrc/batchnorm.hip; dropout / the tiny norms are torch.  No full-sort methods exist in
     the reference."""
 
     input_type = InputType.PAIRWISE
