@@ -41,21 +41,37 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     uint32_t* bits = nullptr;
     bool bad_key = false;
     if constexpr (SAMPLE) {
-        bits = used_bits_all + (threadIdx.x / HW_WAVE) * sa.words;
-        for (int w = lane; w < sa.words; w += HW_WAVE) bits[w] = 0u;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         const int64_t key = sa.keys[b];
         bad_key = key < 0 || key >= sa.n_key_space;
-        if (!bad_key) {
-            const int64_t lo = sa.used_ptr[key], hi = sa.used_ptr[key + 1];
-            for (int64_t q = lo + lane; q < hi; q += HW_WAVE) {
-                const int64_t u = sa.used_idx[q];
-                if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
+        if (S == 4) {
+            // the four waves of the block are the four splits of ONE group (task = 4 * block + wave): one bitmap of the
+            // key's used set for all of them, built by the whole block (the launcher only sends full blocks here)
+            bits = used_bits_all;
+            for (int w = threadIdx.x; w < sa.words; w += 256) bits[w] = 0u;
+            __syncthreads();
+            if (!bad_key) {
+                const int64_t lo = sa.used_ptr[key], hi = sa.used_ptr[key + 1];
+                for (int64_t q = lo + threadIdx.x; q < hi; q += 256) {
+                    const int64_t u = sa.used_idx[q];
+                    if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
+                }
             }
+            __syncthreads();
+        } else {
+            bits = used_bits_all + (threadIdx.x / HW_WAVE) * sa.words;
+            for (int w = lane; w < sa.words; w += HW_WAVE) bits[w] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (!bad_key) {
+                const int64_t lo = sa.used_ptr[key], hi = sa.used_ptr[key + 1];
+                for (int64_t q = lo + lane; q < hi; q += HW_WAVE) {
+                    const int64_t u = sa.used_idx[q];
+                    if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 
     bool bad = false;
