@@ -690,6 +690,57 @@ def scatter_add_rows_(table, idx, src):
 
 
 # ------------------------------------------------------------------------------------------------
+# device-side routing of a row-sharded lookup (csrc/shard.hip)
+# ------------------------------------------------------------------------------------------------
+def shard_plan(ids, n_rows, n_ranks, cap, overflow):
+    """Route ``ids`` (any shape, int64) of a table with ``n_rows`` rows sharded owner = id % n_ranks.
+    Returns (inv like ids, send_counts int32 [P], send_local int32 [P * cap]); ``overflow`` is a persistent int32 [1]
+    device flag the caller inspects later (no host read here)."""
+    lib = _lib.load()
+    ids = _idx(ids, "ids")
+    flat = ids.reshape(-1).contiguous()
+    dev = flat.device
+    ws = torch.empty(int(lib.hw_shard_plan_workspace_bytes(int(n_rows), int(n_ranks))), dtype=torch.uint8, device=dev)
+    inv = torch.empty(flat.numel(), dtype=torch.int64, device=dev)
+    send_counts = torch.empty(n_ranks, dtype=torch.int32, device=dev)
+    send_local = torch.empty(n_ranks * cap, dtype=torch.int32, device=dev)
+    check(lib.hw_shard_plan(_ptr(flat), flat.numel(), int(n_rows), int(n_ranks), int(cap), _ptr(ws), _ptr(inv),
+                            _ptr(send_counts), _ptr(send_local), _ptr(_dev(overflow, torch.int32, "overflow")),
+                            _ptr(_OobCounter.get(dev)), _stream()), "hw_shard_plan")
+    return inv.view(ids.shape), send_counts, send_local
+
+
+def shard_gather(shard, recv_local, recv_counts, cap, out=None):
+    """out[p * cap + j] = shard[recv_local[p * cap + j]] for j < recv_counts[p]; rows beyond a count stay untouched."""
+    lib = _lib.load()
+    shard = _dev(shard, torch.float32, "shard")
+    P = recv_counts.numel()
+    if shard.dim() != 2 or not shard.is_contiguous() or recv_local.numel() != P * cap:
+        raise ValueError("shape mismatch")
+    if out is None:
+        out = torch.empty((P * cap, shard.shape[1]), dtype=torch.float32, device=shard.device)
+    check(lib.hw_shard_gather(_ptr(shard), shard.shape[0], shard.shape[1], _ptr(_dev(recv_local, torch.int32, "recv_local")),
+                              _ptr(_dev(recv_counts, torch.int32, "recv_counts")), P, int(cap), _ptr(out),
+                              _ptr(_OobCounter.get(shard.device)), _stream()), "hw_shard_gather")
+    return out
+
+
+def shard_scatter_add_(grad_shard, recv_local, recv_counts, cap, src):
+    lib = _lib.load()
+    grad_shard = _dev(grad_shard, torch.float32, "grad_shard")
+    src = _dev(src, torch.float32, "src")
+    P = recv_counts.numel()
+    if (grad_shard.dim() != 2 or not grad_shard.is_contiguous() or not src.is_contiguous()
+            or tuple(src.shape) != (P * cap, grad_shard.shape[1]) or recv_local.numel() != P * cap):
+        raise ValueError("shape mismatch")
+    check(lib.hw_shard_scatter_add(_ptr(grad_shard), grad_shard.shape[0], grad_shard.shape[1],
+                                   _ptr(_dev(recv_local, torch.int32, "recv_local")),
+                                   _ptr(_dev(recv_counts, torch.int32, "recv_counts")), P, int(cap), _ptr(src),
+                                   _ptr(_OobCounter.get(grad_shard.device)), _stream()), "hw_shard_scatter_add")
+    return grad_shard
+
+
+# ------------------------------------------------------------------------------------------------
 # dense fp32 GEMM on the matrix cores
 # ------------------------------------------------------------------------------------------------
 def gemm(a, b, a_k_contiguous=True, b_k_contiguous=True, bias=None, elu=False, out=None, m_rows=None,

@@ -2,17 +2,25 @@
 
 The reference only knows replicated tables under DDP (trainer/trainer.py:83-84, configurator.py:557-562).
 This module adds the layout BASELINE.json's config 4 asks for: entity / user tables sharded row-wise
-(owner = id % P) with an all-to-all lookup, while relation tables and MLPs stay replicated.
+(owner = id % P, local row = id // P) with an all-to-all lookup, while relation tables and MLPs stay replicated.
 
-Exchange of one lookup (forward):   ids --unique--> bucket by owner --all_to_all(counts, ids)--> owner gathers
-rows from its shard --all_to_all(rows)--> requester holds a COMPACT table [n_unique, d] + the inverse map.
+One lookup (forward), with no host read anywhere on the way:
+
+    hw_shard_plan (csrc/shard.hip)     ids -> exact dedup + bucket by owner, on the device: per-owner counts, the
+                                       distinct local rows of each owner (ascending), and inv[i] = owner * cap + slot
+    all_to_all_single x2               counts [P] and local rows [P, cap], fixed size
+    hw_shard_gather                    the owner copies the requested rows of its shard into [P, cap, d]
+    all_to_all_single per table        rows back: the receive buffer [P * cap, d] IS the compact table
+
+`cap` is a fixed per-owner capacity (ceil(n / P * capacity_factor) + 64, at most min(n, rows per shard)), so message
+sizes never depend on data and nothing is read back; an owner asked for more than `cap` distinct rows raises a
+device flag that :meth:`RowShardedKGE.check_overflow` (called one step late, from a pinned copy) turns into an error.
 The fused scorers then run unchanged on the compact tables with remapped ids, so the kernels never see the
-sharding.  Backward is the mirror image: compact row-grads --all_to_all--> owner scatter-adds into its shard grad.
-xGMI is point-to-point (7 links per GPU): all-to-all uses all links at once; there is no ring all-reduce on the
-big tables at all -- only the small replicated parameters are all-reduced.
+sharding.  Backward is the mirror image: compact row-grads --all_to_all--> hw_shard_scatter_add into the owner's
+gradient shard.  xGMI is point-to-point (7 links per GPU): all-to-all uses all links at once; there is no ring
+all-reduce on the big tables at all -- only the small replicated parameters are all-reduced.
 
-The row gather / scatter-add run on the HIP kernels (ops.gather_rows / ops.scatter_add_rows_).  They can be
-replaced with ``set_row_ops`` -- used ONLY by the gloo/CPU tests of the exchange logic.
+``set_shard_ops`` replaces the three device primitives -- used ONLY by the gloo/CPU tests of the exchange logic.
 """
 
 from __future__ import annotations
@@ -23,20 +31,16 @@ from torch import nn
 
 from . import ops
 
-_row_ops = {"gather": None, "scatter_add": None}
+_shard_ops = {"plan": None, "gather": None, "scatter_add": None, "full_sort": None, "full_sort_topk": None, "topk": None}
 
 
-def set_row_ops(gather=None, scatter_add=None):
-    """Override the row primitives (tests of the exchange logic on CPU/gloo).  None restores the HIP kernels."""
-    _row_ops["gather"], _row_ops["scatter_add"] = gather, scatter_add
-
-
-def _gather(table, idx):
-    return (_row_ops["gather"] or ops.gather_rows)(table, idx)
-
-
-def _scatter_add_(table, idx, src):
-    return (_row_ops["scatter_add"] or ops.scatter_add_rows_)(table, idx, src)
+def set_shard_ops(**fns):
+    """Override device primitives (plan, gather, scatter_add, full_sort, full_sort_topk, topk) with CPU stand-ins -- tests of
+    the exchange logic under gloo only.  No arguments restores the HIP kernels."""
+    for k in _shard_ops:
+        _shard_ops[k] = fns.pop(k, None)
+    if fns:
+        raise KeyError(f"unknown shard ops: {sorted(fns)}")
 
 
 def world(group=None):
@@ -54,100 +58,121 @@ def local_rows(n_rows, rank, P):
     return (n_rows - rank + P - 1) // P
 
 
-class _Plan:
-    """Routing of one lookup, shared by every table looked up with the same ids."""
+def capacity(n_ids, n_rows, P, factor):
+    """Distinct rows one owner can be asked for in one lookup of ``n_ids`` ids."""
+    worst = max(1, min(int(n_ids), (int(n_rows) + P - 1) // P))
+    if P == 1:
+        return worst
+    return max(1, min(worst, int(n_ids / P * factor) + 64))
 
-    def __init__(self, ids, group):
+
+class _Plan:
+    """Routing of one lookup, shared by every table looked up with the same ids.  Device-resident; no host sync."""
+
+    def __init__(self, ids, n_rows, group, factor, overflow):
         rank, P = world(group)
         self.group, self.P = group, P
-        uniq, inv = torch.unique(ids.reshape(-1), return_inverse=True)
-        owner = uniq % P
-        order = torch.argsort(owner, stable=True)
-        self.uniq_sorted = uniq[order]
-        self.order = order
-        self.inv = inv.reshape(ids.shape)
-        self.n_unique = uniq.numel()
-        send = torch.bincount(owner, minlength=P)
+        self.cap = capacity(ids.numel(), n_rows, P, factor)
+        plan = _shard_ops["plan"] or ops.shard_plan
+        self.inv, self.send_counts, self.send_local = plan(ids, n_rows, P, self.cap, overflow)
         if P > 1:
-            recv = torch.empty_like(send)
-            dist.all_to_all_single(recv, send, group=group)
-            self.send_counts, self.recv_counts = send.tolist(), recv.tolist()
-            self.recv_ids = torch.empty(sum(self.recv_counts), dtype=ids.dtype, device=ids.device)
-            dist.all_to_all_single(self.recv_ids, self.uniq_sorted, self.recv_counts, self.send_counts, group=group)
+            self.recv_counts = torch.empty_like(self.send_counts)
+            dist.all_to_all_single(self.recv_counts, self.send_counts, group=group)
+            self.recv_local = torch.empty_like(self.send_local)
+            dist.all_to_all_single(self.recv_local, self.send_local, group=group)
         else:
-            self.send_counts = self.recv_counts = [self.n_unique]
-            self.recv_ids = self.uniq_sorted
-        self.recv_local = torch.div(self.recv_ids, P, rounding_mode="floor")
+            self.recv_counts, self.recv_local = self.send_counts, self.send_local
+        self.rows = P * self.cap  # rows of a compact table
 
 
 class _ShardedLookup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, *shards):
-        d_each = [s.shape[1] for s in shards]
-        rows = torch.cat([_gather(s, plan.recv_local) for s in shards], dim=1) if len(shards) > 1 else _gather(
-            shards[0], plan.recv_local)
-        if plan.P > 1:
-            back = torch.empty((plan.n_unique, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-            dist.all_to_all_single(back, rows.contiguous(), plan.send_counts, plan.recv_counts, group=plan.group)
-        else:
-            back = rows
-        compact = torch.empty_like(back)
-        compact[plan.order] = back  # undo the owner sort: row i belongs to the i-th unique id
-        ctx.plan, ctx.d_each = plan, d_each
-        ctx.shapes = [s.shape for s in shards]
+        gather = _shard_ops["gather"] or ops.shard_gather
+        outs = []
+        for s in shards:
+            rows = gather(s, plan.recv_local, plan.recv_counts, plan.cap)
+            if plan.P > 1:
+                back = torch.empty_like(rows)
+                dist.all_to_all_single(back, rows, group=plan.group)
+            else:
+                back = rows
+            outs.append(back)
+        ctx.plan = plan
         ctx.save_for_backward(*shards)
-        return tuple(c.contiguous() for c in compact.split(d_each, dim=1)) if len(shards) > 1 else (compact,)
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         plan = ctx.plan
         shards = ctx.saved_tensors
-        g = torch.cat([gi.contiguous() for gi in grads], dim=1) if len(grads) > 1 else grads[0].contiguous()
-        g_sorted = g[plan.order].contiguous()
-        if plan.P > 1:
-            recv = torch.empty((len(plan.recv_local), g.shape[1]), dtype=g.dtype, device=g.device)
-            dist.all_to_all_single(recv, g_sorted, plan.recv_counts, plan.send_counts, group=plan.group)
-        else:
-            recv = g_sorted
+        scatter = _shard_ops["scatter_add"] or ops.shard_scatter_add_
         outs = []
-        for s, part in zip(shards, recv.split(ctx.d_each, dim=1)):
+        for s, g in zip(shards, grads):
+            g = g.contiguous()
+            if plan.P > 1:
+                recv = torch.empty_like(g)
+                dist.all_to_all_single(recv, g, group=plan.group)
+            else:
+                recv = g
             sink = ops._live_sink(s) if not torch.is_grad_enabled() else None
             if sink is not None:  # optim.FusedAdam's persistent .grad: add the rows there, nothing for autograd to add
-                _scatter_add_(sink[0], plan.recv_local, part.contiguous())
+                scatter(sink[0], plan.recv_local, plan.recv_counts, plan.cap, recv)
                 sink[1].dirty = True
                 outs.append(None)
                 continue
             gs = torch.zeros_like(s)
-            _scatter_add_(gs, plan.recv_local, part.contiguous())
+            scatter(gs, plan.recv_local, plan.recv_counts, plan.cap, recv)
             outs.append(gs)
         return (None, *outs)
 
 
-def sharded_lookup(shards, ids, group=None):
-    """Rows of the row-sharded tables ``shards`` (same sharding, e.g. re/im) for ``ids``.
-    Returns (compact tables tuple [n_unique, d], inverse map shaped like ids)."""
-    plan = _Plan(ids, group)
-    return _ShardedLookup.apply(plan, *shards), plan.inv
+def sharded_lookup(shards, ids, n_rows, group=None, capacity_factor=1.25, overflow=None):
+    """Rows of the row-sharded tables ``shards`` (same sharding, e.g. re/im; ``n_rows`` = rows of the full table) for
+    ``ids``.  Returns (compact tables tuple [P * cap, d], inverse map shaped like ids, overflow flag tensor)."""
+    if overflow is None:
+        overflow = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    plan = _Plan(ids, n_rows, group, capacity_factor, overflow)
+    return _ShardedLookup.apply(plan, *shards), plan.inv, overflow
+
+
+class _GradScale(torch.autograd.Function):
+    """Identity whose backward multiplies by ``scale`` (1 / P: ranks' losses are averaged, like DDP averages gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
 
 
 class RowShardedKGE(nn.Module):
     """A KGE model (hopwise_amd.model.{TransE,RotatE,ComplEx,DistMult}) with its user and entity tables
-    row-sharded over the process group.  ``calculate_loss`` has the reference semantics on this rank's batch;
-    call :meth:`sync_grads` before the optimizer step (the replicated relation tables are all-reduced,
-    everything is averaged over ranks like DDP does)."""
+    row-sharded over the process group.  ``calculate_loss`` has the reference semantics on this rank's batch (its
+    backward is pre-scaled by 1 / P); call :meth:`sync_grads` before the optimizer step (only the replicated relation
+    tables are all-reduced -- the big tables' row gradients went back to their owners in the reverse all-to-all).
 
-    def __init__(self, model, group=None):
+    Evaluation shards the candidate tails instead: every rank scores the same queries
+    against its own rows, keeps a local top-k, and ``merge_topk`` ranks the k * P candidates."""
+
+    def __init__(self, model, group=None, capacity_factor=1.25):
         super().__init__()
         self.group = group
         self.rank, self.P = world(group)
         self.model = model
-        self.n_users, self.n_entities = model.n_users, model.n_entities
+        self.capacity_factor = float(capacity_factor)
+        self.n_users, self.n_entities, self.n_items = model.n_users, model.n_entities, getattr(model, "n_items", None)
         for n in model.USER_TABLES + model.ENTITY_TABLES:
             emb = getattr(model, n)
             sh = nn.Parameter(shard_rows(emb.weight.data, self.rank, self.P))
             delattr(model, n)
             self.register_parameter("shard_" + n, sh)
         self._compact = None
+        self._overflow = None  # int32 [1] on the tables' device: max distinct rows asked of one owner, when > cap
+        self._ovf_host, self._ovf_event = None, None
         outer = self
 
         def _tables(side):
@@ -161,32 +186,131 @@ class RowShardedKGE(nn.Module):
     def _shards(self, names):
         return tuple(getattr(self, "shard_" + n) for n in names)
 
+    # -- overflow of the fixed exchange capacity: detected on the device, reported one call late, never a stall --------
+    def _flag(self, device):
+        if self._overflow is None or self._overflow.device != device:
+            self._overflow = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._overflow
+
+    def check_overflow(self, wait=True):
+        """Raise if an earlier lookup asked one owner for more distinct rows than the exchange capacity."""
+        if self._overflow is None:
+            return
+        if self._overflow.is_cuda:
+            if self._ovf_event is None:
+                if not wait:
+                    return
+                seen = int(self._overflow.item())
+            else:
+                self._ovf_event.synchronize()
+                seen = int(self._ovf_host.item())
+                if wait:
+                    seen = max(seen, int(self._overflow.item()))
+        else:
+            seen = int(self._overflow.item())
+        if seen:
+            raise RuntimeError(
+                f"row-sharded lookup: an owner was asked for {seen} distinct rows, more than the exchange capacity "
+                f"(capacity_factor={self.capacity_factor}); the affected step is invalid -- raise capacity_factor "
+                f"(P = {self.P} is the worst case)")
+
+    def _post_overflow_copy(self):
+        if self._overflow is not None and self._overflow.is_cuda:
+            if self._ovf_host is None:
+                self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._ovf_event = torch.cuda.Event()
+            self._ovf_host.copy_(self._overflow, non_blocking=True)
+            self._ovf_event.record()
+
+    def _lookup(self, names, ids, n_rows):
+        return sharded_lookup(self._shards(names), ids, n_rows, self.group, self.capacity_factor, self._flag(ids.device))[:2]
+
     def calculate_loss(self, interaction):
         m = self.model
-        ent_ids = torch.cat([interaction[k].reshape(-1) for k in
-                             (m.ITEM_ID, m.NEG_ITEM_ID, m.HEAD_ENTITY_ID, m.TAIL_ENTITY_ID, m.NEG_TAIL_ENTITY_ID)])
-        ent_rows, ent_inv = sharded_lookup(self._shards(m.ENTITY_TABLES), ent_ids, self.group)
-        usr_rows, usr_inv = sharded_lookup(self._shards(m.USER_TABLES), interaction[m.USER_ID], self.group)
-        sizes = [interaction[k].numel() for k in
-                 (m.ITEM_ID, m.NEG_ITEM_ID, m.HEAD_ENTITY_ID, m.TAIL_ENTITY_ID, m.NEG_TAIL_ENTITY_ID)]
-        pi, ni, h, t, nt = torch.split(ent_inv, sizes)
+        self.check_overflow(wait=False)  # the previous call's flag: its copy landed long ago, no stall
+        keys = (m.ITEM_ID, m.NEG_ITEM_ID, m.HEAD_ENTITY_ID, m.TAIL_ENTITY_ID, m.NEG_TAIL_ENTITY_ID)
+        ent_ids = torch.cat([interaction[k].reshape(-1) for k in keys])
+        ent_rows, ent_inv = self._lookup(m.ENTITY_TABLES, ent_ids, self.n_entities)
+        usr_rows, usr_inv = self._lookup(m.USER_TABLES, interaction[m.USER_ID], self.n_users)
+        self._post_overflow_copy()
+        pi, ni, h, t, nt = torch.split(ent_inv, [interaction[k].numel() for k in keys])
         remapped = {m.USER_ID: usr_inv, m.ITEM_ID: pi, m.NEG_ITEM_ID: ni, m.HEAD_ENTITY_ID: h,
                     m.RELATION_ID: interaction[m.RELATION_ID], m.TAIL_ENTITY_ID: t, m.NEG_TAIL_ENTITY_ID: nt}
         self._compact = {"user": usr_rows, "entity": ent_rows}
         try:
-            return m.calculate_loss(remapped)
+            losses = m.calculate_loss(remapped)
         finally:
             self._compact = None
+        loss = sum(losses) if isinstance(losses, tuple) else losses
+        return _GradScale.apply(loss, 1.0 / self.P) if self.P > 1 else loss
 
     def sync_grads(self):
+        """Sum the replicated parameters' gradients over ranks (each already carries the 1 / P of the loss average)."""
         if self.P == 1:
             return
         for n, p in self.named_parameters():
-            if p.grad is None:
-                continue
-            if not n.startswith("shard_"):
+            if p.grad is not None and not n.startswith("shard_"):
                 dist.all_reduce(p.grad, group=self.group)
-            p.grad.div_(self.P)
+
+    # -- evaluation: tails sharded, queries replicated (every rank passes the SAME interaction) ----------------------------
+    def _queries(self, interaction, kg):
+        m = self.model
+        if kg:
+            rows, inv = self._lookup(m.ENTITY_TABLES, interaction[m.HEAD_ENTITY_ID], self.n_entities)
+            return rows, inv, interaction[m.RELATION_ID], 0
+        rows, inv = self._lookup(m.USER_TABLES, interaction[m.USER_ID], self.n_users)
+        return rows, inv, None, m._rec_rel_full_sort()
+
+    def _local_cols(self, kg):
+        n = self.n_entities if kg else self.n_items
+        return n, local_rows(n, self.rank, self.P)
+
+    @torch.no_grad()
+    def full_sort_topk(self, interaction, k, history_index=None, kg=False):
+        """Global masked top-k (trainer.py:731-734 + collector.py:173-183): (values [B, k], global ids [B, k]), ordered
+        (value desc, id asc) exactly like the unsharded ``full_sort_topk``.  Rec side: candidate items are the entity rows
+        [0, n_items), of which this rank owns ids rank, rank + P, ..."""
+        m = self.model
+        head, inv, r_idx, r_fixed = self._queries(interaction, kg)
+        n, n_loc = self._local_cols(kg)
+        hist = None
+        if history_index is not None:  # entries owned elsewhere get column -1, which the mask builder ignores
+            hr, hc = history_index
+            hist = (hr, torch.where(hc % self.P == self.rank, torch.div(hc, self.P, rounding_mode="floor"),
+                                    torch.full_like(hc, -1)))
+        kk = min(int(k), n_loc)
+        val, idx = (_shard_ops["full_sort_topk"] or ops.kge_full_sort_topk)(m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx,
+                                          r_fixed, 0, n_loc, kk, hist, self.rank == 0, m.margin)
+        gid = idx * self.P + self.rank  # column 0 = [PAD] lives on rank 0 only
+        if kk < k:  # fewer local candidates than k: pad with -inf / ids past the table so they lose every comparison
+            pad = int(k) - kk
+            val = torch.cat([val, torch.full((val.shape[0], pad), float("-inf"), device=val.device)], 1)
+            gid = torch.cat([gid, torch.full((gid.shape[0], pad), n, dtype=gid.dtype, device=gid.device)], 1)
+        return merge_topk(val, gid, int(k), self.group)
+
+    @torch.no_grad()
+    def _full_sort(self, interaction, kg):
+        m = self.model
+        head, inv, r_idx, r_fixed = self._queries(interaction, kg)
+        n, n_loc = self._local_cols(kg)
+        local = (_shard_ops["full_sort"] or ops.kge_full_sort)(m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx, r_fixed,
+                                  0, n_loc, m.margin).view(-1, n_loc)
+        if self.P == 1:
+            return local
+        B, width = local.shape[0], local_rows(n, 0, self.P)
+        pad = torch.zeros((B, width), dtype=local.dtype, device=local.device)
+        pad[:, :n_loc] = local
+        parts = [torch.empty_like(pad) for _ in range(self.P)]
+        dist.all_gather(parts, pad, group=self.group)
+        full = torch.stack(parts, dim=2).reshape(B, width * self.P)[:, :n]  # column = local * P + rank
+        return full.contiguous()
+
+    def full_sort_predict(self, interaction):
+        """[B, n_items] (trainer.py:731 views it as that); all ranks pass the same interaction."""
+        return self._full_sort(interaction, kg=False)
+
+    def full_sort_predict_kg(self, interaction):
+        return self._full_sort(interaction, kg=True)
 
     def full_state_dict(self):
         """Reassemble the reference-compatible state_dict (all ranks participate; rank 0 gets full tables)."""
@@ -222,7 +346,7 @@ def merge_topk(local_vals, local_ids, k, group=None, topk_fn=None):
     # order candidates by global id first so that "index asc" among equal values means "global id asc"
     order = torch.argsort(i, dim=1, stable=True)
     v, i = torch.gather(v, 1, order), torch.gather(i, 1, order)
-    tv, ti = (topk_fn or ops.topk_rows)(v.contiguous(), k)
+    tv, ti = (topk_fn or _shard_ops["topk"] or ops.topk_rows)(v.contiguous(), k)
     return tv, torch.gather(i, 1, ti.clamp_min(0))
 
 

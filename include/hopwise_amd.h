@@ -438,6 +438,28 @@ int hw_gather_rows(const float* table, int64_t n_table_rows, int32_t dim, const 
 int hw_scatter_add_rows(float* table, int64_t n_table_rows, int32_t dim, const int64_t* idx, int64_t n,
                         const float* src, void* stream);
 
+/* Device-side routing of one sharded lookup ("bucket indices by owner -> all_to_all(ids) -> local
+ * gather -> all_to_all(rows)"; owner = id % n_ranks, local row = id / n_ranks).  No host read anywhere:
+ *   inv[i]                      = owner(ids[i]) * cap + rank of ids[i] among the owner's distinct ids (ascending id)
+ *   send_counts[o]              = distinct ids asked of owner o (<= cap)
+ *   send_local[o * cap + j]     = local row of the j-th of them
+ *   *overflow                   = max distinct count seen when some owner is asked for more than cap rows (else untouched;
+ *                                 zero it before the first call); the plan is then unusable and the caller raises.
+ * The three fixed-size all-to-alls (counts, send_local, rows) are the caller's (torch.distributed / RCCL); the buffer
+ * the rows return into is the compact table, indexed by inv.  workspace: hw_shard_plan_workspace_bytes(n_rows, n_ranks). */
+int64_t hw_shard_plan_workspace_bytes(int64_t n_rows, int32_t n_ranks);
+int hw_shard_plan(const int64_t* ids, int64_t n, int64_t n_rows, int32_t n_ranks, int32_t cap, void* workspace,
+                  int64_t* inv, int32_t* send_counts, int32_t* send_local, int32_t* overflow, int32_t* oob_counter,
+                  void* stream);
+/* Owner side.  out[p * cap + j, :] = shard[recv_local[p * cap + j], :] for j < recv_counts[p] (other rows untouched);
+ * grad_shard[recv_local[p * cap + j], :] += src[p * cap + j, :] (float atomics: two peers may send the same row). */
+int hw_shard_gather(const float* shard, int64_t n_local_rows, int32_t dim, const int32_t* recv_local,
+                    const int32_t* recv_counts, int32_t n_ranks, int32_t cap, float* out, int32_t* oob_counter,
+                    void* stream);
+int hw_shard_scatter_add(float* grad_shard, int64_t n_local_rows, int32_t dim, const int32_t* recv_local,
+                         const int32_t* recv_counts, int32_t n_ranks, int32_t cap, const float* src,
+                         int32_t* oob_counter, void* stream);
+
 /* ---- CAFE inference (model/knowledge_aware_recommender/cafe.py) ----------------------------------------------
  * y[r, :] = log_softmax(x[r, :]) (cafe.py:597-598, :819-820). */
 int hw_log_softmax_rows(const float* x, int64_t ld, int64_t n_rows, int64_t n_cols, float* y, int64_t ldy,

@@ -1,7 +1,8 @@
 """world_size-2 gloo (CPU) tests of the multi-GPU host logic: row-sharded lookup (forward + backward exchange),
 the sharded KGE wrapper's id remapping and gradient routing, global top-k merge, max-over-ranks timing.
-The row gather / scatter-add primitives are replaced by torch CPU indexing here (parallel.set_row_ops) --
-only the exchange logic is under test; the HIP primitives have their own GPU tests."""
+The device primitives (routing plan, row gather / scatter-add, full sort) are replaced by CPU stand-ins here
+(parallel.set_shard_ops, oracle/shard_plan.py) -- only the exchange logic is under test; the HIP primitives have
+their own GPU tests (tests/test_gpu_shard.py), which check them against the same oracle."""
 
 import os
 import socket
@@ -23,12 +24,54 @@ def _free_port():
     return p
 
 
-def _cpu_gather(table, idx):
-    return table[idx]
+def _cpu_plan(ids, n_rows, P, cap, overflow):
+    from oracle import shard_plan as osp
+
+    inv, counts, local, ovf = osp.plan(ids.numpy(), n_rows, P, cap)
+    if ovf:
+        overflow[0] = max(int(overflow[0]), ovf)
+    return torch.from_numpy(inv), torch.from_numpy(counts), torch.from_numpy(np.maximum(local, 0))
 
 
-def _cpu_scatter_add(table, idx, src):
-    return table.index_add_(0, idx, src)
+def _cpu_gather(shard, recv_local, recv_counts, cap):
+    from oracle import shard_plan as osp
+
+    # rows past a peer's count are garbage on the device: poison them here so that any use shows up
+    return torch.from_numpy(osp.gather(shard.detach().numpy(), recv_local.numpy(), recv_counts.numpy(), cap, fill=np.nan))
+
+
+def _cpu_scatter_add(grad, recv_local, recv_counts, cap, src):
+    from oracle import shard_plan as osp
+
+    osp.scatter_add(grad.numpy(), recv_local.numpy(), recv_counts.numpy(), cap, src.numpy())
+    return grad
+
+
+def _rotate_scores(head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin):
+    """[B, hi - lo] RotatE scores of queries (h, r) against tail rows [lo, hi) -- torch CPU stand-in of the HIP full sort."""
+    r = rel[0][r_idx] if r_idx is not None else rel[0][r_fixed].expand(len(h_idx), -1)
+    rr, ri = torch.cos(r), torch.sin(r)
+    hre, him = head[0][h_idx], head[1][h_idx]
+    qre, qim = rr * hre - ri * him, rr * him + ri * hre
+    re = qre[:, None, :] - tail[0][lo:hi][None]
+    im = qim[:, None, :] - tail[1][lo:hi][None]
+    return margin - torch.sqrt((re * re + im * im).sum(-1))
+
+
+def _cpu_full_sort(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin=0.0):
+    return _rotate_scores(head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin).reshape(-1)
+
+
+def _cpu_full_sort_topk(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, k, history_index=None, mask_first_col=True,
+                        margin=0.0):
+    sc = _rotate_scores(head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin)
+    if mask_first_col:
+        sc[:, 0] = -np.inf
+    if history_index is not None:
+        hr, hc = history_index
+        ok = (hc >= 0) & (hc < sc.shape[1])
+        sc[hr[ok], hc[ok]] = -np.inf
+    return _cpu_topk(sc, k)
 
 
 def _cpu_topk(v, k):
@@ -44,12 +87,13 @@ class _StubModel(torch.nn.Module):
     USER_TABLES = ("user_embedding", "user_embedding_im")
     ENTITY_TABLES = ("entity_embedding", "entity_embedding_im")
     RELATION_TABLES = ("relation_embedding",)
+    MODEL, margin = "RotatE", 1.0
     USER_ID, ITEM_ID, NEG_ITEM_ID = "user_id", "item_id", "neg_item_id"
     HEAD_ENTITY_ID, RELATION_ID, TAIL_ENTITY_ID, NEG_TAIL_ENTITY_ID = "head_id", "relation_id", "tail_id", "neg_tail_id"
 
-    def __init__(self, tables, n_users, n_entities):
+    def __init__(self, tables, n_users, n_entities, n_items=None):
         super().__init__()
-        self.n_users, self.n_entities = n_users, n_entities
+        self.n_users, self.n_entities, self.n_items = n_users, n_entities, n_items
         for k, v in tables.items():
             emb = torch.nn.Embedding(*v.shape)
             emb.weight.data.copy_(torch.from_numpy(v))
@@ -57,6 +101,9 @@ class _StubModel(torch.nn.Module):
 
     def _w(self, names):
         return tuple(getattr(self, n).weight for n in names)
+
+    def _rec_rel_full_sort(self):
+        return self.relation_embedding.weight.shape[0] - 1
 
     def _tables(self, side):
         head = self._w(self.USER_TABLES if side == "rec" else self.ENTITY_TABLES)
@@ -84,7 +131,8 @@ def _worker(rank, world_size, port, tmp):
     torch.set_num_threads(1)
     from hopwise_amd import parallel as par
 
-    par.set_row_ops(_cpu_gather, _cpu_scatter_add)
+    par.set_shard_ops(plan=_cpu_plan, gather=_cpu_gather, scatter_add=_cpu_scatter_add, full_sort=_cpu_full_sort,
+                      full_sort_topk=_cpu_full_sort_topk, topk=_cpu_topk)
     try:
         # ---- 1. lookup forward / backward against a dense table -----------------------------------------
         rng = np.random.default_rng(0)  # same on every rank
@@ -94,8 +142,10 @@ def _worker(rank, world_size, port, tmp):
         sa = par.shard_rows(full_a, rank, world_size).requires_grad_(True)
         sb = par.shard_rows(full_b, rank, world_size).requires_grad_(True)
         ids = torch.from_numpy(np.random.default_rng(10 + rank).integers(0, N, (7, 5)))  # differs per rank, repeats
-        (ca, cb), inv = par.sharded_lookup((sa, sb), ids)
+        (ca, cb), inv, ovf = par.sharded_lookup((sa, sb), ids, N)
+        assert int(ovf.item()) == 0
         assert torch.equal(ca[inv], full_a[ids]) and torch.equal(cb[inv], full_b[ids])
+        assert ca.shape[0] == world_size * par.capacity(ids.numel(), N, world_size, 1.25)  # fixed-size exchange
         w = torch.from_numpy(np.random.default_rng(20 + rank).standard_normal((7, 5, d)).astype(np.float32))
         ((ca[inv] * w).sum() + 2.0 * (cb[inv] * w).sum()).backward()
         # dense expectation: every rank's contribution, summed at the owner
@@ -121,10 +171,11 @@ def _worker(rank, world_size, port, tmp):
         ref = _StubModel(tables, nU, nE)
         ref_loss = sum(ref.calculate_loss(batch(r)) for r in range(world_size)) / world_size
         ref_loss.backward()
-        sharded = par.RowShardedKGE(_StubModel(tables, nU, nE))
+        sharded = par.RowShardedKGE(_StubModel(tables, nU, nE, nI))
         loss = sharded.calculate_loss(batch(rank))
         loss.backward()
         sharded.sync_grads()
+        sharded.check_overflow()
         for n in _StubModel.USER_TABLES + _StubModel.ENTITY_TABLES:
             want = getattr(ref, n).weight.grad[rank::world_size]
             assert torch.allclose(getattr(sharded, "shard_" + n).grad, want, atol=1e-6), n
@@ -135,6 +186,40 @@ def _worker(rank, world_size, port, tmp):
         sd = sharded.full_state_dict()
         for k, v in tables.items():
             assert torch.equal(sd[k + ".weight"], torch.from_numpy(v)), k
+
+        # ---- 2b. sharded full sort == unsharded full sort, values and ranked ids exact ---------------
+        full = _StubModel(tables, nU, nE, nI)
+        users = torch.tensor([3, 1, 16, 3, 9])
+        hr, hc = torch.tensor([0, 0, 2, 4, 4, 1]), torch.tensor([5, 2, 7, 1, 10, 3])
+        for kg, inter, n_cols in ((False, {"user_id": users}, nI),
+                                  (True, {"head_id": torch.tensor([4, 28, 1, 17]), "relation_id": torch.tensor([1, 3, 0, 2])}, nE)):
+            H, R, T = full._tables("kg" if kg else "rec")
+            q = inter["head_id"] if kg else users
+            want = _rotate_scores(H, R, T, q, inter.get("relation_id"), full._rec_rel_full_sort(), 0, n_cols, 1.0)
+            got = (sharded.full_sort_predict_kg if kg else sharded.full_sort_predict)(inter).view(-1, n_cols)
+            assert torch.equal(got, want), kg
+            hist = None if kg else (hr, hc)
+            masked = want.clone()
+            masked[:, 0] = -np.inf
+            if hist is not None:
+                masked[hist] = -np.inf
+            for k in (3, 10):
+                rv, ri = okge.topk_desc(masked.detach().numpy(), k)
+                tv, ti = sharded.full_sort_topk(inter, k, hist, kg=kg)
+                assert np.array_equal(ti.numpy(), ri) and np.array_equal(tv.numpy(), rv), (kg, k)
+        sharded.check_overflow()
+
+        # ---- 2c. capacity overflow is detected, not silently wrong -------------------------------------------------
+        tight = par.RowShardedKGE(_StubModel(tables, nU, nE, nI), capacity_factor=0.01)
+        tight.capacity_factor = 0.0
+        _orig_cap = par.capacity
+        par.capacity = lambda n, rows, P, f: 2  # two distinct rows per owner: the 12-triple batch cannot fit
+        try:
+            tight.calculate_loss(batch(rank))
+            with pytest.raises(RuntimeError, match="capacity"):
+                tight.check_overflow()
+        finally:
+            par.capacity = _orig_cap
 
         # ---- 3. global top-k merge ---------------------------------------------------------------------------
         rng = np.random.default_rng(5)
@@ -151,7 +236,7 @@ def _worker(rank, world_size, port, tmp):
         assert par.max_over_ranks(1.0 + rank, torch.device("cpu")) == float(world_size)
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
-        par.set_row_ops(None, None)
+        par.set_shard_ops()
         dist.destroy_process_group()
 
 

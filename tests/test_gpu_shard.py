@@ -1,0 +1,118 @@
+"""Device-side routing of the row-sharded lookup (csrc/shard.hip) against oracle/shard_plan.py, bit for bit, and a
+multi-owner exchange simulated on ONE GPU: P virtual ranks, the all-to-alls done by hand with tensor slicing, so that the
+P > 1 code path of the kernels (owner-major bitmap, per-peer counts, capacity padding) runs on hardware even though the
+box has one card.  The real multi-process exchange is tests/test_dist_gloo.py (CPU stand-ins) and bench.py --gpus N (RCCL).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import shard_plan as osp
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("P,n_rows,shape", [(1, 97, (40,)), (2, 53, (7, 5)), (3, 1000, (4096,)), (8, 90962, (5, 8192)),
+                                            (8, 45920, (8192,)), (4, 33, (1,)), (8, 5, (64,))])
+def test_plan_matches_oracle(P, n_rows, shape):
+    from hopwise_amd import ops, parallel as par
+
+    rng = np.random.default_rng(P * 1000 + n_rows)
+    ids = rng.integers(0, n_rows, shape)
+    if ids.size > 10:
+        ids.reshape(-1)[:5] = ids.reshape(-1)[5:10]  # repeats
+    cap = par.capacity(ids.size, n_rows, P, 1.25)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev())
+    inv, counts, local = ops.shard_plan(torch.from_numpy(ids).to(dev()), n_rows, P, cap, ovf)
+    r_inv, r_counts, r_local, r_ovf = osp.plan(ids, n_rows, P, cap)
+    assert r_ovf == 0 and int(ovf.item()) == 0
+    assert np.array_equal(inv.cpu().numpy(), r_inv) and inv.shape == ids.shape
+    assert np.array_equal(counts.cpu().numpy(), r_counts)
+    local = local.cpu().numpy()
+    for o in range(P):  # slots past the count are unspecified
+        c = r_counts[o]
+        assert np.array_equal(local[o * cap : o * cap + c], r_local[o * cap : o * cap + c])
+    # the defining property: id = local * P + owner at the slot inv points to
+    own, slot = r_inv.reshape(-1) // cap, r_inv.reshape(-1) % cap
+    assert np.array_equal(local[own * cap + slot].astype(np.int64) * P + own, ids.reshape(-1))
+
+
+def test_plan_overflow_flag_and_oob():
+    from hopwise_amd import ops
+
+    ids = np.arange(0, 64, dtype=np.int64) * 4  # all owned by rank 0 of 4
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev())
+    inv, counts, local = ops.shard_plan(torch.from_numpy(ids).to(dev()), 1000, 4, 10, ovf)
+    assert int(ovf.item()) == 64 and counts.cpu().tolist() == [10, 0, 0, 0]
+    assert int(inv.max().item()) < 4 * 10  # clamped into the compact table
+    before = ops.oob_count(dev())
+    bad = torch.tensor([5, -1, 2000], device=dev())
+    ops.shard_plan(bad, 1000, 4, 8, torch.zeros(1, dtype=torch.int32, device=dev()))
+    assert ops.oob_count(dev()) == before + 2
+
+
+@pytest.mark.parametrize("P,dim", [(1, 64), (2, 200), (8, 256), (3, 7)])
+def test_virtual_ranks_exchange_roundtrip(P, dim):
+    """Forward rows and backward row-gradients through plan -> gather -> (hand-made all-to-all) -> scatter-add for P
+    virtual ranks, each with its own ids, against dense indexing."""
+    from hopwise_amd import ops, parallel as par
+
+    n_rows, n = 777, 500
+    rng = np.random.default_rng(P + dim)
+    full = rng.standard_normal((n_rows, dim)).astype(np.float32)
+    shards = [torch.from_numpy(np.ascontiguousarray(full[r::P])).to(dev()) for r in range(P)]
+    ids = [rng.integers(0, n_rows, n) for _ in range(P)]
+    cap = par.capacity(n, n_rows, P, 1.25)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev())
+    plans = [ops.shard_plan(torch.from_numpy(i).to(dev()), n_rows, P, cap, ovf) for i in ids]
+    assert int(ovf.item()) == 0
+    # all-to-all by hand: what rank r receives from rank s is s's slice for owner r
+    recv_counts = [torch.stack([plans[s][1][r] for s in range(P)]) for r in range(P)]
+    recv_local = [torch.cat([plans[s][2][r * cap : (r + 1) * cap] for s in range(P)]) for r in range(P)]
+    sent = [ops.shard_gather(shards[r], recv_local[r], recv_counts[r], cap) for r in range(P)]  # [P * cap, d] per owner
+    for s in range(P):
+        compact = torch.cat([sent[r][s * cap : (s + 1) * cap] for r in range(P)])  # rows back at requester s
+        got = compact[plans[s][0]].cpu().numpy()
+        assert np.array_equal(got, full[ids[s]])
+    # backward: requester s holds dense compact gradients; owner r adds what every s sends it
+    g = [rng.standard_normal((P * cap, dim)).astype(np.float32) for _ in range(P)]
+    want = np.zeros((n_rows, dim), np.float64)
+    for s in range(P):
+        inv = plans[s][0].cpu().numpy()
+        used = np.unique(inv)
+        uniq_ids = np.zeros(P * cap, np.int64)
+        uniq_ids[inv] = ids[s]
+        np.add.at(want, uniq_ids[used], g[s][used].astype(np.float64))
+    for r in range(P):
+        acc = torch.zeros_like(shards[r])
+        back = torch.cat([torch.from_numpy(g[s][r * cap : (r + 1) * cap]) for s in range(P)]).to(dev())
+        ops.shard_scatter_add_(acc, recv_local[r], recv_counts[r], cap, back)
+        np.testing.assert_allclose(acc.cpu().numpy(), want[r::P], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("model", ["RotatE", "ComplEx"])
+def test_sharded_full_sort_single_rank_matches_plain(model):
+    from hopwise_amd import parallel as par
+    from tests.helpers import random_tables
+    from tests.test_gpu_kge import build
+
+    dim, nU, nI, nE, nR = 64, 40, 30, 90, 7
+    tables = random_tables(model, nU, nE, nR, dim, seed=4)
+    plain = build(model, tables, dim, nU, nI, nE, nR)
+    sh = par.RowShardedKGE(build(model, tables, dim, nU, nI, nE, nR))
+    users = torch.tensor([3, 1, 16, 3, 9], device=dev())
+    hist = (torch.tensor([0, 0, 2, 4], device=dev()), torch.tensor([5, 2, 7, 1], device=dev()))
+    with torch.no_grad():
+        assert torch.equal(sh.full_sort_predict({"user_id": users}), plain.full_sort_predict({"user_id": users}))
+        kg = {"head_id": torch.tensor([4, 28, 1], device=dev()), "relation_id": torch.tensor([1, 3, 0], device=dev())}
+        assert torch.equal(sh.full_sort_predict_kg(kg), plain.full_sort_predict_kg(kg))
+        for inter, h, is_kg in (({"user_id": users}, hist, False), (kg, None, True)):
+            v0, i0 = plain.full_sort_topk(inter, 10, h, kg=is_kg)
+            v1, i1 = sh.full_sort_topk(inter, 10, h, kg=is_kg)
+            assert torch.equal(v0, v1) and torch.equal(i0, i1)
+    sh.check_overflow()
