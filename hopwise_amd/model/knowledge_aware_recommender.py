@@ -26,7 +26,7 @@ import torch
 from torch import nn
 
 from .. import pgpr_ops as P
-from ..utils import InputType
+from ..utils import InputType, seed_for_rank
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
 from .knowledge_graph_embedding_recommender import _cfg
 
@@ -66,6 +66,7 @@ class _EpisodeLoss(torch.autograd.Function):
 
 class PGPR(KnowledgeRecommender, ExplainableRecommender):
     input_type = InputType.USERWISE
+    other_parameter_name = ["_drop_calls"]  # trainer.py:296-304 saves other_parameter(); resume continues the stream
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -107,8 +108,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.l2 = nn.Linear(self.hidden_sizes[0], self.hidden_sizes[1])
         self.actor = nn.Linear(self.hidden_sizes[1], self.act_dim)
         self.critic = nn.Linear(self.hidden_sizes[1], 1)
-        self._drop_calls = 0
-        self._seed = int(_cfg(config, "seed", 2020))
+        self._drop_calls = 0  # Philox offset of the policy dropout / action draws; rides in the checkpoint (other_parameter)
+        self._seed = seed_for_rank(_cfg(config, "seed", 2020))
 
         # training (pgpr.py:40-46, 90-104)
         self.gamma = float(_cfg(config, "gamma", 0.99))
@@ -187,7 +188,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         P.mlp_layer(buf["x2"], self.actor.weight, self.actor.bias, buf["logits"], n_rows, rmax, False)
 
     @torch.no_grad()
-    def beam_search_device(self, users, hops=None, drops=None, keep_trace=False):
+    def beam_search_device(self, users, hops=None, drops=None, keep_trace=False, keep_buffers=False):
         """Expand ``users`` (int64 tensor on the device) hop by hop; returns a :class:`BeamResult` of leaf rows.
         ``drops``: optional per hop (mask1 [rows, h0], mask2 [rows, h1]) multiplicative masks."""
         hops = list(self.beam_search_hop if hops is None else hops)
@@ -228,6 +229,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         res = BeamResult(buf["paths"][-1], buf["probs"][-1], nr[len(hops) : len(hops) + 1])
         res.n_rows_per_hop = nr
         res.trace = trace
+        res.buffers = buf if keep_buffers else None  # per-hop path rows / action counts (bench_pgpr's byte accounting)
         return res
 
     def _user_vec(self):

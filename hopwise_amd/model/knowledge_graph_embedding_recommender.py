@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ..utils import InputType
+from ..utils import InputType, seed_for_rank
 from .abstract_recommender import KnowledgeRecommender
 
 
@@ -505,6 +505,8 @@ class TuckER(KnowledgeRecommender):
     hidden_dropout1 and the sigmoid + BCE with its gradient are fused kernels (csrc/tucker.hip); BatchNorm and the two
     [B, d] dropouts are torch modules (a few hundred KB of traffic next to GBs of logits)."""
 
+    other_parameter_name = ["_drop_calls"]  # Philox offset of hidden_dropout1: saved with the checkpoint (trainer.py:296-304)
+
     input_type = InputType.PAIRWISE
 
     def __init__(self, config, dataset):
@@ -523,7 +525,7 @@ class TuckER(KnowledgeRecommender):
         self.bn1 = nn.BatchNorm1d(d)
         self.apply(xavier_normal_initialization)
         self.forced_masks = None  # tests: {"rec": (m0 [B,d], m1 [B,d,d], m2 [B,d]), "kg": (...)} multiplicative masks
-        self._seed, self._drop_calls = int(_cfg(config, "seed", 2020)), 0
+        self._seed, self._drop_calls = seed_for_rank(_cfg(config, "seed", 2020)), 0
 
     def _drop(self, module, x, forced):
         if forced is not None:

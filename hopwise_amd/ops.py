@@ -183,6 +183,7 @@ def _live_sink(t):
     if p is None:
         del _GRAD_SINKS[t.data_ptr()]
         return None
+    hit[1].check_distributed()
     g = p.grad
     if g is None or g.shape != t.shape or g.dtype != torch.float32 or not g.is_contiguous() or p.shape != t.shape:
         return None
@@ -239,7 +240,7 @@ class KgeScoreGrouped(torch.autograd.Function):
                         grads_out.append(None)  # shared buffer already returned for an earlier slot
                     elif (sink := _live_sink(t)) is not None and torch.is_grad_enabled() is False:
                         bufs[key] = sink[0]  # accumulate straight into p.grad; autograd gets nothing to add
-                        sink[1].dirty = True
+                        sink[1].touch(t.data_ptr())
                         grads_out.append(None)
                     else:
                         bufs[key] = torch.zeros_like(t)
@@ -294,7 +295,7 @@ def _grad_slots(desc_tables, needs, bufs, grads_out_by_pos, positions):
                 sink = _live_sink(t) if not torch.is_grad_enabled() else None
                 if sink is not None:
                     bufs[key] = sink[0]
-                    sink[1].dirty = True
+                    sink[1].touch(t.data_ptr())
                 else:
                     bufs[key] = torch.zeros_like(t)
                     grads_out_by_pos[p] = bufs[key]

@@ -12,6 +12,10 @@ layout, but
 * registers those persistent gradients as *sinks* for the scorer's backward (``ops.KgeScoreGrouped``): the gradient
   kernel accumulates straight into ``p.grad`` instead of into a fresh zero-filled buffer that autograd then adds
   (so ``loss.backward()`` is the supported way to differentiate; ``torch.autograd.grad`` would see no table gradients).
+  Sinks bypass autograd's AccumulateGrad, hence DistributedDataParallel's reducer: with torch.distributed initialised
+  at world size > 1 they are REFUSED (``grad_sinks=False`` keeps DDP correct; ``grad_sinks="caller_syncs"`` is for
+  callers that all-reduce ``p.grad`` themselves, e.g. ``parallel.RowShardedKGE.sync_grads``).  Parameters no backward
+  touched since the last step are skipped, as torch.optim.Adam skips ``grad is None``.
 
 There is no CPU path: parameters must be contiguous fp32 HIP tensors."""
 import ctypes as C
@@ -22,10 +26,35 @@ from . import _lib, ops
 
 
 class _SinkState:
-    __slots__ = ("dirty",)
+    """Bookkeeping of the gradient sinks of one optimizer: whether anything accumulated since the last step (``dirty``),
+    WHICH parameters did (``touched``: torch.optim.Adam skips a parameter whose ``.grad`` is None, i.e. one no backward
+    reached -- its moments do not decay and weight decay is not applied; the sink buffers are never None, so that is
+    tracked here), and whether writing straight into ``p.grad`` is safe under torch.distributed."""
 
-    def __init__(self):
+    __slots__ = ("dirty", "touched", "caller_syncs")
+
+    def __init__(self, caller_syncs=False):
         self.dirty = True
+        self.touched = set()
+        self.caller_syncs = caller_syncs
+
+    def touch(self, data_ptr):
+        self.dirty = True
+        self.touched.add(data_ptr)
+
+    def check_distributed(self):
+        """Sinks bypass autograd's AccumulateGrad, so DistributedDataParallel's reducer hooks never fire for these
+        parameters and replicas would diverge silently.  Refuse unless the caller all-reduces ``p.grad`` itself."""
+        if self.caller_syncs:
+            return
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise _lib.HopwiseAmdError(
+                "FusedAdam gradient sinks write into p.grad without passing through autograd: under torch.distributed "
+                "(world size > 1) DDP would never all-reduce them.  Build the optimizer with grad_sinks=False (DDP works "
+                "unchanged), or with grad_sinks='caller_syncs' if you all-reduce p.grad yourself before step() "
+                "(hopwise_amd.parallel.RowShardedKGE.sync_grads does)")
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -37,9 +66,14 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError("FusedAdam: invalid hyper-parameter")
         # capturable: the step counter is a device tensor (what driver.GraphedTrainStep asks of an optimizer)
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, capturable=True))
-        self._sinks = _SinkState() if grad_sinks else None
+        if grad_sinks not in (True, False, "caller_syncs"):
+            raise ValueError("grad_sinks: True, False or 'caller_syncs'")
+        self._sinks = _SinkState(caller_syncs=(grad_sinks == "caller_syncs")) if grad_sinks else None
+        if self._sinks is not None:
+            self._sinks.check_distributed()
         self._decoupled = bool(decoupled_weight_decay)
         self._launch_cache = {}
+        self._counter_members, self._counter_keepalive = {}, {}
         devices = set()
         for group in self.param_groups:
             for p in group["params"]:
@@ -54,8 +88,19 @@ class FusedAdam(torch.optim.Optimizer):
                     ops.register_grad_sink(p, self._sinks)
                     p.register_post_accumulate_grad_hook(self._mark_dirty)
 
-    def _mark_dirty(self, _p):
-        self._sinks.dirty = True
+    def _mark_dirty(self, p):
+        self._sinks.touch(p.data_ptr())
+
+    def mark_touched(self, params=None):
+        """For code that writes into the persistent ``p.grad`` buffers by hand (not through ``backward``): declare the
+        parameters (default: all) as having a gradient this step, as assigning ``p.grad`` would for torch.optim.Adam."""
+        if self._sinks is None:
+            return
+        for group in self.param_groups:
+            for p in (group["params"] if params is None else params):
+                self._sinks.touch(p.data_ptr())
+            if params is not None:
+                break
 
     def zero_grad(self, set_to_none=True):
         """With gradient sinks the buffers stay allocated whatever ``set_to_none`` says, and are only written when
@@ -74,6 +119,7 @@ class FusedAdam(torch.optim.Optimizer):
         if dirty:
             torch._foreach_zero_(dirty)
         self._sinks.dirty = False
+        self._sinks.touched.clear()
 
     def load_state_dict(self, state_dict):
         """Accepts torch.optim.Adam checkpoints (the reference trainer's ``optimizer`` entry, trainer.py:296-304)."""
@@ -83,6 +129,8 @@ class FusedAdam(torch.optim.Optimizer):
                 raise _lib.HopwiseAmdError("FusedAdam: amsgrad / maximize checkpoints are not supported")
             group["capturable"] = True
         self._launch_cache.clear()
+        self._counter_members.clear()
+        self._counter_keepalive.clear()
 
     def _state_of(self, p):
         st = self.state[p]
@@ -95,34 +143,73 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     def _launches(self, group):
-        """[(AdamArgs, step tensor)] for the group's parameters that have a gradient, 16 per launch; cached on
-        the identity of every buffer involved."""
+        """[(AdamArgs, step tensor)] for the group's parameters that have a gradient, 16 per launch; cached per
+        composition on the identity of every buffer involved.
+
+        A launch reads ONE device step counter, so parameters share a counter only while they are always stepped
+        together: a parameter that sits a step out (untouched, see _SinkState) is split off with its own counter."""
         ps = [p for p in group["params"] if p.grad is not None]
+        if self._sinks is not None:  # as torch.optim.Adam: a parameter no backward reached since the last step is skipped
+            ps = [p for p in ps if p.data_ptr() in self._sinks.touched]
         states = [self._state_of(p) for p in ps]
         key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
                      s["step"].data_ptr()) for p, s in zip(ps, states))
-        hit = self._launch_cache.get(id(group))
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        cache = self._launch_cache.setdefault(id(group), {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit
+        for p in ps:
+            if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.is_sparse:
+                raise _lib.HopwiseAmdError("FusedAdam: gradients must be dense contiguous fp32")
+        # 1. counters shared with a parameter that is NOT in this composition are split (clone keeps the value)
+        present = {id(p) for p in ps}
+        by_counter = {}
+        for p, s in zip(ps, states):
+            by_counter.setdefault(id(s["step"]), []).append((p, s))
+        for cid, members in by_counter.items():
+            owners = self._counter_members.get(cid)
+            if owners is not None and not owners <= present:
+                fresh = members[0][1]["step"].clone()
+                for _, s in members:
+                    s["step"] = fresh
+                self._counter_members[cid] = owners - {id(p) for p, _ in members}
+                self._counter_members[id(fresh)] = {id(p) for p, _ in members}
+        # 2. counters at the same value that only serve parameters of this composition are merged: one counter per launch
+        #    (the kernel advances the counter it is given, so the 16-segment chunks of a long list each own one)
+        by_value = {}
+        for p, s in zip(ps, states):
+            by_value.setdefault(int(s["step"]), []).append((p, s))  # device read: composition changes only
         out = []
-        for lo in range(0, len(ps), _lib.ADAM_MAX_SEGS):
-            chunk, cst = ps[lo : lo + _lib.ADAM_MAX_SEGS], states[lo : lo + _lib.ADAM_MAX_SEGS]
-            step = cst[0]["step"]
-            for p, s in zip(chunk, cst):
-                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous() or p.grad.is_sparse:
-                    raise _lib.HopwiseAmdError("FusedAdam: gradients must be dense contiguous fp32")
-                if s["step"] is not step:  # one device counter per launch
-                    if int(s["step"]) != int(step):
-                        raise _lib.HopwiseAmdError("FusedAdam: parameters of one group are at different steps")
-                    s["step"] = step
-            args = _lib.AdamArgs()
-            args.n_segs = len(chunk)
-            for i, (p, s) in enumerate(zip(chunk, cst)):
-                args.seg[i].p, args.seg[i].g = p.data_ptr(), p.grad.data_ptr()
-                args.seg[i].m, args.seg[i].v = s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()
-                args.seg[i].n = p.numel()
-            out.append((args, step))
-        self._launch_cache[id(group)] = (key, out)
+        for _, members in sorted(by_value.items()):
+            for lo in range(0, len(members), _lib.ADAM_MAX_SEGS):
+                chunk = members[lo : lo + _lib.ADAM_MAX_SEGS]
+                ids = {id(p) for p, _ in chunk}
+                shared = None
+                for _, s in chunk:  # reuse a counter that already serves exactly (a subset of) this chunk
+                    if self._counter_members.get(id(s["step"]), ids) <= ids:
+                        shared = s["step"]
+                        break
+                if shared is None:
+                    shared = chunk[0][1]["step"].clone()
+                for _, s in chunk:
+                    if s["step"] is not shared:
+                        old = self._counter_members.get(id(s["step"]))
+                        if old is not None:
+                            old -= ids
+                        s["step"] = shared
+                self._counter_members[id(shared)] = set(ids)
+                self._counter_keepalive[id(shared)] = shared  # ids stay unique while the bookkeeping refers to them
+                args = _lib.AdamArgs()
+                args.n_segs = len(chunk)
+                for i, (p, s) in enumerate(chunk):
+                    args.seg[i].p, args.seg[i].g = p.data_ptr(), p.grad.data_ptr()
+                    args.seg[i].m, args.seg[i].v = s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()
+                    args.seg[i].n = p.numel()
+                out.append((args, shared))
+        # the merge may have changed step pointers: file the result under the key the NEXT identical call will compute
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
+                     s["step"].data_ptr()) for p, s in zip(ps, states))
+        cache[key] = out
         return out
 
     @torch.no_grad()
@@ -142,4 +229,5 @@ class FusedAdam(torch.optim.Optimizer):
                 _lib.check(rc, "hw_adam_step")
         if self._sinks is not None:
             self._sinks.dirty = False
+            self._sinks.touched.clear()
         return loss

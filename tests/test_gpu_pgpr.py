@@ -169,33 +169,25 @@ def test_policy_forward_kernels(tag):
                 np.testing.assert_array_equal(val.cpu().numpy()[r, :kk], key[r, order[r, :kk]])
 
 
-def safe_leaves(orc, users, hops, tol=2e-6):
-    """Oracle leaf paths none of whose hop selections sits within `tol` of the value of the first action that was
-    cut off (those selections cannot be flipped by float32 rounding differences)."""
-    paths, probs, trace = orc.beam_search(users, hops)
-    # replay to know each leaf's parent row per hop
-    safe = []
-    row_safe = [True] * len(users)
-    for hop, k in enumerate(hops):
-        t = trace[hop]
-        new_safe = []
-        for row in range(len(t["acts"])):
-            na = len(t["acts"][row])
-            vals = np.sort(t["probs"][row][:na].astype(np.float64))[::-1]
-            cut = vals[k] if na > k else None
-            for idx, v in zip(t["topk_idx"][row], t["topk_val"][row]):
-                if idx >= na:
-                    continue
-                ok = row_safe[row] and (cut is None or float(v) - cut > tol)
-                new_safe.append(ok)
-        row_safe = new_safe
-    return paths, probs, row_safe
+safe_leaves = op.safe_leaves
+
+
+# Overlap of the device beams with the oracle's / the reference's, as (leaves, safe, device ∩ oracle, device ∩ reference)
+# per (tag, hops) measured on MI355X (deterministic: identity dropout, deterministic split-K).  A lower number is a
+# regression and fails; the differences that remain are float32 ties at a top-k cut, each one proven below.
+BEAM_PINNED = {}
+_pin_path = os.path.join(os.path.dirname(__file__), "golden", "pgpr_beam_overlap.json")
+if os.path.exists(_pin_path):
+    import json as _json
+
+    BEAM_PINNED = _json.load(open(_pin_path))
 
 
 @pytest.mark.parametrize("tag", TAGS)
 def test_beam_search_device(tag):
     g, z, orc, m = build_model(tag)
     users = torch.from_numpy(z["users"]).to(dev())
+    observed = {}
     for hn in beam_names(z):
         hops = [int(x) for x in z[f"beam.{hn}.hops"]]
         res = m.beam_search_device(users, hops)
@@ -204,25 +196,42 @@ def test_beam_search_device(tag):
         got = {tuple((-1 if r == "self_loop" else r, 0 if t == "user" else 1, n) for r, t, n in p): np.asarray(q)
                for p, q in zip(got_paths, got_probs)}
         opaths, oprobs, safe = safe_leaves(orc, z["users"], hops)
-        n_safe = 0
-        for p, q, s in zip(opaths, oprobs, safe):
-            key = tuple(map(tuple, p))
-            if s:
-                assert key in got, (tag, hn, key)
-                n_safe += 1
-            if key in got:
-                np.testing.assert_allclose(got[key], np.asarray(q, np.float32), rtol=3e-6, atol=0)
-        assert n_safe >= 0.5 * len(opaths)
-        overlap = sum(tuple(map(tuple, p)) in got for p in opaths)
-        assert overlap >= 0.97 * len(opaths), (tag, hn, overlap, len(opaths))
-        # and against the reference's own run (same tolerance logic: identical unless ties / rounding at a cut)
+        okeys = [tuple(map(tuple, p)) for p in opaths]
+        unsafe = {k for k, s in zip(okeys, safe) if not s}
+        n_safe = len(okeys) - len(unsafe)
+        # 1. the proof: an oracle leaf the device did not emit has a hop whose selected value sits within 2e-6 of the
+        #    first value that was cut (float32 rounding can flip exactly those selections and no others)
+        missing = [k for k in okeys if k not in got]
+        assert all(k in unsafe for k in missing), (tag, hn, [k for k in missing if k not in unsafe][:3])
+        # 2. every leaf both sides emit carries the same hop probabilities
+        for k, q in zip(okeys, oprobs):
+            if k in got:
+                np.testing.assert_allclose(got[k], np.asarray(q, np.float32), rtol=3e-6, atol=0)
+        overlap = len(okeys) - len(missing)
+        # 3. the reference's own beams: identical to the device's except at those same ties
         ref = {tuple(map(tuple, p)) for p in dec_paths(z[f"beam.{hn}.paths"])}
-        if not m.fix_scores_sorting_bug:
-            assert len(ref & set(got)) >= 0.97 * len(ref), (tag, hn)
+        ref_overlap = len(ref & set(got))
+        if not m.fix_scores_sorting_bug:  # (under the flag the reference's argsort tie order is unpinnable)
+            stray = [k for k in ref if k not in got and k not in unsafe]
+            assert not stray, (tag, hn, "reference leaves missing without a tie at a cut", stray[:3])
+        observed[hn] = [len(okeys), n_safe, overlap, ref_overlap, len(ref)]
+        msg = (f"{tag}/{hn}: {len(okeys)} oracle leaves, {n_safe} safe ({n_safe / max(len(okeys), 1):.4f}), device∩oracle "
+               f"{overlap} ({overlap / max(len(okeys), 1):.4f}), device∩reference {ref_overlap}/{len(ref)}")
+        pin = BEAM_PINNED.get(f"{tag}/{hn}")
+        if pin is not None:
+            assert overlap >= pin[2] and (m.fix_scores_sorting_bug or ref_overlap >= pin[3]), ("regression: " + msg, pin)
+        assert overlap >= 0.97 * len(okeys), msg
         # children are emitted in row order: users appear in batch order
         first_user = [int(r[0]) for r in gp]
         order = [u for i, u in enumerate(first_user) if i == 0 or first_user[i - 1] != u]
         assert order == [int(u) for u in z["users"] if int(u) in set(first_user)]
+    dump = os.environ.get("HW_DUMP_BEAM_OVERLAP")
+    if dump:
+        import json
+
+        cur = json.load(open(dump)) if os.path.exists(dump) else {}
+        cur.update({f"{tag}/{hn}": v for hn, v in observed.items()})
+        json.dump(cur, open(dump, "w"), indent=1, sort_keys=True)
 
 
 def test_reference_dropout_mode_runs_and_is_stochastic():
