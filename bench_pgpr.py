@@ -166,9 +166,9 @@ def run(dev, n_users=32, steps=5, warmup=1, cpu_users=0, rank=0):
         if stray:
             raise AssertionError(f"PGPR full-size parity: {len(stray)} oracle leaves missing from the device search "
                                  f"without a float32 tie at a cut, e.g. {stray[:2]}")
-        out["parity"] = {"users": int(cpu_users), "oracle_leaves": len(okeys), "device_leaves": len(got),
-                         "common": len(okeys) - len(missing), "missing_all_at_ties": True,
-                         "safe_leaves": len(okeys) - len(unsafe),
+        out["parity"] = {"users": int(cpu_users), "oracle_leaves": len(set(okeys)), "device_leaves": len(got),
+                         "common": len(set(okeys) & got), "missing_all_at_ties": True,
+                         "safe_leaves": len(set(okeys) - unsafe),
                          "rule": "every oracle leaf the device did not emit has a hop whose selected value is within 2e-6 "
                                  "of the first value cut (oracle.pgpr.safe_leaves)"}
         del m_id

@@ -51,6 +51,33 @@ def build(force=False, verbose=True):
     return LIB
 
 
+TORCH_LIB = os.path.join(CSRC, "libhopwise_amd_torch.so")
+
+
+def build_torch_ops(force=False, verbose=True):
+    """csrc/torch_bind.cpp -> libhopwise_amd_torch.so: the TORCH_LIBRARY(hopwise_amd) registration of the C ABI, compiled
+    against the installed torch's headers and linked to libhopwise_amd.so (found next to it through $ORIGIN)."""
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    src = os.path.join(CSRC, "torch_bind.cpp")
+    hdrs = glob.glob(os.path.join(CSRC, "..", "..", "include", "*.h"))
+    build(force=False, verbose=verbose)
+    if not (force or _stale(TORCH_LIB, [src, LIB] + hdrs)):
+        return TORCH_LIB
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-unused-result", "-Wno-deprecated-declarations"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + ["-I/opt/rocm/include"]
+    cmd += [src, "-o", TORCH_LIB, f"-L{CSRC}", "-lhopwise_amd", "-Wl,-rpath,$ORIGIN", f"-L{tlib}", "-ltorch", "-ltorch_cpu",
+            "-ltorch_hip", "-lc10", "-lc10_hip", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB)
+    print(build_torch_ops(force="--force" in sys.argv))

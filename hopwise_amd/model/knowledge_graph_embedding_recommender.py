@@ -127,19 +127,31 @@ class _GatherKGE(KnowledgeRecommender):
         """The reference's calculate_loss as one autograd node (ops.FusedPairLoss): rec side (user, [UI-Relation], item /
         neg item) + kg side (head, relation, tail / neg tail).  ``group_rec``: the rec batch tiles each positive
         sample_num times (abstract_dataloader.py:192-198); score it as [P, 1 + K] groups, positives weighted K."""
-        params, pos = [], {}
+        # table positions in the parameter list are static per model: built once (unless the tables are supplied per call,
+        # as parallel.RowShardedKGE does with its compact tables)
+        static = "_tables" not in self.__dict__
+        cache = self.__dict__.get("_pair_layout") if static else None
+        if cache is None:
+            params, pos = [], {}
 
-        def at(t):
-            if id(t) not in pos:
-                pos[id(t)] = len(params)
-                params.append(t)
-            return pos[id(t)]
+            def at(t):
+                if id(t) not in pos:
+                    pos[id(t)] = len(params)
+                    params.append(t)
+                return pos[id(t)]
+
+            layout = {}
+            for name in ("rec", "kg"):
+                head, rel, tail = self._tables(name)
+                layout[name] = ([at(t) for t in head], [at(t) for t in rel], [at(t) for t in tail])
+            cache = (params, layout)
+            if static:
+                self.__dict__["_pair_layout"] = cache
+        params, layout = cache
 
         def side(name, h_idx, r_idx, r_fixed, t_idx, pos_weight=1.0):
-            head, rel, tail = self._tables(name)
             tail_rows = self.n_items if (name == "rec" and self._narrow_rec_tails) else None
-            return ops.PairSide([at(t) for t in head], [at(t) for t in rel], [at(t) for t in tail], h_idx, r_idx, r_fixed,
-                                t_idx, tail_rows, pos_weight)
+            return ops.PairSide(*layout[name], h_idx, r_idx, r_fixed, t_idx, tail_rows, pos_weight)
 
         if group_rec:
             users, tails = self._rec_grouped_from_tiled(interaction)

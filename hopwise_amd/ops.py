@@ -97,7 +97,12 @@ class _OobCounter:
 def oob_count(device=None) -> int:
     """Number of out-of-range ids seen so far on ``device`` (synchronises)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    return int(_OobCounter.get(device).item())
+    n = int(_OobCounter.get(device).item())
+    from . import torch_ops
+
+    if torch_ops._state["loaded"]:  # the registered ops keep their own counter
+        n += int(torch.ops.hopwise_amd.oob_count(_OobCounter.get(device)))
+    return n
 
 
 def kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, t_idx, j_major_out=False):
@@ -418,6 +423,12 @@ class FusedPairLoss(torch.autograd.Function):
 
 
 def fused_pair_loss(model, kind, margin, eps, scale, sides, params):
+    """One autograd node for calculate_loss: through torch.ops.hopwise_amd.pair_loss(_backward) when the registered-op
+    library is built (two Python -> C++ crossings per step), else through the ctypes binding (FusedPairLoss)."""
+    from . import torch_ops
+
+    if torch_ops.enabled():
+        return torch_ops.pair_loss(model, kind, margin, eps, scale, sides, params)
     return FusedPairLoss.apply(model, kind, float(margin), float(eps), float(scale), sides, *params)
 
 

@@ -27,3 +27,5 @@ def _built_library():
 
     if not os.path.exists(hb.LIB) and os.path.exists(hb.HIPCC):
         hb.build(verbose=False)
+    if not os.path.exists(hb.TORCH_LIB) and os.path.exists(hb.HIPCC):
+        hb.build_torch_ops(verbose=False)

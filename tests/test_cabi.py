@@ -60,3 +60,22 @@ def test_single_hip_runtime_mapped():
     _lib.load()
     maps = open("/proc/self/maps").read()
     assert len(set(re.findall(r"/\S*libamdhip64\S*", maps))) == 1
+
+
+def test_torch_ops_namespace_registered():
+    """csrc/torch_bind.cpp: the TORCH_LIBRARY(hopwise_amd) namespace loads (no GPU needed) and carries the ops SURVEY.md
+    §8(b) lists, and a CPU tensor is refused rather than computed on."""
+    import pytest
+    import torch
+
+    from hopwise_amd import torch_ops
+
+    ns = torch_ops.load()
+    for name in ("kge_score_grouped", "kge_score_grouped_backward", "kge_full_sort", "kge_full_sort_topk", "kg_neg_sample",
+                 "pair_loss", "pair_loss_backward", "pgpr_expand", "pgpr_collect"):
+        assert hasattr(ns, name), name
+    schema = str(ns.kge_score_grouped.default._schema)
+    assert "Tensor[] head" in schema and "Tensor? r_idx" in schema and schema.endswith("-> Tensor")
+    with pytest.raises((RuntimeError, NotImplementedError)):  # no CPU kernel is registered: the dispatcher refuses
+        ns.kge_full_sort(0, [torch.zeros(4, 8)], [torch.zeros(2, 8)], [torch.zeros(4, 8)], torch.zeros(2, dtype=torch.int64),
+                         None, 0, 0, 4, 0.0)
