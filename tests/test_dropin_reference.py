@@ -69,4 +69,6 @@ def test_reference_loader_batch_is_what_the_model_indexes(report, name):
     # KGBatcher's layout for the same settings (train_batch_size 64, sample_num 4): rec rows (64 // 4) * 4, kg rows 64
     assert batch["user_id"][0] == [(64 // 4) * 4] and batch["head_id"][0] == [64]
     assert rec["n"] == [201, 301, 6136, 26]
-    assert rec["cpu_loss"] == "RuntimeError"  # no CPU fallback: a CPU batch is refused, not scored
+    # no CPU fallback: a CPU batch is refused, not scored (RuntimeError from the ctypes binding, NotImplementedError from
+    # the dispatcher when the registered ops are loaded: no CPU kernel exists)
+    assert rec["cpu_loss"] in ("RuntimeError", "NotImplementedError")
