@@ -35,9 +35,12 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
                                                                   const float* __restrict__ w,
                                                                   const float* __restrict__ mask, int d, float drop_p,
                                                                   uint64_t seed, uint64_t offset,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, int64_t w_stride,
+                                                                  const int64_t* __restrict__ w_index) {
     const int b = blockIdx.x;
-    const float* __restrict__ wb = w + (size_t)b * d * d;
+    // w_stride = d * d with w_index == NULL: the reference's [B, d, d] tensor; with w_index: matrix w_index[b] of a small
+    // set (one per relation); w_stride = 0: one [d, d] matrix shared by the whole batch
+    const float* __restrict__ wb = w + (size_t)(w_index ? w_index[b] : b) * w_stride;
     const float* __restrict__ mb = MODE == 1 ? mask + (size_t)b * d * d : nullptr;
     const float* __restrict__ xb = x + (size_t)b * d;
     const int nq = (d + 3) >> 2;
@@ -81,10 +84,11 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
                                                                   const float* __restrict__ mask,
                                                                   const float* __restrict__ go, int d, float drop_p,
                                                                   uint64_t seed, uint64_t offset,
-                                                                  float* __restrict__ gx, float* __restrict__ gw) {
+                                                                  float* __restrict__ gx, float* __restrict__ gw,
+                                                                  int64_t w_stride, const int64_t* __restrict__ w_index) {
     const int b = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float* __restrict__ wb = w + (size_t)b * d * d;
+    const float* __restrict__ wb = w + (size_t)(w_index ? w_index[b] : b) * w_stride;
     const float* __restrict__ mb = MODE == 1 ? mask + (size_t)b * d * d : nullptr;
     const float* __restrict__ gob = go + (size_t)b * d;
     const int nq = (d + 3) >> 2;
@@ -132,6 +136,98 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
             const float v = group_sum<64>(acc[k]);
             if (gx && lane == 0 && 4 * q + k < d) gx[(size_t)b * d + 4 * q + k] = v;
         }
+    }
+}
+
+// Gradient of a [d, d] matrix SHARED by the whole batch (the rec side of TuckER: every row uses the [UI-Relation] row, so
+// r . W is one matrix): gw[i, j] = sum_b x[b, i] go[b, j] m[b, i, j].  Block (q, c) owns rows i = 4q .. 4q + 3 and the
+// batch rows of chunk c; thread j accumulates in registers; the chunk partials are summed in fixed order afterwards
+// (deterministic).  Same Philox words as the forward.
+constexpr int TGW_CHUNK = 64;
+template <int MODE>
+__global__ __launch_bounds__(256) void tucker_gw_shared_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                               const float* __restrict__ go, int64_t batch, int d,
+                                                               float drop_p, uint64_t seed, uint64_t offset,
+                                                               float* __restrict__ partial) {
+    const int q = blockIdx.x, c = blockIdx.y;
+    const int nq = (d + 3) >> 2;
+    const float inv_keep = 1.f / (1.f - drop_p);
+    const int64_t b0 = (int64_t)c * TGW_CHUNK, b1 = min(batch, b0 + TGW_CHUNK);
+    for (int j = threadIdx.x; j < d; j += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t b = b0; b < b1; ++b) {
+            uint32_t rw[4] = {0u, 0u, 0u, 0u};
+            if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+            const float gj = go[(size_t)b * d + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(4 * q + k, d - 1);  // clamped: the out-of-range rows of the last quad are not stored
+                float m = 1.f;
+                if constexpr (MODE == 1) m = mask[((size_t)b * d + i) * d + j];
+                if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
+                acc[k] = fmaf(x[(size_t)b * d + i] * m, gj, acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * q + k < d) partial[((size_t)c * d + 4 * q + k) * d + j] = acc[k];
+    }
+}
+
+// The same for a SET of matrices selected per row (kg side: one matrix per relation, a few dozen of them): `order` lists the
+// batch rows sorted by matrix index, block (q, c) walks 64 consecutive sorted rows and flushes its register sums with
+// float atomics whenever the matrix changes (a matrix receives a handful of flushes per address).  gw is zeroed by the caller.
+template <int MODE>
+__global__ __launch_bounds__(256) void tucker_gw_indexed_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                                const float* __restrict__ go,
+                                                                const int64_t* __restrict__ order,
+                                                                const int64_t* __restrict__ w_index, int64_t n_mats,
+                                                                int64_t batch, int d, float drop_p, uint64_t seed,
+                                                                uint64_t offset, float* __restrict__ gw) {
+    const int q = blockIdx.x, c = blockIdx.y;
+    const int nq = (d + 3) >> 2;
+    const float inv_keep = 1.f / (1.f - drop_p);
+    const int64_t s0 = (int64_t)c * TGW_CHUNK, s1 = min(batch, s0 + TGW_CHUNK);
+    for (int j = threadIdx.x; j < d; j += 256) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int64_t cur = -1;
+        for (int64_t s = s0; s <= s1; ++s) {
+            int64_t b = 0, mat = -1;
+            if (s < s1) {
+                b = min(max(order[s], (int64_t)0), batch - 1);
+                mat = min(max(w_index[b], (int64_t)0), n_mats - 1);
+            }
+            if (mat != cur) {  // uniform across the block: every thread walks the same rows
+                if (cur >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (4 * q + k < d) atomicAdd(gw + ((size_t)cur * d + 4 * q + k) * d + j, acc[k]);
+                }
+                acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+                cur = mat;
+            }
+            if (s == s1) break;
+            uint32_t rw[4] = {0u, 0u, 0u, 0u};
+            if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+            const float gj = go[(size_t)b * d + j];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(4 * q + k, d - 1);
+                float m = 1.f;
+                if constexpr (MODE == 1) m = mask[((size_t)b * d + i) * d + j];
+                if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
+                acc[k] = fmaf(x[(size_t)b * d + i] * m, gj, acc[k]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tucker_gw_reduce_kernel(const float* __restrict__ partial, int chunks, int64_t n,
+                                                               float* __restrict__ gw) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        for (int c = 0; c < chunks; ++c) v += partial[(size_t)c * n + i];
+        gw[i] = v;
     }
 }
 
@@ -213,15 +309,16 @@ using namespace hw;
 
 static int contract_launch(int mode, const float* x, const float* w, const float* mask, const float* gout, int64_t batch,
                            int32_t dim, float drop_p, uint64_t seed, uint64_t offset, float* out, float* gx, float* gw,
-                           bool backward, void* stream) {
+                           bool backward, void* stream, bool shared_w = false, const int64_t* w_index = nullptr) {
+    const int64_t w_stride = (shared_w && !w_index) ? 0 : (int64_t)dim * dim;
     if (!x || !w || batch < 0 || dim < 1 || batch > INT32_MAX) return HW_ERR_INVALID_ARG;
     if (mode == 2 && !(drop_p >= 0.f && drop_p < 1.f)) return HW_ERR_INVALID_ARG;
     if (backward ? !gout : !out) return HW_ERR_INVALID_ARG;
     if (batch == 0) return HW_OK;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
-#define FWD(M) hipLaunchKernelGGL((tucker_contract_fwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, dim, drop_p, seed, offset, out)
-#define BWD(M) hipLaunchKernelGGL((tucker_contract_bwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, gout, dim, drop_p, seed, offset, gx, gw)
+#define FWD(M) hipLaunchKernelGGL((tucker_contract_fwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, dim, drop_p, seed, offset, out, w_stride, w_index)
+#define BWD(M) hipLaunchKernelGGL((tucker_contract_bwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, gout, dim, drop_p, seed, offset, gx, gw, w_stride, w_index)
     if (!backward) {
         if (mode == 2) FWD(2);
         else if (mode == 1) FWD(1);
@@ -255,6 +352,59 @@ extern "C" int hw_tucker_contract_dropout_grad(const float* x, const float* w, c
                                                int32_t dim, float drop_p, uint64_t seed, uint64_t offset, float* gx,
                                                float* gw, void* stream) {
     return contract_launch(2, x, w, nullptr, gout, batch, dim, drop_p, seed, offset, nullptr, gx, gw, true, stream);
+}
+
+extern "C" int hw_tucker_contract_shared(const float* x, const float* w, const int64_t* w_index, const float* mask,
+                                         int64_t batch, int32_t dim, float drop_p, uint64_t seed, uint64_t offset,
+                                         float* out, void* stream) {
+    const int mode = mask ? 1 : (drop_p > 0.f ? 2 : 0);
+    return contract_launch(mode, x, w, mask, nullptr, batch, dim, mode == 2 ? drop_p : 0.f, seed, offset, out, nullptr,
+                           nullptr, false, stream, true, w_index);
+}
+
+extern "C" int64_t hw_tucker_contract_shared_workspace_floats(int64_t batch, int32_t dim) {
+    return batch < 0 || dim < 1 ? 0 : ((batch + TGW_CHUNK - 1) / TGW_CHUNK) * (int64_t)dim * dim;
+}
+
+extern "C" int hw_tucker_contract_shared_grad(const float* x, const float* w, const int64_t* w_index,
+                                              const int64_t* order, int64_t n_mats, const float* mask, const float* gout,
+                                              int64_t batch, int32_t dim, float drop_p, uint64_t seed, uint64_t offset,
+                                              float* gx, float* gw, float* workspace, int64_t workspace_floats,
+                                              void* stream) {
+    const int mode = mask ? 1 : (drop_p > 0.f ? 2 : 0);
+    if (!x || !w || !gout || batch < 0 || dim < 1 || batch > INT32_MAX || n_mats < 1) return HW_ERR_INVALID_ARG;
+    if (w_index && gw && !order) return HW_ERR_INVALID_ARG;
+    if (batch == 0) return HW_OK;
+    if (gx) {
+        const int rc = contract_launch(mode, x, w, mask, gout, batch, dim, mode == 2 ? drop_p : 0.f, seed, offset, nullptr,
+                                       gx, nullptr, true, stream, true, w_index);
+        if (rc) return rc;
+    }
+    if (!gw) return HW_OK;
+    const int64_t chunks = (batch + TGW_CHUNK - 1) / TGW_CHUNK, n = (int64_t)dim * dim;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((dim + 3) / 4), (unsigned)chunks);
+    const float p = mode == 2 ? drop_p : 0.f;
+    if (w_index) {  // one matrix per relation: atomic flushes into gw (zeroed here)
+        if (hipMemsetAsync(gw, 0, (size_t)n_mats * n * sizeof(float), st) != hipSuccess) return HW_ERR_LAUNCH;
+#define GWI(M) hipLaunchKernelGGL((tucker_gw_indexed_kernel<M>), grid, dim3(256), 0, st, x, mask, gout, order, w_index, n_mats, batch, dim, p, seed, offset, gw)
+        if (mode == 2) GWI(2);
+        else if (mode == 1) GWI(1);
+        else GWI(0);
+#undef GWI
+        return HW_LAUNCH_RC();
+    }
+    if (!workspace || workspace_floats < chunks * n) return HW_ERR_WORKSPACE;
+#define GWS(M) hipLaunchKernelGGL((tucker_gw_shared_kernel<M>), grid, dim3(256), 0, st, x, mask, gout, batch, dim, p, seed, offset, workspace)
+    if (mode == 2) GWS(2);
+    else if (mode == 1) GWS(1);
+    else GWS(0);
+#undef GWS
+    int64_t rg = (n + 255) / 256;
+    if (rg > 2048) rg = 2048;
+    hipLaunchKernelGGL(tucker_gw_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, st, workspace, (int)chunks, n, gw);
+    return HW_LAUNCH_RC();
 }
 
 extern "C" int64_t hw_tucker_bce_workspace_floats(void) { return TB_BLOCKS; }

@@ -537,6 +537,8 @@ class TuckER(KnowledgeRecommender):
         self.bn1 = nn.BatchNorm1d(d)
         self.apply(xavier_normal_initialization)
         self.forced_masks = None  # tests: {"rec": (m0 [B,d], m1 [B,d,d], m2 [B,d]), "kg": (...)} multiplicative masks
+        # False: the per-row mm(r, W) of the reference; True (default): one matrix per distinct relation (see _features)
+        self.share_relation_matrices = bool(_cfg(config, "share_relation_matrices", True))
         self._seed, self._drop_calls = seed_for_rank(_cfg(config, "seed", 2020)), 0
 
     def _drop(self, module, x, forced):
@@ -553,8 +555,24 @@ class TuckER(KnowledgeRecommender):
         d = self.embedding_size
         fm = self.forced_masks[side] if self.forced_masks is not None else (None, None, None)
         h = ops.embedding(self.user_embedding.weight if side == "rec" else self.entity_embedding.weight, h_idx)
-        r = ops.embedding(self.relation_embedding.weight, r_idx)
         x = self._drop(self.input_dropout, self.bn0(h), fm[0])
+        if self.share_relation_matrices and h_idx.numel() > 0:
+            # mm(r, W) has one distinct row per distinct relation: ONE on the rec side (every row carries [UI-Relation],
+            # self._ui) and n_relations at most on the kg side, against B = 2048 rows.  Form those few [d, d] matrices once
+            # ([n_rel, d] x [d, d^2] instead of [B, d] x [d, d^2], forward and twice backward) and let each batch row pick
+            # its matrix; the per-row dropout masks (explicit or Philox) are untouched, so the result is the reference's.
+            if side == "rec":
+                rows, index = ops.embedding(self.relation_embedding.weight, r_idx[:1]), None
+            else:
+                rows, index = self.relation_embedding.weight, r_idx
+            w_set = ops.matmul_nn(rows, self.weights.view(d, d * d)).view(-1, d, d)
+            if fm[1] is None and self.training and self.hidden_dropout1.p > 0:
+                self._drop_calls += 1
+                x = ops.tucker_contract_shared(x, w_set, index, None, self.hidden_dropout1.p, self._seed, self._drop_calls)
+            else:
+                x = ops.tucker_contract_shared(x, w_set, index, fm[1])
+            return self._drop(self.hidden_dropout2, self.bn1(x), fm[2])
+        r = ops.embedding(self.relation_embedding.weight, r_idx)
         w_mat = ops.matmul_nn(r, self.weights.view(d, d * d)).view(-1, d, d)
         if fm[1] is None and self.training and self.hidden_dropout1.p > 0:
             # hidden_dropout1 over the [B, d, d] tensor is drawn inside the contraction (Philox), never materialised

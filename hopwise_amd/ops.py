@@ -1076,6 +1076,65 @@ class TuckerContractDropout(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
+class TuckerContractShared(torch.autograd.Function):
+    """out[b, :] = x[b, :] @ (w[index[b]] * m[b]) with a SMALL set of matrices w [n_mats, d, d] instead of the [B, d, d]
+    tensor of tucker.py:74-79: mm(r, W) has one distinct row per distinct relation of the batch -- one on the rec side
+    (index None: every row uses w[0]), a few dozen on the kg side.  m[b]: explicit mask [B, d, d], or Philox dropout
+    (p > 0, same words as TuckerContractDropout), or none."""
+
+    @staticmethod
+    def forward(ctx, x, w, index, mask, p, seed, offset):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "x").contiguous()
+        w = _dev(w, torch.float32, "w").contiguous()
+        B, d = x.shape
+        if w.dim() != 3 or tuple(w.shape[1:]) != (d, d) or (mask is not None and tuple(mask.shape) != (B, d, d)):
+            raise ValueError("w must be [n_mats, d, d], mask [B, d, d]")
+        if index is not None:
+            index = _idx(index, "index").contiguous()
+            if index.numel() != B:
+                raise ValueError("index must have one entry per batch row")
+        elif w.shape[0] != 1:
+            raise ValueError("without an index w must hold one matrix")
+        if mask is not None:
+            mask = _dev(mask, torch.float32, "mask").contiguous()
+        out = torch.empty((B, d), dtype=torch.float32, device=x.device)
+        check(lib.hw_tucker_contract_shared(_ptr(x), _ptr(w), _ptr(index), _ptr(mask), B, d, float(p), C.c_uint64(seed),
+                                            C.c_uint64(offset), _ptr(out), _stream()), "hw_tucker_contract_shared")
+        ctx.args = (float(p), int(seed), int(offset), index is not None, mask is not None)
+        ctx.save_for_backward(x, w, *([index] if index is not None else []), *([mask] if mask is not None else []))
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        lib = _lib.load()
+        p, seed, offset, has_index, has_mask = ctx.args
+        saved = list(ctx.saved_tensors)
+        x, w = saved[0], saved[1]
+        index = saved[2] if has_index else None
+        mask = saved[-1] if has_mask else None
+        B, d = x.shape
+        go = go.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = ws = order = None
+        n_ws = 0
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(w)
+            if index is None:
+                n_ws = int(lib.hw_tucker_contract_shared_workspace_floats(B, d))
+                ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
+            else:
+                order = torch.argsort(index, stable=True)  # 2048 ids: rows grouped by matrix
+        check(lib.hw_tucker_contract_shared_grad(_ptr(x), _ptr(w), _ptr(index), _ptr(order), w.shape[0], _ptr(mask), _ptr(go),
+                                                 B, d, p, C.c_uint64(seed), C.c_uint64(offset), _ptr(gx), _ptr(gw), _ptr(ws),
+                                                 n_ws, _stream()), "hw_tucker_contract_shared_grad")
+        return gx, gw, None, None, None, None, None
+
+
+def tucker_contract_shared(x, w, index=None, mask=None, p=0.0, seed=0, offset=0):
+    return TuckerContractShared.apply(x, w, index, mask, float(p), int(seed), int(offset))
+
+
 def tucker_contract(x, w, mask=None):
     return TuckerContract.apply(x, w, mask)
 

@@ -329,6 +329,23 @@ int hw_tucker_contract_dropout(const float* x, const float* w, int64_t batch, in
 int hw_tucker_contract_dropout_grad(const float* x, const float* w, const float* gout, int64_t batch, int32_t dim,
                                     float drop_p, uint64_t seed, uint64_t offset, float* gx, float* gw, void* stream);
 
+/* mm(r, W.view(d, d^2)) (tucker.py:74) has as many DISTINCT rows as the batch has distinct relations: one on the rec side
+ * (every row carries [UI-Relation], tucker.py:100-101 / :133 / :158), a few dozen on the kg side.  These entry points
+ * take the small set w [n_mats, d, d] (= mm(R_distinct, W)) and w_index [batch] (matrix of each row; NULL = every row
+ * uses matrix 0) instead of the [B, d, d] tensor.  The dropout mask still differs per batch row: `mask` [batch, d, d]
+ * (nullable; 0 or 1/(1-p)) or, when mask == NULL and drop_p > 0, the Philox words of hw_tucker_contract_dropout.
+ * *_grad: gx [batch, d] (nullable) and gw [n_mats, d, d] (nullable) = sum over the rows of each matrix of
+ * x[b, i] gout[b, j] m[b, i, j].  With w_index, `order` = the batch rows sorted by w_index (stable) and gw is accumulated
+ * with float atomics; without it the reduction runs in fixed order through `workspace`
+ * (hw_tucker_contract_shared_workspace_floats(batch, dim) floats). */
+int hw_tucker_contract_shared(const float* x, const float* w, const int64_t* w_index, const float* mask, int64_t batch,
+                              int32_t dim, float drop_p, uint64_t seed, uint64_t offset, float* out, void* stream);
+int64_t hw_tucker_contract_shared_workspace_floats(int64_t batch, int32_t dim);
+int hw_tucker_contract_shared_grad(const float* x, const float* w, const int64_t* w_index, const int64_t* order,
+                                   int64_t n_mats, const float* mask, const float* gout, int64_t batch, int32_t dim,
+                                   float drop_p, uint64_t seed, uint64_t offset, float* gx, float* gw, float* workspace,
+                                   int64_t workspace_floats, void* stream);
+
 /* sigmoid + nn.BCELoss(mean) against target[b, c] = target_scale * pos_flag[c] + target_add (tucker.py:111-125:
  * the union-of-the-batch multi-hot with label smoothing).  pred / glogits nullable.  workspace:
  * hw_tucker_bce_workspace_floats() floats. */

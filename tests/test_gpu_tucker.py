@@ -155,3 +155,44 @@ def test_score_loss_in_gemm_epilogue_equals_gemm_then_bce(shape, with_bias, monk
     for a, c in zip(out[0][1:], out[1][1:]):
         if a is not None:
             np.testing.assert_allclose(a, c, rtol=2e-4, atol=1e-7 * max(1.0, float(np.abs(c).max())))
+
+
+@pytest.mark.parametrize("d,B", [(200, 150), (24, 7), (64, 65)])
+def test_shared_relation_matrices_equal_per_row_product(d, B):
+    """The rec side with mm(r, W) computed ONCE ([UI-Relation] is the relation of every row) against the reference's
+    per-row [B, d] x [d, d^2] product: same Philox dropout words, so the training forward is identical bit for bit and the
+    gradients agree to summation order; also the explicit-mask and the eval paths."""
+    import copy
+
+    from hopwise_amd.model import TuckER
+
+    rng = np.random.default_rng(d)
+    nU, nI, nE, nR = 120, 70, 300, 7
+    cfg = make_config(dev(), d, 1.0, label_smoothing=0.1, input_dropout=0.0, input_dropout1=0.4, input_dropout2=0.0)
+    torch.manual_seed(3)
+    a = TuckER(cfg, FakeDataset(nU, nI, nE, nR)).to(dev())
+    with torch.no_grad():
+        a.weights.mul_(0.05)
+    b = copy.deepcopy(a)
+    b.share_relation_matrices = False
+    it = {k: torch.from_numpy(v).to(dev()) for k, v in dict(
+        user_id=rng.integers(1, nU, B), item_id=rng.integers(1, nI, B), head_id=rng.integers(1, nE, B),
+        relation_id=rng.integers(1, nR - 1, B), tail_id=rng.integers(1, nE, B)).items()}
+    for mode in ("train", "eval", "forced"):
+        for m in (a, b):
+            m.train(mode != "eval")
+            m._drop_calls = 0
+            m.forced_masks = None
+            if mode == "forced":
+                g = torch.Generator(device=dev()).manual_seed(5)
+                mk = lambda *s: (torch.rand(*s, device=dev(), generator=g) > 0.3).float() / 0.7
+                m.forced_masks = {"rec": (mk(B, d), mk(B, d, d), mk(B, d)), "kg": (mk(B, d), mk(B, d, d), mk(B, d))}
+            m.zero_grad()
+        la, lb = a.calculate_loss(it), b.calculate_loss(it)
+        assert la.item() == lb.item(), mode
+        la.backward()
+        lb.backward()
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            ref = q.grad.cpu().numpy()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=3e-4, atol=3e-6 * (np.abs(ref).max() + 1e-12) + 1e-9,
+                                       err_msg=f"{mode}:{k}")
