@@ -282,6 +282,125 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
         }
 }
 
+// ---- narrow-N variant: 192 < N <= 208 ------------------------------------------------------------------------------------
+// The TuckER / ConvE backward products have N = d = 200 output columns (dX = dS . E, dE = dS^T . x): 128-wide tiles pad
+// that to 256 and spend 22 % of the MFMA passes on zeros.  This kernel covers the whole row with 13 tiles of
+// v_mfma_f32_16x16x4_f32 (208 columns, 4 % padding; same FLOP rate as the 32x32x2 form): block = 512 threads = 8 waves,
+// tile 128 x 208 x 16, wave w owns rows 16 w .. 16 w + 15 and all 13 column tiles (52 accumulator registers), so A is
+// read once instead of once per 128-column block.  LDS tiles are k-major with row strides 144 and 208 floats (= 16 mod 64):
+// the operand read of a 16x16x4 MFMA (lane l -> element l & 15 of k-row l >> 4) touches 64 distinct banks.  Same two-stage
+// software pipeline as gemm_f32_kernel; plain epilogue only (no bias / activation / dropout), split-K through `partial`.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int NB_M = 128, NB_N = 208, NB_LDA = 144, NB_LDB = 208, NB_TILES = 13;
+
+template <bool KC, int ROWS, int LD>
+__device__ __forceinline__ void nb_fetch(const float* __restrict__ X, int64_t ld, int rows, int K, int r0, int k0, int f,
+                                         f32x4& v) {
+    if constexpr (KC) {  // X [rows, K], K contiguous: float4 along k
+        const int r = f >> 2, kq = (f & 3) * 4;
+        const int gr = min(r0 + r, rows - 1), gk = min(k0 + kq, ((K + 3) & ~3) - 4);
+        v = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ld + gk);
+    } else {  // X [K, rows], row index contiguous: float4 along rows
+        constexpr int Q = ROWS / 4;
+        const int k = f / Q, rq = (f % Q) * 4;
+        const int gk = min(k0 + k, K - 1), gr = min(r0 + rq, ((rows + 3) & ~3) - 4);
+        v = *reinterpret_cast<const f32x4*>(X + (size_t)gk * ld + gr);
+    }
+}
+
+// SWZ: element (k, col) lives at column col ^ (((k >> 2) & 3) << 4).  With a row stride of 16 mod 64 the MFMA operand read
+// (k-rows kk .. kk + 3, 16 columns) is conflict-free either way; the K-contiguous staging write (k-rows j, 4 + j, 8 + j,
+// 12 + j of one 16-column block in one instruction) would hit the same 16 banks four times -- the swizzle sends the four
+// k-groups to four different column blocks.  Needs the tile width to be a multiple of 64 columns (the A tile; not B's 208).
+template <bool SWZ>
+__device__ __forceinline__ int nb_col(int k, int col) {
+    return SWZ ? col ^ (((k >> 2) & 3) << 4) : col;
+}
+
+template <bool KC, int ROWS, int LD, bool SWZ>
+__device__ __forceinline__ void nb_put(const f32x4& v, int K, int k0, int f, float (*T)[LD]) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (KC) {
+        const int r = f >> 2, kq = (f & 3) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) T[kq + j][nb_col<SWZ>(kq + j, r)] = k0 + kq + j < K ? x[j] : 0.f;
+    } else {
+        constexpr int Q = ROWS / 4;
+        const int k = f / Q, rq = (f % Q) * 4;
+        const bool live = k0 + k < K;
+        *reinterpret_cast<f32x4*>(&T[k][nb_col<SWZ>(k, rq)]) =
+            f32x4{live ? x[0] : 0.f, live ? x[1] : 0.f, live ? x[2] : 0.f, live ? x[3] : 0.f};
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_f32_n208_kernel(const float* __restrict__ A, int64_t lda,
+                                                               const float* __restrict__ B, int64_t ldb,
+                                                               float* __restrict__ C, int64_t ldc,
+                                                               const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
+                                                               int k_len, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float As2[2][BK][NB_LDA];
+    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][NB_LDB];
+    const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
+    const int m0 = blockIdx.x * NB_M;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave * 16;
+    f32x4v acc[NB_TILES];
+#pragma unroll
+    for (int t = 0; t < NB_TILES; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const int k_begin = blockIdx.z * k_len;
+    const int k_end = min(K, k_begin + k_len);
+    // B tile = 208 x 16 floats = 832 float4: threads 0..319 carry a second one (the others re-fetch slot 831: same data,
+    // same LDS address -- branch-free so the loads stay in flight across the MFMAs)
+    const int fb1 = min(tid + 512, NB_N * BK / 4 - 1);
+    f32x4 ra, rb0, rb1;
+    nb_fetch<A_KC, NB_M, NB_LDA>(A, lda, M, k_end, m0, k_begin, tid, ra);
+    nb_fetch<B_KC, NB_N, NB_LDB>(B, ldb, N, k_end, 0, k_begin, tid, rb0);
+    nb_fetch<B_KC, NB_N, NB_LDB>(B, ldb, N, k_end, 0, k_begin, fb1, rb1);
+    nb_put<A_KC, NB_M, NB_LDA, true>(ra, k_end, k_begin, tid, As2[0]);
+    nb_put<B_KC, NB_N, NB_LDB, false>(rb0, k_end, k_begin, tid, Bs2[0]);
+    nb_put<B_KC, NB_N, NB_LDB, false>(rb1, k_end, k_begin, fb1, Bs2[0]);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
+        nb_fetch<A_KC, NB_M, NB_LDA>(A, lda, M, k_end, m0, k0 + BK, tid, ra);
+        nb_fetch<B_KC, NB_N, NB_LDB>(B, ldb, N, k_end, 0, k0 + BK, tid, rb0);
+        nb_fetch<B_KC, NB_N, NB_LDB>(B, ldb, N, k_end, 0, k0 + BK, fb1, rb1);
+        __builtin_amdgcn_sched_barrier(0);
+        float (*Ac)[NB_LDA] = As2[cur];
+        float (*Bc)[NB_LDB] = Bs2[cur];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            const int kr = kk + (lane >> 4);
+            const float a = Ac[kr][nb_col<true>(kr, wm + (lane & 15))];
+            float b[NB_TILES];
+#pragma unroll
+            for (int t = 0; t < NB_TILES; ++t) b[t] = Bc[kr][t * 16 + (lane & 15)];
+#pragma unroll
+            for (int t = 0; t < NB_TILES; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        nb_put<A_KC, NB_M, NB_LDA, true>(ra, k_end, k0 + BK, tid, As2[cur ^ 1]);
+        nb_put<B_KC, NB_N, NB_LDB, false>(rb0, k_end, k0 + BK, tid, Bs2[cur ^ 1]);
+        nb_put<B_KC, NB_N, NB_LDB, false>(rb1, k_end, k0 + BK, fb1, Bs2[cur ^ 1]);
+        __syncthreads();
+    }
+    // C/D map of a 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+    for (int t = 0; t < NB_TILES; ++t) {
+        const int gn = t * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = m0 + wm + 4 * (lane >> 4) + r;
+            if (gm < M && gn < N) {
+                if (partial) partial[((size_t)blockIdx.z * m_max + gm) * N + gn] = acc[t][r];
+                else C[(size_t)gm * ldc + gn] = acc[t][r];
+            }
+        }
+    }
+}
+
 // second stage of split-K: C = epilogue(sum_z partial[z]) in fixed z order (deterministic)
 template <int ACT>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
@@ -322,6 +441,49 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
                        int64_t ldc, const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, const float* bias,
                        int act, const float* drop_mask, int drop_mode, uint64_t seed, uint64_t offset,
                        float* workspace, int64_t workspace_floats, hipStream_t st, GemmBce bce = GemmBce{}) {
+    // narrow-N products (TuckER / ConvE backward: N = d = 200): whole-row tiles of 16x16x4 MFMAs, see gemm_f32_n208_kernel
+    {
+        // Measured on MI355X (tools/bench_gemm_tucker.py, iFashion shapes): with an M-contiguous A (dE = dS^T . x) the
+        // whole-row kernel runs 104-107 TF/s against 85-94 for the 128-wide tiles; with a K-contiguous A streamed over a
+        // long K (dX = dS . E, 16 strided rows of 64 B per wave load) it is 84-86 against 88-93, so that case stays on the
+        // wide tiles unless HW_GEMM_NARROW=2 forces it.
+        const char* ne = getenv("HW_GEMM_NARROW");
+        const int nmode = ne ? atoi(ne) : 1;
+        const bool want = nmode == 2 || (nmode == 1 && !a_kc);
+        if (want && act == 0 && !bias && drop_mode == 0 && n > 192 && n <= NB_N && aligned16(a, lda) && aligned16(b, ldb) &&
+            k >= 4 && m_max >= 4) {
+            const int64_t gmn = (m_max + NB_M - 1) / NB_M;
+            int splits = 1;
+            if (workspace && gmn < 512 && k >= 16 * BK) {
+                int64_t wantz = (768 + gmn - 1) / gmn;
+                const int64_t kmax = k / (8 * BK);
+                if (wantz > kmax) wantz = kmax;
+                const int64_t fit = workspace_floats / (m_max * n);
+                if (wantz > fit) wantz = fit;
+                if (wantz > 1) splits = (int)wantz;
+            }
+            int k_len = (int)k;
+            if (splits > 1) {
+                k_len = (int)(((k + splits - 1) / splits + BK - 1) / BK * BK);
+                splits = (int)((k + k_len - 1) / k_len);
+            }
+            float* partial = splits > 1 ? workspace : nullptr;
+            dim3 grid((unsigned)gmn, 1, (unsigned)splits);
+#define GON(AK, BK_) hipLaunchKernelGGL((gemm_f32_n208_kernel<AK, BK_>), grid, dim3(512), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, k_len, partial)
+            if (a_kc && b_kc) GON(true, true);
+            else if (a_kc && !b_kc) GON(true, false);
+            else if (!a_kc && !b_kc) GON(false, false);
+            else GON(false, true);
+#undef GON
+            if (splits > 1) {
+                int64_t rg = (m_max * n + 255) / 256;
+                if (rg > 4096) rg = 4096;
+                hipLaunchKernelGGL((gemm_splitk_reduce_kernel<0>), dim3((unsigned)rg), dim3(256), 0, st, partial, splits, m_rows,
+                                   (int)m_max, (int)n, c, ldc, bias, drop_mask, drop_mode, seed, offset);
+            }
+            return HW_OK;
+        }
+    }
     const int64_t gm = (m_max + BM - 1) / BM, gn = (n + BN - 1) / BN;
     // split-K when the output grid cannot fill the chip and K is long (e.g. dX = dY [2048, 144779] . E [144779, 200])
     int splits = 1;

@@ -346,7 +346,9 @@ def test_gemm_pipelined_loop_on_padded_operands():
         return buf[:, :c]
 
     for M, K, N in ((5, 3, 7), (37, 201, 129), (300, 18, 259), (129, 130, 131), (1000, 403, 70), (130, 5003, 41),
-                    (2048, 6001, 200), (4, 4, 4)):
+                    (2048, 6001, 200), (4, 4, 4),
+                    # 192 < N <= 208: the whole-row 16x16x4 kernel (gemm_f32_n208_kernel), ragged M / K, split-K
+                    (5, 3, 200), (129, 130, 208), (1000, 403, 193), (300, 20011, 205), (144, 2048, 200), (4, 4, 196)):
         A = rng.standard_normal((M, K)).astype(np.float32)
         B = rng.standard_normal((N, K)).astype(np.float32)
         ref = A.astype(np.float64) @ B.astype(np.float64).T

@@ -22,10 +22,16 @@ shapes = [
     ("tucker dr [2048,40000]x[200,40000]^T", 2048, 40000, 200, True, True),
     ("square 4096", 4096, 4096, 4096, True, True),
 ]
+def padded(r, c):
+    """[r, c] view of a buffer whose rows are padded to 32 floats -- what the engine does with its own [B, N] buffers
+    (N = 144 779 is odd: unpadded rows start at arbitrary 4-byte offsets and the GEMM falls back to its unpipelined loop)."""
+    return torch.randn((r, (c + 31) // 32 * 32), device=dev)[:, :c]
+
+
 for name, M, K, N, akc, bkc in shapes:
-    a = torch.randn((M, K) if akc else (K, M), device=dev)
-    b = torch.randn((N, K) if bkc else (K, N), device=dev)
-    out = torch.empty((M, N), device=dev)
+    a = padded(*((M, K) if akc else (K, M)))
+    b = padded(*((N, K) if bkc else (K, N)))
+    out = padded(M, N)
     for _ in range(2):
         ops.gemm(a, b, akc, bkc, out=out)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
