@@ -311,6 +311,161 @@ extern "C" int hw_cafe_level_loss_grad(const float* logits, int64_t ld, int64_t 
     return HW_LAUNCH_RC();
 }
 
+// ---- collect_results + the ranking loop of run_program (cafe.py:417-441, :859-867), one workgroup per user ---------------
+// The reference appends every leaf path to `tmp` in leaf order with score = reduce(mul) over its np.float32 log-probs,
+// inst[item] keeps the LAST path that reached an item, tmp is sorted by score (stable, descending) and an entry is emitted
+// when it beats results[item] -- i.e. per item the first entry in sorted order, carrying inst[item]'s path (not necessarily
+// its own).  Here: entry e = (leaf ordinal, row) in leaf order; pass 1 takes per item the max of key(score, e) = (orderable
+// score, ~e) and the max of e (global atomics on this user's [n_items] rows); pass 2 keeps the winners' keys in LDS and sorts
+// them (bitonic, descending: score desc, entry asc = the reference's emission order); pass 3 writes one record per winner.
+constexpr int CAFE_MAX_ENTRIES = 4096;
+constexpr int CAFE_MAX_LEAVES = 64;
+
+__device__ __forceinline__ uint32_t orderable(float s) {
+    const uint32_t u = __float_as_uint(s);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void cafe_collect_kernel(const hw_cafe_node* __restrict__ nodes,
+                                                           const int32_t* __restrict__ node_ptr,
+                                                           const int64_t* __restrict__ slot_ptr,
+                                                           const int32_t* __restrict__ ids, const float* __restrict__ vals,
+                                                           const int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ leaf_nodes, int n_leaves, int n_items,
+                                                           unsigned long long* __restrict__ best_ws,
+                                                           int32_t* __restrict__ last_ws, float* __restrict__ results,
+                                                           int max_rec, int32_t* __restrict__ rec_item,
+                                                           float* __restrict__ rec_score, int32_t* __restrict__ rec_leaf,
+                                                           int32_t* __restrict__ rec_ids, int32_t* __restrict__ rec_count,
+                                                           int32_t* __restrict__ overflow) {
+    __shared__ unsigned long long keys[CAFE_MAX_ENTRIES];
+    __shared__ int pre[CAFE_MAX_LEAVES + 1];
+    __shared__ int l_off[CAFE_MAX_LEAVES], l_dep[CAFE_MAX_LEAVES];
+    __shared__ int n_win;
+    const int task = blockIdx.x, tid = threadIdx.x;
+    const int n0 = node_ptr[task];
+    const int64_t slot0 = slot_ptr[task];
+    unsigned long long* best = best_ws + (size_t)task * n_items;
+    int32_t* last = last_ws + (size_t)task * n_items;
+    float* res = results + (size_t)task * n_items;
+    for (int i = tid; i < n_items; i += 256) {
+        res[i] = -INFINITY;
+        best[i] = 0ull;
+        last[i] = -1;
+    }
+    if (tid == 0) {
+        int acc = 0;
+        for (int l = 0; l < n_leaves; ++l) {
+            const int ni = leaf_nodes[(size_t)task * n_leaves + l];
+            pre[l] = acc;
+            if (ni >= 0) {
+                const hw_cafe_node nd = nodes[n0 + ni];
+                l_off[l] = nd.slot_off;
+                l_dep[l] = nd.depth;
+                acc += counts[n0 + ni];
+            } else {
+                l_off[l] = 0, l_dep[l] = 1;
+            }
+        }
+        pre[n_leaves] = acc;
+        n_win = 0;
+        if (acc > CAFE_MAX_ENTRIES) atomicMax(overflow, acc);
+    }
+    __syncthreads();
+    const int n = min(pre[n_leaves], CAFE_MAX_ENTRIES);
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    auto entry = [&](int e, int& item, float& score, int& leaf, int& row) {
+        int l = 0;
+        while (l + 1 < n_leaves && pre[l + 1] <= e) ++l;
+        leaf = l, row = e - pre[l];
+        const size_t s = (size_t)(slot0 + l_off[l] + row) * 3;
+        const int dep = l_dep[l];
+        float sc = vals[s];
+        for (int d = 1; d < dep; ++d) sc = __fmul_rn(sc, vals[s + d]);  // reduce(mul), float32, left to right
+        score = sc;
+        item = ids[s + dep - 1];
+    };
+    for (int e = tid; e < n; e += 256) {
+        int item, leaf, row;
+        float score;
+        entry(e, item, score, leaf, row);
+        if (item >= 0 && item < n_items) {
+            atomicMax(last + item, e);  // inst[item]: the last path to the item, whatever its score
+            if (score > -INFINITY)
+                atomicMax(best + item, ((unsigned long long)orderable(score) << 32) | (0xFFFFFFFFu - (uint32_t)e));
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < np2; e += 256) {
+        unsigned long long k = 0ull;
+        if (e < n) {
+            int item, leaf, row;
+            float score;
+            entry(e, item, score, leaf, row);
+            if (item >= 0 && item < n_items && score > -INFINITY) {
+                const unsigned long long mine = ((unsigned long long)orderable(score) << 32) | (0xFFFFFFFFu - (uint32_t)e);
+                if (__hip_atomic_load(best + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine) {
+                    k = mine;
+                    atomicAdd(&n_win, 1);
+                }
+            }
+        }
+        keys[e] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= np2; size <<= 1) {  // bitonic sort, descending
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool desc = (i & size) == 0;
+                    const unsigned long long a = keys[i], b = keys[j];
+                    if (desc ? a < b : a > b) keys[i] = b, keys[j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int nw = min(n_win, max_rec);
+    if (tid == 0) rec_count[task] = nw;
+    for (int j = tid; j < nw; j += 256) {
+        const int e = (int)(0xFFFFFFFFu - (uint32_t)(keys[j] & 0xFFFFFFFFull));
+        int item, leaf, row;
+        float score;
+        entry(e, item, score, leaf, row);
+        res[item] = score;
+        int it2, sl, sr;
+        float s2;
+        entry(__hip_atomic_load(last + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), it2, s2, sl, sr);  // inst[item]'s path
+        const size_t o = (size_t)task * max_rec + j;
+        rec_item[o] = item;
+        rec_score[o] = score;
+        rec_leaf[o] = sl;
+        const size_t s = (size_t)(slot0 + l_off[sl] + sr) * 3;
+        rec_ids[o * 3 + 0] = ids[s], rec_ids[o * 3 + 1] = ids[s + 1], rec_ids[o * 3 + 2] = ids[s + 2];
+    }
+}
+
+extern "C" int hw_cafe_collect(const hw_cafe_node* nodes, const int32_t* node_ptr, const int64_t* slot_ptr,
+                               const int32_t* ids, const float* vals, const int32_t* counts, const int32_t* leaf_nodes,
+                               int64_t n_tasks, int32_t n_leaves, int32_t n_items, uint64_t* best_ws, int32_t* last_ws,
+                               float* results, int32_t max_rec, int32_t* rec_item, float* rec_score, int32_t* rec_leaf,
+                               int32_t* rec_ids, int32_t* rec_count, int32_t* overflow, void* stream) {
+    if (!nodes || !node_ptr || !slot_ptr || !ids || !vals || !counts || !leaf_nodes || !best_ws || !last_ws || !results ||
+        !rec_item || !rec_score || !rec_leaf || !rec_ids || !rec_count || !overflow)
+        return HW_ERR_INVALID_ARG;
+    if (n_tasks < 0 || n_tasks > INT32_MAX || n_leaves < 1 || n_items < 1 || max_rec < 1) return HW_ERR_INVALID_ARG;
+    if (n_leaves > CAFE_MAX_LEAVES) return HW_ERR_UNSUPPORTED;
+    if (n_tasks == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(cafe_collect_kernel, dim3((unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, nodes, node_ptr,
+                       slot_ptr, ids, vals, counts, leaf_nodes, (int)n_leaves, (int)n_items,
+                       (unsigned long long*)best_ws, last_ws, results, (int)max_rec, rec_item, rec_score, rec_leaf, rec_ids,
+                       rec_count, overflow);
+    return HW_LAUNCH_RC();
+}
+
 extern "C" int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
                                const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task,
                                const float* logprobs, int64_t logprob_ld, const uint32_t* excluded_init,

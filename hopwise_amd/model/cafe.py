@@ -204,76 +204,90 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
         return torch.from_numpy(bits.view(np.int32)).to(self.user_embedding.device)
 
     @torch.no_grad()
-    def _run_programs(self, users, programs, ks, grow_excluded, exclude):
+    def _run_programs(self, users, programs, ks, grow_excluded, exclude, raw=False):
         """programs[b] = list of (parent index, relation name) in execution order for user b; ks[b][i] = k of node i.
-        Returns per user a list of (count, ids [count, depth], vals [count, depth]) per node."""
+        Returns per user a list of (count, ids [count, depth], vals [count, depth]) per node -- or, with ``raw``, the
+        interpreter's device buffers and the node tables (what :meth:`run_program` hands to the device collector).
+
+        Host work is array-wise over all (user, node) rows: the programs of a batch are flattened once into numpy columns
+        (parent row, relation, depth, capacity, slot offset) and every level's module inputs are one index_select."""
         dev = self.user_embedding.device
         users_np = users.cpu().numpy()
         B = len(users_np)
-        # 1) node vectors, level by level, batched by relation across users
-        vecs = [[None] * len(p) for p in programs]
+        lens = np.fromiter((len(p) for p in programs), np.int64, B)
+        node_ptr = np.zeros(B + 1, np.int64)
+        np.cumsum(lens, out=node_ptr[1:])
+        total = int(node_ptr[-1])
+        row_b = np.repeat(np.arange(B), lens)
+        row_i = np.arange(total) - node_ptr[row_b]
+        par_i = np.fromiter((q[0] for p in programs for q in p), np.int64, total)
+        rel_names = [q[1] for p in programs for q in p]
+        k_of = np.fromiter((int(x) for kk in ks for x in kk), np.int64, total)
+        par_row = np.where(par_i < 0, -1, node_ptr[row_b] + par_i)
+        names = sorted(set(rel_names))
+        code = {n: j for j, n in enumerate(names)}
+        rel_code = np.fromiter((code[n] for n in rel_names), np.int64, total)
+        mods = [self._module(n) for n in names]
+        # parents precede children inside a program: depth, capacity and leaf flags by program position
+        depth = np.ones(total, np.int64)
+        cap = k_of.copy()
+        for pos in range(int(lens.max()) if B else 0):
+            rows = np.nonzero((row_i == pos) & (par_i >= 0))[0]
+            depth[rows] = depth[par_row[rows]] + 1
+            cap[rows] = cap[par_row[rows]] * k_of[rows]
+        is_leaf = np.ones(total, np.int64)
+        is_leaf[par_row[par_row >= 0]] = 0
+        cum = np.cumsum(cap)
+        slot_ptr = np.concatenate([[0], cum[node_ptr[1:] - 1]]) if total else np.zeros(B + 1, np.int64)
+        slot_off = cum - cap - slot_ptr[row_b]
+        # 1) node vectors, level by level, one module call per (level, relation) over all users
         user_vec = self.user_embedding[users.to(dev)]
-        depth_of = [[0] * len(p) for p in programs]
-        max_depth = 0
-        for b, prog in enumerate(programs):
-            for i, (par, _) in enumerate(prog):
-                depth_of[b][i] = 1 if par < 0 else depth_of[b][par] + 1
-                max_depth = max(max_depth, depth_of[b][i])
-        for dep in range(1, max_depth + 1):
-            by_rel = {}
-            for b, prog in enumerate(programs):
-                for i, (par, rel) in enumerate(prog):
-                    if depth_of[b][i] == dep:
-                        by_rel.setdefault(rel, []).append((b, i, par))
-            for rel, lst in by_rel.items():
-                eh = torch.stack([user_vec[b] if par < 0 else vecs[b][par] for b, i, par in lst])
-                uv = torch.stack([user_vec[b] for b, i, par in lst])
-                out = self._module(rel)((eh, uv)).view(len(lst), -1)
-                for j, (b, i, par) in enumerate(lst):
-                    vecs[b][i] = out[j]
+        d = user_vec.shape[1]
+        vec_all = torch.zeros((max(total, 1), d), dtype=torch.float32, device=dev)
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        for dep in range(1, int(depth.max()) + 1 if total else 1):
+            src = torch.cat([user_vec, vec_all]) if dep > 1 else user_vec
+            at_dep = depth == dep
+            for j, mod in enumerate(mods):
+                rows = np.nonzero(at_dep & (rel_code == j))[0]
+                if not len(rows):
+                    continue
+                eh = src.index_select(0, t(np.where(par_row[rows] < 0, row_b[rows], B + par_row[rows])))
+                uv = user_vec.index_select(0, t(row_b[rows]))
+                vec_all.index_copy_(0, t(rows), mod((eh, uv)).view(len(rows), -1))
         # 2) log-probabilities of every node over its tail vocabulary: one GEMM per entity type + row log_softmax
-        rows = [(b, i) for b, prog in enumerate(programs) for i in range(len(prog))]
         width = max(self.n_users, self.n_entities)
-        lp = torch.empty((max(len(rows), 1), width), dtype=torch.float32, device=dev)
-        row_of = {}
-        by_type = {}
-        for r, (b, i) in enumerate(rows):
-            row_of[(b, i)] = r
-            by_type.setdefault(self._module(programs[b][i][1]).et_name, []).append(r)
-        for et, rs in by_type.items():
-            idx = torch.tensor(rs, device=dev)
-            v = torch.stack([vecs[rows[r][0]][rows[r][1]] for r in rs]).contiguous()
-            sc = ops.gemm(v, self.embeddings[et])  # [n, d] @ E^T
-            lp[idx, : self._vocab[et]] = P.log_softmax_rows(sc)
+        lp = torch.empty((max(total, 1), width), dtype=torch.float32, device=dev)
+        et_of = np.array([m.et_name for m in mods])[rel_code] if total else np.zeros(0, "<U6")
+        for et in np.unique(et_of):
+            rs = np.nonzero(et_of == et)[0]
+            whole = len(rs) == total
+            sc = ops.gemm(vec_all if whole else vec_all.index_select(0, t(rs)), self.embeddings[str(et)])  # [n, d] @ E^T
+            if whole:
+                P.log_softmax_rows(sc, out=lp[:, : self._vocab[str(et)]])
+            else:
+                lp[t(rs), : self._vocab[str(et)]] = P.log_softmax_rows(sc)
         # 3) interpret
-        nodes = np.zeros(len(rows), P.CAFE_NODE_DTYPE)
-        node_ptr, slot_ptr = [0], [0]
-        r = 0
-        for b, prog in enumerate(programs):
-            caps, off = [], 0
-            for i, (par, rel) in enumerate(prog):
-                mod = self._module(rel)
-                k = int(ks[b][i])
-                cap = (1 if par < 0 else caps[par]) * k
-                caps.append(cap)
-                leaf = not any(pp == i for pp, _ in prog)
-                nodes[r] = (par, self.relation2rid[rel], int(mod.eh_name == "entity"), k, int(leaf), row_of[(b, i)],
-                            depth_of[b][i], self._vocab[mod.et_name], cap, off)
-                off += cap
-                r += 1
-            node_ptr.append(r)
-            slot_ptr.append(slot_ptr[-1] + off)
+        nodes = np.zeros(total, P.CAFE_NODE_DTYPE)
+        nodes["parent"], nodes["k"], nodes["is_leaf"], nodes["depth"] = par_i, k_of, is_leaf, depth
+        nodes["rel"] = np.array([self.relation2rid[n] for n in names], np.int64)[rel_code] if total else 0
+        nodes["eh_is_entity"] = np.array([int(m.eh_name == "entity") for m in mods], np.int64)[rel_code] if total else 0
+        nodes["vocab"] = np.array([self._vocab[m.et_name] for m in mods], np.int64)[rel_code] if total else 0
+        nodes["lp_row"], nodes["cap"], nodes["slot_off"] = np.arange(total), cap, slot_off
         excl = self._excluded_bits(users_np, exclude)
-        ids, vals, counts = P.cafe_execute(self.graph, nodes, node_ptr, users.to(dev, torch.int64).contiguous(), lp, excl,
-                                           grow_excluded, slot_ptr, slot_ptr[-1])
+        users_dev = users.to(dev, torch.int64).contiguous()
+        ids, vals, counts, nodes_dev, node_ptr_dev, slot_ptr_dev = P.cafe_execute(
+            self.graph, nodes, node_ptr, users_dev, lp, excl, grow_excluded, slot_ptr, int(slot_ptr[-1]), keep_tables=True)
+        if raw:
+            return dict(ids=ids, vals=vals, counts=counts, nodes=nodes_dev, node_ptr=node_ptr_dev, slot_ptr=slot_ptr_dev,
+                        cap=cap, node_ptr_np=node_ptr)
         ids, vals, counts = ids.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
         out = []
-        for b, prog in enumerate(programs):
+        for b in range(B):
             per = []
-            for i in range(len(prog)):
-                nd = nodes[node_ptr[b] + i]
-                s0 = slot_ptr[b] + nd["slot_off"]
-                c, dep = int(counts[node_ptr[b] + i]), int(nd["depth"])
+            for r in range(int(node_ptr[b]), int(node_ptr[b + 1])):
+                s0 = int(slot_ptr[b] + slot_off[r])
+                c, dep = int(counts[r]), int(depth[r])
                 per.append((c, ids[s0 : s0 + c, :dep], vals[s0 : s0 + c, :dep]))
             out.append(per)
         return out
@@ -340,56 +354,49 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
         return leaves
 
     def run_program(self, users, path_counts=None, predicted_paths=None, manual_topk=5):
-        """(scores [B, n_items], [[user, item, score, path], ...]) -- cafe.py:406-447.  Paths carry relation NAMES."""
+        """(scores [B, n_items], [[user, item, score, path], ...]) -- cafe.py:406-447.  Paths carry relation NAMES.
+
+        collect_results and the ranking loop (cafe.py:417-441: every leaf path scored by the product of its float32
+        log-probs, inst[item] = the LAST path to an item, stable sort by score, first entry per item emitted with inst[item]'s
+        path) run on the device (hw_cafe_collect, one workgroup per user); the host only turns the returned records into
+        the reference's Python lists."""
         users = torch.as_tensor(users)
         users_np = users.cpu().numpy()
+        B = len(users_np)
         orders = [self._bfs_program() for _ in users_np]
         programs = [[(par, rel) for par, rel, _ in o] for o in orders]
         ks = [[manual_topk] * len(o) for o in orders]
-        res = self._run_programs(users, programs, ks, grow_excluded=True, exclude=True)
+        raw = self._run_programs(users, programs, ks, grow_excluded=True, exclude=True, raw=True)
         leaves = self._leaf_chains()
-        results = np.full((len(users_np), self.n_items), -np.inf, np.float32)
-        collected = []
-        # collect_results + the ranking loop of run_program (cafe.py:417-441), array-wise per user.  In the reference every
-        # path is appended to tmp in leaf order, inst[item] keeps the LAST path to an item, tmp is sorted by score
-        # (stable, descending) and an entry is emitted when it beats results[item] -- i.e. the first valid entry per item
-        # in sorted order, carrying inst[item]'s path (not necessarily its own).
-        for b, (u, order, per) in enumerate(zip(users_np, orders, res)):
-            u = int(u)
+        leaf_nodes = np.full((B, max(len(leaves), 1)), -1, np.int32)
+        for b, order in enumerate(orders):
             index_of_chain = {_chain_of(order, i): i for i in range(len(order))}
-            blocks, items, scores, blk, row = [], [], [], [], []
-            for chain in leaves:
-                c, ids, vals = per[index_of_chain[chain]]
-                if c == 0:
-                    continue
-                sc = vals[:, 0].astype(np.float32)
-                for d in range(1, vals.shape[1]):
-                    sc = sc * vals[:, d].astype(np.float32)  # reduce(mul) over np.float32, left to right (cafe.py:425)
-                items.append(ids[:, -1].astype(np.int64))
-                scores.append(sc)
-                blk.append(np.full(c, len(blocks), np.int64))
-                row.append(np.arange(c, dtype=np.int64))
-                blocks.append((chain, ids))
-            if not blocks:
+            for l, chain in enumerate(leaves):
+                leaf_nodes[b, l] = index_of_chain.get(chain, -1)
+        # most entries a user can have: the capacities of its leaf nodes
+        ptr = raw["node_ptr_np"]
+        max_rec = 1
+        for b in range(B):
+            sel = leaf_nodes[b][leaf_nodes[b] >= 0]
+            max_rec = max(max_rec, int(raw["cap"][ptr[b] + sel].sum()))
+        max_rec = min(max_rec, self.n_items)
+        scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec)
+        cnt = rec["count"].cpu().numpy()
+        item, score, leaf, pid = (rec[k].cpu().numpy() for k in ("item", "score", "leaf", "ids"))
+        # (relation name, tail type) chains of the leaves, and the records as plain Python values in one pass each
+        chains = [tuple((rel, self._module(rel).et_name) for rel in chain) for chain in leaves]
+        collected = []
+        for b in range(B):
+            c = int(cnt[b])
+            if not c:
                 continue
-            items, scores, blk, row = (np.concatenate(x) for x in (items, scores, blk, row))
-            n = len(items)
-            uniq, first_rev = np.unique(items[::-1], return_index=True)
-            last_of = dict(zip(uniq.tolist(), (n - 1 - first_rev).tolist()))  # item -> its last entry: inst[item]
-            srt = np.argsort(-scores, kind="stable")
-            srt = srt[(scores[srt] > -np.inf) & (items[srt] < self.n_items)]  # entries that can beat the -inf fill
-            _, first = np.unique(items[srt], return_index=True)
-            for k in srt[np.sort(first)].tolist():
-                item, score = int(items[k]), scores[k]
-                results[b, item] = score
-                chain, ids = blocks[int(blk[last_of[item]])]
-                r = int(row[last_of[item]])
-                path = [("self_loop", "user", u)]
-                for jj, rel in enumerate(chain):
-                    path.append((rel, self._module(rel).et_name, int(ids[r][jj])))
-                collected.append([u, item, score, path])
-        results = torch.from_numpy(results)
-        return results, collected
+            u = int(users_np[b])
+            start = ("self_loop", "user", u)
+            sc_b = score[b, :c]
+            collected.extend(
+                [u, it, sc_b[j], [start, *((rel, et, e) for (rel, et), e in zip(chains[l], p))]]
+                for j, (it, l, p) in enumerate(zip(item[b, :c].tolist(), leaf[b, :c].tolist(), pid[b, :c].tolist())))
+        return scores.cpu(), collected
 
     def full_sort_predict(self, interaction):
         scores, paths = self.run_program(interaction[self.USER_ID])

@@ -262,7 +262,8 @@ def log_softmax_rows(x, n_cols=None, out=None):
     return out
 
 
-def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, grow_excluded, slot_ptr_np, n_slots):
+def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, grow_excluded, slot_ptr_np, n_slots,
+                 keep_tables=False):
     """Run the program interpreter.  nodes_np: structured array of CafeNode fields; returns (ids [n_slots, 3] int32,
     vals [n_slots, 3] float32, counts [n_nodes] int32) on the device."""
     lib = _lib.load()
@@ -280,7 +281,39 @@ def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, g
                             int(bool(grow_excluded)), _ptr(ids), _ptr(vals), _ptr(counts), _ptr(slot_ptr), _stream()),
         "hw_cafe_execute",
     )
+    if keep_tables:
+        return ids, vals, counts, nodes, node_ptr, slot_ptr
     return ids, vals, counts
+
+
+def cafe_collect(raw, leaf_nodes_np, n_items, max_rec):
+    """collect_results + ranking of run_program on the interpreter's device buffers (hw_cafe_collect).  ``raw``: what
+    CAFE._run_programs(..., raw=True) returns; leaf_nodes_np int32 [n_tasks, n_leaves].  Returns (results [n_tasks, n_items]
+    float32 on the device, dict of record tensors: item / score / leaf [n_tasks, max_rec], ids [n_tasks, max_rec, 3], count)."""
+    lib = _lib.load()
+    dev = raw["ids"].device
+    n_tasks, n_leaves = leaf_nodes_np.shape
+    leaf_nodes = torch.from_numpy(np.ascontiguousarray(leaf_nodes_np, np.int32)).to(dev)
+    best = torch.empty((n_tasks, n_items), dtype=torch.int64, device=dev)
+    last = torch.empty((n_tasks, n_items), dtype=torch.int32, device=dev)
+    results = torch.empty((n_tasks, n_items), dtype=torch.float32, device=dev)
+    rec = dict(item=torch.zeros((n_tasks, max_rec), dtype=torch.int32, device=dev),
+               score=torch.zeros((n_tasks, max_rec), dtype=torch.float32, device=dev),
+               leaf=torch.zeros((n_tasks, max_rec), dtype=torch.int32, device=dev),
+               ids=torch.zeros((n_tasks, max_rec, 3), dtype=torch.int32, device=dev),
+               count=torch.zeros(n_tasks, dtype=torch.int32, device=dev))
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(
+        lib.hw_cafe_collect(_ptr(raw["nodes"]), _ptr(raw["node_ptr"]), _ptr(raw["slot_ptr"]), _ptr(raw["ids"]), _ptr(raw["vals"]),
+                            _ptr(raw["counts"]), _ptr(leaf_nodes), n_tasks, n_leaves, int(n_items), _ptr(best), _ptr(last),
+                            _ptr(results), int(max_rec), _ptr(rec["item"]), _ptr(rec["score"]), _ptr(rec["leaf"]),
+                            _ptr(rec["ids"]), _ptr(rec["count"]), _ptr(overflow), _stream()),
+        "hw_cafe_collect",
+    )
+    seen = int(overflow.item())  # the records are about to be copied to the host anyway
+    if seen:
+        raise RuntimeError(f"hw_cafe_collect: a user has {seen} leaf paths, more than the 4096 one workgroup ranks")
+    return results, rec
 
 
 CAFE_NODE_DTYPE = np.dtype([(n, np.int32) for n in

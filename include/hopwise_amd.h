@@ -518,6 +518,20 @@ int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const
                     int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
                     int32_t* out_count, const int64_t* slot_ptr, void* stream);
 
+/* collect_results + the ranking loop of run_program (cafe.py:417-441, :859-867) on hw_cafe_execute's output, one user
+ * per task: entries = the paths of the task's leaf nodes in `leaf_nodes` order (int32 [n_tasks, n_leaves], node index
+ * inside the task, -1 = absent), score = product of the path's float32 log-probs left to right.  Per item the entry with
+ * the highest score (ties: the earlier entry) is emitted with the path of the LAST entry that reached the item (the
+ * reference's inst[item]); emission order = score descending, entry ascending.  results [n_tasks, n_items] (-inf where
+ * nothing is written); records rec_* [n_tasks, max_rec] (item, score, leaf ordinal of the attached path, its 3 ids) and
+ * rec_count [n_tasks].  best_ws uint64 / last_ws int32 [n_tasks, n_items] scratch.  *overflow (zero it first) = the
+ * largest entry count seen when a task has more than 4096 entries (its output is then truncated). */
+int hw_cafe_collect(const hw_cafe_node* nodes, const int32_t* node_ptr, const int64_t* slot_ptr, const int32_t* ids,
+                    const float* vals, const int32_t* counts, const int32_t* leaf_nodes, int64_t n_tasks, int32_t n_leaves,
+                    int32_t n_items, uint64_t* best_ws, int32_t* last_ws, float* results, int32_t max_rec,
+                    int32_t* rec_item, float* rec_score, int32_t* rec_leaf, int32_t* rec_ids, int32_t* rec_count,
+                    int32_t* overflow, void* stream);
+
 /* ---- nn.BatchNorm2d, training mode, NCHW with few channels (conve.py:62-66, convkb.py:51-56) ------------------------
  * y = (x - mean_c) rstd_c gamma_c + beta_c with the batch statistics over N x HW (biased variance), running_mean / _var
  * updated in place with `momentum` (running_var from the unbiased variance, as torch does); save_mean / save_rstd [C] feed
