@@ -53,17 +53,27 @@ if fetch and write:
         rows.append(dict(kernel=k, launches=len(fv), fetch_kib_raw_median=sorted(fv)[len(fv) // 2],
                          fetch_kib_raw_max=max(fv), write_kib_median=sorted(wv)[len(wv) // 2], write_kib_max=max(wv)))
     json.dump(rows, open(os.path.join(dst, f"pmc_traffic_{tag}.json"), "w"), indent=1)
-    grouped = [r for r in rows if "kge_score_grouped" in r["kernel"]]
-    if grouped:
-        # the bench's timed step runs the most-launched grouped kernel (with the in-kernel sampler when it applies); the
-        # 4.2 GB-table variant is the largest launch of any of them
-        main = max(grouped, key=lambda r: r["launches"])
-        out["kge_score_grouped_bytes_per_launch"] = (2.0 * main["fetch_kib_raw_median"] + main["write_kib_median"]) * 1024.0
-        out["kge_score_grouped_hbm_variant_bytes_per_launch"] = max(
-            (2.0 * r["fetch_kib_raw_max"] + r["write_kib_max"]) * 1024.0 for r in grouped)
-        out["note"] = ("median over launches of the bench step's kernel = ml-1m-small tables (L2 / Infinity Cache resident: "
-                       "fabric-side requests that reach HBM or hit the Infinity Cache); max over all grouped launches = the "
-                       "4.2 GB-table variant. FETCH_SIZE doubled per the gfx950 note.")
+    bytes_of = lambda fk, wk: (2.0 * fk + wk) * 1024.0
+    # bench.py launches the RotatE grouped scorer in four roles, told apart by kernel and by byte volume:
+    #   <1, 64, 4, true, 4, true>   negatives drawn in-kernel = the timed region (configs[1], item tails, L2-resident)
+    #   <1, 64, 4, true, 4, false>  plain kernel: entity-tail variant (22 MB tables) and the 4.2 GB HBM-resident variant
+    #   kge_score_grouped_xcd_kernel<1, ...>  entity-tail variant, XCD-partitioned
+    fv_all, wv_all = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    for k in fv_all:
+        f_, w_ = fv_all[k], wv_all.get(k, [0.0])
+        if "kge_score_grouped_kernel<1, 64, 4, true, 4, true>" in k:
+            out["kge_score_grouped_bytes_per_launch"] = bytes_of(med(f_), med(w_))
+        elif "kge_score_grouped_kernel<1, 64, 4, true, 4, false>" in k:
+            out["kge_score_grouped_hbm_variant_bytes_per_launch"] = bytes_of(max(f_), max(w_))
+            small = [x for x in f_ if x < 0.8 * max(f_)]
+            if small:
+                out["kge_score_grouped_entity_tails_plain_bytes_per_launch"] = bytes_of(med(small), med(w_))
+        elif "kge_score_grouped_xcd_kernel<1," in k:
+            out["kge_score_grouped_entity_tails_xcd_bytes_per_launch"] = bytes_of(med(f_), med(w_))
+    out["note"] = ("fabric-side bytes per launch (FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE): requests that reach HBM "
+                   "or hit the Infinity Cache.  Timed-region kernel = median over its launches; HBM variant = the largest "
+                   "launches of the plain kernel (4.2 GB table); entity-tail variants = the 22 MB tables")
     out["source"] = f"profiles/{rnd}/pmc_traffic_{tag}.json"
     json.dump(out, open(os.path.join(ROOT, "profiles", "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
