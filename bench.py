@@ -440,8 +440,6 @@ def leg_sharded(D, args):
     from hopwise_amd.optim import FusedAdam
     from tests.helpers import FakeDataset, make_config
 
-    if D.world > 1 and D.backend != "nccl":
-        return {"skipped": f"backend {D.backend}: the row exchange needs all_to_all_single on device tensors (RCCL)"}
     nU, nI, nE, nR, _, _ = synthetic.SHAPES["yelp2018"]
     Dm, B, P = 256, args.sharded_batch, D.world
     torch.manual_seed(0)  # same full tables on every rank before sharding
@@ -495,17 +493,19 @@ def leg_sharded(D, args):
                                     "per relation table" if P > 1 else "none (P = 1: the exchange is the identity)",
         },
         "table_bytes_per_rank": 2 * (nU + nE) * Dm * 4 / P, "scaling": "weak", "parallelism": f"row-sharded x{P}",
+        "backend": ("rccl" if D.backend == "nccl" else f"{D.backend} (rehearsal: collectives staged through host memory)")
+        if P > 1 else None,
     }
     if P > 1:  # the fabric alone: the forward row all-to-all of one entity table, back to back
         buf = torch.empty((P * cap_e, Dm), dtype=torch.float32, device=dev)
         back = torch.empty_like(buf)
         for _ in range(3):
-            D.dist.all_to_all_single(back, buf)
+            parallel.all_to_all(back, buf)
         D.barrier()
         t0 = time.perf_counter()
         reps = 20
         for _ in range(reps):
-            D.dist.all_to_all_single(back, buf)
+            parallel.all_to_all(back, buf)
         D.barrier()
         adt = D.reduce(time.perf_counter() - t0, "max") / reps
         res["exchange"]["all_to_all_alone"] = {"message_bytes": buf.numel() * 4, "ms": adt * 1e3,
@@ -593,10 +593,21 @@ def main():
     del ctx
     torch.cuda.empty_cache()
     D.barrier()
+    def guarded(name, fn):
+        """A failing side leg must not take the headline line with it; the error is reported in its place (and on stderr)."""
+        try:
+            out[name] = fn()
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            traceback.print_exc()
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            torch.cuda.empty_cache()
+
     if not args.no_sharded:
-        out["sharded"] = leg_sharded(D, args)
+        guarded("sharded", lambda: leg_sharded(D, args))
     if D.world == 1 and not args.no_tucker:
-        out["tucker"] = leg_tucker(D, args)
+        guarded("tucker", lambda: leg_tucker(D, args))
     if not args.no_pgpr:
         # second half of BASELINE.json's metric: PGPR paths expanded / s (configs[2]); every rank searches its own users
         import bench_pgpr

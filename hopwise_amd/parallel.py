@@ -51,6 +51,45 @@ def _exchange(P):
     return P > 1 or (os.environ.get("HW_FORCE_COLLECTIVES", "0") == "1" and dist.is_available() and dist.is_initialized())
 
 
+def _staged(group, *tensors):
+    """True when the collective must be staged through host memory: a non-RCCL backend (gloo: the rehearsal backend of
+    the tests and of bench.py's HW_BENCH_BACKEND=gloo) asked to move device tensors.  The production path is RCCL on the
+    device buffers; this branch exists so that the multi-rank exchange can run end to end with the real kernels on a box
+    whose ranks share one GPU."""
+    return dist.get_backend(group) != "nccl" and any(t.is_cuda for t in tensors)
+
+
+def all_to_all(out, inp, group=None):
+    if _staged(group, out, inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+    return out
+
+
+def all_reduce_sum(t, group=None):
+    if _staged(group, t):
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def all_gather(parts, t, group=None):
+    if _staged(group, t):
+        cp = [torch.empty(p.shape, dtype=p.dtype) for p in parts]
+        dist.all_gather(cp, t.cpu(), group=group)
+        for p, c in zip(parts, cp):
+            p.copy_(c)
+    else:
+        dist.all_gather(parts, t, group=group)
+    return parts
+
+
 def world(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
@@ -85,9 +124,9 @@ class _Plan:
         self.inv, self.send_counts, self.send_local = plan(ids, n_rows, P, self.cap, overflow)
         if _exchange(P):
             self.recv_counts = torch.empty_like(self.send_counts)
-            dist.all_to_all_single(self.recv_counts, self.send_counts, group=group)
+            all_to_all(self.recv_counts, self.send_counts, group)
             self.recv_local = torch.empty_like(self.send_local)
-            dist.all_to_all_single(self.recv_local, self.send_local, group=group)
+            all_to_all(self.recv_local, self.send_local, group)
         else:
             self.recv_counts, self.recv_local = self.send_counts, self.send_local
         self.rows = P * self.cap  # rows of a compact table
@@ -102,7 +141,7 @@ class _ShardedLookup(torch.autograd.Function):
             rows = gather(s, plan.recv_local, plan.recv_counts, plan.cap)
             if _exchange(plan.P):
                 back = torch.empty_like(rows)
-                dist.all_to_all_single(back, rows, group=plan.group)
+                all_to_all(back, rows, plan.group)
             else:
                 back = rows
             outs.append(back)
@@ -120,7 +159,7 @@ class _ShardedLookup(torch.autograd.Function):
             g = g.contiguous()
             if _exchange(plan.P):
                 recv = torch.empty_like(g)
-                dist.all_to_all_single(recv, g, group=plan.group)
+                all_to_all(recv, g, plan.group)
             else:
                 recv = g
             sink = ops._live_sink(s) if not torch.is_grad_enabled() else None
@@ -258,7 +297,7 @@ class RowShardedKGE(nn.Module):
             return
         for n, p in self.named_parameters():
             if p.grad is not None and not n.startswith("shard_"):
-                dist.all_reduce(p.grad, group=self.group)
+                all_reduce_sum(p.grad, self.group)
 
     # -- evaluation: tails sharded, queries replicated (every rank passes the SAME interaction) ----------------------------
     def _queries(self, interaction, kg):
@@ -309,7 +348,7 @@ class RowShardedKGE(nn.Module):
         pad = torch.zeros((B, width), dtype=local.dtype, device=local.device)
         pad[:, :n_loc] = local
         parts = [torch.empty_like(pad) for _ in range(self.P)]
-        dist.all_gather(parts, pad, group=self.group)
+        all_gather(parts, pad, self.group)
         full = torch.stack(parts, dim=2).reshape(B, width * self.P)[:, :n]  # column = local * P + rank
         return full.contiguous()
 
@@ -332,7 +371,7 @@ class RowShardedKGE(nn.Module):
             pad = torch.zeros((local_rows(n_full, 0, self.P), sh.shape[1]), dtype=sh.dtype, device=sh.device)
             pad[: sh.shape[0]] = sh
             parts = [torch.empty_like(pad) for _ in range(self.P)]
-            dist.all_gather(parts, pad, group=self.group)
+            all_gather(parts, pad, self.group)
             full = torch.empty((n_full, sh.shape[1]), dtype=sh.dtype, device=sh.device)
             for r in range(self.P):
                 full[r :: self.P] = parts[r][: local_rows(n_full, r, self.P)]
@@ -348,8 +387,8 @@ def merge_topk(local_vals, local_ids, k, group=None, topk_fn=None):
         return local_vals[:, :k], local_ids[:, :k]
     vals = [torch.empty_like(local_vals) for _ in range(P)]
     ids = [torch.empty_like(local_ids) for _ in range(P)]
-    dist.all_gather(vals, local_vals.contiguous(), group=group)
-    dist.all_gather(ids, local_ids.contiguous(), group=group)
+    all_gather(vals, local_vals.contiguous(), group)
+    all_gather(ids, local_ids.contiguous(), group)
     v, i = torch.cat(vals, dim=1), torch.cat(ids, dim=1)
     # order candidates by global id first so that "index asc" among equal values means "global id asc"
     order = torch.argsort(i, dim=1, stable=True)
