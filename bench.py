@@ -273,8 +273,10 @@ def leg_kge(D, args, out):
 
     triples_per_batch = B_POS * (1 + K_NEG)
     triples_per_step = triples_per_batch * inner
-    kern_ms_raw = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    kern_ms = max(kern_ms_raw - pair_overhead_ms, 1e-6)  # launch duration: the pair minus what an empty pair measures
+    # launch duration from the event pairs.  A pair around nothing measures `pair_overhead_ms` (reported); the pair is NOT
+    # corrected by it -- record-to-record time is an upper bound of the kernel's duration, so `achieved` is conservative
+    # (rocprofv3's kernel trace of the same command reads ~6 % shorter, profiles/r2/bench_kernel_stats_*.csv)
+    kern_ms = kern_ms_raw = float(np.mean([a.elapsed_time(b) for a, b in events]))
     abytes = algorithmic_bytes_per_triple() * triples_per_batch
     traffic = {}
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
