@@ -99,6 +99,13 @@ SIGNATURES = {
          C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int64, c_f32p, C.c_void_p],
     ),
     "hw_kge_grad_grouped_workspace_floats": (C.c_int64, [C.POINTER(KgeDesc), C.c_int64, C.c_int64, C.c_int32]),
+    "hw_batchnorm1d_workspace_doubles": (C.c_int64, [C.c_int32]),
+    "hw_batchnorm1d_forward": (
+        C.c_int, [c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                  C.c_void_p, C.c_int32, C.c_void_p]),
+    "hw_batchnorm1d_backward": (
+        C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "hw_dropout": (C.c_int, [c_f32p, C.c_int64, C.c_float, C.c_uint64, C.c_uint64, c_f32p, C.c_void_p]),
     "hw_batchnorm2d_workspace_doubles": (C.c_int64, [C.c_int32]),
     "hw_batchnorm2d_forward": (
         C.c_int,

@@ -37,9 +37,9 @@ class RelationModule(nn.Module):
         super().__init__()
         self.name, self.eh_name, self.et_name = info["name"], info["entity_head"], info["entity_tail"]
         self.fc1 = nn.Linear(embedding_size * 2, 256)
-        self.bn1 = nn.BatchNorm1d(256)
+        self.bn1 = ops.BatchNorm1d(256)
         self.fc2 = nn.Linear(256, embedding_size)
-        self.dropout = nn.Dropout(0.5)
+        self.dropout = ops.Dropout(0.5, 2020)
 
     def forward(self, inputs):  # cafe.py:656-667
         eh_vec, user_vec = inputs
@@ -54,11 +54,11 @@ class DeepRelationModule(nn.Module):
         self.name, self.eh_name, self.et_name = info["name"], info["entity_head"], info["entity_tail"]
         n = embedding_size * 2
         self.fc1 = nn.Linear(n, 256)
-        self.bn1 = nn.BatchNorm1d(256)
+        self.bn1 = ops.BatchNorm1d(256)
         self.fc2 = nn.Linear(256, n)
-        self.bn2 = nn.BatchNorm1d(n)
+        self.bn2 = ops.BatchNorm1d(n)
         self.fc3 = nn.Linear(n, embedding_size)
-        self.dropout = nn.Dropout(0.5) if use_dropout else None
+        self.dropout = ops.Dropout(0.5, 2020) if use_dropout else None
 
     def forward(self, inputs):  # cafe.py:686-699; the three Linear layers run on the MFMA GEMM
         eh_vec, user_vec = inputs
@@ -393,9 +393,12 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
             u = int(users_np[b])
             start = ("self_loop", "user", u)
             sc_b = score[b, :c]
+            rows = zip(item[b, :c].tolist(), sc_b, leaf[b, :c].tolist(), pid[b, :c].tolist())
+            # explicit tuples per chain length: a generator per record costs more than the record itself
             collected.extend(
-                [u, it, sc_b[j], [start, *((rel, et, e) for (rel, et), e in zip(chains[l], p))]]
-                for j, (it, l, p) in enumerate(zip(item[b, :c].tolist(), leaf[b, :c].tolist(), pid[b, :c].tolist())))
+                [u, it, sc, ([start, (ch[0][0], ch[0][1], p[0]), (ch[1][0], ch[1][1], p[1]), (ch[2][0], ch[2][1], p[2])]
+                             if len(ch) == 3 else [start, *((rel, et, e) for (rel, et), e in zip(ch, p))])]
+                for it, sc, l, p in rows for ch in (chains[l],))
         return scores.cpu(), collected
 
     def full_sort_predict(self, interaction):

@@ -514,8 +514,8 @@ class TuckER(KnowledgeRecommender):
     (tucker.py:111-115), predict() indexes the user-table logits with the raw item id (tucker.py:139), there is no
     full_sort_predict_kg (tucker.py:164-172 is commented out).
     Dense products (r . W, x . E^T and their gradients) run on hw_gemm_f32; the [B, d, d] contraction with
-    hidden_dropout1 and the sigmoid + BCE with its gradient are fused kernels (csrc/tucker.hip); BatchNorm and the two
-    [B, d] dropouts are torch modules (a few hundred KB of traffic next to GBs of logits)."""
+    hidden_dropout1 and the sigmoid + BCE with its gradient are fused kernels (csrc/tucker.hip); BatchNorm1d and the two
+    [B, d] dropouts run on csrc/batchnorm.hip (ops.BatchNorm1d / ops.Dropout, same state_dict keys)."""
 
     other_parameter_name = ["_drop_calls"]  # Philox offset of hidden_dropout1: saved with the checkpoint (trainer.py:296-304)
 
@@ -530,11 +530,12 @@ class TuckER(KnowledgeRecommender):
         self.entity_embedding = nn.Embedding(self.n_entities, d)
         self.relation_embedding = nn.Embedding(self.n_relations, d)
         self.weights = nn.Parameter(torch.empty(d, d, d).uniform_(-1, 1))
-        self.input_dropout = nn.Dropout(config["input_dropout"])
-        self.hidden_dropout1 = nn.Dropout(config["input_dropout1"])
-        self.hidden_dropout2 = nn.Dropout(config["input_dropout2"])
-        self.bn0 = nn.BatchNorm1d(d)
-        self.bn1 = nn.BatchNorm1d(d)
+        seed = _cfg(config, "seed", 2020)
+        self.input_dropout = ops.Dropout(config["input_dropout"], seed, stream=0)
+        self.hidden_dropout1 = nn.Dropout(config["input_dropout1"])  # only its p: the mask is drawn inside the contraction
+        self.hidden_dropout2 = ops.Dropout(config["input_dropout2"], seed, stream=1)
+        self.bn0 = ops.BatchNorm1d(d)
+        self.bn1 = ops.BatchNorm1d(d)
         self.apply(xavier_normal_initialization)
         self.forced_masks = None  # tests: {"rec": (m0 [B,d], m1 [B,d,d], m2 [B,d]), "kg": (...)} multiplicative masks
         # False: the per-row mm(r, W) of the reference; True (default): one matrix per distinct relation (see _features)
@@ -654,7 +655,8 @@ class ConvE(KnowledgeRecommender):
     ``score[:, tail]`` -- a [B, B] matrix (:162), full_sort_predict_kg reads attributes that do not exist (:183-186) and
     therefore raises AttributeError, lookups skip the gradient of id 0 (padding_idx) while the 1-vs-all product does not.
     The convolution (csrc/conv.hip), the two BatchNorm2d layers (csrc/batchnorm.hip), the two dense products and sigmoid +
-    BCE are HIP; BatchNorm1d / dropout modules are torch (a few MB next to the [B, N] logits), as for TuckER."""
+    BCE are HIP, and so are BatchNorm1d and the element-wise dropouts (ops.BatchNorm1d / ops.Dropout); only the channel-wise
+    Dropout2d is torch's."""
 
     input_type = InputType.PAIRWISE
 
@@ -670,13 +672,14 @@ class ConvE(KnowledgeRecommender):
         self.user_embedding = nn.Embedding(self.n_users + self.n_items, d, padding_idx=0)
         self.entity_embedding = nn.Embedding(self.n_entities, d, padding_idx=0)
         self.relations_embeddings = nn.Embedding(self.n_relations, d, padding_idx=0)
-        self.inp_drop = nn.Dropout(config["input_dropout"])
-        self.hidden_drop = nn.Dropout(config["hidden_dropout"])
+        seed = _cfg(config, "seed", 2020)
+        self.inp_drop = ops.Dropout(config["input_dropout"], seed, stream=0)
+        self.hidden_drop = ops.Dropout(config["hidden_dropout"], seed, stream=1)
         self.feature_map_drop = nn.Dropout2d(config["feature_dropout"])
         self.conv1 = nn.Conv2d(1, 32, (3, 3), 1, 0, bias=self.use_bias)
         self.bn0 = ops.BatchNorm2d(1)
         self.bn1 = ops.BatchNorm2d(32)
-        self.bn2 = nn.BatchNorm1d(d)
+        self.bn2 = ops.BatchNorm1d(d)
         self.register_parameter("b_users", nn.Parameter(torch.zeros(self.n_users + self.n_items)))
         self.register_parameter("b_entities", nn.Parameter(torch.zeros(self.n_entities)))
         self.fc = nn.Linear(self.hidden_size, d)
@@ -778,7 +781,7 @@ class ConvKB(KnowledgeRecommender):
         self.conv1_bn = ops.BatchNorm2d(1)
         self.conv_layer = nn.Conv2d(1, self.out_channels, (self.kernel_size, 3))
         self.conv2_bn = ops.BatchNorm2d(self.out_channels)
-        self.dropout = nn.Dropout(self.drop_prob)
+        self.dropout = ops.Dropout(self.drop_prob, _cfg(config, "seed", 2020), stream=0)
         self.fc_layer = nn.Linear((d - self.kernel_size + 1) * self.out_channels, 1, bias=False)
         self.apply(xavier_normal_initialization)
         self.forced_masks = None  # tests: list of multiplicative dropout masks, one per forward call

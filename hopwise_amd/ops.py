@@ -880,6 +880,113 @@ class BatchNorm2d(torch.nn.BatchNorm2d):
         return super().forward(x)
 
 
+class _BatchNorm1dTrain(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "x").contiguous()
+        N, Cc = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(Cc, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(int(lib.hw_batchnorm1d_workspace_doubles(Cc)), dtype=torch.float64, device=x.device)
+        check(lib.hw_batchnorm1d_forward(_ptr(x), N, Cc, _ptr(weight), _ptr(bias), float(eps), float(momentum),
+                                         _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), _ptr(y), _ptr(ws), 1,
+                                         _stream()), "hw_batchnorm1d_forward")
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        N, Cc = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dg = torch.empty(Cc, dtype=torch.float32, device=x.device) if weight is not None and ctx.needs_input_grad[1] else None
+        db = torch.empty(Cc, dtype=torch.float32, device=x.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        ws = torch.empty(int(lib.hw_batchnorm1d_workspace_doubles(Cc)), dtype=torch.float64, device=x.device)
+        check(lib.hw_batchnorm1d_backward(_ptr(x), _ptr(dy), N, Cc, _ptr(weight), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg),
+                                          _ptr(db), _ptr(ws), _stream()), "hw_batchnorm1d_backward")
+        return dx, dg, db, None, None, None, None
+
+
+class BatchNorm1d(torch.nn.BatchNorm1d):
+    """nn.BatchNorm1d on the HIP kernels of csrc/batchnorm.hip (same parameters, buffers, state_dict keys): training mode
+    with autograd, evaluation under no_grad; anything else (non-fp32, 3-D input, eval with gradients) goes to torch."""
+
+    def forward(self, x):
+        ok = x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.track_running_stats and x.shape[0] > 0
+        if ok and self.training and self.momentum is not None and x.shape[0] > 1:
+            if self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return _BatchNorm1dTrain.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                           self.momentum)
+        if ok and not self.training and not (torch.is_grad_enabled() and (x.requires_grad or (
+                self.weight is not None and self.weight.requires_grad))):
+            lib = _lib.load()
+            x = x.contiguous()
+            y = torch.empty_like(x)
+            check(lib.hw_batchnorm1d_forward(_ptr(x), x.shape[0], x.shape[1], _ptr(self.weight), _ptr(self.bias),
+                                             float(self.eps), 0.0, _ptr(self.running_mean), _ptr(self.running_var), None, None,
+                                             _ptr(y), None, 0, _stream()), "hw_batchnorm1d_forward")
+            return y
+        return super().forward(x)
+
+
+_TORCH_F_DROPOUT = torch.nn.functional.dropout
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        lib = _lib.load()
+        x = _dev(x, torch.float32, "x").contiguous()
+        y = torch.empty_like(x)
+        check(lib.hw_dropout(_ptr(x), x.numel(), float(p), C.c_uint64(seed), C.c_uint64(offset), _ptr(y), _stream()),
+              "hw_dropout")
+        ctx.args = (float(p), int(seed), int(offset))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        p, seed, offset = ctx.args
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.hw_dropout(_ptr(dy), dy.numel(), p, C.c_uint64(seed), C.c_uint64(offset), _ptr(dx), _stream()), "hw_dropout")
+        return dx, None, None, None
+
+
+class Dropout(torch.nn.Dropout):
+    """nn.Dropout drawn from a device Philox stream keyed by (seed, rank) with one offset per call (distribution-equal to
+    torch's, reproducible per seed).  ``state_dict`` is empty like nn.Dropout's; the call counter rides in the owning
+    model's ``other_parameter`` when it lists one."""
+
+    _next_stream = 0
+
+    def __init__(self, p=0.5, seed=2020, stream=None):
+        super().__init__(p)
+        from .utils import seed_for_rank
+
+        if stream is None:  # one Philox key per module instance, in construction order
+            stream = 1000 + Dropout._next_stream
+            Dropout._next_stream += 1
+        self._seed = (seed_for_rank(seed) + 0x632BE59BD9B4E019 * (int(stream) + 1)) & 0xFFFFFFFFFFFFFFFF
+        self.calls = 0
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        # a patched torch.nn.functional.dropout (tests replaying the reference's recorded masks) keeps its say
+        if (not (x.is_cuda and x.dtype == torch.float32) or self.p >= 1.0
+                or torch.nn.functional.dropout is not _TORCH_F_DROPOUT):
+            return super().forward(x)
+        self.calls += 1
+        return _DropoutFn.apply(x, self.p, self._seed, self.calls)
+
+
 class LinearAct(torch.autograd.Function):
     """y = act(x @ w^T + b) (nn.Linear + optional ReLU / ELU) with the backward on the HIP kernels: the activation's
     derivative is recovered from y, the three gradients are two GEMMs and a column sum."""

@@ -544,6 +544,21 @@ int hw_batchnorm2d_backward(const float* x, const float* dy, int64_t batch, int3
                             const float* gamma, const float* save_mean, const float* save_rstd, float* dx, float* dgamma,
                             float* dbeta, double* workspace, void* stream);
 
+/* nn.BatchNorm1d over [batch, channels] rows (tucker.py:58-59 bn0 / bn1, conve.py:67 bn2, cafe.py:667-690): training != 0
+ * uses the batch statistics (biased variance; running stats updated in place with `momentum`, running_var from the
+ * unbiased variance; save_mean / save_rstd feed the backward), training == 0 the running statistics.  gamma / beta nullable.
+ * workspace: hw_batchnorm1d_workspace_doubles(channels) float64 (training and backward). */
+int64_t hw_batchnorm1d_workspace_doubles(int32_t channels);
+int hw_batchnorm1d_forward(const float* x, int64_t batch, int32_t channels, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, float* save_mean, float* save_rstd,
+                           float* y, double* workspace, int32_t training, void* stream);
+int hw_batchnorm1d_backward(const float* x, const float* dy, int64_t batch, int32_t channels, const float* gamma,
+                            const float* save_mean, const float* save_rstd, float* dx, float* dgamma, float* dbeta,
+                            double* workspace, void* stream);
+/* nn.Dropout on n floats: element i kept with probability 1 - drop_p and scaled by 1 / (1 - drop_p), from Philox word i of
+ * the (seed, offset) stream; the backward is the same call on the upstream gradient. */
+int hw_dropout(const float* x, int64_t n, float drop_p, uint64_t seed, uint64_t offset, float* y, void* stream);
+
 /* ---- dense Adam over all tables of a model in one launch (trainer/trainer.py:189-190: optim.Adam(params, lr,
  * weight_decay), the reference's default learner; torch/optim/adam.py update rule, no amsgrad / maximize).
  * *step is a DEVICE counter, incremented by the call (so the launch replays inside a HIP graph); every segment is

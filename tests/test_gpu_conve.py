@@ -153,3 +153,54 @@ def test_batchnorm2d_kernels_match_torch_in_training_mode(shape):
     ref.eval()
     x = torch.randn(shape, generator=g)
     np.testing.assert_allclose(mine(x.to(dev)).detach().cpu().numpy(), ref(x.double()).detach().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("N,C", [(2048, 200), (7, 5), (130, 64), (33, 257)])
+def test_batchnorm1d_and_dropout_modules(N, C):
+    """ops.BatchNorm1d against nn.BatchNorm1d (training forward, gradients, running statistics; evaluation forward) and
+    ops.Dropout's Philox mask (keep rate, scaling, backward = same mask, reproducible per call counter)."""
+    import copy
+
+    from hopwise_amd import ops
+    from oracle.philox import philox_words
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(N + C)
+    x = (torch.randn(N, C, generator=g) * 2 + 0.5).to(dev)
+    ref = torch.nn.BatchNorm1d(C).to(dev)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.normal_()
+    mine = ops.BatchNorm1d(C).to(dev)
+    mine.load_state_dict(copy.deepcopy(ref.state_dict()))
+    w = torch.randn(N, C, generator=g).to(dev)
+    for m in (ref, mine):
+        m.train()
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = ref(xa), mine(xb)
+    np.testing.assert_allclose(yb.detach().cpu().numpy(), ya.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(mine.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(mine.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    for k in ("running_mean", "running_var", "num_batches_tracked"):
+        np.testing.assert_allclose(getattr(mine, k).cpu().numpy(), getattr(ref, k).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for m in (ref, mine):
+        m.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(mine(x).cpu().numpy(), ref(x).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # dropout
+    d = ops.Dropout(0.3, seed=11, stream=5).to(dev)
+    d.train()
+    xd = x.clone().requires_grad_()
+    y = d(xd)
+    words = philox_words(d._seed, 1, np.arange(N * C, dtype=np.uint64))
+    keep = ((words >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0) >= np.float32(0.3)).reshape(N, C)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), np.where(keep, x.cpu().numpy() / np.float32(0.7), 0.0), rtol=1e-6)
+    y.sum().backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), np.where(keep, 1.0 / 0.7, 0.0).astype(np.float32), rtol=1e-6)
+    y2 = d(x)
+    assert not torch.equal(y2, y.detach())  # next call, next offset
+    d.eval()
+    assert torch.equal(d(x), x)
