@@ -135,8 +135,8 @@ extern "C" int64_t hw_shard_plan_workspace_bytes(int64_t n_rows, int32_t n_ranks
 extern "C" int hw_shard_plan(const int64_t* ids, int64_t n, int64_t n_rows, int32_t n_ranks, int32_t cap, void* workspace,
                              int64_t* inv, int32_t* send_counts, int32_t* send_local, int32_t* overflow,
                              int32_t* oob_counter, void* stream) {
-    if (!ids || !workspace || !inv || !send_counts || !send_local || !overflow || n < 0 || n_rows < 1 || n_ranks < 1 ||
-        n_ranks > 1024 || cap < 1)
+    if (!workspace || !send_counts || !send_local || !overflow || n < 0 || n_rows < 1 || n_ranks < 1 || n_ranks > 1024 ||
+        cap < 1 || (n > 0 && (!ids || !inv)))
         return HW_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int64_t seg_words = ((n_rows + n_ranks - 1) / n_ranks + 31) / 32, seg_bits = seg_words * 32;

@@ -42,6 +42,16 @@ def test_plan_matches_oracle(P, n_rows, shape):
     assert np.array_equal(local[own * cap + slot].astype(np.int64) * P + own, ids.reshape(-1))
 
 
+def test_plan_of_an_empty_lookup():
+    from hopwise_amd import ops
+
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev())
+    inv, counts, local = ops.shard_plan(torch.zeros(0, dtype=torch.int64, device=dev()), 100, 4, 3, ovf)
+    assert inv.numel() == 0 and counts.cpu().tolist() == [0, 0, 0, 0] and int(ovf.item()) == 0
+    out = ops.shard_gather(torch.ones(25, 8, device=dev()), local, counts, 3)
+    assert tuple(out.shape) == (12, 8)  # nothing requested: no row is written, none is read
+
+
 def test_plan_overflow_flag_and_oob():
     from hopwise_amd import ops
 
