@@ -6,9 +6,11 @@
 
 One *batch* = one pass of the scoring hot path over 2048 (user, positive item) groups, inputs resident in HBM:
     1. device negative sampling: 256 negatives per group over the item rows [1, n_items), rejecting the user's
-       interacted items (drawn inside the scorer launch, hw_kge_score_grouped_sampled);
+       interacted items;
     2. grouped RotatE scorer over 2048 x (1 + 256) = 526 336 (h, r, t) triples;
-    3. self-adversarial negative-weighting loss over the [2048, 257] scores (hw_loss_self_adversarial).
+    3. self-adversarial negative-weighting loss over the [2048, 257] scores
+   -- all three in ONE launch (hw_kge_score_grouped_sampled_selfadv; --unfused-loss / --unfused-sampler run them as the
+   separate launches they equal bit for bit).
 One *step* = `batches_per_step` such batches back to back (chosen so that the K timed steps hold >= 0.75 s of GPU
 work whatever K is: a lone batch is 66 us).  value = triples scored per second over the whole job (all ranks).
 
@@ -62,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--no-tucker", action="store_true")
     ap.add_argument("--unfused-sampler", action="store_true", help="run hw_neg_sample as its own launch before the scorer")
+    ap.add_argument("--unfused-loss", action="store_true", help="run hw_loss_self_adversarial as its own launches after the scorer")
     ap.add_argument("--pgpr-steps", type=int, default=5)
     ap.add_argument("--pgpr-users", type=int, default=256,
                     help="users per beam search: 64 -> 5.8 G paths/s, 256 -> 6.7 G (the first hops' fixed cost amortised), ~8 GB of work buffers")
@@ -216,6 +219,15 @@ def leg_kge(D, args, out):
     fused_args = (C.byref(desc), P(users), None, kg.ui_relation, P(t_idx), t_idx.stride(0), t_idx.stride(1), B_POS,
                   1 + K_NEG, P(uptr), P(uidx), uptr.numel() - 1, P(users), kg.n_items, seed)
     fused_tail = (P(scores), scores.stride(0), scores.stride(1), P(oob), stream)
+    # ... and the loss inside the same launch (the block that scores a group reduces it, the last block sums the groups):
+    # hw_kge_score_grouped_sampled_selfadv = the two calls below it, bit for bit (tests/test_gpu_sampler.py)
+    fused_loss = fused and not args.unfused_loss
+    group_ws = torch.empty(B_POS, dtype=torch.float32, device=dev)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    loss_tail = (P(scores), scores.stride(0), scores.stride(1), C.c_float(1.0), P(loss), P(group_ws), P(counter), P(oob),
+                 stream)
+    if fused_loss and lib.hw_kge_score_grouped_sampled_selfadv(*fused_args, C.c_uint64(0), *loss_tail) != 0:
+        fused_loss = False
     events = []
 
     def batch(i, ev=None):
@@ -224,13 +236,16 @@ def leg_kge(D, args, out):
             rc = lib.hw_neg_sample(*samp_head, C.c_uint64(i), *samp_tail)
         if ev is not None:
             ev[0].record()
-        if fused:
+        if fused_loss:
+            rc |= lib.hw_kge_score_grouped_sampled_selfadv(*fused_args, C.c_uint64(i), *loss_tail)
+        elif fused:
             rc |= lib.hw_kge_score_grouped_sampled(*fused_args, C.c_uint64(i), *fused_tail)
         else:
             rc |= lib.hw_kge_score_grouped(*score_args)
         if ev is not None:
             ev[1].record()
-        rc |= lib.hw_loss_self_adversarial(*loss_args)
+        if not fused_loss:
+            rc |= lib.hw_loss_self_adversarial(*loss_args)
         if rc:
             raise RuntimeError(f"launch failed: {rc}")
 
@@ -310,7 +325,7 @@ def leg_kge(D, args, out):
         },
     })
     l2 = {
-        "bound": "l2", "kernel": "kge_score_grouped_kernel<RotatE" + (", SAMPLE>" if fused else ">"),
+        "bound": "l2", "kernel": "kge_score_grouped_kernel<RotatE" + (", SAMPLE, LOSS>" if fused_loss else ", SAMPLE>" if fused else ">"),
         "achieved": abytes / (kern_ms * 1e-3) / 1e9, "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
         "frac": abytes / (kern_ms * 1e-3) / 1e9 / L2_GATHER_PEAK_GBS,
         "traffic": traffic.get("kge_score_grouped_bytes_per_launch"), "kernel_ms": kern_ms,

@@ -79,6 +79,18 @@ struct SamplerArgs {
 };
 constexpr int SAMPLER_MAX_ATTEMPTS_FUSED = 1 << 16;
 
+// Self-adversarial loss folded into the sampled grouped scorer (hw_kge_score_grouped_sampled_selfadv): the block that scores
+// a group also reduces it; a one-block finish kernel sums the per-group terms.
+struct SelfAdvArgs {
+    float alpha, inv_b;
+    float* group_loss;  // [n_groups]
+    float* loss_out;    // [1]
+};
+
+__device__ __forceinline__ float log_sigmoid(float x) {  // -(max(-x,0) + log1p(exp(-|x|)))
+    return -(fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))));
+}
+
 // ---- DPP helpers ------------------------------------------------------------------------------------
 // Cross-lane adds inside a 16-lane row cost one VALU op with a DPP modifier (no LDS-crossbar round trip):
 // quad_perm for xor 1 / xor 2, row_half_mirror / row_mirror to finish the row.  Crossing rows (xor 16 / 32)

@@ -81,9 +81,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void margin_ranking_kernel(const floa
     if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
 
-__device__ __forceinline__ float log_sigmoid(float x) {  // -(max(-x,0) + log1p(exp(-|x|)))
-    return -(fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x))));
-}
 // one wave per group row [1 + K]
 __global__ __launch_bounds__(256) void self_adv_kernel(const float* __restrict__ sc, int64_t n_groups, int n_cols,
                                                        float alpha, float inv_b, float* __restrict__ gsc,

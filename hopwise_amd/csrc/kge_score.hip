@@ -30,6 +30,28 @@ extern "C" int hw_kge_score_grouped_sampled(const hw_kge_desc* desc, const int64
                                  out, o_stride_b, o_stride_j, oob_counter, stream, &sa);
 }
 
+extern "C" int hw_kge_score_grouped_sampled_selfadv(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx,
+                                                    int64_t r_fixed, int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
+                                                    int64_t n_groups, int64_t n_tail_per_group, const int64_t* used_ptr,
+                                                    const int64_t* used_idx, int64_t n_key_space, const int64_t* keys,
+                                                    int64_t value_num, uint64_t seed, uint64_t offset, float* out,
+                                                    int64_t o_stride_b, int64_t o_stride_j, float alpha, float* loss_out,
+                                                    float* group_loss_ws, int32_t* counter_ws, int32_t* oob_counter,
+                                                    void* stream) {
+    if (!desc || !used_ptr || !keys || !t_idx || !loss_out || !group_loss_ws || n_key_space < 1 ||
+        value_num < 2 || n_groups < 1 || n_tail_per_group < 2)
+        return HW_ERR_INVALID_ARG;
+    if (HW_FAMILY_OF(desc->model) != 0 || value_num > 65536) return HW_ERR_UNSUPPORTED;
+    SamplerArgs sa;
+    sa.used_ptr = used_ptr, sa.used_idx = used_idx, sa.keys = keys, sa.n_key_space = n_key_space;
+    sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = (int)((value_num + 31) / 32);
+    SelfAdvArgs la;
+    la.alpha = alpha, la.inv_b = 1.0f / (float)n_groups, la.group_loss = group_loss_ws, la.loss_out = loss_out;
+    (void)counter_ws;
+    return score_grouped_impl<0>(desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, n_tail_per_group,
+                                 out, o_stride_b, o_stride_j, oob_counter, stream, &sa, &la);
+}
+
 extern "C" int hw_kge_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
                                 int64_t n_heads, int64_t tail_lo, int64_t tail_hi, float* out, int64_t out_ld,
                                 int32_t* oob_counter, void* stream) {

@@ -21,16 +21,22 @@ namespace hw {
 // the Philox counters and the rejection rule of neg_sample_kernel, so the ids equal hw_neg_sample's bit for bit) and
 // written back to t_idx for the gradient pass; column 0 (the positive) is read.  The key's used set is an LDS bitmap per
 // wave, built once per task.  Saves the sampler launch and the read of the id matrix.
-template <int MODEL, int G, int NE, bool VEC, int U, bool SAMPLE = false>
+// LOSS = true (with SAMPLE, S == 4 only: the block's four waves are the four splits of ONE group): the group's 1 + K scores
+// are also kept in LDS, and wave 0 evaluates the self-adversarial term of hw_loss_self_adversarial for the group (same
+// arithmetic, same order) -- the per-group pass of the loss without its launch and without re-reading the score matrix;
+// selfadv_finish_kernel then adds the n_groups terms.
+constexpr int LOSS_MAX_TAILS = 1024;
+template <int MODEL, int G, int NE, bool VEC, int U, bool SAMPLE = false, bool LOSS = false>
 __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
     int64_t* t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
-    float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob, SamplerArgs sa) {
+    float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob, SamplerArgs sa, SelfAdvArgs la = SelfAdvArgs{}) {
     using SC = Scorer<MODEL, G, NE, VEC>;
     using MT = ModelTraits<MODEL>;
     using R = Row<G, NE, VEC>;
     constexpr int NS = HW_WAVE / G;
     extern __shared__ uint32_t used_bits_all[];
+    __shared__ float sh_scores[(SAMPLE && LOSS) ? LOSS_MAX_TAILS : 1];  // the group's scores, for the fused loss
 
     const int lane = threadIdx.x & (HW_WAVE - 1);
     const int sub = lane / G, gl = lane % G;
@@ -142,11 +148,68 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
             const float tot = group_reduce_multi<G, U>(p, gl, which);
             // one writer lane per tail: the first lane of the sub-block that ended up owning it
             const int jw = j_of(q0 + (k + which) * NS + sub);
-            if ((gl & (G / U - 1)) == 0 && jw < ntail) ob[(int64_t)jw * osj] = SC::finalize(tot, d.margin);
+            if ((gl & (G / U - 1)) == 0 && jw < ntail) {
+                const float sv = SC::finalize(tot, d.margin);
+                ob[(int64_t)jw * osj] = sv;
+                if constexpr (SAMPLE && LOSS) sh_scores[jw] = sv;
+            }
         }
     }
     if (oob && __any(bad)) {
         if (lane == 0) atomicAdd(oob, 1);
+    }
+    if constexpr (SAMPLE && LOSS) {
+        // The transcendental work (one exp and one log-sigmoid per negative) is spread over the block's 256 threads; the
+        // sums stay in wave 0, in self_adv_kernel's order (lane l adds j = 1 + l, 65 + l, ... then the wave butterfly), so
+        // the group term equals that kernel's bit for bit.
+        __shared__ float sh_e[LOSS_MAX_TAILS], sh_ls[LOSS_MAX_TAILS], sh_mx[4];
+        __syncthreads();  // every wave's scores of this group sit in sh_scores (written next to the global stores)
+        float mx = -INFINITY;
+        for (int j = 1 + (int)threadIdx.x; j < ntail; j += 256) mx = fmaxf(mx, la.alpha * sh_scores[j]);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) sh_mx[threadIdx.x / HW_WAVE] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(sh_mx[0], sh_mx[1]), fmaxf(sh_mx[2], sh_mx[3]));
+        for (int j = 1 + (int)threadIdx.x; j < ntail; j += 256) {
+            const float sj = sh_scores[j];
+            sh_e[j] = expf(la.alpha * sj - mx);
+            sh_ls[j] = log_sigmoid(-sj);
+        }
+        __syncthreads();
+        if (threadIdx.x < HW_WAVE) {
+            float z = 0.f;
+            for (int j = 1 + lane; j < ntail; j += 64) z += sh_e[j];
+            z = group_sum<64>(z);
+            const float inv_z = z > 0.f ? 1.f / z : 0.f;
+            float acc = 0.f;
+            for (int j = 1 + lane; j < ntail; j += 64) {
+                const float p = sh_e[j] * inv_z;
+                acc -= p * sh_ls[j];
+            }
+            acc = group_sum<64>(acc);
+            if (lane == 0) la.group_loss[b] = acc - log_sigmoid(sh_scores[0]);
+        }
+    }
+}
+
+// loss = mean of the per-group terms, added in finish_mean_kernel's order (kge_loss.hip): thread t takes t, t + 256, ...,
+// then the wave sums, then the four wave totals in order.  A launch of its own: a cross-workgroup hand-off inside the scorer
+// would need an agent-scope release per block, which on this part writes the XCD's L2 back (measured: 47 -> 118 us).
+static __global__ __launch_bounds__(256) void selfadv_finish_kernel(const float* __restrict__ group_loss, int n, float inv_n,
+                                                             float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += group_loss[i];
+    v = group_sum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x / HW_WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += red[i];
+        loss_out[0] = t * inv_n;
     }
 }
 
@@ -603,7 +666,7 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
                                     int64_t r_fixed, const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
                                     int64_t n_groups, int64_t n_tail_per_group, float* out, int64_t o_stride_b,
                                     int64_t o_stride_j, int32_t* oob_counter, void* stream,
-                                    const SamplerArgs* sampler = nullptr) {
+                                    const SamplerArgs* sampler = nullptr, const SelfAdvArgs* selfadv = nullptr) {
     int rc = check_desc(desc);
     if (rc) return rc;
     if (!h_idx || !t_idx || !out || n_groups < 0 || n_tail_per_group < 0) return HW_ERR_INVALID_ARG;
@@ -661,9 +724,19 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
     const int64_t n_tasks = n_groups * S;
     const int64_t n_blocks = (n_tasks + 3) / 4;
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    // the fused loss needs a block to own a whole group (the four splits of it) and int32 group counts
+    if (selfadv && (!sampler || S != 4 || n_groups > INT32_MAX || ntail > LOSS_MAX_TAILS)) return HW_ERR_UNSUPPORTED;
 #define CALL(MODEL, G_, NE_, VEC_)                                                                              \
     do {                                                                                                        \
         if constexpr (FAMILY == 0) {                                                                            \
+            if (sampler && selfadv) {                                                                           \
+                hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U, true, true>),             \
+                                   dim3((unsigned)n_blocks), dim3(256), (size_t)sampler->words * 16, st, *desc,  \
+                                   h_idx, r_idx, r_fixed, const_cast<int64_t*>(t_idx), t_stride_b, t_stride_j,   \
+                                   n_groups, ntail, S, out, o_stride_b, o_stride_j, oob_counter, *sampler,       \
+                                   *selfadv);                                                                    \
+                break;                                                                                          \
+            }                                                                                                   \
             if (sampler) {                                                                                      \
                 hipLaunchKernelGGL((kge_score_grouped_kernel<MODEL, G_, NE_, VEC_, U, true>),                   \
                                    dim3((unsigned)n_blocks), dim3(256), (size_t)sampler->words * 16, st, *desc,  \
@@ -685,6 +758,9 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
     }
     HW_DISPATCH_MODEL(desc->model, shape, CALL);
 #undef CALL
+    if (selfadv)
+        hipLaunchKernelGGL(selfadv_finish_kernel, dim3(1), dim3(256), 0, st, selfadv->group_loss, (int)n_groups,
+                           selfadv->inv_b, selfadv->loss_out);
     return HW_LAUNCH_RC();
 }
 

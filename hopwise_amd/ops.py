@@ -154,6 +154,32 @@ def kge_score_grouped_sampled_raw(desc, h_idx, r_idx, r_fixed, t_idx, used_ptr, 
     return out
 
 
+def kge_score_grouped_sampled_selfadv_raw(desc, h_idx, r_idx, r_fixed, t_idx, used_ptr, used_idx, keys, value_num, seed,
+                                         offset, alpha=1.0):
+    """kge_score_grouped_sampled_raw + the self-adversarial loss of the scores in the same launch: (scores, loss [1]).
+    Raises HopwiseAmdError(unsupported) when a group cannot be owned by one workgroup."""
+    lib = _lib.load()
+    h_idx = _idx(h_idx, "h_idx").contiguous()
+    t_idx = _idx(t_idx, "t_idx")
+    keys = _idx(keys, "keys").contiguous()
+    if r_idx is not None:
+        r_idx = _idx(r_idx, "r_idx").contiguous()
+    B, G = t_idx.shape
+    dev = h_idx.device
+    out = torch.empty((B, G), dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    ws = torch.empty(B, dtype=torch.float32, device=dev)
+    counter = torch.zeros(1, dtype=torch.int32, device=dev)
+    used_ptr, used_idx = _idx(used_ptr, "used_ptr").contiguous(), _idx(used_idx, "used_idx").contiguous()
+    rc = lib.hw_kge_score_grouped_sampled_selfadv(
+        C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), _ptr(t_idx), t_idx.stride(0), t_idx.stride(1), B, G,
+        _ptr(used_ptr), _ptr(used_idx), used_ptr.numel() - 1, _ptr(keys), int(value_num), C.c_uint64(seed),
+        C.c_uint64(offset), _ptr(out), out.stride(0), out.stride(1), float(alpha), _ptr(loss), _ptr(ws), _ptr(counter),
+        _ptr(_OobCounter.get(dev)), _stream())
+    check(rc, "hw_kge_score_grouped_sampled_selfadv")
+    return out, loss, counter
+
+
 def kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi):
     lib = _lib.load()
     h_idx = _idx(h_idx, "h_idx").contiguous()

@@ -103,6 +103,19 @@ int hw_kge_score_grouped_sampled(const hw_kge_desc* desc, const int64_t* h_idx, 
                                  uint64_t offset, float* out, int64_t o_stride_b, int64_t o_stride_j,
                                  int32_t* oob_counter, void* stream);
 
+/* hw_kge_score_grouped_sampled followed by hw_loss_self_adversarial(scores, alpha) (loss only, no gradient) with the loss's
+ * per-group pass inside the scorer launch: the block that scores a group keeps its scores in LDS and reduces them; a
+ * one-block finish kernel adds the per-group terms -- same arithmetic and order as the separate calls, so ids, scores and
+ * loss are equal bit for bit.  group_loss_ws: n_groups floats; counter_ws: reserved (may be NULL).  HW_ERR_UNSUPPORTED when a group cannot be owned
+ * by one workgroup (fewer than ~32 tails per split, or the cases hw_kge_score_grouped_sampled refuses): use the two calls. */
+int hw_kge_score_grouped_sampled_selfadv(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx,
+                                         int64_t r_fixed, int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
+                                         int64_t n_groups, int64_t n_tail_per_group, const int64_t* used_ptr,
+                                         const int64_t* used_idx, int64_t n_key_space, const int64_t* keys,
+                                         int64_t value_num, uint64_t seed, uint64_t offset, float* out, int64_t o_stride_b,
+                                         int64_t o_stride_j, float alpha, float* loss_out, float* group_loss_ws,
+                                         int32_t* counter_ws, int32_t* oob_counter, void* stream);
+
 /* Full sort: out[b, n - tail_lo] = score(h_idx[b], r, n) for every tail row n in [tail_lo, tail_hi).
  * Replaces full_sort_predict / full_sort_predict_kg (rotate.py:161-220, transe.py:112-154,
  * complex.py:162-219, distmult.py:119-146) without the [B, N, d] temporaries. */

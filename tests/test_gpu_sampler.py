@@ -182,3 +182,39 @@ def test_scorer_with_in_kernel_sampler_equals_sampler_then_scorer(model, dim):
     np.testing.assert_array_equal(b.cpu().numpy(), a.cpu().numpy())
     np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
     assert ops.oob_count(dev) == oob_before
+
+
+@pytest.mark.parametrize("model,dim,B,K,alpha", [("RotatE", 200, 2048, 256, 1.0), ("TransE", 64, 93, 130, 0.5),
+                                                 ("ComplEx", 100, 7, 511, 2.0), ("DistMult", 24, 300, 127, 1.0)])
+def test_sampler_scorer_and_loss_in_one_launch(model, dim, B, K, alpha):
+    """hw_kge_score_grouped_sampled_selfadv == hw_kge_score_grouped_sampled + hw_loss_self_adversarial: ids, scores and the
+    loss bit for bit (the block that scores a group reduces it; the last block sums the groups in the finish kernel's order),
+    twice in a row."""
+    from hopwise_amd import ops
+    from hopwise_amd.data import synthetic
+    from oracle import kge as okge
+    from tests.helpers import random_tables
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(B + K)
+    nU, nI, nE, nR = 200, 2985, 4000, 7
+    iu, ii = rng.integers(1, nU, 30000), rng.integers(1, nI, 30000)
+    ptr, idx = synthetic.used_csr(iu, ii, nU)
+    ptr, idx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+    tabs = {k: torch.from_numpy(v).to(dev) for k, v in random_tables(model, nU, nE, nR, dim, seed=1).items()}
+    hn, rn, tn = okge.slots(model, "rec")
+    desc = ops.make_desc(model, tuple(tabs[n] for n in hn), tuple(tabs[n] for n in rn), tuple(tabs[n] for n in tn),
+                         margin=1.0, tail_rows=nI)
+    users = torch.from_numpy(rng.integers(1, nU, B)).to(dev)
+    a = torch.zeros((B, 1 + K), dtype=torch.int64, device=dev)
+    a[:, 0] = torch.from_numpy(rng.integers(1, nI, B)).to(dev)
+    b = a.clone()
+    for offset in (5, 6):
+        ref = ops.kge_score_grouped_sampled_raw(desc, users, None, nR - 1, a, ptr, idx, users, nI, 11, offset)
+        ref_loss = ops.self_adversarial_mean(ref, alpha)
+        got, loss, counter = ops.kge_score_grouped_sampled_selfadv_raw(desc, users, None, nR - 1, b, ptr, idx, users, nI, 11,
+                                                                        offset, alpha)
+        assert torch.equal(b, a) and torch.equal(got, ref)
+        assert loss.item() == ref_loss.item(), (loss.item(), ref_loss.item())
+    # against the oracle as well
+    np.testing.assert_allclose(loss.item(), okge.self_adversarial_loss(ref.cpu().numpy(), alpha), rtol=1e-5)
