@@ -481,6 +481,20 @@ def leg_sharded(D, args):
         opt.step()
         last["loss"] = loss
 
+    # full-size parity, outside the timed region: on the same batch the sharded model's loss is the plain model's
+    # (the exchange and the compact tables change where rows live, not what is computed)
+    with torch.no_grad():
+        l_sh = float(sharded.calculate_loss(batches[0]))
+    parity = None
+    if P == 1:
+        torch.manual_seed(0)
+        plain = ComplEx(make_config(dev, Dm, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
+        with torch.no_grad():
+            l_pl = float(plain.calculate_loss(batches[0]))
+        if abs(l_sh - l_pl) > 1e-6 * abs(l_pl):
+            raise AssertionError(f"sharded loss {l_sh} != plain loss {l_pl}")
+        parity = {"sharded_loss": l_sh, "plain_loss": l_pl, "rule": "same batch, same tables: equal to 1e-6 relative"}
+        del plain
     dt = timed(D, step, args.sharded_steps, 3)
     sharded.check_overflow()
     loss = float(last["loss"].detach())
@@ -500,7 +514,7 @@ def leg_sharded(D, args):
                   "calculate_loss -> backward -> all-reduce of the relation tables -> Adam on the local shards",
         "value": P * 4 * B * args.sharded_steps / dt, "unit": "triples/s", "per_gpu": 4 * B * args.sharded_steps / dt,
         "n_gpus": P, "steps": args.sharded_steps, "ms_per_step": dt / args.sharded_steps * 1e3,
-        "batch_per_rank": {"rec": B, "kg": B, "triples": 4 * B}, "loss": loss,
+        "batch_per_rank": {"rec": B, "kg": B, "triples": 4 * B}, "loss": loss, "parity": parity,
         "exchange": {
             "capacity_rows_per_owner": {"entity": cap_e, "user": cap_u, "factor": sharded.capacity_factor},
             "distinct_rows_per_step_per_rank": {"entity": ent_u, "user": usr_u},
@@ -582,6 +596,19 @@ def leg_tucker(D, args):
         ms = ea.elapsed_time(eb) / reps
         res[mode] = {"ms": ms, "achieved": flops_fwd * mult / (ms * 1e-3) / 1e12,
                      "frac": flops_fwd * mult / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    # full-size parity, outside the timed region: one matrix per distinct relation (the engine's default) against the
+    # reference's per-row mm(r, W) on the same batch and dropout stream -- the same loss, bit for bit
+    def loss_with(shared):
+        m.share_relation_matrices, m._drop_calls = shared, 0
+        m.input_dropout.calls = m.hidden_dropout2.calls = 0  # same Philox offsets for the [B, d] dropouts too
+        with torch.no_grad():
+            return float(m.calculate_loss(it))
+
+    l_set, l_row = loss_with(True), loss_with(False)
+    m.share_relation_matrices = True
+    if l_set != l_row:
+        raise AssertionError(f"TuckER: relation-set loss {l_set} != per-row loss {l_row}")
+    res["parity"] = {"loss_relation_sets": l_set, "loss_per_row_product": l_row, "rule": "bit-identical training-mode loss"}
     mpath = os.path.join(ROOT, "profiles", "tucker_mfma_latest.json")
     if os.path.exists(mpath):
         try:
