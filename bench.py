@@ -503,7 +503,7 @@ def leg_sharded(D, args):
     cap_e = parallel.capacity(5 * B, nE, P, sharded.capacity_factor)
     cap_u = parallel.capacity(B, nU, P, sharded.capacity_factor)
     remote = (P - 1) / P
-    ids_bytes = remote * P * (cap_e + cap_u) * 4 + remote * 2 * P * 4
+    ids_bytes = remote * P * (2 + cap_e + cap_u) * 4  # one [count, local rows...] int32 message per peer and lookup
     row_bytes = remote * P * (cap_e + cap_u) * 2 * Dm * 4  # 2 tables (re, im) per lookup
     xbytes = ids_bytes + 2 * row_bytes  # rows forward + row gradients backward
     b0 = batches[0]
@@ -520,15 +520,16 @@ def leg_sharded(D, args):
             "distinct_rows_per_step_per_rank": {"entity": ent_u, "user": usr_u},
             "bytes_per_step_per_rank": xbytes,
             "xgmi_GBps_per_gpu_over_step": xbytes / (dt / args.sharded_steps) / 1e9,
-            "collectives_per_step": "2 x (counts + ids) all-to-all, 4 row all-to-alls forward, 4 backward, 1 all-reduce "
-                                    "per relation table" if P > 1 else "none (P = 1: the exchange is the identity)",
+            "collectives_per_step": "6 all-to-alls (per lookup -- entity ids, user ids -- one int32 [count, rows] message, one "
+                                    "float message with both tables' rows forward, one with their gradients backward) + 1 "
+                                    "all-reduce per relation table" if P > 1 else "none (P = 1: the exchange is the identity)",
         },
         "table_bytes_per_rank": 2 * (nU + nE) * Dm * 4 / P, "scaling": "weak", "parallelism": f"row-sharded x{P}",
         "backend": ("rccl" if D.backend == "nccl" else f"{D.backend} (rehearsal: collectives staged through host memory)")
         if P > 1 else None,
     }
     if P > 1:  # the fabric alone: the forward row all-to-all of one entity table, back to back
-        buf = torch.empty((P * cap_e, Dm), dtype=torch.float32, device=dev)
+        buf = torch.empty((P * 2 * cap_e, Dm), dtype=torch.float32, device=dev)  # the entity lookup's row message (re + im)
         back = torch.empty_like(buf)
         for _ in range(3):
             parallel.all_to_all(back, buf)

@@ -305,13 +305,15 @@ SIGNATURES = {
     "hw_shard_plan_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
     "hw_shard_plan": (
         C.c_int,
-        [c_i64p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, c_i64p, c_i32p, c_i32p, c_i32p, c_i32p,
-         C.c_void_p],
+        [c_i64p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, c_i64p, C.c_int64, c_i32p, C.c_int64, c_i32p,
+         C.c_int64, c_i32p, c_i32p, C.c_void_p],
     ),
     "hw_shard_gather": (
-        C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, c_i32p, C.c_void_p]),
+        C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i32p, C.c_int64, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_f32p,
+                  C.c_int64, C.c_int64, c_i32p, C.c_void_p]),
     "hw_shard_scatter_add": (
-        C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, c_f32p, c_i32p, C.c_void_p]),
+        C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i32p, C.c_int64, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_f32p,
+                  C.c_int64, C.c_int64, c_i32p, C.c_void_p]),
     "hw_log_softmax_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_void_p]),
     "hw_cafe_collect": (
         C.c_int,

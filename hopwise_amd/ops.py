@@ -730,50 +730,59 @@ def scatter_add_rows_(table, idx, src):
 # ------------------------------------------------------------------------------------------------
 # device-side routing of a row-sharded lookup (csrc/shard.hip)
 # ------------------------------------------------------------------------------------------------
-def shard_plan(ids, n_rows, n_ranks, cap, overflow):
+def shard_plan(ids, n_rows, n_ranks, cap, overflow, n_tables=1):
     """Route ``ids`` (any shape, int64) of a table with ``n_rows`` rows sharded owner = id % n_ranks.
-    Returns (inv like ids, send_counts int32 [P], send_local int32 [P * cap]); ``overflow`` is a persistent int32 [1]
-    device flag the caller inspects later (no host read here)."""
+    Returns (inv like ids, meta int32 [P, 1 + cap]): meta[o, 0] = distinct ids asked of owner o, meta[o, 1:] = their local
+    rows (ascending) -- ONE message per peer.  inv[i] = owner * (n_tables * cap) + slot: the index into the compact tables
+    of a lookup whose ``n_tables`` tables travel packed as [P, n_tables, cap, d] (see shard_gather).  ``overflow`` is a
+    persistent int32 [1] device flag the caller inspects later (no host read here)."""
     lib = _lib.load()
     ids = _idx(ids, "ids")
     flat = ids.reshape(-1).contiguous()
     dev = flat.device
     ws = torch.empty(int(lib.hw_shard_plan_workspace_bytes(int(n_rows), int(n_ranks))), dtype=torch.uint8, device=dev)
     inv = torch.empty(flat.numel(), dtype=torch.int64, device=dev)
-    send_counts = torch.empty(n_ranks, dtype=torch.int32, device=dev)
-    send_local = torch.empty(n_ranks * cap, dtype=torch.int32, device=dev)
+    meta = torch.empty((n_ranks, 1 + cap), dtype=torch.int32, device=dev)
     check(lib.hw_shard_plan(_ptr(flat), flat.numel(), int(n_rows), int(n_ranks), int(cap), _ptr(ws), _ptr(inv),
-                            _ptr(send_counts), _ptr(send_local), _ptr(_dev(overflow, torch.int32, "overflow")),
-                            _ptr(_OobCounter.get(dev)), _stream()), "hw_shard_plan")
-    return inv.view(ids.shape), send_counts, send_local
+                            int(n_tables) * int(cap), C.c_void_p(meta.data_ptr()), 1 + cap, C.c_void_p(meta.data_ptr() + 4),
+                            1 + cap, _ptr(_dev(overflow, torch.int32, "overflow")), _ptr(_OobCounter.get(dev)), _stream()),
+          "hw_shard_plan")
+    return inv.view(ids.shape), meta
 
 
-def shard_gather(shard, recv_local, recv_counts, cap, out=None):
-    """out[p * cap + j] = shard[recv_local[p * cap + j]] for j < recv_counts[p]; rows beyond a count stay untouched."""
+def _meta_ptrs(meta, cap):
+    meta = _dev(meta, torch.int32, "meta")
+    if meta.dim() != 2 or meta.shape[1] != 1 + cap or not meta.is_contiguous():
+        raise ValueError("meta must be contiguous int32 [P, 1 + cap]")
+    return C.c_void_p(meta.data_ptr() + 4), C.c_void_p(meta.data_ptr()), meta.shape[0]
+
+
+def shard_gather(shard, meta, cap, out, table=0, n_tables=1):
+    """Owner side: out.view(P, n_tables, cap, d)[p, table, j] = shard[meta[p, 1 + j]] for j < meta[p, 0]; other rows stay
+    untouched.  ``out``: float32 [P * n_tables * cap, d], one buffer for all tables of the lookup."""
     lib = _lib.load()
     shard = _dev(shard, torch.float32, "shard")
-    P = recv_counts.numel()
-    if shard.dim() != 2 or not shard.is_contiguous() or recv_local.numel() != P * cap:
+    local, counts, P = _meta_ptrs(meta, cap)
+    out = _dev(out, torch.float32, "out")
+    if (shard.dim() != 2 or not shard.is_contiguous() or not out.is_contiguous()
+            or tuple(out.shape) != (P * n_tables * cap, shard.shape[1]) or not 0 <= table < n_tables):
         raise ValueError("shape mismatch")
-    if out is None:
-        out = torch.empty((P * cap, shard.shape[1]), dtype=torch.float32, device=shard.device)
-    check(lib.hw_shard_gather(_ptr(shard), shard.shape[0], shard.shape[1], _ptr(_dev(recv_local, torch.int32, "recv_local")),
-                              _ptr(_dev(recv_counts, torch.int32, "recv_counts")), P, int(cap), _ptr(out),
-                              _ptr(_OobCounter.get(shard.device)), _stream()), "hw_shard_gather")
+    check(lib.hw_shard_gather(_ptr(shard), shard.shape[0], shard.shape[1], local, 1 + cap, counts, 1 + cap, P, int(cap),
+                              _ptr(out), n_tables * cap, table * cap, _ptr(_OobCounter.get(shard.device)), _stream()),
+          "hw_shard_gather")
     return out
 
 
-def shard_scatter_add_(grad_shard, recv_local, recv_counts, cap, src):
+def shard_scatter_add_(grad_shard, meta, cap, src, table=0, n_tables=1):
     lib = _lib.load()
     grad_shard = _dev(grad_shard, torch.float32, "grad_shard")
     src = _dev(src, torch.float32, "src")
-    P = recv_counts.numel()
+    local, counts, P = _meta_ptrs(meta, cap)
     if (grad_shard.dim() != 2 or not grad_shard.is_contiguous() or not src.is_contiguous()
-            or tuple(src.shape) != (P * cap, grad_shard.shape[1]) or recv_local.numel() != P * cap):
+            or tuple(src.shape) != (P * n_tables * cap, grad_shard.shape[1]) or not 0 <= table < n_tables):
         raise ValueError("shape mismatch")
-    check(lib.hw_shard_scatter_add(_ptr(grad_shard), grad_shard.shape[0], grad_shard.shape[1],
-                                   _ptr(_dev(recv_local, torch.int32, "recv_local")),
-                                   _ptr(_dev(recv_counts, torch.int32, "recv_counts")), P, int(cap), _ptr(src),
+    check(lib.hw_shard_scatter_add(_ptr(grad_shard), grad_shard.shape[0], grad_shard.shape[1], local, 1 + cap, counts,
+                                   1 + cap, P, int(cap), _ptr(src), n_tables * cap, table * cap,
                                    _ptr(_OobCounter.get(grad_shard.device)), _stream()), "hw_shard_scatter_add")
     return grad_shard
 

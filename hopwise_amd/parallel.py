@@ -4,13 +4,14 @@ The reference only knows replicated tables under DDP (trainer/trainer.py:83-84, 
 This module adds the layout BASELINE.json's config 4 asks for: entity / user tables sharded row-wise
 (owner = id % P, local row = id // P) with an all-to-all lookup, while relation tables and MLPs stay replicated.
 
-One lookup (forward), with no host read anywhere on the way:
+One lookup (forward), with no host read anywhere on the way, in TWO collectives:
 
     hw_shard_plan (csrc/shard.hip)     ids -> exact dedup + bucket by owner, on the device: per-owner counts, the
-                                       distinct local rows of each owner (ascending), and inv[i] = owner * cap + slot
-    all_to_all_single x2               counts [P] and local rows [P, cap], fixed size
-    hw_shard_gather                    the owner copies the requested rows of its shard into [P, cap, d]
-    all_to_all_single per table        rows back: the receive buffer [P * cap, d] IS the compact table
+                                       distinct local rows of each owner (ascending), inv[i] = owner * T * cap + slot
+    all_to_all_single                  ONE int32 message per peer: [count, local rows...] = [P, 1 + cap], fixed size
+    hw_shard_gather x T                the owner copies the requested rows of its T tables (re, im, ...) into [P, T, cap, d]
+    all_to_all_single                  ONE float message per peer with every table's rows; the receive buffer holds the
+                                       T compact tables (table t starts t * cap rows in; overlapping views, no copy)
 
 `cap` is a fixed per-owner capacity (ceil(n / P * capacity_factor) + 64, at most min(n, rows per shard)), so message
 sizes never depend on data and nothing is read back; an owner asked for more than `cap` distinct rows raises a
@@ -114,72 +115,99 @@ def capacity(n_ids, n_rows, P, factor):
 
 
 class _Plan:
-    """Routing of one lookup, shared by every table looked up with the same ids.  Device-resident; no host sync."""
+    """Routing of one lookup, shared by every table looked up with the same ids.  Device-resident; no host sync.
+    One int32 message per peer carries the count and the local rows ([P, 1 + cap])."""
 
-    def __init__(self, ids, n_rows, group, factor, overflow):
+    def __init__(self, ids, n_rows, group, factor, overflow, n_tables):
         rank, P = world(group)
-        self.group, self.P = group, P
+        self.group, self.P, self.T = group, P, int(n_tables)
         self.cap = capacity(ids.numel(), n_rows, P, factor)
         plan = _shard_ops["plan"] or ops.shard_plan
-        self.inv, self.send_counts, self.send_local = plan(ids, n_rows, P, self.cap, overflow)
+        self.inv, self.send_meta = plan(ids, n_rows, P, self.cap, overflow, self.T)
         if _exchange(P):
-            self.recv_counts = torch.empty_like(self.send_counts)
-            all_to_all(self.recv_counts, self.send_counts, group)
-            self.recv_local = torch.empty_like(self.send_local)
-            all_to_all(self.recv_local, self.send_local, group)
+            self.recv_meta = torch.empty_like(self.send_meta)
+            all_to_all(self.recv_meta, self.send_meta, group)
         else:
-            self.recv_counts, self.recv_local = self.send_counts, self.send_local
-        self.rows = P * self.cap  # rows of a compact table
+            self.recv_meta = self.send_meta
+        self.rows = P * self.T * self.cap  # rows of the packed row message
+
+
+def _table_views(buf, T, cap, d):
+    """The T compact tables inside one [P, T, cap, d] message: table t starts t * cap rows in and is indexed by
+    inv = owner * (T * cap) + slot -- overlapping contiguous [rows, d] views, no copy."""
+    flat = buf.view(-1)
+    rows = buf.shape[0] - (T - 1) * cap  # the same row count for every table (the scorers ask for that); the largest
+    return tuple(flat[t * cap * d : (t * cap + rows) * d].view(rows, d) for t in range(T))  # index is rows - 1
 
 
 class _ShardedLookup(torch.autograd.Function):
+    """All tables of a lookup travel in ONE row message per direction: [P, T, cap, d] (xGMI wants few, large collectives)."""
+
     @staticmethod
     def forward(ctx, plan, *shards):
         gather = _shard_ops["gather"] or ops.shard_gather
-        outs = []
-        for s in shards:
-            rows = gather(s, plan.recv_local, plan.recv_counts, plan.cap)
-            if _exchange(plan.P):
-                back = torch.empty_like(rows)
-                all_to_all(back, rows, plan.group)
-            else:
-                back = rows
-            outs.append(back)
+        d = shards[0].shape[1]
+        send = torch.empty((plan.rows, d), dtype=shards[0].dtype, device=shards[0].device)
+        for t, s in enumerate(shards):
+            gather(s, plan.recv_meta, plan.cap, send, t, plan.T)
+        if _exchange(plan.P):
+            back = torch.empty_like(send)
+            all_to_all(back, send, plan.group)
+        else:
+            back = send
         ctx.plan = plan
         ctx.save_for_backward(*shards)
-        return tuple(outs)
+        return _table_views(back, plan.T, plan.cap, d)
 
     @staticmethod
     def backward(ctx, *grads):
         plan = ctx.plan
         shards = ctx.saved_tensors
         scatter = _shard_ops["scatter_add"] or ops.shard_scatter_add_
+        d, P, T, cap = shards[0].shape[1], plan.P, plan.T, plan.cap
+        if not _exchange(P) and P == 1:  # nothing travels: table t's gradient rows [0, cap) are the owner's rows already
+            outs = []
+            for s, g in zip(shards, grads):
+                sink = ops._live_sink(s) if not torch.is_grad_enabled() else None
+                dst = sink[0] if sink is not None else torch.zeros_like(s)
+                scatter(dst, plan.recv_meta, cap, g.contiguous()[:cap], 0, 1)
+                if sink is not None:
+                    sink[1].touch(s.data_ptr())
+                outs.append(None if sink is not None else dst)
+            return (None, *outs)
+        if T == 1:
+            send = grads[0].contiguous()
+        else:  # pack the T dense compact gradients into the message layout (chunk (p, t) = rows p * T * cap .. + cap of g_t)
+            send = torch.empty((plan.rows, d), dtype=grads[0].dtype, device=grads[0].device)
+            sv = send.view(P, T, cap, d)
+            for t, g in enumerate(grads):
+                sv[:, t].copy_(g.contiguous().as_strided((P, cap, d), (T * cap * d, d, 1)))
+        if _exchange(P):
+            recv = torch.empty_like(send)
+            all_to_all(recv, send, plan.group)
+        else:
+            recv = send
         outs = []
-        for s, g in zip(shards, grads):
-            g = g.contiguous()
-            if _exchange(plan.P):
-                recv = torch.empty_like(g)
-                all_to_all(recv, g, plan.group)
-            else:
-                recv = g
+        for t, s in enumerate(shards):
             sink = ops._live_sink(s) if not torch.is_grad_enabled() else None
             if sink is not None:  # optim.FusedAdam's persistent .grad: add the rows there, nothing for autograd to add
-                scatter(sink[0], plan.recv_local, plan.recv_counts, plan.cap, recv)
+                scatter(sink[0], plan.recv_meta, cap, recv, t, T)
                 sink[1].touch(s.data_ptr())
                 outs.append(None)
                 continue
             gs = torch.zeros_like(s)
-            scatter(gs, plan.recv_local, plan.recv_counts, plan.cap, recv)
+            scatter(gs, plan.recv_meta, cap, recv, t, T)
             outs.append(gs)
         return (None, *outs)
 
 
 def sharded_lookup(shards, ids, n_rows, group=None, capacity_factor=1.25, overflow=None):
     """Rows of the row-sharded tables ``shards`` (same sharding, e.g. re/im; ``n_rows`` = rows of the full table) for
-    ``ids``.  Returns (compact tables tuple [P * cap, d], inverse map shaped like ids, overflow flag tensor)."""
+    ``ids``.  Returns (compact tables tuple (views of one [P * T * cap, d] buffer), inverse map shaped like ids, overflow
+    flag tensor)."""
     if overflow is None:
         overflow = torch.zeros(1, dtype=torch.int32, device=ids.device)
-    plan = _Plan(ids, n_rows, group, capacity_factor, overflow)
+    plan = _Plan(ids, n_rows, group, capacity_factor, overflow, len(shards))
     return _ShardedLookup.apply(plan, *shards), plan.inv, overflow
 
 

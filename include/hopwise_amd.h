@@ -470,25 +470,30 @@ int hw_scatter_add_rows(float* table, int64_t n_table_rows, int32_t dim, const i
 
 /* Device-side routing of one sharded lookup ("bucket indices by owner -> all_to_all(ids) -> local
  * gather -> all_to_all(rows)"; owner = id % n_ranks, local row = id / n_ranks).  No host read anywhere:
- *   inv[i]                      = owner(ids[i]) * cap + rank of ids[i] among the owner's distinct ids (ascending id)
- *   send_counts[o]              = distinct ids asked of owner o (<= cap)
- *   send_local[o * cap + j]     = local row of the j-th of them
- *   *overflow                   = max distinct count seen when some owner is asked for more than cap rows (else untouched;
- *                                 zero it before the first call); the plan is then unusable and the caller raises.
- * The three fixed-size all-to-alls (counts, send_local, rows) are the caller's (torch.distributed / RCCL); the buffer
- * the rows return into is the compact table, indexed by inv.  workspace: hw_shard_plan_workspace_bytes(n_rows, n_ranks). */
+ *   inv[i]                               = owner(ids[i]) * inv_stride + rank of ids[i] among the owner's distinct ids (ascending)
+ *   send_counts[o * count_stride]        = distinct ids asked of owner o (<= cap)
+ *   send_local[o * local_stride + j]     = local row of the j-th of them
+ *   *overflow                            = max distinct count seen when some owner is asked for more than cap rows (else
+ *                                          untouched; zero it before the first call); the plan is then unusable.
+ * The strides let ONE int32 message per peer carry the count and the list ([P, 1 + cap]: send_counts = msg, send_local =
+ * msg + 1, both strides 1 + cap) and ONE float message per peer carry the rows of every table of the lookup ([P, T, cap, d]:
+ * inv_stride = peer_rows = T * cap, table t at row_offset t * cap); the receive buffer of the row message is then the set
+ * of compact tables (table t = the buffer from float t * cap * d on, indexed by inv).  The fixed-size all-to-alls are the
+ * caller's (torch.distributed / RCCL).  workspace: hw_shard_plan_workspace_bytes(n_rows, n_ranks). */
 int64_t hw_shard_plan_workspace_bytes(int64_t n_rows, int32_t n_ranks);
 int hw_shard_plan(const int64_t* ids, int64_t n, int64_t n_rows, int32_t n_ranks, int32_t cap, void* workspace,
-                  int64_t* inv, int32_t* send_counts, int32_t* send_local, int32_t* overflow, int32_t* oob_counter,
-                  void* stream);
-/* Owner side.  out[p * cap + j, :] = shard[recv_local[p * cap + j], :] for j < recv_counts[p] (other rows untouched);
- * grad_shard[recv_local[p * cap + j], :] += src[p * cap + j, :] (float atomics: two peers may send the same row). */
-int hw_shard_gather(const float* shard, int64_t n_local_rows, int32_t dim, const int32_t* recv_local,
-                    const int32_t* recv_counts, int32_t n_ranks, int32_t cap, float* out, int32_t* oob_counter,
-                    void* stream);
+                  int64_t* inv, int64_t inv_stride, int32_t* send_counts, int64_t count_stride, int32_t* send_local,
+                  int64_t local_stride, int32_t* overflow, int32_t* oob_counter, void* stream);
+/* Owner side.  buf row of (peer p, slot j) = p * peer_rows + row_offset + j:
+ * out[that row, :] = shard[recv_local[p * local_stride + j], :] for j < recv_counts[p * count_stride] (others untouched);
+ * grad_shard[recv_local[...], :] += src[that row, :] (float atomics: two peers may send the same row). */
+int hw_shard_gather(const float* shard, int64_t n_local_rows, int32_t dim, const int32_t* recv_local, int64_t local_stride,
+                    const int32_t* recv_counts, int64_t count_stride, int32_t n_ranks, int32_t cap, float* out,
+                    int64_t peer_rows, int64_t row_offset, int32_t* oob_counter, void* stream);
 int hw_shard_scatter_add(float* grad_shard, int64_t n_local_rows, int32_t dim, const int32_t* recv_local,
-                         const int32_t* recv_counts, int32_t n_ranks, int32_t cap, const float* src,
-                         int32_t* oob_counter, void* stream);
+                         int64_t local_stride, const int32_t* recv_counts, int64_t count_stride, int32_t n_ranks,
+                         int32_t cap, const float* src, int64_t peer_rows, int64_t row_offset, int32_t* oob_counter,
+                         void* stream);
 
 /* ---- CAFE inference (model/knowledge_aware_recommender/cafe.py) ----------------------------------------------
  * y[r, :] = log_softmax(x[r, :]) (cafe.py:597-598, :819-820). */

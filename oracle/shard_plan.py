@@ -7,38 +7,41 @@ SURVEY.md §8(e) row 1 (owner = id % P, bucket by owner, all-to-all, local gathe
 import numpy as np
 
 
-def plan(ids, n_rows, P, cap):
-    """-> (inv like ids, send_counts int32 [P], send_local int32 [P * cap] (unused slots -1), overflow int)."""
+def plan(ids, n_rows, P, cap, n_tables=1):
+    """-> (inv like ids, meta int32 [P, 1 + cap] (meta[o, 0] = count, meta[o, 1:] = local rows, unused slots -1),
+    overflow int).  inv = owner * (n_tables * cap) + slot."""
     ids = np.asarray(ids, np.int64)
     flat = np.clip(ids.reshape(-1), 0, n_rows - 1)
     inv = np.zeros(flat.size, np.int64)
-    send_counts = np.zeros(P, np.int32)
-    send_local = np.full(P * cap, -1, np.int32)
+    meta = np.full((P, 1 + cap), -1, np.int32)
     overflow = 0
     for o in range(P):
         mine = np.unique(flat[flat % P == o])  # ascending ids = ascending local rows
         if mine.size > cap:
             overflow = max(overflow, int(mine.size))
         keep = mine[:cap]
-        send_counts[o] = keep.size
-        send_local[o * cap : o * cap + keep.size] = keep // P
+        meta[o, 0] = keep.size
+        meta[o, 1 : 1 + keep.size] = keep // P
         sel = flat % P == o
         slot = np.minimum(np.searchsorted(mine, flat[sel]), cap - 1)
-        inv[sel] = o * cap + slot
-    return inv.reshape(ids.shape), send_counts, send_local, overflow
+        inv[sel] = o * (n_tables * cap) + slot
+    return inv.reshape(ids.shape), meta, overflow
 
 
-def gather(shard, recv_local, recv_counts, cap, fill=0.0):
-    P = len(recv_counts)
-    out = np.full((P * cap, shard.shape[1]), fill, shard.dtype)
+def gather(shard, meta, cap, out, table=0, n_tables=1):
+    """out [P * n_tables * cap, d] viewed [P, n_tables, cap, d]: fills [p, table, :count_p]."""
+    P = meta.shape[0]
+    v = out.reshape(P, n_tables, cap, -1)
     for p in range(P):
-        c = int(recv_counts[p])
-        out[p * cap : p * cap + c] = shard[recv_local[p * cap : p * cap + c]]
+        c = int(meta[p, 0])
+        v[p, table, :c] = shard[meta[p, 1 : 1 + c]]
     return out
 
 
-def scatter_add(grad_shard, recv_local, recv_counts, cap, src):
-    for p in range(len(recv_counts)):
-        c = int(recv_counts[p])
-        np.add.at(grad_shard, recv_local[p * cap : p * cap + c], src[p * cap : p * cap + c])
+def scatter_add(grad_shard, meta, cap, src, table=0, n_tables=1):
+    P = meta.shape[0]
+    v = src.reshape(P, n_tables, cap, -1)
+    for p in range(P):
+        c = int(meta[p, 0])
+        np.add.at(grad_shard, meta[p, 1 : 1 + c], v[p, table, :c])
     return grad_shard

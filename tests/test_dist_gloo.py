@@ -24,26 +24,28 @@ def _free_port():
     return p
 
 
-def _cpu_plan(ids, n_rows, P, cap, overflow):
+def _cpu_plan(ids, n_rows, P, cap, overflow, n_tables=1):
     from oracle import shard_plan as osp
 
-    inv, counts, local, ovf = osp.plan(ids.numpy(), n_rows, P, cap)
+    inv, meta, ovf = osp.plan(ids.numpy(), n_rows, P, cap, n_tables)
     if ovf:
         overflow[0] = max(int(overflow[0]), ovf)
-    return torch.from_numpy(inv), torch.from_numpy(counts), torch.from_numpy(np.maximum(local, 0))
+    return torch.from_numpy(inv), torch.from_numpy(np.maximum(meta, 0))
 
 
-def _cpu_gather(shard, recv_local, recv_counts, cap):
+def _cpu_gather(shard, meta, cap, out, table=0, n_tables=1):
     from oracle import shard_plan as osp
 
     # rows past a peer's count are garbage on the device: poison them here so that any use shows up
-    return torch.from_numpy(osp.gather(shard.detach().numpy(), recv_local.numpy(), recv_counts.numpy(), cap, fill=np.nan))
+    out.view(meta.shape[0], n_tables, cap, -1)[:, table] = float("nan")
+    osp.gather(shard.detach().numpy(), meta.numpy(), cap, out.numpy(), table, n_tables)
+    return out
 
 
-def _cpu_scatter_add(grad, recv_local, recv_counts, cap, src):
+def _cpu_scatter_add(grad, meta, cap, src, table=0, n_tables=1):
     from oracle import shard_plan as osp
 
-    osp.scatter_add(grad.numpy(), recv_local.numpy(), recv_counts.numpy(), cap, src.numpy())
+    osp.scatter_add(grad.numpy(), meta.numpy(), cap, src.numpy(), table, n_tables)
     return grad
 
 
@@ -145,7 +147,8 @@ def _worker(rank, world_size, port, tmp):
         (ca, cb), inv, ovf = par.sharded_lookup((sa, sb), ids, N)
         assert int(ovf.item()) == 0
         assert torch.equal(ca[inv], full_a[ids]) and torch.equal(cb[inv], full_b[ids])
-        assert ca.shape[0] == world_size * par.capacity(ids.numel(), N, world_size, 1.25)  # fixed-size exchange
+        cap_ = par.capacity(ids.numel(), N, world_size, 1.25)
+        assert ca.shape[0] == cb.shape[0] == world_size * 2 * cap_ - cap_  # two tables in one fixed-size message
         w = torch.from_numpy(np.random.default_rng(20 + rank).standard_normal((7, 5, d)).astype(np.float32))
         ((ca[inv] * w).sum() + 2.0 * (cb[inv] * w).sum()).backward()
         # dense expectation: every rank's contribution, summed at the owner
