@@ -495,7 +495,8 @@ def leg_sharded(D, args):
             raise AssertionError(f"sharded loss {l_sh} != plain loss {l_pl}")
         parity = {"sharded_loss": l_sh, "plain_loss": l_pl, "rule": "same batch, same tables: equal to 1e-6 relative"}
         del plain
-    dt = timed(D, step, args.sharded_steps, 3)
+    n_steps, n_warm = (args.steps, args.warmup) if args.workload == "sharded" else (args.sharded_steps, 3)
+    dt = timed(D, step, n_steps, n_warm)
     sharded.check_overflow()
     loss = float(last["loss"].detach())
     assert math.isfinite(loss)
@@ -512,14 +513,14 @@ def leg_sharded(D, args):
     res = {
         "metric": "ComplEx d=256 training triples per second, user/entity tables row-sharded owner = id % P (Yelp2018 shape): "
                   "calculate_loss -> backward -> all-reduce of the relation tables -> Adam on the local shards",
-        "value": P * 4 * B * args.sharded_steps / dt, "unit": "triples/s", "per_gpu": 4 * B * args.sharded_steps / dt,
-        "n_gpus": P, "steps": args.sharded_steps, "ms_per_step": dt / args.sharded_steps * 1e3,
+        "value": P * 4 * B * n_steps / dt, "unit": "triples/s", "per_gpu": 4 * B * n_steps / dt,
+        "n_gpus": P, "steps": n_steps, "warmup": n_warm, "ms_per_step": dt / n_steps * 1e3,
         "batch_per_rank": {"rec": B, "kg": B, "triples": 4 * B}, "loss": loss, "parity": parity,
         "exchange": {
             "capacity_rows_per_owner": {"entity": cap_e, "user": cap_u, "factor": sharded.capacity_factor},
             "distinct_rows_per_step_per_rank": {"entity": ent_u, "user": usr_u},
             "bytes_per_step_per_rank": xbytes,
-            "xgmi_GBps_per_gpu_over_step": xbytes / (dt / args.sharded_steps) / 1e9,
+            "xgmi_GBps_per_gpu_over_step": xbytes / (dt / n_steps) / 1e9,
             "collectives_per_step": "6 all-to-alls (per lookup -- entity ids, user ids -- one int32 [count, rows] message, one "
                                     "float message with both tables' rows forward, one with their gradients backward) + 1 "
                                     "all-reduce per relation table" if P > 1 else "none (P = 1: the exchange is the identity)",
@@ -667,7 +668,7 @@ def main():
     if args.workload == "sharded" and "value" in out.get("sharded", {}):
         sh = out["sharded"]
         out["replica_configs1"] = {k: out[k] for k in ("metric", "value", "unit", "ms_per_step", "config")}
-        out.update(metric=sh["metric"], value=sh["value"], unit=sh["unit"], steps=sh["steps"], warmup=3,
+        out.update(metric=sh["metric"], value=sh["value"], unit=sh["unit"], steps=sh["steps"], warmup=sh["warmup"],
                    ms_per_step=sh["ms_per_step"],
                    config={"workload": "configs[3]: ComplEx dim=256, Yelp2018-shaped KG, user/entity tables row-sharded",
                            "parallelism": sh["parallelism"], "global_batch_triples": sh["batch_per_rank"]["triples"] * D.world})
