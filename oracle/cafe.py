@@ -209,3 +209,45 @@ class CafeOracle:
                     results[i, item] = sc
                     collected.append([u, item, sc, inst[item]])
         return results, collected
+
+
+def collect_records(leaf_entries, n_items):
+    """collect_results + the ranking loop of run_program for ONE user (cafe.py:417-441, :859-867), array-wise.
+
+    ``leaf_entries``: per leaf, in collect_results order, (ids [c, depth] int, vals [c, depth] float32).  The reference
+    appends every path to ``tmp`` in leaf order with score = reduce(mul) over its np.float32 values, ``inst[item]`` keeps the
+    LAST path that reached an item, ``tmp`` is sorted by score (stable, descending) and an entry is emitted when it beats
+    results[item] -- i.e. per item the first entry in sorted order, carrying inst[item]'s path.
+    Returns (results [n_items] float32 with -inf holes, records [(item, score, leaf ordinal, row)] in emission order)."""
+    items, scores, blk, row = [], [], [], []
+    for l, (ids, vals) in enumerate(leaf_entries):
+        c = len(ids)
+        if c == 0:
+            continue
+        sc = vals[:, 0].astype(np.float32)
+        for d in range(1, vals.shape[1]):
+            sc = sc * vals[:, d].astype(np.float32)
+        items.append(ids[:, -1].astype(np.int64))
+        scores.append(sc)
+        blk.append(np.full(c, l, np.int64))
+        row.append(np.arange(c, dtype=np.int64))
+    results = np.full(n_items, -np.inf, np.float32)
+    if not items:
+        return results, []
+    items, scores, blk, row = (np.concatenate(x) for x in (items, scores, blk, row))
+    n = len(items)
+    last_of = {}
+    for e in range(n):
+        last_of[int(items[e])] = e
+    srt = np.argsort(-scores, kind="stable")
+    srt = srt[(scores[srt] > -np.inf) & (items[srt] < n_items) & (items[srt] >= 0)]
+    seen, out = set(), []
+    for k in srt.tolist():
+        it = int(items[k])
+        if it in seen:
+            continue
+        seen.add(it)
+        results[it] = scores[k]
+        src = last_of[it]
+        out.append((it, scores[k], int(blk[src]), int(row[src])))
+    return results, out

@@ -205,3 +205,62 @@ def test_calculate_loss_samples_valid_paths_and_trains():
     reg, rank = m.calculate_loss({m.USER_ID: users})
     assert reg.requires_grad and rank.requires_grad and torch.isfinite(reg) and torch.isfinite(rank)
     (reg + rank).backward()
+
+
+@pytest.mark.parametrize("n_leaves,cap,n_items,seed", [(6, 125, 2985, 0), (13, 125, 301, 1), (1, 5, 50, 2), (32, 128, 4000, 3)])
+def test_collect_kernel_against_restatement(n_leaves, cap, n_items, seed):
+    """hw_cafe_collect on synthetic interpreter output (ragged leaf counts, duplicate items across leaves, equal scores,
+    -inf scores, ids beyond the item range, up to 4096 entries per user) against oracle.cafe.collect_records."""
+    from hopwise_amd import pgpr_ops as P
+
+    rng = np.random.default_rng(seed)
+    B = 5
+    nodes = np.zeros(B * n_leaves, P.CAFE_NODE_DTYPE)
+    counts = np.zeros(B * n_leaves, np.int32)
+    node_ptr = np.arange(B + 1, dtype=np.int32) * n_leaves
+    slot_ptr = np.arange(B + 1, dtype=np.int64) * n_leaves * cap
+    ids = np.zeros((B * n_leaves * cap, 3), np.int32)
+    vals = np.zeros((B * n_leaves * cap, 3), np.float32)
+    leaf_nodes = np.zeros((B, n_leaves), np.int32)
+    expect = []
+    for b in range(B):
+        order = rng.permutation(n_leaves)  # leaf ordinal l -> node index order[l] inside the task
+        entries = []
+        for l in range(n_leaves):
+            ni = int(order[l])
+            leaf_nodes[b, l] = ni if (b + l) % 7 != 3 else -1  # some leaves absent
+            depth = int(rng.integers(1, 4))
+            c = int(rng.integers(0, cap + 1)) if l % 3 else cap
+            r = b * n_leaves + ni
+            nodes[r]["depth"], nodes[r]["slot_off"], nodes[r]["cap"] = depth, ni * cap, cap
+            counts[r] = c
+            s0 = int(slot_ptr[b]) + ni * cap
+            pid = rng.integers(0, int(n_items * 1.1), (c, 3)).astype(np.int32)  # some items beyond the range
+            pv = -rng.random((c, 3)).astype(np.float32) * 3
+            pv[rng.random((c, 3)) < 0.02] = -np.inf
+            if c > 4:
+                pv[1] = pv[0]  # equal scores: the earlier entry wins
+                pid[2, depth - 1] = pid[0, depth - 1]  # the same item twice inside a leaf
+            ids[s0 : s0 + c], vals[s0 : s0 + c] = pid, pv
+            if leaf_nodes[b, l] >= 0:
+                entries.append((pid[:, :depth], pv[:, :depth]))
+            else:
+                entries.append((pid[:0, :depth], pv[:0, :depth]))
+        expect.append(oc.collect_records(entries, n_items))
+    t = lambda a: torch.from_numpy(a).to(dev())
+    raw = dict(ids=t(ids), vals=t(vals), counts=t(counts), nodes=t(nodes.view(np.int32).reshape(-1, 10).copy()),
+               node_ptr=t(node_ptr), slot_ptr=t(slot_ptr))
+    max_rec = min(n_leaves * cap, n_items)
+    scores, rec = P.cafe_collect(raw, leaf_nodes, n_items, max_rec)
+    scores = scores.cpu().numpy()
+    cnt = rec["count"].cpu().numpy()
+    item, score, leaf, pid = (rec[k].cpu().numpy() for k in ("item", "score", "leaf", "ids"))
+    for b in range(B):
+        res, out = expect[b]
+        assert np.array_equal(scores[b], res), b
+        assert cnt[b] == len(out), (b, cnt[b], len(out))
+        for j, (it, sc, l, r) in enumerate(out):
+            assert item[b, j] == it and score[b, j] == sc and leaf[b, j] == l, (b, j)
+            ni = leaf_nodes[b, l]
+            s0 = int(slot_ptr[b]) + int(ni) * cap + r
+            assert np.array_equal(pid[b, j], ids[s0]), (b, j)

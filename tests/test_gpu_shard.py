@@ -19,7 +19,8 @@ def dev():
 
 @pytest.mark.parametrize("T", [1, 2])
 @pytest.mark.parametrize("P,n_rows,shape", [(1, 97, (40,)), (2, 53, (7, 5)), (3, 1000, (4096,)), (8, 90962, (5, 8192)),
-                                            (8, 45920, (8192,)), (4, 33, (1,)), (8, 5, (64,))])
+                                            (8, 45920, (8192,)), (4, 33, (1,)), (8, 5, (64,)), (8, 2621440, (1000003,)),
+                                            (7, 144779, (300, 257))])
 def test_plan_matches_oracle(P, n_rows, shape, T):
     from hopwise_amd import ops, parallel as par
 
