@@ -9,8 +9,10 @@ One *batch* = one pass of the scoring hot path over 2048 (user, positive item) g
        interacted items;
     2. grouped RotatE scorer over 2048 x (1 + 256) = 526 336 (h, r, t) triples;
     3. self-adversarial negative-weighting loss over the [2048, 257] scores
-   -- all three in ONE launch (hw_kge_score_grouped_sampled_selfadv; --unfused-loss / --unfused-sampler run them as the
-   separate launches they equal bit for bit).
+   -- all three in ONE launch (hw_kge_score_grouped_sampled_selfadv_chained: the one-block sum of batch i's 2048 group
+   terms rides in block 0 of batch i + 1's launch, the step's last one is flushed by hw_selfadv_finish inside the timed
+   region; --unchained-loss / --unfused-loss / --unfused-sampler run the pieces as the separate launches they equal bit
+   for bit).
 One *step* = `batches_per_step` such batches back to back (chosen so that the K timed steps hold >= 0.75 s of GPU
 work whatever K is: a lone batch is 66 us).  value = triples scored per second over the whole job (all ranks).
 
@@ -65,6 +67,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-tucker", action="store_true")
     ap.add_argument("--unfused-sampler", action="store_true", help="run hw_neg_sample as its own launch before the scorer")
     ap.add_argument("--unfused-loss", action="store_true", help="run hw_loss_self_adversarial as its own launches after the scorer")
+    ap.add_argument("--unchained-loss", action="store_true",
+                    help="finish every batch's loss with its own one-block launch instead of inside the next batch's launch")
     ap.add_argument("--pgpr-steps", type=int, default=5)
     ap.add_argument("--pgpr-users", type=int, default=256,
                     help="users per beam search: 64 -> 5.8 G paths/s, 256 -> 6.7 G (the first hops' fixed cost amortised), ~8 GB of work buffers")
@@ -228,6 +232,28 @@ def leg_kge(D, args, out):
                  stream)
     if fused_loss and lib.hw_kge_score_grouped_sampled_selfadv(*fused_args, C.c_uint64(0), *loss_tail) != 0:
         fused_loss = False
+    # ... and as a chain over the stream of batches (--unchained-loss: one finish launch per batch): batch i's 2048 group
+    # terms are added by block 0 of batch i + 1's launch, the last batch's by hw_selfadv_finish inside the timed region, so
+    # every batch's loss exists when the clock stops (tests/test_gpu_sampler.py: equal to the unchained losses bit for bit)
+    chained = fused_loss and not args.unchained_loss
+    group_ws2 = (group_ws, torch.empty(B_POS, dtype=torch.float32, device=dev))
+    chain = {"cur": 0, "pending": False}
+    chain_head = (P(scores), scores.stride(0), scores.stride(1), C.c_float(1.0))
+
+    def chained_batch(i):
+        cur = chain["cur"]
+        prev = (P(group_ws2[cur ^ 1]), B_POS, P(loss)) if chain["pending"] else (None, 0, None)
+        rc = lib.hw_kge_score_grouped_sampled_selfadv_chained(*fused_args, C.c_uint64(i), *chain_head, P(group_ws2[cur]),
+                                                              *prev, P(oob), stream)
+        chain["cur"], chain["pending"] = cur ^ 1, True
+        return rc
+
+    def chain_flush():
+        if chain["pending"]:
+            if lib.hw_selfadv_finish(P(group_ws2[chain["cur"] ^ 1]), B_POS, P(loss), stream):
+                raise RuntimeError("hw_selfadv_finish failed")
+            chain["pending"] = False
+
     events = []
 
     def batch(i, ev=None):
@@ -236,7 +262,9 @@ def leg_kge(D, args, out):
             rc = lib.hw_neg_sample(*samp_head, C.c_uint64(i), *samp_tail)
         if ev is not None:
             ev[0].record()
-        if fused_loss:
+        if chained:
+            rc |= chained_batch(i)
+        elif fused_loss:
             rc |= lib.hw_kge_score_grouped_sampled_selfadv(*fused_args, C.c_uint64(i), *loss_tail)
         elif fused:
             rc |= lib.hw_kge_score_grouped_sampled(*fused_args, C.c_uint64(i), *fused_tail)
@@ -265,6 +293,7 @@ def leg_kge(D, args, out):
     t0 = time.perf_counter()
     for i in range(64):
         batch(16 + i)
+    chain_flush()
     torch.cuda.synchronize()
     t_batch = (time.perf_counter() - t0) / 64
     inner = args.batches_per_step or max(1, math.ceil(TARGET_TIMED_SECONDS / (max(args.steps, 1) * t_batch)))
@@ -280,6 +309,7 @@ def leg_kge(D, args, out):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 events.append(ev)
             batch(base + j, ev)
+        chain_flush()  # the step's last loss, inside the timed region
 
     with torch.no_grad():
         dt = timed(D, step, args.steps, args.warmup)
@@ -321,6 +351,10 @@ def leg_kge(D, args, out):
             "n_users": kg.n_users, "n_items": kg.n_items, "n_entities": kg.n_entities, "n_relations": kg.n_relations,
             "triples_per_batch": triples_per_batch, "batches_per_step": inner, "triples_per_step": triples_per_step,
             "us_per_batch": dt / args.steps / inner * 1e6,
+            "launches_per_batch": ("1 (sampler + scorer + loss; the 2048-term sum of a batch rides in the next batch's launch, "
+                                   "one hw_selfadv_finish per step)" if chained else
+                                   "2 (sampler + scorer + per-group loss, one-block finish)" if fused_loss else
+                                   "3 (sampler + scorer, loss, finish)" if fused else "4"),
             "parallelism": f"replicas x{D.world} (tables replicated, batches per rank, no data-path collective)",
         },
     })

@@ -88,6 +88,13 @@ SIGNATURES = {
          C.c_int64, c_i64p, C.c_int64, C.c_uint64, C.c_uint64, c_f32p, C.c_int64, C.c_int64, C.c_float, c_f32p, c_f32p,
          c_i32p, c_i32p, C.c_void_p],
     ),
+    "hw_kge_score_grouped_sampled_selfadv_chained": (
+        C.c_int,
+        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p,
+         C.c_int64, c_i64p, C.c_int64, C.c_uint64, C.c_uint64, c_f32p, C.c_int64, C.c_int64, C.c_float, c_f32p, c_f32p,
+         C.c_int64, c_f32p, c_i32p, C.c_void_p],
+    ),
+    "hw_selfadv_finish": (C.c_int, [c_f32p, C.c_int64, c_f32p, C.c_void_p]),
     "hw_kge_full_sort": (
         C.c_int,
         [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64,

@@ -84,7 +84,11 @@ constexpr int SAMPLER_MAX_ATTEMPTS_FUSED = 1 << 16;
 struct SelfAdvArgs {
     float alpha, inv_b;
     float* group_loss;  // [n_groups]
-    float* loss_out;    // [1]
+    float* loss_out;    // [1]; nullptr: the group terms stay in group_loss for a later launch to add (chained form)
+    // chained form: the group terms an EARLIER launch on this stream left behind, added by block 0 of this launch
+    const float* prev_group_loss = nullptr;
+    float* prev_loss_out = nullptr;
+    int prev_n = 0;
 };
 
 __device__ __forceinline__ float log_sigmoid(float x) {  // -(max(-x,0) + log1p(exp(-|x|)))

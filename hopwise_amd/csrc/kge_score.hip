@@ -30,6 +30,29 @@ extern "C" int hw_kge_score_grouped_sampled(const hw_kge_desc* desc, const int64
                                  out, o_stride_b, o_stride_j, oob_counter, stream, &sa);
 }
 
+static int selfadv_launch(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed, int64_t* t_idx,
+                          int64_t t_stride_b, int64_t t_stride_j, int64_t n_groups, int64_t n_tail_per_group,
+                          const int64_t* used_ptr, const int64_t* used_idx, int64_t n_key_space, const int64_t* keys,
+                          int64_t value_num, uint64_t seed, uint64_t offset, float* out, int64_t o_stride_b,
+                          int64_t o_stride_j, float alpha, float* loss_out, float* group_loss_ws,
+                          const float* prev_group_loss, int64_t prev_n_groups, float* prev_loss_out, int32_t* oob_counter,
+                          void* stream) {
+    if (!desc || !used_ptr || !keys || !t_idx || !group_loss_ws || n_key_space < 1 || value_num < 2 || n_groups < 1 ||
+        n_tail_per_group < 2)
+        return HW_ERR_INVALID_ARG;
+    if (prev_group_loss && (!prev_loss_out || prev_n_groups < 1 || prev_n_groups > INT32_MAX || prev_group_loss == group_loss_ws))
+        return HW_ERR_INVALID_ARG;
+    if (HW_FAMILY_OF(desc->model) != 0 || value_num > 65536) return HW_ERR_UNSUPPORTED;
+    SamplerArgs sa;
+    sa.used_ptr = used_ptr, sa.used_idx = used_idx, sa.keys = keys, sa.n_key_space = n_key_space;
+    sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = (int)((value_num + 31) / 32);
+    SelfAdvArgs la;
+    la.alpha = alpha, la.inv_b = 1.0f / (float)n_groups, la.group_loss = group_loss_ws, la.loss_out = loss_out;
+    if (prev_group_loss) la.prev_group_loss = prev_group_loss, la.prev_loss_out = prev_loss_out, la.prev_n = (int)prev_n_groups;
+    return score_grouped_impl<0>(desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, n_tail_per_group,
+                                 out, o_stride_b, o_stride_j, oob_counter, stream, &sa, &la);
+}
+
 extern "C" int hw_kge_score_grouped_sampled_selfadv(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx,
                                                     int64_t r_fixed, int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
                                                     int64_t n_groups, int64_t n_tail_per_group, const int64_t* used_ptr,
@@ -38,18 +61,30 @@ extern "C" int hw_kge_score_grouped_sampled_selfadv(const hw_kge_desc* desc, con
                                                     int64_t o_stride_b, int64_t o_stride_j, float alpha, float* loss_out,
                                                     float* group_loss_ws, int32_t* counter_ws, int32_t* oob_counter,
                                                     void* stream) {
-    if (!desc || !used_ptr || !keys || !t_idx || !loss_out || !group_loss_ws || n_key_space < 1 ||
-        value_num < 2 || n_groups < 1 || n_tail_per_group < 2)
-        return HW_ERR_INVALID_ARG;
-    if (HW_FAMILY_OF(desc->model) != 0 || value_num > 65536) return HW_ERR_UNSUPPORTED;
-    SamplerArgs sa;
-    sa.used_ptr = used_ptr, sa.used_idx = used_idx, sa.keys = keys, sa.n_key_space = n_key_space;
-    sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = (int)((value_num + 31) / 32);
-    SelfAdvArgs la;
-    la.alpha = alpha, la.inv_b = 1.0f / (float)n_groups, la.group_loss = group_loss_ws, la.loss_out = loss_out;
     (void)counter_ws;
-    return score_grouped_impl<0>(desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, n_tail_per_group,
-                                 out, o_stride_b, o_stride_j, oob_counter, stream, &sa, &la);
+    if (!loss_out) return HW_ERR_INVALID_ARG;
+    return selfadv_launch(desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, n_tail_per_group, used_ptr,
+                          used_idx, n_key_space, keys, value_num, seed, offset, out, o_stride_b, o_stride_j, alpha, loss_out,
+                          group_loss_ws, nullptr, 0, nullptr, oob_counter, stream);
+}
+
+extern "C" int hw_kge_score_grouped_sampled_selfadv_chained(
+    const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed, int64_t* t_idx, int64_t t_stride_b,
+    int64_t t_stride_j, int64_t n_groups, int64_t n_tail_per_group, const int64_t* used_ptr, const int64_t* used_idx,
+    int64_t n_key_space, const int64_t* keys, int64_t value_num, uint64_t seed, uint64_t offset, float* out,
+    int64_t o_stride_b, int64_t o_stride_j, float alpha, float* group_loss_ws, const float* prev_group_loss,
+    int64_t prev_n_groups, float* prev_loss_out, int32_t* oob_counter, void* stream) {
+    return selfadv_launch(desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, n_tail_per_group, used_ptr,
+                          used_idx, n_key_space, keys, value_num, seed, offset, out, o_stride_b, o_stride_j, alpha, nullptr,
+                          group_loss_ws, prev_group_loss, prev_n_groups, prev_loss_out, oob_counter, stream);
+}
+
+extern "C" int hw_selfadv_finish(const float* group_loss, int64_t n_groups, float* loss_out, void* stream) {
+    if (!group_loss || !loss_out || n_groups < 1 || n_groups > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(selfadv_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, group_loss, (int)n_groups,
+                       1.0f / (float)n_groups, loss_out);
+    return HW_LAUNCH_RC();
 }
 
 extern "C" int hw_kge_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,

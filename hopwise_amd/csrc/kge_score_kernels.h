@@ -25,6 +25,25 @@ namespace hw {
 // are also kept in LDS, and wave 0 evaluates the self-adversarial term of hw_loss_self_adversarial for the group (same
 // arithmetic, same order) -- the per-group pass of the loss without its launch and without re-reading the score matrix;
 // selfadv_finish_kernel then adds the n_groups terms.
+// loss = mean of the per-group terms, added in finish_mean_kernel's order (kge_loss.hip): thread t takes t, t + 256, ...,
+// then the wave sums, then the four wave totals in order.  Whole block (256 threads).
+__device__ __forceinline__ void selfadv_finish_block(const float* __restrict__ group_loss, int n, float inv_n,
+                                                     float* __restrict__ loss_out) {
+    __shared__ float red[4];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += group_loss[i];
+    v = group_sum<64>(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x / HW_WAVE] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t += red[i];
+        loss_out[0] = t * inv_n;
+    }
+}
+
 constexpr int LOSS_MAX_TAILS = 1024;
 template <int MODEL, int G, int NE, bool VEC, int U, bool SAMPLE = false, bool LOSS = false>
 __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
@@ -42,6 +61,13 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     const int sub = lane / G, gl = lane % G;
     const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + (threadIdx.x / HW_WAVE);
     if (task >= n_groups * S) return;  // wave-uniform
+    if constexpr (SAMPLE && LOSS) {
+        // chained launches: block 0 (all four waves live: S == 4) first adds the group terms the previous launch on this
+        // stream left in prev_group_loss -- the one-block finish of that launch without a launch of its own (4.6 us of a
+        // 54 us batch).  Kernel boundaries order the two launches; nothing here crosses workgroups.
+        if (blockIdx.x == 0 && la.prev_group_loss)
+            selfadv_finish_block(la.prev_group_loss, la.prev_n, 1.0f / (float)la.prev_n, la.prev_loss_out);
+    }
     const int64_t b = task / S;
     const int s = (int)(task % S);
     uint32_t* bits = nullptr;
@@ -193,24 +219,11 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     }
 }
 
-// loss = mean of the per-group terms, added in finish_mean_kernel's order (kge_loss.hip): thread t takes t, t + 256, ...,
-// then the wave sums, then the four wave totals in order.  A launch of its own: a cross-workgroup hand-off inside the scorer
-// would need an agent-scope release per block, which on this part writes the XCD's L2 back (measured: 47 -> 118 us).
+// The finish as a launch of its own (the unchained form, and the flush of a chain): a cross-workgroup hand-off inside the
+// scorer would need an agent-scope release per block, which on this part writes the XCD's L2 back (measured: 47 -> 118 us).
 static __global__ __launch_bounds__(256) void selfadv_finish_kernel(const float* __restrict__ group_loss, int n, float inv_n,
                                                              float* __restrict__ loss_out) {
-    __shared__ float red[4];
-    float v = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) v += group_loss[i];
-    v = group_sum<64>(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x / HW_WAVE] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t += red[i];
-        loss_out[0] = t * inv_n;
-    }
+    selfadv_finish_block(group_loss, n, inv_n, loss_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -758,7 +771,7 @@ static int score_grouped_impl(const hw_kge_desc* desc, const int64_t* h_idx, con
     }
     HW_DISPATCH_MODEL(desc->model, shape, CALL);
 #undef CALL
-    if (selfadv)
+    if (selfadv && selfadv->loss_out)
         hipLaunchKernelGGL(selfadv_finish_kernel, dim3(1), dim3(256), 0, st, selfadv->group_loss, (int)n_groups,
                            selfadv->inv_b, selfadv->loss_out);
     return HW_LAUNCH_RC();

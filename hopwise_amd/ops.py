@@ -180,6 +180,53 @@ def kge_score_grouped_sampled_selfadv_raw(desc, h_idx, r_idx, r_fixed, t_idx, us
     return out, loss, counter
 
 
+class SelfAdvChain:
+    """A stream of hw_kge_score_grouped_sampled_selfadv batches without the per-batch finish launch: batch i's group terms
+    are added by block 0 of batch i + 1 (hw_kge_score_grouped_sampled_selfadv_chained), the last one by flush().  Every
+    loss lands in the [1] tensor given to (or returned by) its launch() -- after the NEXT launch() or flush() on the stream."""
+
+    def __init__(self, n_groups, device):
+        self.n = int(n_groups)
+        self.ws = [torch.empty(self.n, dtype=torch.float32, device=device) for _ in range(2)]
+        self.cur = 0
+        self.pending = None  # the loss tensor of the launch whose group terms sit in ws[cur ^ 1]
+
+    def launch(self, desc, h_idx, r_idx, r_fixed, t_idx, used_ptr, used_idx, keys, value_num, seed, offset, alpha=1.0,
+               out=None, loss=None):
+        lib = _lib.load()
+        h_idx = _idx(h_idx, "h_idx").contiguous()
+        t_idx = _idx(t_idx, "t_idx")
+        keys = _idx(keys, "keys").contiguous()
+        if r_idx is not None:
+            r_idx = _idx(r_idx, "r_idx").contiguous()
+        B, G = t_idx.shape
+        if B != self.n:
+            raise ValueError(f"chain built for {self.n} groups, batch has {B}")
+        dev = h_idx.device
+        if out is None:
+            out = torch.empty((B, G), dtype=torch.float32, device=dev)
+        if loss is None:
+            loss = torch.empty(1, dtype=torch.float32, device=dev)
+        used_ptr, used_idx = _idx(used_ptr, "used_ptr").contiguous(), _idx(used_idx, "used_idx").contiguous()
+        prev = self.pending
+        rc = lib.hw_kge_score_grouped_sampled_selfadv_chained(
+            C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), _ptr(t_idx), t_idx.stride(0), t_idx.stride(1), B, G,
+            _ptr(used_ptr), _ptr(used_idx), used_ptr.numel() - 1, _ptr(keys), int(value_num), C.c_uint64(seed),
+            C.c_uint64(offset), _ptr(out), out.stride(0), out.stride(1), float(alpha), _ptr(self.ws[self.cur]),
+            _ptr(self.ws[self.cur ^ 1]) if prev is not None else None, self.n if prev is not None else 0, _ptr(prev),
+            _ptr(_OobCounter.get(dev)), _stream())
+        check(rc, "hw_kge_score_grouped_sampled_selfadv_chained")
+        self.pending = loss
+        self.cur ^= 1
+        return out, loss
+
+    def flush(self):
+        if self.pending is not None:
+            check(_lib.load().hw_selfadv_finish(_ptr(self.ws[self.cur ^ 1]), self.n, _ptr(self.pending), _stream()),
+                  "hw_selfadv_finish")
+            self.pending = None
+
+
 def kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi):
     lib = _lib.load()
     h_idx = _idx(h_idx, "h_idx").contiguous()

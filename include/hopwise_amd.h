@@ -116,6 +116,24 @@ int hw_kge_score_grouped_sampled_selfadv(const hw_kge_desc* desc, const int64_t*
                                          int64_t o_stride_j, float alpha, float* loss_out, float* group_loss_ws,
                                          int32_t* counter_ws, int32_t* oob_counter, void* stream);
 
+/* Chained form of hw_kge_score_grouped_sampled_selfadv for a stream of batches (the training loop's forward leg; same
+ * reference lines: sampler.py:226-257 + rotate.py:98-131 + the self-adversarial loss): this launch leaves its n_groups
+ * group terms in group_loss_ws WITHOUT the one-block finish launch, and -- when prev_group_loss is not NULL -- its block 0
+ * adds the prev_n_groups terms an earlier launch on the same stream left in prev_group_loss into prev_loss_out[0] (same
+ * order as the finish kernel: equal bit for bit).  prev_group_loss must not alias group_loss_ws (alternate two buffers).
+ * The last batch of a chain is finished by hw_selfadv_finish.  Saves the 4-5 us finish launch per batch. */
+int hw_kge_score_grouped_sampled_selfadv_chained(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx,
+                                                 int64_t r_fixed, int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
+                                                 int64_t n_groups, int64_t n_tail_per_group, const int64_t* used_ptr,
+                                                 const int64_t* used_idx, int64_t n_key_space, const int64_t* keys,
+                                                 int64_t value_num, uint64_t seed, uint64_t offset, float* out,
+                                                 int64_t o_stride_b, int64_t o_stride_j, float alpha, float* group_loss_ws,
+                                                 const float* prev_group_loss, int64_t prev_n_groups, float* prev_loss_out,
+                                                 int32_t* oob_counter, void* stream);
+
+/* loss_out[0] = mean of group_loss[0 .. n_groups) in the finish order of hw_kge_score_grouped_sampled_selfadv. */
+int hw_selfadv_finish(const float* group_loss, int64_t n_groups, float* loss_out, void* stream);
+
 /* Full sort: out[b, n - tail_lo] = score(h_idx[b], r, n) for every tail row n in [tail_lo, tail_hi).
  * Replaces full_sort_predict / full_sort_predict_kg (rotate.py:161-220, transe.py:112-154,
  * complex.py:162-219, distmult.py:119-146) without the [B, N, d] temporaries. */

@@ -218,3 +218,50 @@ def test_sampler_scorer_and_loss_in_one_launch(model, dim, B, K, alpha):
         assert loss.item() == ref_loss.item(), (loss.item(), ref_loss.item())
     # against the oracle as well
     np.testing.assert_allclose(loss.item(), okge.self_adversarial_loss(ref.cpu().numpy(), alpha), rtol=1e-5)
+
+
+def test_chained_losses_equal_the_unchained_ones():
+    """hw_kge_score_grouped_sampled_selfadv_chained: batch i's group terms are added by block 0 of batch i + 1, the last
+    batch's by hw_selfadv_finish -- ids, scores and every loss equal the unchained launches' bit for bit."""
+    from hopwise_amd import ops
+    from hopwise_amd.data import synthetic
+    from oracle import kge as okge
+    from tests.helpers import random_tables
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    model, dim, B, K, alpha = "RotatE", 40, 96, 255, 1.0
+    nU, nI, nE, nR = 200, 2985, 4000, 7
+    iu, ii = rng.integers(1, nU, 30000), rng.integers(1, nI, 30000)
+    ptr, idx = synthetic.used_csr(iu, ii, nU)
+    ptr, idx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+    tabs = {k: torch.from_numpy(v).to(dev) for k, v in random_tables(model, nU, nE, nR, dim, seed=1).items()}
+    hn, rn, tn = okge.slots(model, "rec")
+    desc = ops.make_desc(model, tuple(tabs[n] for n in hn), tuple(tabs[n] for n in rn), tuple(tabs[n] for n in tn),
+                         margin=1.0, tail_rows=nI)
+    batches = []
+    for _ in range(5):
+        users = torch.from_numpy(rng.integers(1, nU, B)).to(dev)
+        t = torch.zeros((B, 1 + K), dtype=torch.int64, device=dev)
+        t[:, 0] = torch.from_numpy(rng.integers(1, nI, B)).to(dev)
+        batches.append((users, t))
+    want = []
+    for i, (users, t) in enumerate(batches):
+        got, loss, _ = ops.kge_score_grouped_sampled_selfadv_raw(desc, users, None, nR - 1, t.clone(), ptr, idx, users, nI, 11,
+                                                                 i, alpha)
+        want.append((got, loss.item()))
+    chain = ops.SelfAdvChain(B, dev)
+    outs = []
+    for i, (users, t) in enumerate(batches):
+        tt = t.clone()
+        loss = torch.full((1,), float("nan"), device=dev)
+        outs.append(chain.launch(desc, users, None, nR - 1, tt, ptr, idx, users, nI, 11, i, alpha, loss=loss))
+    assert np.isnan(outs[-1][1].item())  # the last batch is not finished before the flush ...
+    assert outs[-2][1].item() == want[-2][1]  # ... the one before it is
+    chain.flush()
+    for (got, loss), (ref, ref_loss) in zip(outs, want):
+        assert torch.equal(got, ref)
+        assert loss.item() == ref_loss
+    chain.flush()  # nothing pending: no launch
+    with pytest.raises(ValueError):
+        chain.launch(desc, batches[0][0][:8], None, nR - 1, batches[0][1][:8].clone(), ptr, idx, batches[0][0][:8], nI, 11, 0)
