@@ -115,6 +115,56 @@ __device__ __forceinline__ void put_tile(const f32x4 (&v)[2], int K, int k0, flo
     }
 }
 
+// ---- fp32 product on the bf16 matrix pipes: three-way split (SPLIT variant of gemm_f32_kernel) --------------------------
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate.  Every fp32 value is the exact sum of three bf16 values
+// (x = hi + mid + lo: 3 x 8 significand bits, each taken round-to-nearest from what the previous ones left), bf16 x bf16
+// products are exact in fp32 and the MFMA accumulates in fp32, so
+//     a b  =  ah bh + (ah bm + am bh) + (ah bl + al bh + am bm)  +  O(2^-24 |a b|)
+// -- six bf16 MFMAs (v_mfma_f32_32x32x16_bf16) per 16 k instead of eight fp32 ones per 2 k x 8: 2.67 x fewer matrix-pipe
+// cycles, and an error per product (<= ~2^-23) of the size of the fp32 rounding of the sum it is added to (measured against
+// float64 next to the FMA loop: tools/check_gemm_split.py).  Used when both operands are K-contiguous (x . W^T: the TuckER /
+// ConvE score products, the policy MLPs); HW_GEMM_SPLIT=0 keeps the exact-FMA loop.  Inf operands give NaN (inf - inf in
+// the split), which the FMA loop would not: operands are embeddings and activations.
+// LDS: per stage and operand three plane images [128 rows][16 k] bf16 (32-byte rows); the MFMA fragment of lane (r, h) is the
+// 16 bytes k = 8 h .. 8 h + 7 of row r, stored at half h ^ ((r >> 3) & 1) so that the four 16-lane groups of a ds_read_b128
+// touch 16 distinct 16-byte slots of the 256-byte bank row.  2 stages x 2 operands x 3 planes x 4 KB = 48 KB: 3 blocks per CU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int SPLIT_PLANE = 128 * 16 * 2, SPLIT_OPERAND = 3 * SPLIT_PLANE, SPLIT_STAGE = 2 * SPLIT_OPERAND;
+
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const f32x2 v = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(h, f32x2);
+    const bf16x2 m = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(m, f32x2);
+    const bf16x2 l = __builtin_convertvector(r2, bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h), mid = __builtin_bit_cast(uint32_t, m), lo = __builtin_bit_cast(uint32_t, l);
+}
+
+__device__ __forceinline__ int split_off(int r, int half) { return r * 32 + ((half ^ ((r >> 3) & 1)) << 4); }
+
+// registers of fetch_tile<true> (rows f >> 2, four consecutive k at (f & 3) * 4) -> the three plane images of one operand
+template <bool FULL>  // FULL: the whole k-tile lies below K (no zeroing)
+__device__ __forceinline__ void put_tile_split(const f32x4 (&v)[2], int K, int k0, uint8_t* __restrict__ img) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + 256 * i;
+        const int r = f >> 2, kq = (f & 3) * 4, kg = k0 + kq;
+        const float x0 = FULL || kg < K ? v[i].x : 0.f, x1 = FULL || kg + 1 < K ? v[i].y : 0.f;
+        const float x2 = FULL || kg + 2 < K ? v[i].z : 0.f, x3 = FULL || kg + 3 < K ? v[i].w : 0.f;
+        uint32_t h0, m0, l0, h1, m1, l1;
+        split_pair(x0, x1, h0, m0, l0);
+        split_pair(x2, x3, h1, m1, l1);
+        uint8_t* dst = img + split_off(r, kq >> 3) + ((kq & 4) << 1);
+        *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+        *reinterpret_cast<uint2*>(dst + SPLIT_PLANE) = uint2{m0, m1};
+        *reinterpret_cast<uint2*>(dst + 2 * SPLIT_PLANE) = uint2{l0, l1};
+    }
+}
+
 // ACT == 3: sigmoid + BCELoss epilogue (TuckER / ConvE 1-vs-all scores, tucker.py:83,124-125): the tile never leaves as
 // scores -- each element becomes dLoss/dscore (what the backward GEMMs consume) and the block's loss terms are summed into
 // loss_partial[linear block id]; target[c] = scale * flag[c] + add.
@@ -124,8 +174,8 @@ struct GemmBce {
     float* loss_partial;
 };
 
-template <bool A_KC, bool B_KC, int ACT>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+template <bool A_KC, bool B_KC, int ACT, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc,
                                                           const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
@@ -136,8 +186,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                                                           GemmBce bce) {
     // two LDS stages: the pipelined loop writes tile k+1 into the stage nobody reads while tile k is multiplied, which
     // leaves one barrier per k-step (the unpipelined fallback uses stage 0 only)
-    __shared__ __attribute__((aligned(16))) float As2[2][BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs2[2][BK][LDT];
+    // (the SPLIT loop: two stages of six bf16 plane images, see above)
+    __shared__ __attribute__((aligned(16))) float lds[SPLIT ? 2 * SPLIT_STAGE / 4 : 4 * BK * LDT];
+    float (*As2)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds);
+    float (*Bs2)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds + 2 * BK * LDT);
     float (*As)[LDT] = As2[0];
     float (*Bs)[LDT] = Bs2[0];
     const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
@@ -154,7 +206,53 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
     // split-K: blockIdx.z owns k in [z * k_len, min(K, (z + 1) * k_len)); partial sums go to `partial[z]`
     const int k_begin = blockIdx.z * k_len;
     const int k_end = min(K, k_begin + k_len);
-    if (pipe) {
+    if constexpr (SPLIT) {
+        static_assert(!SPLIT || (A_KC && B_KC), "the split loop stages K-contiguous operands");
+        uint8_t* const img = reinterpret_cast<uint8_t*>(lds);
+        f32x4 ra[2], rb[2];
+        fetch_tile<true>(A, lda, M, k_end, m0, k_begin, ra);
+        fetch_tile<true>(B, ldb, N, k_end, n0, k_begin, rb);
+        put_tile_split<false>(ra, k_end, k_begin, img);
+        put_tile_split<false>(rb, k_end, k_begin, img + SPLIT_OPERAND);
+        __syncthreads();
+        const int fr = lane & 31, fh = lane >> 5;
+        int cur = 0;
+        for (int k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
+            fetch_tile<true>(A, lda, M, k_end, m0, k0 + BK, ra);  // clamped past the end, stored as zeros
+            fetch_tile<true>(B, ldb, N, k_end, n0, k0 + BK, rb);
+            __builtin_amdgcn_sched_barrier(0);
+            const uint8_t* Ai = img + cur * SPLIT_STAGE;
+            const uint8_t* Bi = Ai + SPLIT_OPERAND;
+            bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    fa[t][p] = *reinterpret_cast<const bf16x8*>(Ai + p * SPLIT_PLANE + split_off(wm + 32 * t + fr, fh));
+                    fb[t][p] = *reinterpret_cast<const bf16x8*>(Bi + p * SPLIT_PLANE + split_off(wn + 32 * t + fr, fh));
+                }
+            // smallest terms first; the four accumulators alternate so that no MFMA waits for the one before it
+#define HW_SPLIT_TERM(PA, PB)                                                                                        \
+    _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)               \
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ti][PA], fb[tj][PB], acc[ti][tj], 0, 0, 0);
+            HW_SPLIT_TERM(1, 1)
+            HW_SPLIT_TERM(2, 0)
+            HW_SPLIT_TERM(0, 2)
+            HW_SPLIT_TERM(1, 0)
+            HW_SPLIT_TERM(0, 1)
+            HW_SPLIT_TERM(0, 0)
+#undef HW_SPLIT_TERM
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 2 * BK <= k_end) {  // block-uniform: the next tile is a whole one
+                put_tile_split<true>(ra, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE);
+                put_tile_split<true>(rb, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE + SPLIT_OPERAND);
+            } else {
+                put_tile_split<false>(ra, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE);
+                put_tile_split<false>(rb, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE + SPLIT_OPERAND);
+            }
+            __syncthreads();
+        }
+    } else if (pipe) {
         f32x4 ra[2], rb[2];
         fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra);
         fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin, rb);
@@ -229,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restric
                 }
             }
         loss = group_sum<64>(loss);
-        __shared__ float red[4];
+        float* red = lds;  // every loop ends with a barrier: no wave still reads the tiles
         if (lane == 0) red[wave] = loss;
         __syncthreads();
         if (tid == 0) bce.loss_partial[blockIdx.x + gridDim.x * blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -508,10 +606,21 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     const char* pe = getenv("HW_GEMM_PIPE");
     // the pipelined loop needs 16-byte loads on both operands and at least one float4 along each inner extent
     const int pipe = (pe ? atoi(pe) : 1) && va && vb && k >= 4 && m_max >= 4 && n >= 4;
-#define GO(AK, BK_, EL)                                                                                              \
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows,       \
-                       (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial,   \
-                       pipe, bce)
+    // both operands K-contiguous and 16-byte aligned: the three-way bf16 split on the bf16 matrix pipes (HW_GEMM_SPLIT=0:
+    // the exact-FMA loop)
+    const char* se = getenv("HW_GEMM_SPLIT");
+    const bool split = a_kc && b_kc && va && vb && k >= 4 && (se ? atoi(se) != 0 : true);
+#define GO(AK, BK_, EL)                                                                                                  \
+    do {                                                                                                                 \
+        if (split && AK && BK_)                                                                                          \
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL, (AK && BK_)>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, \
+                               m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb,     \
+                               k_len, partial, pipe, bce);                                                               \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL, false>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc,    \
+                               m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb,     \
+                               k_len, partial, pipe, bce);                                                               \
+    } while (0)
 #define GO3(AK, BK_)              \
     do {                          \
         if (act == 1) GO(AK, BK_, 1);      \
