@@ -612,7 +612,12 @@ def leg_tucker(D, args):
     flops_fwd = sum(2 * B * d**3 + 2 * B * d * d + 2 * B * d * N for N in (nU + nI, nE))
     m.train()
     res = {"metric": "TuckER d=200 calculate_loss on the Alibaba-iFashion shape (rec + kg side, B=2048 each), fp32 MFMA",
-           "flops_forward": flops_fwd, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma"}
+           "flops_forward": flops_fwd, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma",
+           "gemm": ("fp32 products as three-way bf16 splits on the bf16 matrix pipes (6 v_mfma_f32_32x32x16_bf16 per 16 k, fp32 "
+                    "accumulate; error vs float64 <= the fp32 FMA chain's, tests/test_gpu_gemm_split.py)"
+                    if os.environ.get("HW_GEMM_SPLIT", "1") != "0" else "v_mfma_f32_32x32x2_f32 FMA chains (HW_GEMM_SPLIT=0)"),
+           "peak_note": "peak = the fp32-input MFMA rate (157.3 TFLOP/s at 2.4 GHz); achieved counts the reference's fp32 FLOPs, "
+                        "so the split loop can exceed what fp32-input MFMAs could deliver"}
     for mode, mult in (("forward", 1), ("forward_backward", 3)):
         def step(i):
             m.zero_grad(set_to_none=True)

