@@ -337,7 +337,12 @@ int hw_pgpr_layer1_lookup(const float* const* slot_tables, const float* bias, in
  * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187).
  * workspace (nullable, workspace_floats >= 2 * m_max * n to be useful) enables deterministic split-K for
  * long-K / small-output products (partial slabs summed in fixed order).  `elu` selects the activation:
- * 0 none, 1 ELU, 2 ReLU. */
+ * 0 none, 1 ELU, 2 ReLU.
+ * Numerics: fp32 in, fp32 accumulate.  With 16-byte aligned operands (base and leading dimension) each fp32 product is
+ * evaluated as six bf16 x bf16 products of the exact three-way bf16 splits of its factors on the bf16 matrix pipes; the
+ * error against a float64 product is no larger than that of a chain of fp32 FMAs (<= 3e-6 of sum_k |a_ik b_kj|,
+ * tests/test_gpu_gemm_split.py).  The environment variable HW_GEMM_SPLIT=0 selects fp32-input MFMA FMA chains instead
+ * (also what unaligned operands get).  An infinite operand yields NaN on the split path. */
 int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, const float* b, int64_t ldb,
                 int32_t b_k_contiguous, float* c, int64_t ldc, const int32_t* m_rows, int64_t m_max,
                 int64_t n, int64_t k, const float* bias, int32_t elu, const float* drop_mask,
