@@ -356,7 +356,7 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension is not built. Run `python -m hopwise_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
-    lib = C.CDLL(os.environ.get("HOPWISE_AMD_LIB", LIB_PATH))  # override: kernel experiments built next to the tree
+    lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
