@@ -853,11 +853,57 @@ __global__ __launch_bounds__(256) void policy_topk_kernel(const float* __restric
 // (4 per lane) and are ranked by ONE bitonic sort instead of k arg-max rounds.  p + 1 lies in [1, 2], so its 23
 // mantissa bits order the values; with the 8-bit action index underneath, a 32-bit key gives exactly
 // (value desc, index asc).  p + 1 == 2 only happens for a single valid action (softmax of one logit); that row needs
-// no sort.  21 of the 36 compare-exchange steps cross lanes (4 x ds_bpermute each); the rest are register swaps.
+// no sort.  21 of the 36 compare-exchange steps cross lanes (xor_lane: DPP for 17 of them); the rest are register swaps.
 __device__ __forceinline__ void cmpx(uint32_t& a, uint32_t& b, bool desc) {
     const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
     a = desc ? hi : lo;
     b = desc ? lo : hi;
+}
+
+// lane ^ LM's value without the LDS crossbar where the data-parallel primitives reach: quad permutes for 1 and 2, a pair of
+// row shifts for 4 and 8 (the partner is 4 / 8 lanes up for lanes with that bit clear, down for the others, always inside
+// the 16-lane row), ds_swizzle (no address register) for 16; only the 32-lane exchange goes through ds_bpermute.
+template <int LM>
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v, int lane) {
+    const int x = (int)v;
+    if constexpr (LM == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    else if constexpr (LM == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    else if constexpr (LM == 4 || LM == 8) {
+        const int up = __builtin_amdgcn_update_dpp(0, x, 0x100 + LM, 0xF, 0xF, true);    // row_shl: lane i reads lane i + LM
+        const int down = __builtin_amdgcn_update_dpp(0, x, 0x110 + LM, 0xF, 0xF, true);  // row_shr: lane i reads lane i - LM
+        return (uint32_t)((lane & LM) ? down : up);
+    } else if constexpr (LM == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle(x, 0x401F);  // bit mode: and 0x1F, xor 0x10
+    else return (uint32_t)__shfl_xor(x, LM, 64);
+}
+
+// one compare-exchange step of the bitonic network over e = lane * 4 + i (descending overall), then the smaller strides
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void bitonic_steps(uint32_t (&key)[4], int lane) {
+    if constexpr (STRIDE >= 4) {
+        constexpr int LM = STRIDE >> 2;  // partner lane = lane ^ LM, same register
+        const bool upper = (lane & LM) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = lane * 4 + i;
+            const bool desc = (e & SIZE) == 0;  // blocks alternate direction; the final pass (SIZE 256) is all descending
+            const uint32_t o = xor_lane<LM>(key[i], lane);
+            const bool take_max = desc ? !upper : upper;
+            key[i] = take_max ? (key[i] > o ? key[i] : o) : (key[i] < o ? key[i] : o);
+        }
+    } else if constexpr (STRIDE == 2) {  // partners inside the lane: registers i and i ^ STRIDE
+        cmpx(key[0], key[2], ((lane * 4 + 0) & SIZE) == 0);
+        cmpx(key[1], key[3], ((lane * 4 + 1) & SIZE) == 0);
+    } else {
+        cmpx(key[0], key[1], ((lane * 4 + 0) & SIZE) == 0);
+        cmpx(key[2], key[3], ((lane * 4 + 2) & SIZE) == 0);
+    }
+    if constexpr (STRIDE > 1) bitonic_steps<SIZE, STRIDE / 2>(key, lane);
+}
+
+template <int SIZE>
+__device__ __forceinline__ void bitonic_sort256(uint32_t (&key)[4], int lane) {
+    bitonic_steps<SIZE, SIZE / 2>(key, lane);
+    if constexpr (SIZE < 256) bitonic_sort256<SIZE * 2>(key, lane);
 }
 
 __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __restrict__ logits, int ld, int act_dim,
@@ -908,35 +954,7 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
             key[i] = valid ? ((mant << 8) | (uint32_t)(255 - j)) + 0x80000000u : 0u;
         }
         const bool row_has_two = __any(two);
-        // bitonic sort, descending overall: element index e = lane * 4 + i
-#pragma unroll
-        for (int size = 2; size <= 256; size <<= 1) {
-#pragma unroll
-            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-                if (stride >= 4) {
-                    const int lm = stride >> 2;  // partner lane = lane ^ lm, same register
-                    const bool upper = (lane & lm) != 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int e = lane * 4 + i;
-                        const bool desc = (e & size) == 0;  // blocks alternate direction; final pass (size 256) is all desc
-                        const uint32_t o = __shfl_xor(key[i], lm, 64);
-                        const bool take_max = desc ? !upper : upper;
-                        key[i] = take_max ? (key[i] > o ? key[i] : o) : (key[i] < o ? key[i] : o);
-                    }
-                } else {
-                    // partners inside the lane: registers i and i ^ stride
-                    const int e0 = lane * 4;
-                    if (stride == 2) {
-                        cmpx(key[0], key[2], ((e0 + 0) & size) == 0);
-                        cmpx(key[1], key[3], ((e0 + 1) & size) == 0);
-                    } else {
-                        cmpx(key[0], key[1], ((e0 + 0) & size) == 0);
-                        cmpx(key[2], key[3], ((e0 + 2) & size) == 0);
-                    }
-                }
-            }
-        }
+        bitonic_sort256<2>(key, lane);  // descending overall: element index e = lane * 4 + i
         // ranks 4*lane .. 4*lane+3 are in key[0..3]; emit the first k
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
