@@ -722,62 +722,109 @@ struct L1Tables {
     const float *old_u, *old_e, *old_r;         // slots 4, 5
 };
 
+constexpr int L1_RUN = 16, L1_MAX_H = 512;
+
+// ELU + dropout of four consecutive outputs (row, c .. c + 3) and their store
+__device__ __forceinline__ void l1_finish(f32x4 acc, int row, int c, int H, const float* __restrict__ drop_mask, int drop_mode,
+                                          uint64_t seed, uint64_t offset, float* __restrict__ out, int64_t ld) {
+    float v[4] = {acc.x, acc.y, acc.z, acc.w};
+    // row * H + c is a multiple of 4 (H % 4 == 0, c = 4 * lane + 256 * trip): the four dropout bits of this chunk are the
+    // four words of ONE Philox block (the compiler cannot see that and would evaluate it four times)
+    uint32_t pw[4] = {0u, 0u, 0u, 0u};
+    if (drop_mode == 2) philox_bits4(seed, offset, ((uint64_t)row * H + c) >> 2, pw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float x = v[k];
+        x = x > 0.f ? x : expm1f(x);
+        const uint64_t idx = (uint64_t)row * H + c + k;
+        if (drop_mode == 1) x *= drop_mask[idx];
+        else if (drop_mode == 2) x = (pw[k] & 1u) ? x * 2.f : 0.f;
+        v[k] = x;
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)row * ld + c) = f32x4{v[0], v[1], v[2], v[3]};
+}
+
 __global__ __launch_bounds__(256) void pgpr_layer1_lookup_kernel(L1Tables t, const float* __restrict__ bias, int H,
                                                                  int n_parts, const int32_t* __restrict__ paths,
                                                                  const int32_t* __restrict__ n_rows_ptr,
                                                                  const float* __restrict__ drop_mask, int drop_mode,
                                                                  uint64_t seed, uint64_t offset, float* __restrict__ out,
-                                                                 int64_t ld) {
+                                                                 int64_t ld, int run) {
     const int n_rows = n_rows_ptr[0];
     const int lane = threadIdx.x & 63;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
-        const int32_t* p = paths + (size_t)row * PATH_INTS;
-        const int uid = p[0], len = p[1];
-        // rows of the slot tables (nullptr = zero contribution), following pgpr_state_kernel / _get_state
-        const float* src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        src[0] = t.user0 + (size_t)uid * H;
-        auto node_row = [&](int j, const float* tu, const float* te) -> const float* {
-            if (j == 0) return tu + (size_t)uid * H;
-            const int ty = p[2 + 3 * (j - 1) + 1], n = p[2 + 3 * (j - 1) + 2];
-            return (ty == T_USER ? tu : te) + (size_t)n * H;
-        };
-        auto rel_row = [&](int j, const float* tr) -> const float* {
-            const int r = p[2 + 3 * (j - 1)];
-            return r == SELF_LOOP ? nullptr : tr + (size_t)r * H;
-        };
-        if (len == 1) {
-            src[1] = t.cur_u + (size_t)uid * H;
-        } else {
-            src[1] = node_row(len - 1, t.cur_u, t.cur_e);
-            if (n_parts > 2) {
-                src[2] = node_row(len - 2, t.last_u, t.last_e);
-                src[3] = rel_row(len - 1, t.last_r);
-            }
-            if (n_parts > 4 && len >= 3) {
-                src[4] = node_row(len - 3, t.old_u, t.old_e);
-                src[5] = rel_row(len - 2, t.old_r);
-            }
-        }
-        for (int c = lane * 4; c < H; c += 256) {  // H % 4 == 0 (checked by the launcher)
-            f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+    const bool keep = H <= L1_MAX_H;
+    // A wave walks `run` consecutive rows (1 for the small first hops, L1_RUN once there are rows to spare).  The children of one parent path are consecutive (pgpr_expand_kernel) and share
+    // the user row and the last-node row, so those two gathered rows stay in registers while their addresses repeat: two
+    // 2 KB gathers per row instead of four on the last hop, the same additions in the same order.
+    const f32x4* kept_ptr[2] = {nullptr, nullptr};  // the rows held in kept[]: slot 0 (user) and slot 2 (last node)
+    f32x4 kept[2][L1_MAX_H / 256];
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
-                if (src[q]) acc += *reinterpret_cast<const f32x4*>(src[q] + c);
-            float v[4] = {acc.x, acc.y, acc.z, acc.w};
-            // row * H + c is a multiple of 4 (H % 4 == 0, c = 4 * lane + 256 * trip): the four dropout bits of this chunk
-            // are the four words of ONE Philox block (the compiler cannot see that and would evaluate it four times)
-            uint32_t pw[4] = {0u, 0u, 0u, 0u};
-            if (drop_mode == 2) philox_bits4(seed, offset, ((uint64_t)row * H + c) >> 2, pw);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float x = v[k];
-                x = x > 0.f ? x : expm1f(x);
-                const uint64_t idx = (uint64_t)row * H + c + k;
-                if (drop_mode == 1) x *= drop_mask[idx];
-                else if (drop_mode == 2) x = (pw[k] & 1u) ? x * 2.f : 0.f;
-                v[k] = x;
+        for (int t = 0; t < L1_MAX_H / 256; ++t) kept[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk * run < n_rows; chunk += gridDim.x * 4) {
+        for (int row = chunk * run; row < min(n_rows, (chunk + 1) * run); ++row) {
+            const int32_t* p = paths + (size_t)row * PATH_INTS;
+            const int uid = p[0], len = p[1];
+            // rows of the slot tables (nullptr = zero contribution), following pgpr_state_kernel / _get_state
+            const float* src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            src[0] = t.user0 + (size_t)uid * H;
+            auto node_row = [&](int j, const float* tu, const float* te) -> const float* {
+                if (j == 0) return tu + (size_t)uid * H;
+                const int ty = p[2 + 3 * (j - 1) + 1], n = p[2 + 3 * (j - 1) + 2];
+                return (ty == T_USER ? tu : te) + (size_t)n * H;
+            };
+            auto rel_row = [&](int j, const float* tr) -> const float* {
+                const int r = p[2 + 3 * (j - 1)];
+                return r == SELF_LOOP ? nullptr : tr + (size_t)r * H;
+            };
+            if (len == 1) {
+                src[1] = t.cur_u + (size_t)uid * H;
+            } else {
+                src[1] = node_row(len - 1, t.cur_u, t.cur_e);
+                if (n_parts > 2) {
+                    src[2] = node_row(len - 2, t.last_u, t.last_e);
+                    src[3] = rel_row(len - 1, t.last_r);
+                }
+                if (n_parts > 4 && len >= 3) {
+                    src[4] = node_row(len - 3, t.old_u, t.old_e);
+                    src[5] = rel_row(len - 2, t.old_r);
+                }
             }
-            *reinterpret_cast<f32x4*>(out + (size_t)row * ld + c) = f32x4{v[0], v[1], v[2], v[3]};
+            // refresh the kept rows whose address changed (wave-uniform: every lane reads the same path record)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const f32x4* want = reinterpret_cast<const f32x4*>(src[2 * a]);
+                if (keep && want != kept_ptr[a]) {
+                    kept_ptr[a] = want;
+                    if (want) {
+#pragma unroll
+                        for (int tt = 0; tt < L1_MAX_H / 256; ++tt)
+                            if (lane * 4 + 256 * tt < H) kept[a][tt] = want[lane + 64 * tt];
+                    }
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < L1_MAX_H / 256; ++tt) {  // H % 4 == 0, H <= L1_MAX_H when `keep` (checked by the launcher)
+                const int c = lane * 4 + 256 * tt;
+                if (c >= H) break;
+                f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    if (!src[q]) continue;
+                    if (keep && (q == 0 || q == 2)) acc += kept[q >> 1][tt];
+                    else acc += *reinterpret_cast<const f32x4*>(src[q] + c);
+                }
+                l1_finish(acc, row, c, H, drop_mask, drop_mode, seed, offset, out, ld);
+            }
+            if (H > L1_MAX_H)
+                for (int c = lane * 4 + L1_MAX_H; c < H; c += 256) {  // wider hidden layers: the plain loop for the rest
+                    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+                        if (src[q]) acc += *reinterpret_cast<const f32x4*>(src[q] + c);
+                    l1_finish(acc, row, c, H, drop_mask, drop_mode, seed, offset, out, ld);
+                }
         }
     }
 }
@@ -906,6 +953,25 @@ __device__ __forceinline__ void bitonic_sort256(uint32_t (&key)[4], int lane) {
     if constexpr (SIZE < 256) bitonic_sort256<SIZE * 2>(key, lane);
 }
 
+// bitonic sort of one key per lane, descending
+template <int SIZE, int STRIDE>
+__device__ __forceinline__ void sort64_steps(uint32_t& key, int lane) {
+    const uint32_t o = xor_lane<STRIDE>(key, lane);
+    const bool desc = (lane & SIZE) == 0, upper = (lane & STRIDE) != 0;
+    const bool take_max = desc ? !upper : upper;
+    key = take_max ? (key > o ? key : o) : (key < o ? key : o);
+    if constexpr (STRIDE > 1) sort64_steps<SIZE, STRIDE / 2>(key, lane);
+}
+template <int SIZE>
+__device__ __forceinline__ void sort64(uint32_t& key, int lane) {
+    sort64_steps<SIZE, SIZE / 2>(key, lane);
+    if constexpr (SIZE < 64) sort64<SIZE * 2>(key, lane);
+}
+
+// SELECT (k <= 64): the k-th largest key is found by a bit-by-bit search with wave ballots (4 compares per bit, the counting
+// on the scalar unit; the search stops as soon as exactly k keys lie above the candidate), the k survivors are compacted to
+// one per lane and only those 64 are sorted: ~1/3 of the vector instructions of sorting all 256.  Same output.
+template <bool SELECT>
 __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __restrict__ logits, int ld, int act_dim,
                                                                const int32_t* __restrict__ n_acts,
                                                                const int32_t* __restrict__ n_rows_ptr, int k,
@@ -954,20 +1020,58 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
             key[i] = valid ? ((mant << 8) | (uint32_t)(255 - j)) + 0x80000000u : 0u;
         }
         const bool row_has_two = __any(two);
-        bitonic_sort256<2>(key, lane);  // descending overall: element index e = lane * 4 + i
-        // ranks 4*lane .. 4*lane+3 are in key[0..3]; emit the first k
+        auto emit = [&](uint32_t kk, int rnk) {
+            const bool ok = kk != 0u;
+            const int idx = 255 - (int)(kk & 0xFFu);
+            const uint32_t mant = (kk & 0x7FFFFFFFu) >> 8;
+            const float v = (row_has_two && mant == 0x7FFFFFu) ? 2.0f : __uint_as_float(0x3F800000u | mant);
+            out_idx[(size_t)row * k + rnk] = ok ? idx : -1;
+            out_val[(size_t)row * k + rnk] = ok ? v : 0.f;
+        };
+        if constexpr (SELECT) {
+            __shared__ uint32_t surv_all[4][64];
+            uint32_t* surv = surv_all[threadIdx.x >> 6];
+            auto count_ge = [&](uint32_t c) {
+                int n = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rnk = lane * 4 + i;
-            if (rnk < k) {
-                const uint32_t kk = key[i];
-                const bool ok = kk != 0u;
-                const int idx = 255 - (int)(kk & 0xFFu);
-                const uint32_t mant = (kk & 0x7FFFFFFFu) >> 8;
-                const float v = (row_has_two && mant == 0x7FFFFFu) ? 2.0f : __uint_as_float(0x3F800000u | mant);
-                out_idx[(size_t)row * k + rnk] = ok ? idx : -1;
-                out_val[(size_t)row * k + rnk] = ok ? v : 0.f;
+                for (int i = 0; i < 4; ++i) n += __builtin_popcountll(__ballot(key[i] >= c));
+                return n;  // wave-uniform
+            };
+            // valid keys have the top bit set and are distinct; T = the k-th largest of them (all of them if fewer than k)
+            uint32_t T = 0x80000000u;
+            if (count_ge(T) > k) {
+                for (int bit = 30; bit >= 0; --bit) {
+                    const uint32_t cand = T | (1u << bit);
+                    const int c = count_ge(cand);
+                    if (c >= k) T = cand;
+                    if (c == k) break;
+                }
             }
+            surv[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int base = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool sel = key[i] >= T;  // T >= 0x80000000: invalid slots (key 0) never qualify
+                const uint64_t m = __ballot(sel);
+                const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                if (sel) surv[pos] = key[i];
+                base += __builtin_popcountll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t one = surv[lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // the next row of this wave overwrites surv
+            sort64<2>(one, lane);
+            if (lane < k) emit(one, lane);
+        } else {
+            bitonic_sort256<2>(key, lane);  // descending overall: element index e = lane * 4 + i
+            // ranks 4*lane .. 4*lane+3 are in key[0..3]; emit the first k
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (lane * 4 + i < k) emit(key[i], lane * 4 + i);
         }
     }
 }
@@ -1280,11 +1384,12 @@ extern "C" int hw_pgpr_layer1_lookup(const float* const* slot_tables, const floa
     t.last_r = need > 3 ? slot_tables[5] : nullptr;
     t.old_u = need > 6 ? slot_tables[6] : nullptr, t.old_e = need > 6 ? slot_tables[7] : nullptr;
     t.old_r = need > 6 ? slot_tables[8] : nullptr;
-    int64_t grid = (max_rows + 3) / 4;
+    const int run = max_rows >= 65536 ? L1_RUN : 1;  // rows per wave visit: sibling reuse needs runs, small hops need waves
+    int64_t grid = (max_rows + 4 * run - 1) / (4 * run);
     if (grid > 16384) grid = 16384;
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(pgpr_layer1_lookup_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, t, bias,
-                       hidden, 2 + 2 * state_history, paths, n_rows, drop_mask, drop_mode, seed, offset, out, ld);
+                       hidden, 2 + 2 * state_history, paths, n_rows, drop_mask, drop_mode, seed, offset, out, ld, run);
     return HW_LAUNCH_RC();
 }
 
@@ -1298,9 +1403,12 @@ extern "C" int hw_pgpr_policy_topk(const float* logits, int64_t ld, int32_t act_
     if (grid > 16384) grid = 16384;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
-    if (act_dim <= 256 && k > 8)
-        hipLaunchKernelGGL(policy_topk_sort_kernel, dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim, n_acts,
-                           n_rows, k, out_idx, out_val, probs_out);
+    if (act_dim <= 256 && k > 8 && k <= 64)
+        hipLaunchKernelGGL(policy_topk_sort_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim,
+                           n_acts, n_rows, k, out_idx, out_val, probs_out);
+    else if (act_dim <= 256 && k > 8)
+        hipLaunchKernelGGL(policy_topk_sort_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim,
+                           n_acts, n_rows, k, out_idx, out_val, probs_out);
     else if (act_dim <= 256)
         hipLaunchKernelGGL((policy_topk_kernel<4>), dim3((unsigned)grid), dim3(256), 0, st, logits, (int)ld, act_dim,
                            n_acts, n_rows, k, out_idx, out_val, probs_out);
