@@ -753,7 +753,8 @@ __global__ __launch_bounds__(256) void pgpr_layer1_lookup_kernel(L1Tables t, con
     const int n_rows = n_rows_ptr[0];
     const int lane = threadIdx.x & 63;
     const bool keep = H <= L1_MAX_H;
-    // A wave walks `run` consecutive rows (1 for the small first hops, L1_RUN once there are rows to spare).  The children of one parent path are consecutive (pgpr_expand_kernel) and share
+    // A wave walks `run` consecutive rows (1 for the small first hops, L1_RUN once there are rows to spare).  The children
+    // of one parent path are consecutive (pgpr_expand_kernel) and share
     // the user row and the last-node row, so those two gathered rows stay in registers while their addresses repeat: two
     // 2 KB gathers per row instead of four on the last hop, the same additions in the same order.
     const f32x4* kept_ptr[2] = {nullptr, nullptr};  // the rows held in kept[]: slot 0 (user) and slot 2 (last node)
@@ -763,19 +764,26 @@ __global__ __launch_bounds__(256) void pgpr_layer1_lookup_kernel(L1Tables t, con
 #pragma unroll
         for (int t = 0; t < L1_MAX_H / 256; ++t) kept[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk * run < n_rows; chunk += gridDim.x * 4) {
-        for (int row = chunk * run; row < min(n_rows, (chunk + 1) * run); ++row) {
-            const int32_t* p = paths + (size_t)row * PATH_INTS;
-            const int uid = p[0], len = p[1];
+        for (int row_v = chunk * run; row_v < min(n_rows, (chunk + 1) * run); ++row_v) {
+            // the path record in one go, through the scalar unit (the row index is wave-uniform; saying so lets the compiler
+            // use s_load): indexing the record by a length read from it would chain three memory round trips per row
+            const int row = __builtin_amdgcn_readfirstlane(row_v);
+            static_assert(PATH_INTS == 12, "three 16-byte pieces");
+            const int4* pr = reinterpret_cast<const int4*>(paths + (size_t)row * PATH_INTS);
+            const int4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+            const int uid = q0.x, len = q0.y;
+            // hop j = 1..3: (relation, node type, node id)
+            const int hr[3] = {q0.z, q1.y, q2.x}, ht[3] = {q0.w, q1.z, q2.y}, hn[3] = {q1.x, q1.w, q2.z};
+            auto pick = [](const int (&a)[3], int j) { return j == 1 ? a[0] : (j == 2 ? a[1] : a[2]); };
             // rows of the slot tables (nullptr = zero contribution), following pgpr_state_kernel / _get_state
             const float* src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
             src[0] = t.user0 + (size_t)uid * H;
             auto node_row = [&](int j, const float* tu, const float* te) -> const float* {
                 if (j == 0) return tu + (size_t)uid * H;
-                const int ty = p[2 + 3 * (j - 1) + 1], n = p[2 + 3 * (j - 1) + 2];
-                return (ty == T_USER ? tu : te) + (size_t)n * H;
+                return (pick(ht, j) == T_USER ? tu : te) + (size_t)pick(hn, j) * H;
             };
             auto rel_row = [&](int j, const float* tr) -> const float* {
-                const int r = p[2 + 3 * (j - 1)];
+                const int r = pick(hr, j);
                 return r == SELF_LOOP ? nullptr : tr + (size_t)r * H;
             };
             if (len == 1) {
