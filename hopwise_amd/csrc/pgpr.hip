@@ -72,6 +72,27 @@ constexpr int ACT_LDS_KEYS = 4096;  // candidates whose select keys fit in LDS (
 constexpr int TRIM_WAVE_MAX_DEG = 2048;   // rows trimmed by one wave with the keys in registers
 constexpr int TRIM_BLOCK_MAX_DEG = 8192;  // ... by one block, same scheme; beyond: radix select over LDS / scratch keys
 
+// A path record read whole (three 16-byte loads issued together) before any field is used: indexing the record by the length
+// read from it chains memory round trips (len -> hop fields -> CSR pointers -> edges).
+struct PathRec {
+    int uid, len, batch;      // batch = index of the root user in the search (last int of the record)
+    int hr[3], ht[3], hn[3];  // hop j = 1..3 at [j - 1]: relation, node type, node id
+    __device__ __forceinline__ void load(const int32_t* __restrict__ paths, int row) {
+        static_assert(PATH_INTS == 12, "three 16-byte pieces");
+        const int4* pr = reinterpret_cast<const int4*>(paths + (size_t)row * PATH_INTS);
+        const int4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+        uid = q0.x, len = q0.y;
+        hr[0] = q0.z, ht[0] = q0.w, hn[0] = q1.x;
+        hr[1] = q1.y, ht[1] = q1.z, hn[1] = q1.w;
+        hr[2] = q2.x, ht[2] = q2.y, hn[2] = q2.z;
+        batch = q2.w;
+    }
+    __device__ __forceinline__ static int pick(const int (&a)[3], int j) { return j == 1 ? a[0] : (j == 2 ? a[1] : a[2]); }
+    __device__ __forceinline__ int rel(int j) const { return pick(hr, j); }
+    __device__ __forceinline__ int type(int j) const { return pick(ht, j); }
+    __device__ __forceinline__ int node(int j) const { return pick(hn, j); }
+};
+
 // First pass, one WAVE per row and no block barrier: rows whose unvisited neighbours fit max_acts -- 98 % of the rows of
 // a 64/64/64 beam on the ml-1m-shaped graph, median degree 99 -- are finished here in ONE sweep over their edges with
 // ballot / popcount compaction in CSR (= relation, dst) order; rows that overflow max_acts get n_acts = -1 and are queued
@@ -86,18 +107,19 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
-        const int32_t* p = paths + (size_t)row * PATH_INTS;
-        const int uid = p[0], len = p[1];
+        PathRec rec;
+        rec.load(paths, row);
+        const int uid = rec.uid, len = rec.len;
         int cur_t = T_USER, cur_n = uid;
-        if (len > 1) cur_t = p[2 + 3 * (len - 2) + 1], cur_n = p[2 + 3 * (len - 2) + 2];
+        if (len > 1) cur_t = rec.type(len - 1), cur_n = rec.node(len - 1);
         int vt[4], vn[4];  // visited (type, id); wave-uniform
         bool lead = true;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             int t = -1, n = -1;
             if (k == 0) t = T_USER, n = uid;
-            else if (k < len) t = p[2 + 3 * (k - 1) + 1], n = p[2 + 3 * (k - 1) + 2];
-            if (k >= 1 && k < len) lead = lead && p[2 + 3 * (k - 1)] == SELF_LOOP;
+            else if (k < len) t = rec.ht[k - 1], n = rec.hn[k - 1];
+            if (k >= 1 && k < len) lead = lead && rec.hr[k - 1] == SELF_LOOP;
             if ((flags & 2) && k < len && lead) t = -1;  // training: the start user and its self-loop copies (see below)
             vt[k] = t, vn[k] = n;
         }
@@ -250,10 +272,11 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
     for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_rows; it += gridDim.x * 4) {
         const int row = list ? list[it] : it;
         if (n_acts[row] >= 0) continue;  // wave-uniform: finished by the first pass
-        const int32_t* p = paths + (size_t)row * PATH_INTS;
-        const int uid = p[0], len = p[1];
+        PathRec rec;
+        rec.load(paths, row);
+        const int uid = rec.uid, len = rec.len;
         int cur_t = T_USER, cur_n = uid;
-        if (len > 1) cur_t = p[2 + 3 * (len - 2) + 1], cur_n = p[2 + 3 * (len - 2) + 2];
+        if (len > 1) cur_t = rec.type(len - 1), cur_n = rec.node(len - 1);
         const int64_t gid = cur_t == T_USER ? cur_n : (int64_t)g.n_users + cur_n;
         const int64_t lo = g.ptr[gid];
         const int deg = (int)(g.ptr[gid + 1] - lo);
@@ -264,12 +287,12 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
         for (int k = 0; k < 4; ++k) {
             int t = -1, n = -1;
             if (k == 0) t = T_USER, n = uid;
-            else if (k < len) t = p[2 + 3 * (k - 1) + 1], n = p[2 + 3 * (k - 1) + 2];
-            if (k >= 1 && k < len) lead = lead && p[2 + 3 * (k - 1)] == SELF_LOOP;
+            else if (k < len) t = rec.ht[k - 1], n = rec.hn[k - 1];
+            if (k >= 1 && k < len) lead = lead && rec.hr[k - 1] == SELF_LOOP;
             if ((flags & 2) && k < len && lead) t = -1;
             vt[k] = t, vn[k] = n;
         }
-        const int b = p[PATH_INTS - 1];
+        const int b = rec.batch;
         const double* __restrict__ su = score_user + (size_t)b * g.n_users;
         const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
         const int32_t* __restrict__ erel = g.rel + lo;
@@ -392,10 +415,11 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
     for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
         const int row = list ? list[it] : it;
         if (n_acts[row] >= 0) continue;  // block-uniform
-        const int32_t* p = paths + (size_t)row * PATH_INTS;
-        const int uid = p[0], len = p[1];
+        PathRec rec;
+        rec.load(paths, row);
+        const int uid = rec.uid, len = rec.len;
         int cur_t = T_USER, cur_n = uid;
-        if (len > 1) cur_t = p[2 + 3 * (len - 2) + 1], cur_n = p[2 + 3 * (len - 2) + 2];
+        if (len > 1) cur_t = rec.type(len - 1), cur_n = rec.node(len - 1);
         const int64_t gid = cur_t == T_USER ? cur_n : (int64_t)g.n_users + cur_n;
         const int64_t lo = g.ptr[gid];
         const int deg = (int)(g.ptr[gid + 1] - lo);
@@ -406,12 +430,12 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
         for (int k = 0; k < 4; ++k) {
             int t = -1, n = -1;
             if (k == 0) t = T_USER, n = uid;
-            else if (k < len) t = p[2 + 3 * (k - 1) + 1], n = p[2 + 3 * (k - 1) + 2];
-            if (k >= 1 && k < len) lead = lead && p[2 + 3 * (k - 1)] == SELF_LOOP;
+            else if (k < len) t = rec.ht[k - 1], n = rec.hn[k - 1];
+            if (k >= 1 && k < len) lead = lead && rec.hr[k - 1] == SELF_LOOP;
             if ((flags & 2) && k < len && lead) t = -1;
             vt[k] = t, vn[k] = n;
         }
-        const int b = p[PATH_INTS - 1];
+        const int b = rec.batch;
         const double* __restrict__ su = score_user + (size_t)b * g.n_users;
         const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
         const int32_t* __restrict__ erel = g.rel + lo;
