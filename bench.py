@@ -445,6 +445,10 @@ def leg_roofline_variants(D, args, out, ctx):
                     "own tables (32 MB) never leave L2 / Infinity Cache, so its launch is reported under configs1_launch "
                     "against the L2 gather ceiling instead",
         "gather_ceiling_note": "the guide's measured random-row gather from HBM is 5.5-5.8 TB/s (1.1-2.3 KB rows)",
+        "traffic_note": "traffic / algorithmic = 1.14: an 800-byte row (d = 200 floats) always occupies 7 lines of 128 B "
+                        "(6.25 needed) whatever its alignment, and RotatE reads two such rows (re, im tables) per tail: 14 lines "
+                        "for 1 600 B = 1.12x, plus the id matrix and the scores.  Not re-reads; storing re | im interleaved in one "
+                        "1 600-byte row (13 lines) is the remaining layout lever (DESIGN.md \u00a78)",
     }
     cfg1 = out["roofline"].pop("configs1_launch")
     ent = out["roofline"].pop("entity_tails")
