@@ -10,9 +10,10 @@ One *batch* = one pass of the scoring hot path over 2048 (user, positive item) g
     2. grouped RotatE scorer over 2048 x (1 + 256) = 526 336 (h, r, t) triples;
     3. self-adversarial negative-weighting loss over the [2048, 257] scores
    -- all three in ONE launch (hw_kge_score_grouped_sampled_selfadv_chained: the one-block sum of batch i's 2048 group
-   terms rides in block 0 of batch i + 1's launch, the step's last one is flushed by hw_selfadv_finish inside the timed
+   terms rides in block 0 of the next launch, the step's last ones are flushed by hw_selfadv_finish inside the timed
    region; --unchained-loss / --unfused-loss / --unfused-sampler run the pieces as the separate launches they equal bit
-   for bit).
+   for bit).  Consecutive batches go to alternating HIP streams (--streams, default 2; own id / score buffers per stream):
+   a launch is one generation of workgroups, and the next batch fills its ramp-up and tail.
 One *step* = `batches_per_step` such batches back to back (chosen so that the K timed steps hold >= 0.75 s of GPU
 work whatever K is: a lone batch is 66 us).  value = triples scored per second over the whole job (all ranks).
 
@@ -67,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-tucker", action="store_true")
     ap.add_argument("--unfused-sampler", action="store_true", help="run hw_neg_sample as its own launch before the scorer")
     ap.add_argument("--unfused-loss", action="store_true", help="run hw_loss_self_adversarial as its own launches after the scorer")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the timed batches alternate over (each with its own id / score buffers and loss chain)")
     ap.add_argument("--unchained-loss", action="store_true",
                     help="finish every batch's loss with its own one-block launch instead of inside the next batch's launch")
     ap.add_argument("--pgpr-steps", type=int, default=5)
@@ -202,78 +205,95 @@ def leg_kge(D, args, out):
     pos = torch.from_numpy(kg.inter_items[pick]).to(dev)
     uptr, uidx = synthetic.used_csr(kg.inter_users, kg.inter_items, kg.n_users)
     uptr, uidx = torch.from_numpy(uptr).to(dev), torch.from_numpy(uidx).to(dev)
-    t_idx = torch.empty((B_POS, 1 + K_NEG), dtype=torch.int64, device=dev)  # one row of tail ids per (h, r) group
-    t_idx[:, 0] = pos
-    neg_view = t_idx[:, 1:]
-
     lib = _lib.load()
-    scores = torch.empty((B_POS, 1 + K_NEG), dtype=torch.float32, device=dev)
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
     ws = torch.empty(int(lib.hw_loss_workspace_floats()) + B_POS, dtype=torch.float32, device=dev)
     oob = torch.zeros(1, dtype=torch.int32, device=dev)
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: C.c_void_p(t.data_ptr())
     seed = C.c_uint64(2024 + 7919 * rank)  # per-rank Philox key (streams keyed by (seed, rank, step))
-    samp_head = (P(uptr), P(uidx), uptr.numel() - 1, P(users), B_POS, K_NEG, kg.n_items, None, None, None, 0, seed)
-    samp_tail = (P(neg_view), neg_view.stride(0), neg_view.stride(1), P(oob), stream)
-    score_args = (C.byref(desc), P(users), None, kg.ui_relation, P(t_idx), t_idx.stride(0), t_idx.stride(1), B_POS,
-                  1 + K_NEG, P(scores), scores.stride(0), scores.stride(1), P(oob), stream)
-    loss_args = (P(scores), B_POS, 1 + K_NEG, C.c_float(1.0), P(loss), None, P(ws), stream)
     fused = not args.unfused_sampler
-    fused_args = (C.byref(desc), P(users), None, kg.ui_relation, P(t_idx), t_idx.stride(0), t_idx.stride(1), B_POS,
-                  1 + K_NEG, P(uptr), P(uidx), uptr.numel() - 1, P(users), kg.n_items, seed)
-    fused_tail = (P(scores), scores.stride(0), scores.stride(1), P(oob), stream)
-    # ... and the loss inside the same launch (the block that scores a group reduces it, the last block sums the groups):
-    # hw_kge_score_grouped_sampled_selfadv = the two calls below it, bit for bit (tests/test_gpu_sampler.py)
     fused_loss = fused and not args.unfused_loss
-    group_ws = torch.empty(B_POS, dtype=torch.float32, device=dev)
-    counter = torch.zeros(1, dtype=torch.int32, device=dev)
-    loss_tail = (P(scores), scores.stride(0), scores.stride(1), C.c_float(1.0), P(loss), P(group_ws), P(counter), P(oob),
-                 stream)
-    if fused_loss and lib.hw_kge_score_grouped_sampled_selfadv(*fused_args, C.c_uint64(0), *loss_tail) != 0:
-        fused_loss = False
-    # ... and as a chain over the stream of batches (--unchained-loss: one finish launch per batch): batch i's 2048 group
-    # terms are added by block 0 of batch i + 1's launch, the last batch's by hw_selfadv_finish inside the timed region, so
-    # every batch's loss exists when the clock stops (tests/test_gpu_sampler.py: equal to the unchained losses bit for bit)
     chained = fused_loss and not args.unchained_loss
-    group_ws2 = (group_ws, torch.empty(B_POS, dtype=torch.float32, device=dev))
-    chain = {"cur": 0, "pending": False}
-    chain_head = (P(scores), scores.stride(0), scores.stride(1), C.c_float(1.0))
 
-    def chained_batch(i):
-        cur = chain["cur"]
-        prev = (P(group_ws2[cur ^ 1]), B_POS, P(loss)) if chain["pending"] else (None, 0, None)
-        rc = lib.hw_kge_score_grouped_sampled_selfadv_chained(*fused_args, C.c_uint64(i), *chain_head, P(group_ws2[cur]),
-                                                              *prev, P(oob), stream)
-        chain["cur"], chain["pending"] = cur ^ 1, True
+    # Lanes: batch i is launched on HIP stream i % n_lanes, each lane with its own id matrix, score matrix, loss slot and
+    # loss chain.  One launch is exactly one generation of workgroups (2048 groups = 256 CUs x 8), so a lone stream leaves
+    # the ramp-up, the tail and the gap between launches idle; the next batch on a second stream fills them (51 -> 40 us per
+    # batch).  --streams 1 is the single-stream schedule.
+    class Lane:
+        pass
+
+    def make_lane(torch_stream):
+        ln = Lane()
+        ln.torch_stream = torch_stream
+        ln.stream = C.c_void_p(torch_stream.cuda_stream)
+        ln.t_idx = torch.empty((B_POS, 1 + K_NEG), dtype=torch.int64, device=dev)  # one row of tail ids per (h, r) group
+        ln.t_idx[:, 0] = pos
+        neg_view = ln.t_idx[:, 1:]
+        ln.scores = torch.empty((B_POS, 1 + K_NEG), dtype=torch.float32, device=dev)
+        ln.loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ln.ws = torch.empty_like(ws)
+        ln.group_ws = (torch.empty(B_POS, dtype=torch.float32, device=dev), torch.empty(B_POS, dtype=torch.float32, device=dev))
+        ln.cur, ln.pending = 0, False
+        t, sc = ln.t_idx, ln.scores
+        ln.samp_head = (P(uptr), P(uidx), uptr.numel() - 1, P(users), B_POS, K_NEG, kg.n_items, None, None, None, 0, seed)
+        ln.samp_tail = (P(neg_view), neg_view.stride(0), neg_view.stride(1), P(oob), ln.stream)
+        ln.score_args = (C.byref(desc), P(users), None, kg.ui_relation, P(t), t.stride(0), t.stride(1), B_POS, 1 + K_NEG, P(sc),
+                         sc.stride(0), sc.stride(1), P(oob), ln.stream)
+        ln.loss_args = (P(sc), B_POS, 1 + K_NEG, C.c_float(1.0), P(ln.loss), None, P(ln.ws), ln.stream)
+        # sampler + scorer in one launch ...
+        ln.fused_args = (C.byref(desc), P(users), None, kg.ui_relation, P(t), t.stride(0), t.stride(1), B_POS, 1 + K_NEG,
+                         P(uptr), P(uidx), uptr.numel() - 1, P(users), kg.n_items, seed)
+        ln.fused_tail = (P(sc), sc.stride(0), sc.stride(1), P(oob), ln.stream)
+        # ... and the loss inside the same launch (the block that scores a group reduces it):
+        # hw_kge_score_grouped_sampled_selfadv = the separate calls, bit for bit (tests/test_gpu_sampler.py) ...
+        ln.loss_tail = (P(sc), sc.stride(0), sc.stride(1), C.c_float(1.0), P(ln.loss), P(ln.group_ws[0]), None, P(oob), ln.stream)
+        # ... and as a chain over the lane's batches (--unchained-loss: one finish launch per batch): batch i's 2048 group
+        # terms are added by block 0 of the lane's next launch, the last one by hw_selfadv_finish inside the timed region, so
+        # every batch's loss exists when the clock stops (equal to the unchained losses bit for bit, same test file)
+        ln.chain_head = (P(sc), sc.stride(0), sc.stride(1), C.c_float(1.0))
+        return ln
+
+    n_lanes = max(1, args.streams)
+    lanes = [make_lane(torch.cuda.current_stream() if n_lanes == 1 else torch.cuda.Stream()) for _ in range(n_lanes)]
+    solo = lanes[0] if n_lanes == 1 else make_lane(torch.cuda.current_stream())  # single-stream launches (calibration, later legs)
+    torch.cuda.synchronize()
+    if fused_loss and lib.hw_kge_score_grouped_sampled_selfadv(*solo.fused_args, C.c_uint64(0), *solo.loss_tail) != 0:
+        fused_loss = chained = False
+
+    def chained_batch(ln, i):
+        prev = (P(ln.group_ws[ln.cur ^ 1]), B_POS, P(ln.loss)) if ln.pending else (None, 0, None)
+        rc = lib.hw_kge_score_grouped_sampled_selfadv_chained(*ln.fused_args, C.c_uint64(i), *ln.chain_head,
+                                                              P(ln.group_ws[ln.cur]), *prev, P(oob), ln.stream)
+        ln.cur, ln.pending = ln.cur ^ 1, True
         return rc
 
-    def chain_flush():
-        if chain["pending"]:
-            if lib.hw_selfadv_finish(P(group_ws2[chain["cur"] ^ 1]), B_POS, P(loss), stream):
-                raise RuntimeError("hw_selfadv_finish failed")
-            chain["pending"] = False
+    def chain_flush(which=None):
+        for ln in (which or lanes):
+            if ln.pending:
+                if lib.hw_selfadv_finish(P(ln.group_ws[ln.cur ^ 1]), B_POS, P(ln.loss), ln.stream):
+                    raise RuntimeError("hw_selfadv_finish failed")
+                ln.pending = False
 
     events = []
 
-    def batch(i, ev=None):
+    def batch(i, ev=None, ln=None):
+        ln = ln or lanes[i % n_lanes]
         rc = 0
         if not fused:
-            rc = lib.hw_neg_sample(*samp_head, C.c_uint64(i), *samp_tail)
+            rc = lib.hw_neg_sample(*ln.samp_head, C.c_uint64(i), *ln.samp_tail)
         if ev is not None:
-            ev[0].record()
+            ev[0].record(ln.torch_stream)
         if chained:
-            rc |= chained_batch(i)
+            rc |= chained_batch(ln, i)
         elif fused_loss:
-            rc |= lib.hw_kge_score_grouped_sampled_selfadv(*fused_args, C.c_uint64(i), *loss_tail)
+            rc |= lib.hw_kge_score_grouped_sampled_selfadv(*ln.fused_args, C.c_uint64(i), *ln.loss_tail)
         elif fused:
-            rc |= lib.hw_kge_score_grouped_sampled(*fused_args, C.c_uint64(i), *fused_tail)
+            rc |= lib.hw_kge_score_grouped_sampled(*ln.fused_args, C.c_uint64(i), *ln.fused_tail)
         else:
-            rc |= lib.hw_kge_score_grouped(*score_args)
+            rc |= lib.hw_kge_score_grouped(*ln.score_args)
         if ev is not None:
-            ev[1].record()
+            ev[1].record(ln.torch_stream)
         if not fused_loss:
-            rc |= lib.hw_loss_self_adversarial(*loss_args)
+            rc |= lib.hw_loss_self_adversarial(*ln.loss_args)
         if rc:
             raise RuntimeError(f"launch failed: {rc}")
 
@@ -313,8 +333,21 @@ def leg_kge(D, args, out):
 
     with torch.no_grad():
         dt = timed(D, step, args.steps, args.warmup)
-    assert torch.isfinite(loss).all().item()
+    assert all(torch.isfinite(ln.loss).all().item() for ln in lanes)
     assert int(oob.item()) == 0 and ops.oob_count(dev) == 0
+    # the launch by itself: the same kernel back to back on ONE stream, event pairs around every 4th launch (untimed pass)
+    overlapped_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else None
+    if n_lanes > 1:
+        events.clear()
+        for j in range(64 + 512):
+            ev = None
+            if j >= 64 and j % 4 == 0:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                events.append(ev)
+            batch(10 ** 6 + j, ev, solo)
+        chain_flush([solo])
+        torch.cuda.synchronize()
+    t_idx, scores, loss = solo.t_idx, solo.scores, solo.loss
 
     triples_per_batch = B_POS * (1 + K_NEG)
     triples_per_step = triples_per_batch * inner
@@ -351,6 +384,7 @@ def leg_kge(D, args, out):
             "n_users": kg.n_users, "n_items": kg.n_items, "n_entities": kg.n_entities, "n_relations": kg.n_relations,
             "triples_per_batch": triples_per_batch, "batches_per_step": inner, "triples_per_step": triples_per_step,
             "us_per_batch": dt / args.steps / inner * 1e6,
+            "streams": n_lanes,
             "launches_per_batch": ("1 (sampler + scorer + loss; the 2048-term sum of a batch rides in the next batch's launch, "
                                    "one hw_selfadv_finish per step)" if chained else
                                    "2 (sampler + scorer + per-group loss, one-block finish)" if fused_loss else
@@ -366,9 +400,19 @@ def leg_kge(D, args, out):
         "event_pair_ms_raw": kern_ms_raw, "empty_event_pair_ms": pair_overhead_ms,
         "algorithmic_bytes_per_launch": abytes, "events": len(events),
         "scorer_only_triples_per_s": triples_per_batch / (kern_ms * 1e-3),
-        "note": "the launch of the timed region: its 4.8 MB of tail rows are served by the XCDs' L2s, so the ceiling is the "
-                "guide's L2 gather rate (16.8-18.8 TB/s chip-wide), not HBM; the kernel is load-issue bound there",
+        "note": "the launch of the timed region, measured back to back on ONE stream (untimed pass after the timed region when "
+                "the timed batches alternate over several streams): its 4.8 MB of tail rows are served by the XCDs' L2s, so "
+                "the ceiling is the guide's L2 gather rate (16.8-18.8 TB/s chip-wide), not HBM; the kernel is load-issue bound there",
     }
+    if n_lanes > 1:
+        us = dt / args.steps / inner * 1e6
+        l2["overlapped"] = {
+            "streams": n_lanes, "us_per_batch": us, "launch_ms_under_overlap": overlapped_ms,
+            "aggregate_algorithmic_GBps": abytes / (us * 1e-6) / 1e9,
+            "note": "timed region: consecutive batches on alternating HIP streams.  One launch is exactly one generation of "
+                    "workgroups, so a lone stream idles during ramp-up, tail and the launch gap; a second stream fills them.  "
+                    "The aggregate rate is bytes per batch / wall time per batch, not a per-launch figure (a launch takes "
+                    "launch_ms_under_overlap while it shares the chip)"}
     out["roofline"] = {"configs1_launch": l2}
     ctx = dict(kg=kg, head=head, rel=rel, tail=tail, users=users, t_idx=t_idx, desc=desc, abytes=abytes,
                triples_per_batch=triples_per_batch, traffic=traffic, tabs=(user_re, user_im, theta, ent_re, ent_im))
