@@ -128,7 +128,7 @@ def run(dev, n_users=32, steps=5, warmup=1, cpu_users=0, rank=0):
             "frac": abytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_search": abytes, "traffic": None,
             "note": "SURVEY §8(d) config 3 byte sum over the parent rows of all three hops (CSR slice + candidate rows of "
                     "over-full nodes + state gather + probs + children) / wall time of the whole search (21 launches).  The "
-                    "search is not one bandwidth-bound kernel: 43 % of it is the policy MLP's small GEMMs and the rest is "
+                    "search is not one bandwidth-bound kernel: 35-40 % of it is the policy MLP's GEMMs and the rest is "
                     "L2-gather / issue bound (DESIGN.md §4), so this fraction is a reported figure, not a target",
         },
     }
