@@ -128,23 +128,24 @@ __device__ __forceinline__ void put_tile(const f32x4 (&v)[2], int K, int k0, flo
 // the split), which the FMA loop would not: operands are embeddings and activations.
 // LDS: per stage and operand three plane images [128 rows][16 k] bf16 (32-byte rows); the MFMA fragment of lane (r, h) is the
 // 16 bytes k = 8 h .. 8 h + 7 of row r, stored at half h ^ ((r >> 3) & 1) so that the four 16-lane groups of a ds_read_b128
-// touch 16 distinct 16-byte slots of the 256-byte bank row.  2 stages x 2 operands x 3 planes x 4 KB = 48 KB: 3 blocks per CU
-// (60 KB and 2 blocks with k-major operands, below).
+// touch 16 distinct 16-byte slots of the 256-byte bank row.  2 stages x 2 operands x 3 planes x 4 KB = 48 KB: 3 blocks per CU.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // A k-major operand (stored [K, rows]) keeps k-major plane images [16 k][128 rows] bf16 -- a thread's float4 (four rows at
 // one k) is one 8-byte store per plane -- and its fragments come back through ds_read_b64_tr_b16, the transposing read: a
 // 16-lane group fetches 4 k-rows x 16 columns and lane i receives column i's four k, so two reads (k = 8 h + 0..3, + 4..7)
-// make the lane's 8-k fragment.  k-rows are 320 bytes apart (256 + 64): the four k-rows of a read then fall on disjoint
-// 16-dword bank ranges.
+// make the lane's 8-k fragment (bank placement: below).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-constexpr int SPLIT_PLANE_KC = 128 * 16 * 2, SPLIT_KM_ROW = 320, SPLIT_PLANE_KM = 16 * SPLIT_KM_ROW;
+// A k-major image's k-rows are 256 bytes (one bank row), so the 64-byte chunks of k-row k are stored at chunk ^ (k & 3): the
+// four k-rows of a transposing read then fall on disjoint 16-dword bank ranges, and an 8-byte piece stays whole.
+constexpr int SPLIT_PLANE = 128 * 16 * 2, SPLIT_KM_ROW = 256;
 template <bool KC>
 struct SplitImg {
-    static constexpr int PLANE = KC ? SPLIT_PLANE_KC : SPLIT_PLANE_KM;
+    static constexpr int PLANE = SPLIT_PLANE;
     static constexpr int OPERAND = 3 * PLANE;
 };
+__device__ __forceinline__ int split_km_off(int k, int col) { return k * SPLIT_KM_ROW + ((col * 2) ^ ((k & 3) << 6)); }
 
 __device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
     const f32x2 v = {x0, x1};
@@ -178,7 +179,7 @@ __device__ __forceinline__ void put_tile_split(const f32x4 (&v)[2], int K, int k
             const int k = f >> 5, rq = (f & 31) * 4;
             const bool live = FULL || k0 + k < K;
             x0 = live ? v[i].x : 0.f, x1 = live ? v[i].y : 0.f, x2 = live ? v[i].z : 0.f, x3 = live ? v[i].w : 0.f;
-            dst = img + k * SPLIT_KM_ROW + rq * 2;
+            dst = img + split_km_off(k, rq);
         }
         uint32_t h0, m0, l0, h1, m1, l1;
         split_pair(x0, x1, h0, m0, l0);
@@ -198,7 +199,7 @@ __device__ __forceinline__ bf16x8 read_frag_split(const uint8_t* __restrict__ pl
         // group g = lane >> 4 covers tile rows 16 (g & 1) .. + 15 at k = 8 (g >> 1) ..; lane 4 q + p of the group addresses
         // k-row q, columns 4 p .. 4 p + 3 of the block
         const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-        const uint8_t* a = plane + (8 * (g >> 1) + q) * SPLIT_KM_ROW + (base + 16 * (g & 1) + 4 * pp) * 2;
+        const uint8_t* a = plane + split_km_off(8 * (g >> 1) + q, base + 16 * (g & 1) + 4 * pp);  // k + 4: same k & 3
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * SPLIT_KM_ROW));
