@@ -425,6 +425,36 @@ def merge_topk(local_vals, local_ids, k, group=None, topk_fn=None):
     return tv, torch.gather(i, 1, ti.clamp_min(0))
 
 
+# ---- replicas: the PGPR / CAFE / TPRec searches (graph, tables and policy replicated, users partitioned,
+# no collective inside a search; only the per-user results are gathered for the metrics) --------------------------------------
+def replica_users(users, group=None):
+    """This rank's share of an evaluation batch of users: positions rank, rank + P, ... (round-robin, so every rank gets the
+    same count +- 1 whatever the order of `users`)."""
+    rank, P = world(group)
+    return users[rank::P]
+
+
+def gather_user_results(local, n_total, group=None, fill=0):
+    """Inverse of replica_users for per-user result rows: `local` [ceil-or-floor(n_total / P), ...] on every rank -> the
+    [n_total, ...] tensor in the original user order, on every rank.  Ranks with one row fewer are padded for the
+    fixed-size all_gather and the padding is dropped."""
+    rank, P = world(group)
+    if P == 1:
+        return local
+    per = (n_total + P - 1) // P
+    pad = local
+    if local.shape[0] < per:
+        pad = torch.cat([local, torch.full((per - local.shape[0],) + tuple(local.shape[1:]), fill, dtype=local.dtype,
+                                           device=local.device)])
+    parts = [torch.empty_like(pad) for _ in range(P)]
+    all_gather(parts, pad.contiguous(), group)
+    out = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(P):
+        n_r = len(range(r, n_total, P))
+        out[r::P] = parts[r][:n_r]
+    return out
+
+
 def max_over_ranks(seconds, device, group=None):
     rank, P = world(group)
     if P == 1:

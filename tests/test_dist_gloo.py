@@ -235,7 +235,17 @@ def _worker(rank, world_size, port, tmp):
         rv, ri = okge.topk_desc(scores, 6)
         assert np.array_equal(ti.numpy(), ri) and np.array_equal(tv.numpy(), rv)
 
-        # ---- 4. timing helper -----------------------------------------------------------------------------------
+        # ---- 4. replicas (the PGPR searches): round-robin user partition, per-user rows back in the original order ----
+        users = torch.arange(100, 100 + 37)
+        for n_total in (37, 36, 1):
+            u = users[:n_total]
+            mine_u = par.replica_users(u)
+            assert mine_u.tolist() == u.tolist()[rank::world_size]
+            res = torch.stack([mine_u * 3, mine_u + 7], dim=1)  # any per-user rows
+            got = par.gather_user_results(res, n_total)
+            assert got.tolist() == torch.stack([u * 3, u + 7], dim=1).tolist()
+
+        # ---- 5. timing helper -----------------------------------------------------------------------------------
         assert par.max_over_ranks(1.0 + rank, torch.device("cpu")) == float(world_size)
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
