@@ -494,6 +494,14 @@ def leg_roofline_variants(D, args, out, ctx):
                         "for 1 600 B = 1.12x, plus the id matrix and the scores.  Not re-reads; storing re | im interleaved in one "
                         "1 600-byte row (13 lines) is the remaining layout lever (DESIGN.md \u00a78)",
     }
+    # "also report vs a measured device-to-device copy on the box" -- one big table copied onto the other
+    # (2.1 GB read + 2.1 GB written per copy), timed like the kernels
+    cms, creps = _time_kernel(torch, lambda: big_im.copy_(big_re), min_seconds=0.15, reps0=5)
+    copy_gbs = 2 * big_re.numel() * 4 / (cms * 1e-3) / 1e9
+    rec["measured_copy"] = {"GBps": copy_gbs, "ms": cms, "copies": creps, "bytes_moved_per_copy": 2 * big_re.numel() * 4,
+                            "achieved_over_copy": ach / copy_gbs,
+                            "note": "torch copy_ of one 2.1 GB table onto the other (read + write counted): what a plain "
+                                    "streaming kernel moves on this box, next to the 8 TB/s vendor peak"}
     cfg1 = out["roofline"].pop("configs1_launch")
     ent = out["roofline"].pop("entity_tails")
     out["roofline"] = {**rec, "configs1_launch": cfg1, "entity_tails": ent}
