@@ -633,7 +633,9 @@ def leg_sharded(D, args):
         adt = D.reduce(time.perf_counter() - t0, "max") / reps
         res["exchange"]["all_to_all_alone"] = {"message_bytes": buf.numel() * 4, "ms": adt * 1e3,
                                               "egress_GBps_per_gpu": remote * buf.numel() * 4 / adt / 1e9,
-                                              "peak_GBps_per_gpu": 7 * 153.0}
+                                              "egress_GBps_per_link": remote * buf.numel() * 4 / adt / 1e9 / (P - 1),
+                                              "peak_GBps_per_link": 153.0, "peak_GBps_per_gpu": 7 * 153.0,
+                                              "links_used": P - 1}
     # sharded evaluation: 256 users x all items, local top-10 per rank + merge
     users = torch.from_numpy(np.random.default_rng(5).integers(1, nU, 256)).to(dev)
     hr = torch.arange(256, device=dev).repeat_interleave(50)
