@@ -26,7 +26,8 @@ row gradients + all-reduce of the replicated relation tables inside the timed st
 
 Legs in the JSON line: `roofline` (the scorer kernel: HBM-resident variant as the roofline of record, the configs[1]
 launch against the L2 gather ceiling, the entity-tail variants), `cpu_baseline` (oracle/kge_ref.c on the host
-cores), `sharded` (configs[3]), `tucker` (configs[4], N = 1), `pgpr` (configs[2]).
+cores), `sharded` (configs[3]), `tucker` (configs[4], N = 1), `reference_layout` (configs[1] in the reference's batch
+layout through the model class, N = 1), `pgpr` (configs[2]).
 """
 
 import argparse
@@ -719,6 +720,76 @@ def leg_tucker(D, args):
     return res
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[1], shape (i) of SURVEY §8(d): the reference's own batch layout through the model class
+# ---------------------------------------------------------------------------------------------------------------------
+def leg_reference_layout(D, args):
+    """RotatE d=200, sample_num=256 in the layout hopwise's KnowledgeBasedDataLoader yields: rec side 8 positives x 256
+    negatives tiled (2048 rows) + kg side 2048 x (1 pos + 1 neg) = 8 192 scored triples per calculate_loss, through
+    hopwise_amd.model.RotatE (the drop-in class): forward, and forward + backward + dense Adam (the trainer's step)."""
+    import numpy as np
+
+    torch, dev = D.torch, D.dev
+    import hopwise_amd.model as M
+    from hopwise_amd.optim import FusedAdam
+    from tests.helpers import FakeDataset, make_config
+
+    nU, nI, nE, nR, K, B = 6041, 2985, 13805, 13, 256, 2048
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    m = M.RotatE(make_config(dev, DIM, 1.0, train_neg_sample_args={"sample_num": K}), FakeDataset(nU, nI, nE, nR)).to(dev)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    pos_n = B // K
+    users, pos = rng.integers(1, nU, pos_n), rng.integers(1, nI, pos_n)
+    it = {k: torch.from_numpy(v).to(dev) for k, v in dict(
+        user_id=np.tile(users, K), item_id=np.tile(pos, K), neg_item_id=rng.integers(1, nI, B),
+        head_id=rng.integers(1, nE, B), relation_id=rng.integers(1, nR - 1, B), tail_id=rng.integers(1, nE, B),
+        neg_tail_id=rng.integers(1, nE, B)).items()}
+    res = {"metric": "RotatE d=200 calculate_loss in the reference's batch layout (8 192 triples per step), model-class path",
+           "triples_per_step": 4 * B}
+
+    def fwd():
+        with torch.no_grad():
+            return m.calculate_loss(it)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = m.calculate_loss(it)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for name, fn in (("forward", fwd), ("forward_backward_adam", step)):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        res[name] = {"ms": dt * 1e3, "triples_per_s": 4 * B / dt}
+    # the same step captured once and replayed from a HIP graph (the eager step is host-bound: ~0.1 ms of GPU work behind
+    # the Python / autograd dispatch)
+    from hopwise_amd.driver import GraphedTrainStep
+
+    gstep = GraphedTrainStep(m, opt, it)
+    for _ in range(10):
+        gstep(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        gstep(it)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 300
+    res["forward_backward_adam_graph_replay"] = {"ms": dt * 1e3, "triples_per_s": 4 * B / dt}
+    res["note"] = "eager steps are host-bound; BASELINE.md's CPU probe of the reference: 0.52 M triples/s forward, 0.24 M forward+backward"
+    del gstep, m, opt
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -751,6 +822,7 @@ def main():
         guarded("sharded", lambda: leg_sharded(D, args))
     if D.world == 1 and not args.no_tucker:
         guarded("tucker", lambda: leg_tucker(D, args))
+        guarded("reference_layout", lambda: leg_reference_layout(D, args))
     if not args.no_pgpr:
         # second half of BASELINE.json's metric: PGPR paths expanded / s (configs[2]); every rank searches its own users
         import bench_pgpr
