@@ -492,8 +492,9 @@ def leg_roofline_variants(D, args, out, ctx):
         "gather_ceiling_note": "the guide's measured random-row gather from HBM is 5.5-5.8 TB/s (1.1-2.3 KB rows)",
         "traffic_note": "traffic / algorithmic = 1.14: an 800-byte row (d = 200 floats) always occupies 7 lines of 128 B "
                         "(6.25 needed) whatever its alignment, and RotatE reads two such rows (re, im tables) per tail: 14 lines "
-                        "for 1 600 B = 1.12x, plus the id matrix and the scores.  Not re-reads; storing re | im interleaved in one "
-                        "1 600-byte row (13 lines) is the remaining layout lever (DESIGN.md \u00a78)",
+                        "for 1 600 B = 1.12x, plus the id matrix and the scores.  Not re-reads, and not what bounds the launch: "
+                        "with re | im interleaved in one 1 600-byte row (13 lines; row-strided descriptor, measured) the same "
+                        "launch takes the same 153.8 us (DESIGN.md \u00a78)",
     }
     # the same launches alternating over two streams (what the timed region of the headline does): aggregate rate only --
     # the roofline of record stays the lone launch above
