@@ -44,7 +44,10 @@ __global__ void rel_replica_reduce_kernel(const float* __restrict__ rep, int n_t
     float s = 0.f;
     for (int q = 0; q < REL_REPLICAS; ++q) s += rep[((size_t)q * n_tables + k) * row_len + c];
     float* gdst = k == 0 ? g0 : (k == 1 ? g1 : g2);
-    if (gdst) gdst[(size_t)r_fixed * row_len + c] += s;
+    // an atomic like every other access to a gradient table between its clear and its consumer (the kg-side launch of
+    // the same step adds to other rows of the same lines): one access class per buffer, no plain read-modify-write of a
+    // line that memory-side atomics have just updated
+    if (gdst) atomicAdd(gdst + (size_t)r_fixed * row_len + c, s);
 }
 
 template <int MODEL, int NE>
