@@ -310,6 +310,98 @@ def gen_tucker(out_dir):
         print("tucker", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks))
 
 
+WIDE = dict(nU=300, nI=170, nE=900, nR=9, d=200, b_rec=40, b_kg=44, core_seed=20200, core_scale=0.05, stride=5)
+
+
+def wide_core(seed, d, scale):
+    """The [d, d, d] core of the d = 200 golden, regenerated by the tests instead of stored (32 MB): numpy's frozen legacy
+    MT19937 stream (RandomState is guaranteed stable across numpy versions), scaled like a trained core."""
+    return (np.random.RandomState(seed).uniform(-1.0, 1.0, (d, d, d)) * scale).astype(np.float32)
+
+
+def gen_tucker_wide(out_dir):
+    """TuckER at BASELINE configs[4]'s width (d = 200) on a small ragged id space: the reference's eval-mode outputs, loss and
+    gradients, and one training-mode step with recorded dropout masks.  Kept small by NOT storing what can be regenerated or
+    summarised: the core tensor comes from `wide_core` (seed stored, probe values stored to validate the regeneration), the
+    [B, d, d] dropout masks are stored as packed bits, and the core gradient as its [::5, ::5, ::5] sample plus float64 sums."""
+    import torch.nn.functional as F
+    from hopwise.model.knowledge_graph_embedding_recommender.tucker import TuckER
+
+    from make_golden_pgpr import RecordingDropout
+
+    W = WIDE
+    nU, nI, nE, nR, d = W["nU"], W["nI"], W["nE"], W["nR"], W["d"]
+    torch.manual_seed(777)
+    config = dict(FIELDS, embedding_size=d, device=torch.device("cpu"), label_smoothing=0.1, input_dropout=0.3,
+                  input_dropout1=0.4, input_dropout2=0.5)
+    model = TuckER(config, FakeDataset(nU, nI, nE, nR))
+    core = wide_core(W["core_seed"], d, W["core_scale"])
+    with torch.no_grad():
+        model.weights.copy_(torch.from_numpy(core))
+        for bn in (model.bn0, model.bn1):
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+            bn.running_mean.normal_(0, 0.1)
+            bn.running_var.uniform_(0.5, 2.0)
+    rng = np.random.default_rng(4200)
+    inter_np = make_batch(rng, nU, nI, nE, nR, W["b_rec"], W["b_kg"])
+    inter_np["item_id"] = np.maximum(inter_np["item_id"], 0)
+    inter = {k: torch.from_numpy(v) for k, v in inter_np.items()}
+    out = {f"p.{k}": v.detach().numpy().copy() for k, v in model.state_dict().items() if k != "weights"}
+    out["shape"] = np.array([nU, nI, nE, nR, d], dtype=np.int64)
+    out["core.seed"], out["core.scale"] = np.int64(W["core_seed"]), np.float64(W["core_scale"])
+    out["core.probe"] = core[::40, ::40, ::40].copy()
+    out["core.sum"] = np.float64(core.astype(np.float64).sum())
+    out.update({f"inter.{k}": v for k, v in inter_np.items()})
+    s = W["stride"]
+
+    def put_grads(prefix):
+        for k, prm in model.named_parameters():
+            gnp = prm.grad.numpy()
+            if k == "weights":
+                out[f"{prefix}.grad.weights.sample"] = gnp[::s, ::s, ::s].copy()
+                out[f"{prefix}.grad.weights.sum"] = np.float64(gnp.astype(np.float64).sum())
+                out[f"{prefix}.grad.weights.abs_sum"] = np.float64(np.abs(gnp.astype(np.float64)).sum())
+                out[f"{prefix}.grad.weights.max_abs"] = np.float64(np.abs(gnp).max())
+            else:
+                out[f"{prefix}.grad.{k}"] = gnp.copy()
+
+    model.eval()
+    with torch.no_grad():
+        out["eval.predict"] = model.predict(inter).numpy()
+        out["eval.predict_kg"] = model.predict_kg(inter).numpy()
+        users = torch.tensor([1, 5, 0, 299, 123])
+        out["eval.fs_users"] = users.numpy()
+        out["eval.fs"] = model.full_sort_predict({"user_id": users}).numpy()
+    model.zero_grad()
+    loss = model.calculate_loss(inter)
+    loss.backward()
+    out["eval.loss"] = loss.detach().numpy()
+    put_grads("eval")
+    model.train()
+    rec = RecordingDropout(99)
+    real = F.dropout
+    F.dropout = rec
+    model.zero_grad()
+    loss = model.calculate_loss(inter)
+    loss.backward()
+    F.dropout = real
+    out["train.loss"] = loss.detach().numpy()
+    ps = (0.3, 0.4, 0.5, 0.3, 0.4, 0.5)
+    for i, m in enumerate(rec.masks):  # values are 0 or 1 / (1 - p): one bit each
+        out[f"train.maskbits{i}"] = np.packbits((m != 0).reshape(-1))
+        out[f"train.maskshape{i}"] = np.array(m.shape, dtype=np.int64)
+        out[f"train.maskp{i}"] = np.float64(ps[i])
+        assert np.array_equal(m, (m != 0).astype(np.float32) / np.float32(1.0 - ps[i])), i
+    put_grads("train")
+    for k, v in model.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            out[f"train.after.{k}"] = v.numpy().copy()
+    np.savez_compressed(os.path.join(out_dir, "tucker_wide_d200.npz"), **out)
+    print("tucker wide", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks),
+          os.path.getsize(os.path.join(out_dir, "tucker_wide_d200.npz")))
+
+
 def gen_conve(out_dir):
     """ConvE: eval-mode outputs + loss + grads, and a train-mode step with recorded dropout / dropout2d masks."""
     import torch.nn.functional as F
@@ -567,6 +659,8 @@ if __name__ == "__main__":
         gen_conve(HERE)
     if what in ("tucker", "all"):
         gen_tucker(HERE)
+    if what in ("tucker_wide", "all"):
+        gen_tucker_wide(HERE)
     if what in ("pgpr", "all"):
         from make_golden_pgpr import gen_pgpr
 
