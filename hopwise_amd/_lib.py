@@ -264,6 +264,13 @@ SIGNATURES = {
         [C.POINTER(C.c_void_p), c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p, C.c_int64, c_f32p, C.c_int32, C.c_uint64,
          C.c_uint64, c_f32p, C.c_int64, C.c_void_p],
     ),
+    "hw_pgpr_policy_planes_bytes": (C.c_int64, [C.c_int32]),
+    "hw_pgpr_policy_prepare": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hw_pgpr_policy_fused": (
+        C.c_int,
+        [C.POINTER(C.c_void_p), c_f32p, c_f32p, C.c_int32, C.c_void_p, c_f32p, c_f32p, C.c_int32, C.c_int32, c_i32p, c_i32p,
+         C.c_int64, C.c_int32, c_f32p, c_f32p, C.c_uint64, C.c_uint64, C.c_uint64, c_f32p, C.c_int64, C.c_void_p],
+    ),
     "hw_pgpr_policy_topk": (
         C.c_int,
         [c_f32p, C.c_int64, C.c_int32, c_i32p, c_i32p, C.c_int64, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_void_p],

@@ -1,0 +1,432 @@
+// PGPR policy network of one beam-search hop in ONE launch (pgpr.py:175-187 + the state of :296-333):
+//   first layer as a slot-table lookup (hw_pgpr_layer1_lookup's sum) -> ELU -> dropout -> [rows, H1] x W2^T on the bf16 matrix
+//   pipes (three-way split = fp32-level error, gemm.hip) -> ELU -> dropout -> x Wa^T -> logits.
+// The unfused pipeline writes and re-reads x1 [rows, 512] and x2 [rows, 256] (6 GB per 1 M beam rows) between its three
+// launches; here neither ever leaves the registers of the wave that owns the row.
+//
+// Shape of the computation (everything transposed, so that a lane owns a beam row from the gather to the logits):
+//   * block = 4 waves x 32 beam rows.  Lane (b, g) of a wave (b = lane & 31, g = lane >> 5) works for beam row b.
+//   * layer 2, D2' [n, b] = W2 [n, k] . x1^T [k, b]:  the MFMA B operand of lane (b, g) at k-step t of chunk c is
+//     x1[b][32 c + 16 g + 8 t + 0..7] -- over a chunk the lane needs 64 contiguous bytes of each slot-table row, the two
+//     half-waves together one whole 128-B line per row.  x1 is produced in registers straight into MFMA operand layout:
+//     no LDS, no shuffle.  The A operand (weights, shared by all rows) streams through LDS as pre-split, pre-swizzled bf16
+//     plane images prepared once per weight version (hw_pgpr_policy_prepare).
+//   * the accumulator of a 32x32 tile leaves lane (b, g) with h2[b][n], n = 32 T + 8 (v >> 2) + 4 g + (v & 3): exactly a
+//     B operand of layer 3 (D3' [a, b] = Wa [a, n] . h2^T [n, b]) once the k-slots of Wa are permuted to that order --
+//     which hw_pgpr_policy_prepare does.  Layer 2's output feeds layer 3 from the same registers.
+//   * dropout (reference semantics: always on, p = 0.5): one Philox4x32-10 block yields 128 keep bits here (element idx of
+//     the [rows, H] activation: block idx >> 7, word (idx >> 5) & 3, bit idx & 31) -- 6 Philox evaluations per beam row for
+//     both layers; the unfused kernels' stream (hw_common.h:philox_bits, one block per 4 elements) costs 192 per row, about
+//     as many cycles as the matrix products.  Mode 1 (explicit masks, the parity tests) and mode 0 (identity) as before.
+#include "hw_common.h"
+
+namespace hw {
+
+typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 pf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t pf_u32x4 __attribute__((ext_vector_type(4)));  // HIP's uint4 is a struct the optimiser keeps in memory
+
+constexpr int PF_ROWS = 128;                     // beam rows per block
+constexpr int PF_H2 = 256;                       // second hidden width = rows of W2 = k of the actor layer
+constexpr int PF_A = 256;                        // action slots (act_dim padded)
+constexpr int PF_KC = 32;                        // k per weight chunk
+constexpr int PF_PLANE = 256 * PF_KC * 2;        // [256 rows][32 k] bf16 = 16 KB
+constexpr int PF_CHUNK = 3 * PF_PLANE;           // hi / mid / lo = 48 KB
+constexpr int PF_PATH_INTS = HW_PGPR_ROW_INTS;
+constexpr int PF_SELF_LOOP = -1, PF_T_USER = 0;
+
+__device__ __forceinline__ void pf_split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const pf_f32x2 v = {x0, x1};
+    const pf_bf16x2 h = __builtin_convertvector(v, pf_bf16x2);
+    const pf_f32x2 r1 = v - __builtin_convertvector(h, pf_f32x2);
+    const pf_bf16x2 m = __builtin_convertvector(r1, pf_bf16x2);
+    const pf_f32x2 r2 = r1 - __builtin_convertvector(m, pf_f32x2);
+    const pf_bf16x2 l = __builtin_convertvector(r2, pf_bf16x2);
+    hi = __builtin_bit_cast(uint32_t, h), mid = __builtin_bit_cast(uint32_t, m), lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// byte offset of fragment slot `slot` (8 k = 16 B) of row r inside one plane image: 64-byte rows, the four slots XOR-swizzled
+// by the row so that eight consecutive rows reading the same logical slot touch eight different 16-byte bank groups
+__device__ __host__ __forceinline__ int pf_off(int r, int slot) { return r * 64 + (((slot ^ (r >> 1)) & 3) << 4); }
+
+// ---- weight preparation: fp32 -> three bf16 planes per chunk, already in LDS image order ---------------------------------
+// chunk q < H1 / 32: W2 [256, H1], slot (2 g + t) of row n holds k = 32 q + 16 g + 8 t + 0..7
+// chunk H1 / 32 + T: Wa [act_dim, 256] padded to 256 rows, slot (2 g + h) of row a holds n = 32 T + 16 h + 4 g + 0..3 and
+//                    32 T + 16 h + 8 + 4 g + 0..3: the order in which lane (b, g) holds layer 2's output tile T
+__global__ __launch_bounds__(256) void pgpr_policy_prep_kernel(const float* __restrict__ w2, int H1,
+                                                               const float* __restrict__ wa, int act_dim,
+                                                               uint8_t* __restrict__ planes) {
+    const int q = blockIdx.x;        // chunk
+    const int n2 = H1 / PF_KC;
+    for (int e = threadIdx.x; e < 256 * 4 * 4; e += 256) {  // (row, slot, pair of k)
+        const int r = e >> 4, slot = (e >> 2) & 3, pr = e & 3;
+        const int g = slot >> 1, th = slot & 1;
+        float x0, x1;
+        if (q < n2) {
+            const int k = PF_KC * q + 16 * g + 8 * th + 2 * pr;
+            x0 = w2[(size_t)r * H1 + k], x1 = w2[(size_t)r * H1 + k + 1];
+        } else {
+            const int T = q - n2, j = 2 * pr;  // j = 0, 2: first four; 4, 6: second four
+            const int k = 32 * T + 16 * th + 4 * g + (j < 4 ? j : 8 + (j - 4));
+            x0 = r < act_dim ? wa[(size_t)r * PF_H2 + k] : 0.f;
+            x1 = r < act_dim ? wa[(size_t)r * PF_H2 + k + 1] : 0.f;
+        }
+        uint32_t h, m, l;
+        pf_split_pair(x0, x1, h, m, l);
+        uint8_t* dst = planes + (size_t)q * PF_CHUNK + pf_off(r, slot) + 4 * pr;
+        *reinterpret_cast<uint32_t*>(dst) = h;
+        *reinterpret_cast<uint32_t*>(dst + PF_PLANE) = m;
+        *reinterpret_cast<uint32_t*>(dst + 2 * PF_PLANE) = l;
+    }
+}
+
+struct PfTables {
+    const float* user0;
+    const float *cur_u, *cur_e;
+    const float *last_u, *last_e, *last_r;
+    const float *old_u, *old_e, *old_r;
+    const float* zero;  // H1 zeros: the row a missing slot contributes
+};
+
+struct PfDrop {
+    int mode;                 // 0 identity, 1 explicit masks, 3 Philox, 128 keep bits per block
+    const float* mask1;       // [rows, H1]
+    const float* mask2;       // [rows, 256]
+    uint64_t seed, offset1, offset2;
+};
+
+// ELU without a branch: expm1f is a library call with divergent paths, which a wave that also has to keep the matrix pipe
+// fed cannot afford per element.  x <= 0: exp(x) - 1 through v_exp_f32 where the result is not small (absolute error ~1e-7),
+// the degree-6 Taylor polynomial for -0.25 < x <= 0 (truncation < 2e-8 |x|) -- within 2 ulp of expm1f at fp32.
+__device__ __forceinline__ float pf_elu(float x) {
+    const float xm = fminf(x, 0.f);
+    const float u = __builtin_amdgcn_exp2f(xm * 1.44269504088896341f) - 1.f;
+    float p = 1.f / 720.f;
+    p = fmaf(p, xm, 1.f / 120.f);
+    p = fmaf(p, xm, 1.f / 24.f);
+    p = fmaf(p, xm, 1.f / 6.f);
+    p = fmaf(p, xm, 0.5f);
+    p = fmaf(p, xm, 1.f);
+    p *= xm;
+    const float em1 = xm > -0.25f ? p : u;
+    return x > 0.f ? x : em1;
+}
+
+// 16 keep bits of elements idx0 .. idx0 + 15 (idx0 % 16 == 0) of the stream (seed, offset); `blk` / `w` cache the last block
+__device__ __forceinline__ uint32_t pf_keep16(uint64_t seed, uint64_t offset, uint64_t idx0, uint64_t& blk, uint32_t (&w)[4]) {
+    const uint64_t b = idx0 >> 7;
+    if (b != blk) {
+        blk = b;
+        philox_bits4(seed, offset, b, w);
+    }
+    const int ws = (int)(idx0 >> 5) & 3;
+    const uint32_t word = ws == 0 ? w[0] : (ws == 1 ? w[1] : (ws == 2 ? w[2] : w[3]));
+    return (word >> (idx0 & 31)) & 0xFFFFu;
+}
+
+template <int NPARTS, int MODE>
+__global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, const float* __restrict__ b1, int H1,
+                                                                   const uint8_t* __restrict__ planes,
+                                                                   const float* __restrict__ b2,
+                                                                   const float* __restrict__ ba, int act_dim,
+                                                                   const int32_t* __restrict__ paths,
+                                                                   const int32_t* __restrict__ n_rows_ptr, PfDrop dr,
+                                                                   float* __restrict__ logits, int64_t ld) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * PF_CHUNK];
+    const int n_rows = n_rows_ptr[0];
+    const int row0 = blockIdx.x * PF_ROWS;
+    if (row0 >= n_rows) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = lane & 31, g = lane >> 5;
+    const int row = row0 + wave * 32 + b;
+    const int rowc = row < n_rows ? row : n_rows - 1;
+    const int n2 = H1 / PF_KC;
+
+    // ---- slot-table rows of this lane's beam row (pgpr_layer1_lookup_kernel's selection, per lane) ----
+    const float* src[NPARTS];
+    {
+        // the whole record as three native 16-byte vectors, every field selected by value (v_cndmask): picking fields through
+        // array references let the compiler fold the selection into a dependent load at a computed address inside the
+        // record -- a second memory round trip per row, and the NPARTS = 2 instantiation of that form faulted on four-node
+        // paths (entity id into the user table)
+        typedef int pf_i32x4 __attribute__((ext_vector_type(4)));
+        const pf_i32x4* pr = reinterpret_cast<const pf_i32x4*>(paths + (size_t)rowc * PF_PATH_INTS);
+        const pf_i32x4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+        const int uid = q0.x, len = q0.y;
+        // hop j = 1..3: relation, node type, node id
+        const int r1 = q0.z, t1 = q0.w, d1 = q1.x, r2 = q1.y, t2 = q1.z, d2 = q1.w, r3 = q2.x, t3 = q2.y, d3 = q2.z;
+        auto sel = [](int j, int v1, int v2, int v3) { return j == 1 ? v1 : (j == 2 ? v2 : v3); };
+        auto node_row = [&](int j, const float* tu, const float* te) -> const float* {  // j >= 0
+            const int ty = j == 0 ? PF_T_USER : sel(j, t1, t2, t3);
+            const int id = j == 0 ? uid : sel(j, d1, d2, d3);
+            return (ty == PF_T_USER ? tu : te) + (size_t)id * H1;
+        };
+        auto rel_row = [&](int j, const float* tr) -> const float* {
+            const int r = sel(j, r1, r2, r3);
+            return r == PF_SELF_LOOP ? tb.zero : tr + (size_t)r * H1;
+        };
+#pragma unroll
+        for (int q = 0; q < NPARTS; ++q) src[q] = tb.zero;
+        src[0] = tb.user0 + (size_t)uid * H1;
+        const int lc = len < 1 ? 1 : (len > 4 ? 4 : len);  // a record always holds 1..4 nodes; clamp against garbage rows
+        src[1] = node_row(lc - 1, tb.cur_u, tb.cur_e);
+        if constexpr (NPARTS > 2) {
+            if (lc >= 2) {
+                src[2] = node_row(lc - 2, tb.last_u, tb.last_e);
+                src[3] = rel_row(lc - 1, tb.last_r);
+            }
+        }
+        if constexpr (NPARTS > 4) {
+            if (lc >= 3) {
+                src[4] = node_row(lc - 3, tb.old_u, tb.old_e);
+                src[5] = rel_row(lc - 2, tb.old_r);
+            }
+        }
+    }
+
+    // ---- weight chunk pipeline: global -> registers -> LDS stage (q & 1) ----
+    pf_u32x4 wreg[12];
+    auto w_fetch = [&](int q) {
+        const pf_u32x4* s = reinterpret_cast<const pf_u32x4*>(planes + (size_t)q * PF_CHUNK);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) wreg[i] = s[tid + 256 * i];
+    };
+    auto w_put = [&](int q) {
+        pf_u32x4* d = reinterpret_cast<pf_u32x4*>(lds + (q & 1) * PF_CHUNK);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d[tid + 256 * i] = wreg[i];
+    };
+
+    // ---- x1 chunk of this lane: 16 values k = 32 c + 16 g + 0..15, as gathered sums (before ELU) ----
+    f32x4 xs[NPARTS][4];
+    f32x4 xm[4];  // explicit mask (mode 1)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xm[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+    auto x_fetch = [&](int c) {
+        const int k0 = PF_KC * c + 16 * g;
+#pragma unroll
+        for (int q = 0; q < NPARTS; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xs[q][i] = *reinterpret_cast<const f32x4*>(src[q] + k0 + 4 * i);
+        if constexpr (MODE == 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xm[i] = *reinterpret_cast<const f32x4*>(dr.mask1 + (size_t)rowc * H1 + k0 + 4 * i);
+    };
+    uint64_t pblk = ~0ull;
+    uint32_t pw[4] = {0u, 0u, 0u, 0u};
+    pf_bf16x8 xb[2][3];  // B operands of the current chunk: [k-step][plane]
+    auto x_finish = [&](int c) {
+        const int k0 = PF_KC * c + 16 * g;
+        uint32_t keep = 0xFFFFu;
+        if constexpr (MODE == 3) keep = pf_keep16(dr.seed, dr.offset1, (uint64_t)rowc * H1 + k0, pblk, pw);
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + k0 + 4 * i);
+#pragma unroll
+            for (int q = 0; q < NPARTS; ++q) acc += xs[q][i];
+            const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+            const float mk[4] = {xm[i].x, xm[i].y, xm[i].z, xm[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = pf_elu(v[j]);
+                if constexpr (MODE == 1) x *= mk[j];
+                else if constexpr (MODE == 3) x = ((keep >> (4 * i + j)) & 1u) ? x * 2.f : 0.f;
+                e[4 * i + j] = x;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint32_t h[4], m[4], l[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) pf_split_pair(e[8 * t + 2 * p], e[8 * t + 2 * p + 1], h[p], m[p], l[p]);
+            xb[t][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{h[0], h[1], h[2], h[3]});
+            xb[t][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{m[0], m[1], m[2], m[3]});
+            xb[t][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{l[0], l[1], l[2], l[3]});
+        }
+    };
+
+    // one chunk of matrix work: acc[T] += W[chunk] (rows 32 T ..) . B operands, T = 0..7, both k-steps
+    auto mma_chunk = [&](const uint8_t* stage, f32x16 (&acc)[8], const pf_bf16x8 (&bop)[2][3]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                pf_bf16x8 fa[4][3];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        fa[i][p] = *reinterpret_cast<const pf_bf16x8*>(stage + p * PF_PLANE +
+                                                                       pf_off(32 * (4 * half + i) + b, 2 * g + t));
+#define PF_TERM(PA_, PB_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[4 * half + i] =                                              \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA_], bop[t][PB_], acc[4 * half + i], 0, 0, 0);
+                PF_TERM(1, 1)
+                PF_TERM(2, 0)
+                PF_TERM(0, 2)
+                PF_TERM(1, 0)
+                PF_TERM(0, 1)
+                PF_TERM(0, 0)
+#undef PF_TERM
+            }
+    };
+
+    f32x16 acc2[8];
+#pragma unroll
+    for (int T = 0; T < 8; ++T) acc2[T] = f32x16{0};
+
+    w_fetch(0);
+    x_fetch(0);
+    w_put(0);
+    x_finish(0);
+    __syncthreads();
+    for (int c = 0; c < n2; ++c) {
+        w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
+        // no test around the gathers (a load that leaves its block through a phi is waited for at the end of that block,
+        // i.e. in front of the MFMAs): the last trip re-reads its own chunk and throws the result away
+        const int cn = c + 1 < n2 ? c + 1 : n2 - 1;
+        x_fetch(cn);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk(lds + (c & 1) * PF_CHUNK, acc2, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        w_put(c + 1);
+        x_finish(cn);
+        __syncthreads();
+    }
+
+    // ---- layer 3: h2 tile T (this lane: n = 32 T + 8 (v >> 2) + 4 g + (v & 3)) is the B operand of actor chunk T ----
+    f32x16 acc3[8];
+#pragma unroll
+    for (int T = 0; T < 8; ++T) acc3[T] = f32x16{0};
+    uint64_t pblk2 = ~0ull;
+    uint32_t pw2[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        const int q = n2 + T;
+        if (T + 1 < 8) w_fetch(q + 1);
+        // bias, ELU, dropout of the 16 values of tile T; element (row, n): keep bit of idx = row * 256 + n
+        uint32_t word = 0u;
+        if constexpr (MODE == 3) {  // n = 32 T + ...: block (row * 256 + 32 T) >> 7, word T & 3, bit n & 31
+            const uint64_t idx0 = (uint64_t)rowc * PF_H2 + 32 * T;
+            const uint64_t blk = idx0 >> 7;
+            if (blk != pblk2) {
+                pblk2 = blk;
+                philox_bits4(dr.seed, dr.offset2, blk, pw2);
+            }
+            const int ws = (int)(idx0 >> 5) & 3;
+            word = ws == 0 ? pw2[0] : (ws == 1 ? pw2[1] : (ws == 2 ? pw2[2] : pw2[3]));
+        }
+        float e[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int nl = 8 * (v >> 2) + 4 * g + (v & 3);  // n - 32 T
+            float x = pf_elu(acc2[T][v] + b2[32 * T + nl]);
+            if constexpr (MODE == 1) x *= dr.mask2[(size_t)rowc * PF_H2 + 32 * T + nl];
+            else if constexpr (MODE == 3) x = ((word >> nl) & 1u) ? x * 2.f : 0.f;
+            e[v] = x;
+        }
+        pf_bf16x8 hb[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) pf_split_pair(e[8 * h + 2 * p], e[8 * h + 2 * p + 1], hh[p], mm[p], ll[p]);
+            hb[h][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{hh[0], hh[1], hh[2], hh[3]});
+            hb[h][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{mm[0], mm[1], mm[2], mm[3]});
+            hb[h][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{ll[0], ll[1], ll[2], ll[3]});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_chunk(lds + (q & 1) * PF_CHUNK, acc3, hb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (T + 1 < 8) {
+            w_put(q + 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- logits: lane (b, g) holds actions a = 32 Ta + 8 (v >> 2) + 4 g + (v & 3) of its beam row ----
+    if (row < n_rows) {
+        float* out = logits + (size_t)row * ld;
+#pragma unroll
+        for (int Ta = 0; Ta < 8; ++Ta)
+#pragma unroll
+            for (int vq = 0; vq < 4; ++vq) {
+                const int a0 = 32 * Ta + 8 * vq + 4 * g;
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(ba + a0);  // padded to 256 by the caller
+                f32x4 o = {acc3[Ta][4 * vq] + bias.x, acc3[Ta][4 * vq + 1] + bias.y, acc3[Ta][4 * vq + 2] + bias.z,
+                           acc3[Ta][4 * vq + 3] + bias.w};
+                if (a0 + 3 < ld) *reinterpret_cast<f32x4*>(out + a0) = o;
+            }
+    }
+}
+
+}  // namespace hw
+
+using namespace hw;
+
+extern "C" int64_t hw_pgpr_policy_planes_bytes(int32_t hidden1) {
+    if (hidden1 < 32 || hidden1 % 128) return 0;
+    return (int64_t)(hidden1 / PF_KC + PF_H2 / 32) * PF_CHUNK;
+}
+
+extern "C" int hw_pgpr_policy_prepare(const float* w2, int32_t hidden1, int32_t hidden2, const float* wa, int32_t act_dim,
+                                      void* planes, void* stream) {
+    if (!w2 || !wa || !planes || hidden2 != PF_H2 || hidden1 < 128 || hidden1 % 128 || hidden1 > 1024 || act_dim < 1 ||
+        act_dim > PF_A)
+        return HW_ERR_UNSUPPORTED;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(pgpr_policy_prep_kernel, dim3((unsigned)(hidden1 / PF_KC + PF_H2 / 32)), dim3(256), 0,
+                       (hipStream_t)stream, w2, hidden1, wa, act_dim, (uint8_t*)planes);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_policy_fused(const float* const* slot_tables, const float* zero_row, const float* b1,
+                                    int32_t hidden1, const void* planes, const float* b2, const float* ba_padded,
+                                    int32_t act_dim, int32_t state_history, const int32_t* paths, const int32_t* n_rows,
+                                    int64_t max_rows, int32_t drop_mode, const float* mask1, const float* mask2,
+                                    uint64_t seed, uint64_t offset1, uint64_t offset2, float* logits, int64_t ld,
+                                    void* stream) {
+    if (!slot_tables || !zero_row || !b1 || !planes || !b2 || !ba_padded || !paths || !n_rows || !logits)
+        return HW_ERR_INVALID_ARG;
+    if (hidden1 < 128 || hidden1 % 128 || hidden1 > 1024 || act_dim < 1 || act_dim > PF_A) return HW_ERR_UNSUPPORTED;
+    if (state_history < 0 || state_history > 2) return HW_ERR_INVALID_ARG;
+    if (!(drop_mode == 0 || drop_mode == 1 || drop_mode == 3) || (drop_mode == 1 && (!mask1 || !mask2)))
+        return HW_ERR_INVALID_ARG;
+    if (ld < PF_A || (ld & 3) || (((uintptr_t)logits | (uintptr_t)b1 | (uintptr_t)ba_padded | (uintptr_t)planes |
+                                   (uintptr_t)zero_row) & 15))
+        return HW_ERR_INVALID_ARG;
+    if (drop_mode == 1 && (((uintptr_t)mask1) & 15)) return HW_ERR_INVALID_ARG;
+    const int need = state_history == 0 ? 3 : (state_history == 1 ? 6 : 9);
+    for (int i = 0; i < need; ++i)
+        if (!slot_tables[i] || (((uintptr_t)slot_tables[i]) & 15)) return HW_ERR_INVALID_ARG;
+    if (max_rows <= 0) return HW_OK;
+    PfTables t;
+    t.user0 = slot_tables[0], t.cur_u = slot_tables[1], t.cur_e = slot_tables[2];
+    t.last_u = need > 3 ? slot_tables[3] : nullptr, t.last_e = need > 3 ? slot_tables[4] : nullptr;
+    t.last_r = need > 3 ? slot_tables[5] : nullptr;
+    t.old_u = need > 6 ? slot_tables[6] : nullptr, t.old_e = need > 6 ? slot_tables[7] : nullptr;
+    t.old_r = need > 6 ? slot_tables[8] : nullptr;
+    t.zero = zero_row;
+    PfDrop dr{drop_mode, mask1, mask2, seed, offset1, offset2};
+    const int64_t grid = (max_rows + PF_ROWS - 1) / PF_ROWS;
+    if (grid > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+#define PF_GO(NP, MD)                                                                                                   \
+    hipLaunchKernelGGL((pgpr_policy_fused_kernel<NP, MD>), dim3((unsigned)grid), dim3(256), 0, st, t, b1, hidden1,      \
+                       (const uint8_t*)planes, b2, ba_padded, act_dim, paths, n_rows, dr, logits, ld)
+#define PF_BY_MODE(NP)                 \
+    do {                               \
+        if (drop_mode == 0) PF_GO(NP, 0);      \
+        else if (drop_mode == 1) PF_GO(NP, 1); \
+        else PF_GO(NP, 3);                     \
+    } while (0)
+    if (state_history == 0) PF_BY_MODE(2);
+    else if (state_history == 1) PF_BY_MODE(4);
+    else PF_BY_MODE(6);
+#undef PF_BY_MODE
+#undef PF_GO
+    return HW_LAUNCH_RC();
+}

@@ -21,6 +21,8 @@ explicit masks passed to :meth:`beam_search` (what the parity tests use).
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -80,6 +82,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.fix_scores_sorting_bug = bool(config["fix_scores_sorting_bug"])
         self.policy_dropout = _cfg(config, "policy_dropout", "reference")
         self.l1_lookup = bool(_cfg(config, "l1_lookup", True))  # beam search: first policy layer from slot tables
+        # beam search: the whole policy network of a hop in one launch when the shapes allow (HW_PGPR_FUSED=0: three launches)
+        self.fused_policy = bool(_cfg(config, "fused_policy", os.environ.get("HW_PGPR_FUSED", "1") != "0"))
         self.user_chunk = int(_cfg(config, "beam_user_chunk", 64))
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         dev = torch.device(self.device)
@@ -147,7 +151,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             state=f32(rmax, self.state_dim),
             x1=f32(rmax, self.hidden_sizes[0]),
             x2=f32(rmax, self.hidden_sizes[1]),
-            logits=f32(rmax, self.act_dim),
+            # rows padded to 256 floats: the fused policy kernel stores whole 16-byte pieces; the top-k reads [:, :act_dim]
+            logits=f32(rmax, max(256, self.act_dim))[:, : self.act_dim],
             tk_idx=i32(rmax, max(hops)),
             tk_val=f32(rmax, max(hops)),
             offsets=i32(rmax),
@@ -165,6 +170,18 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             self._l1_cache_key = key
         return self._l1_cache
 
+    def _fused_policy_state(self):
+        """(weight planes, zero row, padded actor bias) of hw_pgpr_policy_fused for the current l2 / actor parameters."""
+        key = tuple((t._version, t.data_ptr()) for t in (self.l2.weight, self.actor.weight, self.actor.bias))
+        if getattr(self, "_fused_key", None) != key:
+            dev = self.l2.weight.device
+            ba = torch.zeros(256, dtype=torch.float32, device=dev)
+            ba[: self.act_dim] = self.actor.bias.detach()
+            self._fused_cache = (P.policy_prepare(self.l2.weight, self.actor.weight),
+                                 torch.zeros(self.hidden_sizes[0], dtype=torch.float32, device=dev), ba)
+            self._fused_key = key
+        return self._fused_cache
+
     def _policy_logits(self, buf, n_rows, rmax, drops, hop, paths=None):
         """l1 -> ELU -> dropout -> l2 -> ELU -> dropout -> actor (pgpr.py:175-187), logits into buf['logits'].
         With ``paths`` the first layer is the table-lookup form (no state tensor, no first GEMM)."""
@@ -177,6 +194,15 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             else:
                 modes.append((None, 0))
         self._drop_calls += 1
+        if paths is not None and self.fused_policy and P.policy_fused_supported(self.hidden_sizes, self.act_dim):
+            # lookup -> l2 -> actor in one launch (csrc/pgpr_policy.hip); its Philox dropout stream packs 128 keep bits per
+            # block (drop_mode 3), the three-launch form below keeps hw_common.h:philox_bits' stream (drop_mode 2)
+            planes, zero_row, ba_pad = self._fused_policy_state()
+            P.policy_fused(self._l1_slot_tables(), zero_row, self.l1.bias.detach(), planes, self.l2.bias.detach(), ba_pad,
+                           self.act_dim, self.state_history, paths, n_rows, rmax, buf["logits"],
+                           drop_mode={0: 0, 1: 1, 2: 3}[modes[0][1]], mask1=modes[0][0], mask2=modes[1][0],
+                           seed=self._seed, offset1=2 * self._drop_calls, offset2=2 * self._drop_calls + 1)
+            return
         if paths is not None:
             P.layer1_lookup(self._l1_slot_tables(), self.l1.bias.detach(), self.state_history, paths, n_rows, rmax,
                             buf["x1"], modes[0][0], modes[0][1], self._seed, 2 * self._drop_calls)

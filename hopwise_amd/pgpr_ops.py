@@ -193,6 +193,42 @@ def layer1_lookup(slot_tables, bias, state_history, paths, n_rows, max_rows, out
     )
 
 
+def policy_fused_supported(hidden_sizes, act_dim):
+    """Shapes hw_pgpr_policy_fused covers (hopwise's PGPR.yaml default [512, 256], max_acts 250 is one)."""
+    return (len(hidden_sizes) == 2 and hidden_sizes[1] == 256 and hidden_sizes[0] % 128 == 0 and
+            128 <= hidden_sizes[0] <= 1024 and 1 <= act_dim <= 256)
+
+
+def policy_prepare(w2, wa):
+    """l2.weight [256, H1], actor.weight [act_dim, 256] -> the pre-split, pre-swizzled bf16 plane images the fused policy
+    kernel streams through LDS (once per weight version)."""
+    lib = _lib.load()
+    w2 = w2.detach().contiguous()
+    wa = wa.detach().contiguous()
+    n = int(lib.hw_pgpr_policy_planes_bytes(w2.shape[1]))
+    if n <= 0:
+        raise _lib.HopwiseAmdError("hw_pgpr_policy_prepare: unsupported hidden size")
+    planes = torch.empty(n, dtype=torch.uint8, device=w2.device)
+    check(lib.hw_pgpr_policy_prepare(_ptr(w2), w2.shape[1], w2.shape[0], _ptr(wa), wa.shape[0], _ptr(planes), _stream()),
+          "hw_pgpr_policy_prepare")
+    return planes
+
+
+def policy_fused(slot_tables, zero_row, b1, planes, b2, ba_padded, act_dim, state_history, paths, n_rows, max_rows, logits,
+                 drop_mode=0, mask1=None, mask2=None, seed=0, offset1=0, offset2=0):
+    """logits[row, :act_dim] of the whole policy network for every beam row, one launch (csrc/pgpr_policy.hip).
+    ``logits`` is [max_rows, >= 256]."""
+    lib = _lib.load()
+    arr = (C.c_void_p * len(slot_tables))(*[t.data_ptr() for t in slot_tables])
+    check(
+        lib.hw_pgpr_policy_fused(arr, _ptr(zero_row), _ptr(b1), b1.numel(), _ptr(planes), _ptr(b2), _ptr(ba_padded),
+                                 int(act_dim), int(state_history), _ptr(paths), _ptr(n_rows), int(max_rows), int(drop_mode),
+                                 _ptr(mask1), _ptr(mask2), C.c_uint64(seed), C.c_uint64(offset1), C.c_uint64(offset2),
+                                 _ptr(logits), logits.stride(0), _stream()),
+        "hw_pgpr_policy_fused",
+    )
+
+
 def policy_topk(logits, act_dim, n_acts, n_rows, max_rows, k, out_idx, out_val, probs_out=None):
     lib = _lib.load()
     check(

@@ -332,6 +332,29 @@ int hw_pgpr_layer1_lookup(const float* const* slot_tables, const float* bias, in
                           const int32_t* paths, const int32_t* n_rows, int64_t max_rows, const float* drop_mask,
                           int32_t drop_mode, uint64_t seed, uint64_t offset, float* out, int64_t ld, void* stream);
 
+/* The whole policy network of one beam-search hop in one launch (pgpr.py:175-187 over the state of :296-333; beam search,
+ * fixed weights): logits[row, :] = actor(dropout(ELU(l2(dropout(ELU(l1(state[row]))))))) with the first layer in
+ * hw_pgpr_layer1_lookup's table form and both matrix products on the bf16 matrix pipes as three-way splits (fp32-level
+ * error); x1 / x2 never leave the registers of the wave that owns the row.  hidden2 must be 256, hidden1 a multiple of 128
+ * (<= 1024), act_dim <= 256 (hopwise's PGPR.yaml: [512, 256], max_acts 250); other shapes: HW_ERR_UNSUPPORTED, callers use
+ * the three-launch form.
+ * hw_pgpr_policy_prepare: l2.weight [256, hidden1] and actor.weight [act_dim, 256] -> `planes`
+ * (hw_pgpr_policy_planes_bytes(hidden1) bytes, 16-byte aligned), once per weight version.
+ * hw_pgpr_policy_fused: slot_tables as hw_pgpr_layer1_lookup; zero_row = hidden1 zeros; ba_padded = actor.bias padded to
+ * 256 floats; logits [max_rows, ld], ld >= 256, ld % 4 == 0 (columns act_dim..255 receive 0).
+ * drop_mode 0: none; 1: multiply by mask1[row, hidden1] / mask2[row, 256]; 3: Philox keep-prob 1/2, kept values x2, ONE
+ * Philox4x32-10 block per 128 elements: element i of the [rows, H] activation keeps iff bit (i & 31) of word (i >> 5) & 3
+ * of block i >> 7 of stream (seed, offset1 for the first layer's output, offset2 for the second's) is set
+ * (oracle/philox.py:keep_bits_packed). */
+int64_t hw_pgpr_policy_planes_bytes(int32_t hidden1);
+int hw_pgpr_policy_prepare(const float* w2, int32_t hidden1, int32_t hidden2, const float* wa, int32_t act_dim, void* planes,
+                           void* stream);
+int hw_pgpr_policy_fused(const float* const* slot_tables, const float* zero_row, const float* b1, int32_t hidden1,
+                         const void* planes, const float* b2, const float* ba_padded, int32_t act_dim,
+                         int32_t state_history, const int32_t* paths, const int32_t* n_rows, int64_t max_rows,
+                         int32_t drop_mode, const float* mask1, const float* mask2, uint64_t seed, uint64_t offset1,
+                         uint64_t offset2, float* logits, int64_t ld, void* stream);
+
 /* General fp32 MFMA GEMM: c[m, n] = f(op(a)[m, :] . op(b)[:, n] + bias[n]).  a is [m, k] row-major when
  * a_k_contiguous, else stored transposed [k, m]; b is [n, k] row-major (nn.Linear weight) when b_k_contiguous, else
  * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187).

@@ -28,3 +28,12 @@ def philox_words(seed, offset, idx):
         k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
     w = np.stack([c0, c1, c2, c3], -1)
     return np.take_along_axis(w, (idx & np.uint64(3)).astype(np.int64)[..., None], -1)[..., 0].astype(np.uint32)
+
+
+def keep_bits_packed(seed, offset, n):
+    """Keep bits (0 / 1, p = 1/2) of elements 0 .. n - 1 of the packed dropout stream of csrc/pgpr_policy.hip
+    (hw_pgpr_policy_fused, drop_mode 3): element i keeps iff bit (i & 31) of word (i >> 5) & 3 of Philox block i >> 7 is
+    set -- 128 keep bits per Philox4x32-10 block instead of philox_words' 4."""
+    i = np.arange(n, dtype=np.uint64)
+    words = philox_words(seed, offset, ((i >> np.uint64(7)) << np.uint64(2)) | ((i >> np.uint64(5)) & np.uint64(3)))
+    return ((words >> (i & np.uint64(31)).astype(np.uint32)) & np.uint32(1)).astype(np.uint8)

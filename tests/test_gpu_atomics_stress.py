@@ -96,8 +96,7 @@ def test_adam_clear_then_grad_atomics_is_exact_under_repetition():
         t = torch.randint(1, nE, (B, 1 + K), generator=g)
         w = torch.randint(-2, 3, (B, 1 + K), generator=g).float()
         hd, td, wd = h.to(dev()), t.to(dev()), w.to(dev())
-        desc = ops.make_desc("DistMult", (Ud,), (Rd,), (Ed,))
-        s = ops.kge_score_grouped(desc, hd, None, nR - 1, td)  # autograd node of the grouped scorer
+        s = ops.kge_score_grouped("DistMult", (Ud,), (Rd,), (Ed,), hd, None, nR - 1, td)  # the grouped scorer's autograd node
         (s * wd).sum().backward()
         # expected (CPU, exact): dU[h] += sum_j w * r * E[t_j];  dE[t_j] += w * r * U[h];  dR[-1] += sum w * U[h] * E[t]
         r = R[nR - 1]
