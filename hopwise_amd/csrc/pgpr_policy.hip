@@ -48,8 +48,10 @@ __device__ __forceinline__ void pf_split_pair(float x0, float x1, uint32_t& hi, 
 }
 
 // byte offset of fragment slot `slot` (8 k = 16 B) of row r inside one plane image: 64-byte rows, the four slots XOR-swizzled
-// by the row so that eight consecutive rows reading the same logical slot touch eight different 16-byte bank groups
-__device__ __host__ __forceinline__ int pf_off(int r, int slot) { return r * 64 + (((slot ^ (r >> 1)) & 3) << 4); }
+// by (r >> 2) so that the 16 lanes a ds_read_b128 serves together (16 consecutive rows, one logical slot) touch the 16
+// different 16-byte slots of the 256-byte bank row (r & 3 picks the 64-byte quarter, (r >> 2) & 3 the slot inside it);
+// swizzling by (r >> 1) measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.39
+__device__ __host__ __forceinline__ int pf_off(int r, int slot) { return r * 64 + (((slot ^ (r >> 2)) & 3) << 4); }
 
 // ---- weight preparation: fp32 -> three bf16 planes per chunk, already in LDS image order ---------------------------------
 // chunk q < H1 / 32: W2 [256, H1], slot (2 g + t) of row n holds k = 32 q + 16 g + 8 t + 0..7
@@ -97,33 +99,12 @@ struct PfDrop {
     uint64_t seed, offset1, offset2;
 };
 
-// ELU without a branch: expm1f is a library call with divergent paths, which a wave that also has to keep the matrix pipe
-// fed cannot afford per element.  x <= 0: exp(x) - 1 through v_exp_f32 where the result is not small (absolute error ~1e-7),
-// the degree-6 Taylor polynomial for -0.25 < x <= 0 (truncation < 2e-8 |x|) -- within 2 ulp of expm1f at fp32.
+// ELU without a branch and without expm1f (a library call with divergent paths; a wave that also has to keep the matrix
+// pipe fed cannot afford it per element): exp(x) - 1 through v_exp_f32, absolute error ~1e-7 -- the size of the fp32 rounding
+// of the O(1) sums these values enter.
 __device__ __forceinline__ float pf_elu(float x) {
-    const float xm = fminf(x, 0.f);
-    const float u = __builtin_amdgcn_exp2f(xm * 1.44269504088896341f) - 1.f;
-    float p = 1.f / 720.f;
-    p = fmaf(p, xm, 1.f / 120.f);
-    p = fmaf(p, xm, 1.f / 24.f);
-    p = fmaf(p, xm, 1.f / 6.f);
-    p = fmaf(p, xm, 0.5f);
-    p = fmaf(p, xm, 1.f);
-    p *= xm;
-    const float em1 = xm > -0.25f ? p : u;
-    return x > 0.f ? x : em1;
-}
-
-// 16 keep bits of elements idx0 .. idx0 + 15 (idx0 % 16 == 0) of the stream (seed, offset); `blk` / `w` cache the last block
-__device__ __forceinline__ uint32_t pf_keep16(uint64_t seed, uint64_t offset, uint64_t idx0, uint64_t& blk, uint32_t (&w)[4]) {
-    const uint64_t b = idx0 >> 7;
-    if (b != blk) {
-        blk = b;
-        philox_bits4(seed, offset, b, w);
-    }
-    const int ws = (int)(idx0 >> 5) & 3;
-    const uint32_t word = ws == 0 ? w[0] : (ws == 1 ? w[1] : (ws == 2 ? w[2] : w[3]));
-    return (word >> (idx0 & 31)) & 0xFFFFu;
+    const float u = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.44269504088896341f) - 1.f;
+    return x > 0.f ? x : u;
 }
 
 template <int NPARTS, int MODE>
@@ -135,6 +116,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
                                                                    const int32_t* __restrict__ n_rows_ptr, PfDrop dr,
                                                                    float* __restrict__ logits, int64_t ld) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * PF_CHUNK];
+    // the two hidden biases: read per chunk inside the MFMA shadow, where a global load would have to be waited for with a
+    // vmcnt that also drains the weight prefetch issued before it (vector-memory operations return in order)
+    __shared__ __attribute__((aligned(16))) float bias_lds[1024 + PF_H2];
     const int n_rows = n_rows_ptr[0];
     const int row0 = blockIdx.x * PF_ROWS;
     if (row0 >= n_rows) return;
@@ -142,6 +126,8 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     const int row = row0 + wave * 32 + b;
     const int rowc = row < n_rows ? row : n_rows - 1;
     const int n2 = H1 / PF_KC;
+    for (int i = tid; i < H1; i += 256) bias_lds[i] = b1[i];
+    bias_lds[1024 + tid] = b2[tid];  // 256 threads, PF_H2 = 256
 
     // ---- slot-table rows of this lane's beam row (pgpr_layer1_lookup_kernel's selection, per lane) ----
     const float* src[NPARTS];
@@ -199,35 +185,47 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     };
 
     // ---- x1 chunk of this lane: 16 values k = 32 c + 16 g + 0..15, as gathered sums (before ELU) ----
-    f32x4 xs[NPARTS][4];
-    f32x4 xm[4];  // explicit mask (mode 1)
+    // Two gather buffers and two operand sets: while the matrix pipe works on chunk c, the same wave turns the gathered rows
+    // of chunk c + 1 into MFMA operands (ELU, dropout, split: ~600 vector instructions against 96 MFMAs of 32 cycles -- with
+    // one wave per SIMD nothing else can fill the MFMA shadow) and the gathers of chunk c + 2 are in flight.
+    f32x4 xs[2][NPARTS][4];
+    f32x4 xm[2][4];  // explicit mask (mode 1)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xm[i] = f32x4{1.f, 1.f, 1.f, 1.f};
-    auto x_fetch = [&](int c) {
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xm[u][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+    auto x_fetch = [&](int c, f32x4 (&xq)[NPARTS][4], f32x4 (&mq)[4]) {
         const int k0 = PF_KC * c + 16 * g;
 #pragma unroll
         for (int q = 0; q < NPARTS; ++q)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xs[q][i] = *reinterpret_cast<const f32x4*>(src[q] + k0 + 4 * i);
+            for (int i = 0; i < 4; ++i) xq[q][i] = *reinterpret_cast<const f32x4*>(src[q] + k0 + 4 * i);
         if constexpr (MODE == 1)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xm[i] = *reinterpret_cast<const f32x4*>(dr.mask1 + (size_t)rowc * H1 + k0 + 4 * i);
+            for (int i = 0; i < 4; ++i) mq[i] = *reinterpret_cast<const f32x4*>(dr.mask1 + (size_t)rowc * H1 + k0 + 4 * i);
     };
-    uint64_t pblk = ~0ull;
     uint32_t pw[4] = {0u, 0u, 0u, 0u};
-    pf_bf16x8 xb[2][3];  // B operands of the current chunk: [k-step][plane]
-    auto x_finish = [&](int c) {
+    pf_bf16x8 xb[2][2][3];  // B operands: [set][k-step][plane]
+    // `fresh`: chunk c starts a new 128-element Philox block of this row (c % 4 == 0: H1 % 128 == 0) -- known at compile time
+    // in the unrolled loop, so the region stays one basic block
+    auto x_finish = [&](int c, int cu, const f32x4 (&xq)[NPARTS][4], const f32x4 (&mq)[4], pf_bf16x8 (&out)[2][3]) {
+        // c: chunk (clamped, addresses only); cu = chunk & 3 as the unrolled loop knows it: word cu of the row's current
+        // Philox block holds this chunk's 32 keep bits, this lane's 16 at bit 16 g; a new block every fourth chunk
         const int k0 = PF_KC * c + 16 * g;
         uint32_t keep = 0xFFFFu;
-        if constexpr (MODE == 3) keep = pf_keep16(dr.seed, dr.offset1, (uint64_t)rowc * H1 + k0, pblk, pw);
+        if constexpr (MODE == 3) {
+            if (cu == 0) philox_bits4(dr.seed, dr.offset1, ((uint64_t)rowc * H1 + PF_KC * c) >> 7, pw);
+            const uint32_t word = cu == 0 ? pw[0] : (cu == 1 ? pw[1] : (cu == 2 ? pw[2] : pw[3]));
+            keep = (word >> (16 * g)) & 0xFFFFu;
+        }
         float e[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 acc = *reinterpret_cast<const f32x4*>(b1 + k0 + 4 * i);
+            f32x4 acc = *reinterpret_cast<const f32x4*>(bias_lds + k0 + 4 * i);
 #pragma unroll
-            for (int q = 0; q < NPARTS; ++q) acc += xs[q][i];
+            for (int q = 0; q < NPARTS; ++q) acc += xq[q][i];
             const float v[4] = {acc.x, acc.y, acc.z, acc.w};
-            const float mk[4] = {xm[i].x, xm[i].y, xm[i].z, xm[i].w};
+            const float mk[4] = {mq[i].x, mq[i].y, mq[i].z, mq[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float x = pf_elu(v[j]);
@@ -241,9 +239,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
             uint32_t h[4], m[4], l[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) pf_split_pair(e[8 * t + 2 * p], e[8 * t + 2 * p + 1], h[p], m[p], l[p]);
-            xb[t][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{h[0], h[1], h[2], h[3]});
-            xb[t][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{m[0], m[1], m[2], m[3]});
-            xb[t][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{l[0], l[1], l[2], l[3]});
+            out[t][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{h[0], h[1], h[2], h[3]});
+            out[t][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{m[0], m[1], m[2], m[3]});
+            out[t][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{l[0], l[1], l[2], l[3]});
         }
     };
 
@@ -272,73 +270,75 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #undef PF_TERM
             }
     };
-
     f32x16 acc2[8];
 #pragma unroll
     for (int T = 0; T < 8; ++T) acc2[T] = f32x16{0};
 
     w_fetch(0);
-    x_fetch(0);
+    x_fetch(0, xs[0], xm[0]);
+    x_fetch(1, xs[1], xm[1]);  // n2 >= 4
     w_put(0);
-    x_finish(0);
-    __syncthreads();
-    for (int c = 0; c < n2; ++c) {
-        w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
-        // no test around the gathers (a load that leaves its block through a phi is waited for at the end of that block,
-        // i.e. in front of the MFMAs): the last trip re-reads its own chunk and throws the result away
-        const int cn = c + 1 < n2 ? c + 1 : n2 - 1;
-        x_fetch(cn);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_chunk(lds + (c & 1) * PF_CHUNK, acc2, xb);
-        __builtin_amdgcn_sched_barrier(0);
-        w_put(c + 1);
-        x_finish(cn);
-        __syncthreads();
+    __syncthreads();  // weight chunk 0 and the biases are in LDS
+    x_finish(0, 0, xs[0], xm[0], xb[0]);
+    for (int c0 = 0; c0 < n2; c0 += 4) {  // n2 % 4 == 0; unrolled by four so that buffer parity and `fresh` are static
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u;
+            w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
+            // no test around the gathers (a load that leaves its block through a phi is waited for at the end of that
+            // block, i.e. in front of the MFMAs): the last trips re-read the last chunk and throw the result away
+            const int c2 = c + 2 < n2 ? c + 2 : n2 - 1, c1 = c + 1 < n2 ? c + 1 : n2 - 1;
+            x_fetch(c2, xs[u & 1], xm[u & 1]);  // two chunks ahead; x_finish of the previous trip emptied this buffer
+            __builtin_amdgcn_sched_barrier(0);
+            x_finish(c1, (u + 1) & 3, xs[(u + 1) & 1], xm[(u + 1) & 1], xb[(u + 1) & 1]);
+            mma_chunk(lds + (u & 1) * PF_CHUNK, acc2, xb[u & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            w_put(c + 1);
+            __syncthreads();
+        }
     }
 
     // ---- layer 3: h2 tile T (this lane: n = 32 T + 8 (v >> 2) + 4 g + (v & 3)) is the B operand of actor chunk T ----
     f32x16 acc3[8];
 #pragma unroll
     for (int T = 0; T < 8; ++T) acc3[T] = f32x16{0};
-    uint64_t pblk2 = ~0ull;
     uint32_t pw2[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int T = 0; T < 8; ++T) {
-        const int q = n2 + T;
-        if (T + 1 < 8) w_fetch(q + 1);
-        // bias, ELU, dropout of the 16 values of tile T; element (row, n): keep bit of idx = row * 256 + n
+    pf_bf16x8 hb[2][2][3];
+    // bias, ELU, dropout of the 16 values of tile T -> operand set; element (row, n): keep bit of idx = row * 256 + n
+    auto h_make = [&](int T, pf_bf16x8 (&out)[2][3]) {
         uint32_t word = 0u;
-        if constexpr (MODE == 3) {  // n = 32 T + ...: block (row * 256 + 32 T) >> 7, word T & 3, bit n & 31
+        if constexpr (MODE == 3) {  // block (row * 256 + 32 T) >> 7 (new at T = 0, 4), word T & 3, bit n & 31
             const uint64_t idx0 = (uint64_t)rowc * PF_H2 + 32 * T;
-            const uint64_t blk = idx0 >> 7;
-            if (blk != pblk2) {
-                pblk2 = blk;
-                philox_bits4(dr.seed, dr.offset2, blk, pw2);
-            }
-            const int ws = (int)(idx0 >> 5) & 3;
-            word = ws == 0 ? pw2[0] : (ws == 1 ? pw2[1] : (ws == 2 ? pw2[2] : pw2[3]));
+            if ((T & 3) == 0) philox_bits4(dr.seed, dr.offset2, idx0 >> 7, pw2);
+            word = (T & 3) == 0 ? pw2[0] : ((T & 3) == 1 ? pw2[1] : ((T & 3) == 2 ? pw2[2] : pw2[3]));
         }
         float e[16];
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int nl = 8 * (v >> 2) + 4 * g + (v & 3);  // n - 32 T
-            float x = pf_elu(acc2[T][v] + b2[32 * T + nl]);
+            float x = pf_elu(acc2[T][v] + bias_lds[1024 + 32 * T + nl]);
             if constexpr (MODE == 1) x *= dr.mask2[(size_t)rowc * PF_H2 + 32 * T + nl];
             else if constexpr (MODE == 3) x = ((word >> nl) & 1u) ? x * 2.f : 0.f;
             e[v] = x;
         }
-        pf_bf16x8 hb[2][3];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             uint32_t hh[4], mm[4], ll[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) pf_split_pair(e[8 * h + 2 * p], e[8 * h + 2 * p + 1], hh[p], mm[p], ll[p]);
-            hb[h][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{hh[0], hh[1], hh[2], hh[3]});
-            hb[h][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{mm[0], mm[1], mm[2], mm[3]});
-            hb[h][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{ll[0], ll[1], ll[2], ll[3]});
+            out[h][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{hh[0], hh[1], hh[2], hh[3]});
+            out[h][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{mm[0], mm[1], mm[2], mm[3]});
+            out[h][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{ll[0], ll[1], ll[2], ll[3]});
         }
+    };
+    h_make(0, hb[0]);
+#pragma unroll
+    for (int T = 0; T < 8; ++T) {
+        const int q = n2 + T;
+        if (T + 1 < 8) w_fetch(q + 1);
         __builtin_amdgcn_sched_barrier(0);
-        mma_chunk(lds + (q & 1) * PF_CHUNK, acc3, hb);
+        if (T + 1 < 8) h_make(T + 1, hb[(T + 1) & 1]);
+        mma_chunk(lds + (q & 1) * PF_CHUNK, acc3, hb[T & 1]);
         __builtin_amdgcn_sched_barrier(0);
         if (T + 1 < 8) {
             w_put(q + 1);
@@ -417,12 +417,16 @@ extern "C" int hw_pgpr_policy_fused(const float* const* slot_tables, const float
 #define PF_GO(NP, MD)                                                                                                   \
     hipLaunchKernelGGL((pgpr_policy_fused_kernel<NP, MD>), dim3((unsigned)grid), dim3(256), 0, st, t, b1, hidden1,      \
                        (const uint8_t*)planes, b2, ba_padded, act_dim, paths, n_rows, dr, logits, ld)
+#ifdef PF_ONLY_43
+#define PF_BY_MODE(NP) PF_GO(4, 3)
+#else
 #define PF_BY_MODE(NP)                 \
     do {                               \
         if (drop_mode == 0) PF_GO(NP, 0);      \
         else if (drop_mode == 1) PF_GO(NP, 1); \
         else PF_GO(NP, 3);                     \
     } while (0)
+#endif
     if (state_history == 0) PF_BY_MODE(2);
     else if (state_history == 1) PF_BY_MODE(4);
     else PF_BY_MODE(6);
