@@ -72,39 +72,47 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     const int s = (int)(task % S);
     uint32_t* bits = nullptr;
     bool bad_key = false;
+    int64_t ulo = 0, uhi = 0;  // the key's slice of the used-set CSR
     if constexpr (SAMPLE) {
         const int64_t key = sa.keys[b];
         bad_key = key < 0 || key >= sa.n_key_space;
-        if (S == 4) {
+        if (!bad_key) ulo = sa.used_ptr[key], uhi = sa.used_ptr[key + 1];
+        // sa.words == 0: a value space beyond the LDS bitmap (> 65 536 ids: Yelp2018's entities, HBM-sized tables); the
+        // draws then test membership by binary search in the key's sorted slice, as hw_neg_sample's generic kernel does
+        if (sa.words > 0 && S == 4) {
             // the four waves of the block are the four splits of ONE group (task = 4 * block + wave): one bitmap of the
             // key's used set for all of them, built by the whole block (the launcher only sends full blocks here)
             bits = used_bits_all;
             for (int w = threadIdx.x; w < sa.words; w += 256) bits[w] = 0u;
             __syncthreads();
-            if (!bad_key) {
-                const int64_t lo = sa.used_ptr[key], hi = sa.used_ptr[key + 1];
-                for (int64_t q = lo + threadIdx.x; q < hi; q += 256) {
-                    const int64_t u = sa.used_idx[q];
-                    if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
-                }
+            for (int64_t q = ulo + threadIdx.x; q < uhi; q += 256) {
+                const int64_t u = sa.used_idx[q];
+                if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
             }
             __syncthreads();
-        } else {
+        } else if (sa.words > 0) {
             bits = used_bits_all + (threadIdx.x / HW_WAVE) * sa.words;
             for (int w = lane; w < sa.words; w += HW_WAVE) bits[w] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (!bad_key) {
-                const int64_t lo = sa.used_ptr[key], hi = sa.used_ptr[key + 1];
-                for (int64_t q = lo + lane; q < hi; q += HW_WAVE) {
-                    const int64_t u = sa.used_idx[q];
-                    if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
-                }
+            for (int64_t q = ulo + lane; q < uhi; q += HW_WAVE) {
+                const int64_t u = sa.used_idx[q];
+                if (u >= 0 && u < sa.value_num) atomicOr(&bits[u >> 5], 1u << (u & 31));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
     }
+    auto is_used = [&](int64_t id) -> bool {
+        if (bits) return (bits[id >> 5] >> (id & 31)) & 1u;
+        int64_t a = ulo, e = uhi;
+        while (a < e) {
+            const int64_t m = (a + e) >> 1;
+            if (sa.used_idx[m] < id) a = m + 1;
+            else e = m;
+        }
+        return a < uhi && sa.used_idx[a] == id;
+    };
 
     bool bad = false;
     const int h = clamp_row_flag(h_idx[b], d.n_head, bad);
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
 #pragma unroll
                         for (int t = 0; t < 4 && !ok; ++t) {
                             id = 1 + (int64_t)(((uint64_t)c[t] * (uint64_t)span) >> 32);
-                            ok = !((bits[id >> 5] >> (id & 31)) & 1u);
+                            ok = !is_used(id);
                         }
                     }
                     bad |= !ok;

@@ -192,19 +192,36 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
     def _excluded_bits(self, users_np, exclude):
         """Bitset [B, words] of the ids excluded at leaves: the user's train positives without the 0 padding for the
         executor (cafe.py:421-422), nothing for infer_with_path -- there the reference subtracts a torch tensor from a
-        set of ints (cafe.py:606-607), which removes nothing because tensor elements hash by identity."""
+        set of ints (cafe.py:606-607), which removes nothing because tensor elements hash by identity.
+
+        The bitsets of ALL users are built once (array-wise) and kept on the device when they fit 256 MB; a batch is then
+        one index_select instead of a Python loop over its users."""
+        dev = self.user_embedding.device
+        if not exclude:
+            return torch.zeros((len(users_np), self._bit_words), dtype=torch.int32, device=dev)
+        table = self.__dict__.get("_excluded_table")
+        if table is None and self.positives.shape[0] * self._bit_words * 4 <= (256 << 20):
+            pos = np.asarray(self.positives, np.int64)
+            rows = np.repeat(np.arange(pos.shape[0], dtype=np.int64), pos.shape[1])
+            cols = pos.reshape(-1)
+            ok = (cols > 0) & (cols < self._bit_words * 32)
+            rows, cols = rows[ok], cols[ok]
+            bits = np.zeros(pos.shape[0] * self._bit_words, np.uint32)
+            np.bitwise_or.at(bits, rows * self._bit_words + (cols >> 5), np.uint32(1) << (cols & 31).astype(np.uint32))
+            table = self.__dict__["_excluded_table"] = torch.from_numpy(
+                bits.view(np.int32).reshape(pos.shape[0], self._bit_words)).to(dev)
+        if table is not None:
+            return table.index_select(0, torch.from_numpy(np.asarray(users_np, np.int64)).to(dev)).contiguous()
         bits = np.zeros((len(users_np), self._bit_words), np.uint32)
         for i, u in enumerate(users_np):
-            if not exclude:
-                break
             pos = self.positives[int(u)]
             pos = pos[pos != 0]
             pos = pos[(pos >= 0) & (pos < self._bit_words * 32)]
             np.bitwise_or.at(bits[i], pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
-        return torch.from_numpy(bits.view(np.int32)).to(self.user_embedding.device)
+        return torch.from_numpy(bits.view(np.int32)).to(dev)
 
     @torch.no_grad()
-    def _run_programs(self, users, programs, ks, grow_excluded, exclude, raw=False):
+    def _run_programs(self, users, programs, ks, grow_excluded, exclude, raw=False, flat=None):
         """programs[b] = list of (parent index, relation name) in execution order for user b; ks[b][i] = k of node i.
         Returns per user a list of (count, ids [count, depth], vals [count, depth]) per node -- or, with ``raw``, the
         interpreter's device buffers and the node tables (what :meth:`run_program` hands to the device collector).
@@ -214,19 +231,23 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
         dev = self.user_embedding.device
         users_np = users.cpu().numpy()
         B = len(users_np)
-        lens = np.fromiter((len(p) for p in programs), np.int64, B)
+        if flat is not None:  # run_program: the per-program columns come concatenated from the per-order cache
+            lens, par_i, rel_code, k_of, names = flat["lens"], flat["par_i"], flat["rel_code"], flat["k_of"], flat["names"]
+        else:
+            lens = np.fromiter((len(p) for p in programs), np.int64, B)
         node_ptr = np.zeros(B + 1, np.int64)
         np.cumsum(lens, out=node_ptr[1:])
         total = int(node_ptr[-1])
         row_b = np.repeat(np.arange(B), lens)
         row_i = np.arange(total) - node_ptr[row_b]
-        par_i = np.fromiter((q[0] for p in programs for q in p), np.int64, total)
-        rel_names = [q[1] for p in programs for q in p]
-        k_of = np.fromiter((int(x) for kk in ks for x in kk), np.int64, total)
+        if flat is None:
+            par_i = np.fromiter((q[0] for p in programs for q in p), np.int64, total)
+            rel_names = [q[1] for p in programs for q in p]
+            k_of = np.fromiter((int(x) for kk in ks for x in kk), np.int64, total)
+            names = sorted(set(rel_names))
+            code = {n: j for j, n in enumerate(names)}
+            rel_code = np.fromiter((code[n] for n in rel_names), np.int64, total)
         par_row = np.where(par_i < 0, -1, node_ptr[row_b] + par_i)
-        names = sorted(set(rel_names))
-        code = {n: j for j, n in enumerate(names)}
-        rel_code = np.fromiter((code[n] for n in rel_names), np.int64, total)
         mods = [self._module(n) for n in names]
         # parents precede children inside a program: depth, capacity and leaf flags by program position
         depth = np.ones(total, np.int64)
@@ -321,22 +342,50 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
         return {int(u): np.zeros(len(self.metapaths)) for u in torch.as_tensor(users).cpu().numpy()}
 
     # -- MetaProgramExecutor.execute + collect_results + run_program ----------------------------------------------
-    def _bfs_program(self):
-        """Nodes of the layout tree in the executor's BFS order (children of a node visited in self.rng.permutation
-        order, cafe.py:807-808) as (parent index, relation), plus per-node relation / entity chains for the output."""
-        root = self.__dict__.get("_layout_root")  # the tree only depends on the metapaths; the visiting order is drawn per call
-        if root is None:
-            root = self.__dict__["_layout_root"] = build_layout(self.metapaths)
-        order, index = [], {}
-        queue = [(c, -1) for c in root.get_children()]
+    def _layout(self):
+        """The layout tree as integer tables (built once: it only depends on the metapaths): nodes in plain BFS order,
+        children ids per node in insertion order (what TreeNode.get_children returns), the root's children."""
+        lay = self.__dict__.get("_layout_tables")
+        if lay is None:
+            root = build_layout(self.metapaths)
+            nodes, index, queue = [], {}, list(root.get_children())
+            while queue:
+                n = queue.pop(0)
+                index[id(n)] = len(nodes)
+                nodes.append(n)
+                queue.extend(n.get_children())
+            lay = self.__dict__["_layout_tables"] = dict(
+                root=root, nodes=nodes, kids=[[index[id(c)] for c in n.get_children()] for n in nodes],
+                root_kids=[index[id(c)] for c in root.get_children()], orders={})
+        return lay
+
+    def _bfs_order(self):
+        """One visiting order of the executor (children of a node in self.rng.permutation order, cafe.py:807-808; the
+        draws happen per call, exactly as before) -> its cache entry: the order as (parent index, relation, node) triples
+        plus everything run_program derives from it (flattened program columns, leaf rows, record capacity)."""
+        lay = self._layout()
+        kids_of, nodes = lay["kids"], lay["nodes"]
+        ids, pars, queue = [], [], [(c, -1) for c in lay["root_kids"]]
         while queue:
-            node, par = queue.pop(0)
-            index[id(node)] = len(order)
-            order.append((par, node.relation, node))
-            kids = node.get_children()
-            kids = [kids[j] for j in self.rng.permutation(len(kids))] if len(kids) > 1 else kids
-            queue.extend((k, index[id(node)]) for k in kids)
-        return order
+            nid, par = queue.pop(0)
+            pos = len(ids)
+            ids.append(nid)
+            pars.append(par)
+            kids = kids_of[nid]
+            if len(kids) > 1:
+                kids = [kids[j] for j in self.rng.permutation(len(kids))]
+            queue.extend((k, pos) for k in kids)
+        key = tuple(ids)
+        ent = lay["orders"].get(key)
+        if ent is None:
+            order = [(par, nodes[nid].relation, nodes[nid]) for nid, par in zip(ids, pars)]
+            ent = lay["orders"][key] = dict(order=order, par_i=np.asarray(pars, np.int64),
+                                            rel_names=[nodes[nid].relation for nid in ids])
+        return ent
+
+    def _bfs_program(self):
+        """Nodes of the layout tree in the executor's BFS order as (parent index, relation, node) triples."""
+        return self._bfs_order()["order"]
 
     def _leaf_chains(self):
         """Relation chains of the leaves in collect_results order: plain BFS over the layout tree (cafe.py:859-867)."""
@@ -353,40 +402,65 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
                 leaves.append(tuple(reversed(chain)))
         return leaves
 
+    def run_program_device(self, users, manual_topk=5):
+        """run_program with everything left on the device: (scores [B, n_items] float32, record tensors, leaf chains).
+        Per-user host work is one rng.permutation draw and one dictionary lookup: program columns, leaf rows and record
+        capacities are cached per visiting order of the layout tree."""
+        users = torch.as_tensor(users)
+        users_np = users.cpu().numpy()
+        B = len(users_np)
+        leaves = self._leaf_chains_cached()
+        ents = [self._bfs_order() for _ in users_np]
+        names = self.__dict__.get("_all_rel_names")
+        if names is None:
+            names = self.__dict__["_all_rel_names"] = sorted(self.relation_info)
+            self.__dict__["_rel_code_of"] = {n: j for j, n in enumerate(names)}
+        code = self.__dict__["_rel_code_of"]
+        for e in {id(e): e for e in ents}.values():
+            if "rel_code" not in e:
+                e["rel_code"] = np.fromiter((code[n] for n in e["rel_names"]), np.int64, len(e["rel_names"]))
+                index_of_chain = {_chain_of(e["order"], i): i for i in range(len(e["order"]))}
+                e["leaf_row"] = np.asarray([index_of_chain.get(chain, -1) for chain in leaves] or [-1], np.int32)
+            if e.get("topk") != manual_topk:  # capacity of a node = product of k along its chain
+                cap = np.ones(len(e["order"]), np.int64)
+                for i, (par, _, _) in enumerate(e["order"]):
+                    cap[i] = manual_topk * (cap[par] if par >= 0 else 1)
+                sel = e["leaf_row"][e["leaf_row"] >= 0]
+                e["topk"], e["max_rec"] = manual_topk, int(cap[sel].sum())
+        flat = dict(lens=np.fromiter((len(e["par_i"]) for e in ents), np.int64, B),
+                    par_i=np.concatenate([e["par_i"] for e in ents]) if B else np.zeros(0, np.int64),
+                    rel_code=np.concatenate([e["rel_code"] for e in ents]) if B else np.zeros(0, np.int64), names=names)
+        flat["k_of"] = np.full(len(flat["par_i"]), manual_topk, np.int64)
+        raw = self._run_programs(users, None, None, grow_excluded=True, exclude=True, raw=True, flat=flat)
+        leaf_nodes = np.stack([e["leaf_row"] for e in ents]) if B else np.full((0, max(len(leaves), 1)), -1, np.int32)
+        max_rec = min(max([1] + [e["max_rec"] for e in ents]), self.n_items)
+        scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec)
+        return scores, rec, leaves, users_np
+
+    def _leaf_chains_cached(self):
+        lc = self.__dict__.get("_leaf_chain_cache")
+        if lc is None:
+            lc = self.__dict__["_leaf_chain_cache"] = self._leaf_chains()
+        return lc
+
     def run_program(self, users, path_counts=None, predicted_paths=None, manual_topk=5):
         """(scores [B, n_items], [[user, item, score, path], ...]) -- cafe.py:406-447.  Paths carry relation NAMES.
 
         collect_results and the ranking loop (cafe.py:417-441: every leaf path scored by the product of its float32
         log-probs, inst[item] = the LAST path to an item, stable sort by score, first entry per item emitted with inst[item]'s
-        path) run on the device (hw_cafe_collect, one workgroup per user); the host only turns the returned records into
-        the reference's Python lists."""
-        users = torch.as_tensor(users)
-        users_np = users.cpu().numpy()
-        B = len(users_np)
-        orders = [self._bfs_program() for _ in users_np]
-        programs = [[(par, rel) for par, rel, _ in o] for o in orders]
-        ks = [[manual_topk] * len(o) for o in orders]
-        raw = self._run_programs(users, programs, ks, grow_excluded=True, exclude=True, raw=True)
-        leaves = self._leaf_chains()
-        leaf_nodes = np.full((B, max(len(leaves), 1)), -1, np.int32)
-        for b, order in enumerate(orders):
-            index_of_chain = {_chain_of(order, i): i for i in range(len(order))}
-            for l, chain in enumerate(leaves):
-                leaf_nodes[b, l] = index_of_chain.get(chain, -1)
-        # most entries a user can have: the capacities of its leaf nodes
-        ptr = raw["node_ptr_np"]
-        max_rec = 1
-        for b in range(B):
-            sel = leaf_nodes[b][leaf_nodes[b] >= 0]
-            max_rec = max(max_rec, int(raw["cap"][ptr[b] + sel].sum()))
-        max_rec = min(max_rec, self.n_items)
-        scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec)
+        path) run on the device (hw_cafe_collect, one workgroup per user).  The second return value is a list-like view of
+        the device records: the Python lists the reference's contract asks for are only built when somebody reads them
+        (the ranking metrics of an evaluation never do)."""
+        scores, rec, leaves, users_np = self.run_program_device(users, manual_topk)
+        return scores.cpu(), _LazyRecords(self, rec, leaves, users_np)
+
+    def _records_to_lists(self, rec, leaves, users_np):
         cnt = rec["count"].cpu().numpy()
         item, score, leaf, pid = (rec[k].cpu().numpy() for k in ("item", "score", "leaf", "ids"))
         # (relation name, tail type) chains of the leaves, and the records as plain Python values in one pass each
         chains = [tuple((rel, self._module(rel).et_name) for rel in chain) for chain in leaves]
         collected = []
-        for b in range(B):
+        for b in range(len(users_np)):
             c = int(cnt[b])
             if not c:
                 continue
@@ -399,7 +473,7 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
                 [u, it, sc, ([start, (ch[0][0], ch[0][1], p[0]), (ch[1][0], ch[1][1], p[1]), (ch[2][0], ch[2][1], p[2])]
                              if len(ch) == 3 else [start, *((rel, et, e) for (rel, et), e in zip(ch, p))])]
                 for it, sc, l, p in rows for ch in (chains[l],))
-        return scores.cpu(), collected
+        return collected
 
     def full_sort_predict(self, interaction):
         scores, paths = self.run_program(interaction[self.USER_ID])
@@ -517,6 +591,46 @@ class CAFE(KnowledgeRecommender, ExplainableRecommender):
         reg_loss, rank_loss = self.model(self.metapaths[mpid], torch.from_numpy(pos_paths).to(dev),
                                          torch.from_numpy(neg_pids).to(dev), self.embeddings)
         return reg_loss, rank_loss * self.rank_weight
+
+
+class _LazyRecords(list):
+    """The [[user, item, score, path], ...] list of run_program, materialised from the device records on first use.  A
+    real list afterwards; every way of reading or combining it (len, iteration, indexing, ==, +, the collector's
+    ``previous + value``) fills it first."""
+
+    def __init__(self, model, rec, leaves, users_np):
+        super().__init__()
+        self._pending = (model, rec, leaves, users_np)
+
+    def _fill(self):
+        if self._pending is not None:
+            model, rec, leaves, users_np = self._pending
+            self._pending = None
+            list.extend(self, model._records_to_lists(rec, leaves, users_np))
+        return self
+
+    def __add__(self, other):
+        return list(self._fill()) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self._fill())
+
+    __hash__ = None
+
+
+def _filled(name):
+    def method(self, *a, **k):
+        self._fill()
+        return getattr(list, name)(self, *a, **k)
+
+    method.__name__ = name
+    return method
+
+
+for _n in ("__len__", "__iter__", "__getitem__", "__eq__", "__ne__", "__repr__", "__contains__", "__reversed__", "__iadd__",
+           "__mul__", "__setitem__", "__delitem__", "copy", "count", "index", "sort", "append", "extend", "insert", "pop",
+           "remove", "reverse"):
+    setattr(_LazyRecords, _n, _filled(_n))
 
 
 def _chain_of(order, i):

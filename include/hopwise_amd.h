@@ -94,8 +94,9 @@ int hw_kge_score_grouped(const hw_kge_desc* desc,
 /* The same with the negatives drawn inside the scorer: column 0 of t_idx (the positive) is read, columns
  * 1 .. n_tail_per_group-1 are DRAWN -- uniform over [1, value_num) minus used(keys[b]), the counters and rejection rule of
  * hw_neg_sample with num = n_tail_per_group - 1, so the ids are the ones that call would write -- scored, and written
- * back to t_idx for the gradient pass.  One launch instead of sampler + scorer.  HW_ERR_UNSUPPORTED for the widened
- * scorer set and for value_num > 65536 (the used set is an LDS bitmap per wave): sample and score separately then. */
+ * back to t_idx for the gradient pass.  One launch instead of sampler + scorer.  The key's used set is an LDS bitmap for
+ * value_num <= 65536 and is searched in place (binary search in its sorted CSR slice, as hw_neg_sample's generic kernel
+ * does) beyond that.  HW_ERR_UNSUPPORTED for the widened scorer set: sample and score separately then. */
 int hw_kge_score_grouped_sampled(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
                                  int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j, int64_t n_groups,
                                  int64_t n_tail_per_group, const int64_t* used_ptr, const int64_t* used_idx,

@@ -184,6 +184,46 @@ def test_scorer_with_in_kernel_sampler_equals_sampler_then_scorer(model, dim):
     assert ops.oob_count(dev) == oob_before
 
 
+def test_in_kernel_sampler_on_a_value_space_beyond_the_lds_bitmap():
+    """value_num > 65 536 (Yelp2018's 90 962 entities; the HBM-resident roofline table): the fused kernels test membership by
+    binary search in the key's sorted used slice instead of an LDS bitmap -- still the ids hw_neg_sample writes, bit for bit,
+    with and without the fused loss."""
+    from hopwise_amd import ops
+    from hopwise_amd.data import synthetic
+    from tests.helpers import random_tables
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    nU, nE, nR, B, K, d = 300, 90962, 7, 257, 256, 64
+    # dense used sets on a narrow id range so that rejections actually happen in a 90 k space
+    iu = rng.integers(1, nU, 60000)
+    ii = np.where(rng.random(60000) < 0.5, rng.integers(1, 400, 60000), rng.integers(1, nE, 60000))
+    ptr, idx = synthetic.used_csr(iu, ii, nU)
+    ptr, idx = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev)
+    tabs = {k: torch.from_numpy(v).to(dev) for k, v in random_tables("RotatE", nU, nE, nR, d, seed=2).items()}
+    from oracle import kge as okge
+
+    hn, rn, tn = okge.slots("RotatE", "rec")
+    desc = ops.make_desc("RotatE", tuple(tabs[n] for n in hn), tuple(tabs[n] for n in rn), tuple(tabs[n] for n in tn), margin=1.0)
+    users = torch.from_numpy(rng.integers(1, nU, B)).to(dev)
+    a = torch.zeros((B, 1 + K), dtype=torch.int64, device=dev)
+    a[:, 0] = torch.from_numpy(rng.integers(1, nE, B)).to(dev)
+    b, c = a.clone(), a.clone()
+    ops.neg_sample(ptr, idx, users, K, nE, seed=21, offset=9, out=a[:, 1:])
+    ref = ops.kge_score_grouped_raw(desc, users, None, nR - 1, a)
+    got = ops.kge_score_grouped_sampled_raw(desc, users, None, nR - 1, b, ptr, idx, users, nE, 21, 9)
+    np.testing.assert_array_equal(b.cpu().numpy(), a.cpu().numpy())
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    got2, loss, _ = ops.kge_score_grouped_sampled_selfadv_raw(desc, users, None, nR - 1, c, ptr, idx, users, nE, 21, 9, alpha=1.0)
+    np.testing.assert_array_equal(c.cpu().numpy(), a.cpu().numpy())
+    np.testing.assert_array_equal(got2.cpu().numpy(), ref.cpu().numpy())
+    np.testing.assert_allclose(loss.item(), ops.self_adversarial_mean(ref, 1.0).item(), rtol=1e-6)
+    # the draws avoided the used sets
+    used = set(zip(iu.tolist(), ii.tolist()))
+    av, uv = a.cpu().numpy(), users.cpu().numpy()
+    assert all((int(uv[r]), int(v)) not in used for r in range(B) for v in av[r, 1:])
+
+
 @pytest.mark.parametrize("model,dim,B,K,alpha", [("RotatE", 200, 2048, 256, 1.0), ("TransE", 64, 93, 130, 0.5),
                                                  ("ComplEx", 100, 7, 511, 2.0), ("DistMult", 24, 300, 127, 1.0)])
 def test_sampler_scorer_and_loss_in_one_launch(model, dim, B, K, alpha):
