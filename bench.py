@@ -46,6 +46,9 @@ DIM, K_NEG, B_POS = 200, 256, 2048
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md 'Indexed rows': rows shared in an XCD's L2, 16.8-18.8 TB/s chip-wide
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix rate (MI355X_MICROARCH.md); a three-way split fp32 product costs 6 bf16 MFMAs
+PLAIN_KERNEL = "kge_score_grouped_kernel<1, 64, 4, true, 4, false"   # RotatE d=200 instantiations as rocprofv3 names them
+FUSED_KERNEL = "kge_score_grouped_kernel<1, 64, 4, true, 4, true, true"
 TARGET_TIMED_SECONDS = 0.75
 
 
@@ -67,13 +70,14 @@ def parse_args(argv=None):
     ap.add_argument("--no-pgpr", action="store_true")
     ap.add_argument("--no-sharded", action="store_true")
     ap.add_argument("--no-tucker", action="store_true")
+    ap.add_argument("--no-cafe", action="store_true")
     ap.add_argument("--unfused-sampler", action="store_true", help="run hw_neg_sample as its own launch before the scorer")
     ap.add_argument("--unfused-loss", action="store_true", help="run hw_loss_self_adversarial as its own launches after the scorer")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the timed batches alternate over (each with its own id / score buffers and loss chain)")
     ap.add_argument("--unchained-loss", action="store_true",
                     help="finish every batch's loss with its own one-block launch instead of inside the next batch's launch")
-    ap.add_argument("--pgpr-steps", type=int, default=5)
+    ap.add_argument("--pgpr-steps", type=int, default=0, help="0: enough searches for 0.5 s of timed work (>= 5)")
     ap.add_argument("--pgpr-users", type=int, default=256,
                     help="users per beam search: 64 -> 5.8 G paths/s, 256 -> 6.7 G (the first hops' fixed cost amortised), ~8 GB of work buffers")
     ap.add_argument("--sharded-steps", type=int, default=10)
@@ -276,8 +280,11 @@ def leg_kge(D, args, out):
 
     events = []
 
+    n_launched = [1 if fused_loss else 0]  # the validation launch above
+
     def batch(i, ev=None, ln=None):
         ln = ln or lanes[i % n_lanes]
+        n_launched[0] += 1
         rc = 0
         if not fused:
             rc = lib.hw_neg_sample(*ln.samp_head, C.c_uint64(i), *ln.samp_tail)
@@ -349,6 +356,9 @@ def leg_kge(D, args, out):
         chain_flush([solo])
         torch.cuda.synchronize()
     t_idx, scores, loss = solo.t_idx, solo.scores, solo.loss
+    _log_launches("timed_region_and_single_stream_pass",
+                  FUSED_KERNEL if fused_loss else "kge_score_grouped_kernel<1, 64, 4, true, 4, true, false" if fused else PLAIN_KERNEL,
+                  n_launched[0])
 
     triples_per_batch = B_POS * (1 + K_NEG)
     triples_per_step = triples_per_batch * inner
@@ -416,12 +426,22 @@ def leg_kge(D, args, out):
                     "launch_ms_under_overlap while it shares the chip)"}
     out["roofline"] = {"configs1_launch": l2}
     ctx = dict(kg=kg, head=head, rel=rel, tail=tail, users=users, t_idx=t_idx, desc=desc, abytes=abytes,
+               uptr_np=uptr.cpu().numpy(),
                triples_per_batch=triples_per_batch, traffic=traffic, tabs=(user_re, user_im, theta, ent_re, ent_im))
     return ctx
 
 
-def _time_kernel(torch, fn, min_seconds=0.3, reps0=20):
-    """Average launch duration (ms) of fn() from HIP events on the launch stream, over >= min_seconds of launches."""
+LAUNCH_LOG = []  # [{"tag", "kernel", "launches"}] in launch order; written to $HW_BENCH_LAUNCH_LOG when set
+
+
+def _log_launches(tag, kernel, n):
+    LAUNCH_LOG.append({"tag": tag, "kernel": kernel, "launches": int(n)})
+
+
+def _time_kernel(torch, fn, min_seconds=0.3, reps0=20, tag=None, kernel=None):
+    """Average launch duration (ms) of fn() from HIP events on the launch stream, over >= min_seconds of launches.
+    With ``tag`` the launches are recorded in LAUNCH_LOG: the variants of one kernel run under one name, and the committed
+    profile summary (tools/summarize_profile.py) splits the kernel trace by this log -- one row per variant."""
     for _ in range(3):
         fn()
     ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -437,6 +457,8 @@ def _time_kernel(torch, fn, min_seconds=0.3, reps0=20):
         fn()
     eb.record()
     torch.cuda.synchronize()
+    if tag:
+        _log_launches(tag, kernel, 3 + reps0 + reps)
     return ea.elapsed_time(eb) / reps, reps
 
 
@@ -457,7 +479,8 @@ def leg_roofline_variants(D, args, out, ctx):
     prev = os.environ.get("HW_GROUPED_VARIANT")
     for name, var in (("plain", "0"), ("xcd_partitioned", "1")):
         os.environ["HW_GROUPED_VARIANT"] = var
-        ms, reps = _time_kernel(torch, lambda: ops.kge_score_grouped_raw(edesc, users, None, kg.ui_relation, eidx))
+        ms, reps = _time_kernel(torch, lambda: ops.kge_score_grouped_raw(edesc, users, None, kg.ui_relation, eidx),
+                                tag=f"entity_tails_{name}", kernel="kge_score_grouped_xcd_kernel<1," if var == "1" else PLAIN_KERNEL)
         ent[name] = {"kernel_ms": ms, "launches": reps, "achieved": abytes / (ms * 1e-3) / 1e9,
                      "triples_per_s": tpb / (ms * 1e-3),
                      "traffic": ctx["traffic"].get(f"kge_score_grouped_entity_tails_{'xcd' if var == '1' else 'plain'}_bytes_per_launch")}
@@ -478,17 +501,65 @@ def leg_roofline_variants(D, args, out, ctx):
     big_im = torch.randn(nbig, DIM, device=dev) * 0.01
     bdesc = ops.make_desc("RotatE", ctx["head"], ctx["rel"], (big_re, big_im), margin=1.0)
     bidx = torch.randint(1, nbig, (B_POS, 1 + K_NEG), device=dev, dtype=torch.int64, generator=gen)
-    ms, reps = _time_kernel(torch, lambda: ops.kge_score_grouped_raw(bdesc, users, None, kg.ui_relation, bidx))
+    ms, reps = _time_kernel(torch, lambda: ops.kge_score_grouped_raw(bdesc, users, None, kg.ui_relation, bidx),
+                            tag="hbm_plain", kernel=PLAIN_KERNEL)
     ach = abytes / (ms * 1e-3) / 1e9
+    plain = {"kernel": "kge_score_grouped_kernel<RotatE> (pre-drawn ids, no loss)", "kernel_ms": ms, "launches": reps,
+             "achieved": ach, "frac": ach / HBM_PEAK_GBS, "triples_per_s": tpb / (ms * 1e-3),
+             "traffic": ctx["traffic"].get("kge_score_grouped_hbm_variant_bytes_per_launch")}
+    # the instantiation of the TIMED REGION (sampler + scorer + self-adversarial loss in one launch) on the same 4.2 GB table:
+    # the used sets keep the real interaction counts per user, their ids spread over the big id space (sorted per user: the
+    # fused sampler searches the slice beyond the 65 536-id LDS bitmap)
+    import numpy as np
+
+    counts = np.diff(ctx["uptr_np"])
+    rng = np.random.default_rng(7)
+    big_used = rng.integers(1, nbig, int(counts.sum()))
+    seg = np.repeat(np.arange(len(counts)), counts)
+    big_used = big_used[np.lexsort((big_used, seg))]
+    bptr = torch.from_numpy(ctx["uptr_np"]).to(dev)
+    bused = torch.from_numpy(big_used).to(dev)
+    t_big = bidx.clone()
+    state = {"i": 0}
+    # exactly the launch of the timed region: the chained form (batch i's 2048 group terms are added by block 0 of batch
+    # i + 1, no finish launch per batch), preallocated scores / loss
+    chain = ops.SelfAdvChain(B_POS, dev)
+    f_out = torch.empty((B_POS, 1 + K_NEG), dtype=torch.float32, device=dev)
+    f_loss = torch.empty(1, dtype=torch.float32, device=dev)
+
+    def fused_launch():
+        state["i"] += 1
+        chain.launch(bdesc, users, None, kg.ui_relation, t_big, bptr, bused, users, nbig, 2024, state["i"], alpha=1.0,
+                     out=f_out, loss=f_loss)
+
+    fused = None
+    try:
+        fms, freps = _time_kernel(torch, fused_launch, tag="hbm_fused", kernel=FUSED_KERNEL)
+        chain.flush()
+        torch.cuda.synchronize()
+        assert torch.isfinite(f_loss).all().item()
+        fach = abytes / (fms * 1e-3) / 1e9
+        fused = {"kernel": "kge_score_grouped_kernel<RotatE, SAMPLE, LOSS> (the timed region's instantiation)",
+                 "kernel_ms": fms, "launches": freps, "achieved": fach, "frac": fach / HBM_PEAK_GBS,
+                 "triples_per_s": tpb / (fms * 1e-3),
+                 "traffic": ctx["traffic"].get("kge_score_grouped_hbm_fused_bytes_per_launch"),
+                 "note": "negatives drawn in the launch (Philox + rejection against the user's used slice, binary search: the id "
+                         "space is beyond the LDS bitmap), 257 scores per group reduced to the self-adversarial loss term in the "
+                         "same block, chained like the timed region (hw_kge_score_grouped_sampled_selfadv_chained)"}
+    except Exception as e:  # noqa: BLE001
+        fused = {"error": f"{type(e).__name__}: {e}"[:300]}
+    head = fused if fused and "achieved" in fused else plain
     rec = {
-        "bound": "hbm", "kernel": "kge_score_grouped_kernel<RotatE>", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": ach / HBM_PEAK_GBS, "traffic": ctx["traffic"].get("kge_score_grouped_hbm_variant_bytes_per_launch"),
-        "kernel_ms": ms, "launches": reps, "algorithmic_bytes_per_launch": abytes,
-        "triples_per_s": tpb / (ms * 1e-3),
+        "bound": "hbm", "kernel": head["kernel"], "achieved": head["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": head["achieved"] / HBM_PEAK_GBS, "traffic": head["traffic"],
+        "kernel_ms": head["kernel_ms"], "launches": head["launches"], "algorithmic_bytes_per_launch": abytes,
+        "triples_per_s": head["triples_per_s"],
+        "fused_instantiation": fused, "plain_scorer": plain,
         "workload": f"the configs[1] kernel and batch shape (2048 x 257 triples per launch) on a {2 * nbig * DIM * 4 / 1e9:.1f} GB "
                     f"entity table ({nbig} rows), tails ~ randint(1, {nbig}): every tail row is an HBM miss.  configs[1]'s "
                     "own tables (32 MB) never leave L2 / Infinity Cache, so its launch is reported under configs1_launch "
-                    "against the L2 gather ceiling instead",
+                    "against the L2 gather ceiling instead.  The roofline of record is the instantiation the timed region "
+                    "launches (fused_instantiation); plain_scorer is the same kernel without sampler and loss",
         "gather_ceiling_note": "the guide's measured random-row gather from HBM is 5.5-5.8 TB/s (1.1-2.3 KB rows)",
         "traffic_note": "traffic / algorithmic = 1.14: an 800-byte row (d = 200 floats) always occupies 7 lines of 128 B "
                         "(6.25 needed) whatever its alignment, and RotatE reads two such rows (re, im tables) per tail: 14 lines "
@@ -512,6 +583,7 @@ def leg_roofline_variants(D, args, out, ctx):
     t0 = time.perf_counter()
     pair(n_pair)
     torch.cuda.synchronize()
+    _log_launches("hbm_plain_two_streams", PLAIN_KERNEL, 8 + n_pair)
     per = (time.perf_counter() - t0) / n_pair
     rec["two_streams_aggregate"] = {"us_per_launch": per * 1e6, "GBps": abytes / per / 1e9, "frac_of_peak": abytes / per / 1e9 / HBM_PEAK_GBS,
                                     "launches": n_pair, "note": "wall time per launch with two launches sharing the chip; "
@@ -527,7 +599,7 @@ def leg_roofline_variants(D, args, out, ctx):
     cfg1 = out["roofline"].pop("configs1_launch")
     ent = out["roofline"].pop("entity_tails")
     out["roofline"] = {**rec, "configs1_launch": cfg1, "entity_tails": ent}
-    del big_re, big_im, bidx
+    del big_re, big_im, bidx, t_big, bused
     torch.cuda.empty_cache()
 
 
@@ -692,12 +764,19 @@ def leg_tucker(D, args):
     flops_fwd = sum(2 * B * d**3 + 2 * B * d * d + 2 * B * d * N for N in (nU + nI, nE))
     m.train()
     res = {"metric": "TuckER d=200 calculate_loss on the Alibaba-iFashion shape (rec + kg side, B=2048 each), fp32 MFMA",
-           "flops_forward": flops_fwd, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "bound": "mfma",
+           "flops_forward": flops_fwd, "unit": "TFLOP/s",
+           "peak": (BF16_MFMA_PEAK_TFLOPS / 6.0 if os.environ.get("HW_GEMM_SPLIT", "1") != "0" else FP32_MFMA_PEAK_TFLOPS),
+           "bound": ("bf16-mfma (3-way split)" if os.environ.get("HW_GEMM_SPLIT", "1") != "0" else "mfma"),
            "gemm": ("fp32 products as three-way bf16 splits on the bf16 matrix pipes (6 v_mfma_f32_32x32x16_bf16 per 16 k, fp32 "
                     "accumulate; error vs float64 <= the fp32 FMA chain's, tests/test_gpu_gemm_split.py)"
                     if os.environ.get("HW_GEMM_SPLIT", "1") != "0" else "v_mfma_f32_32x32x2_f32 FMA chains (HW_GEMM_SPLIT=0)"),
-           "peak_note": "peak = the fp32-input MFMA rate (157.3 TFLOP/s at 2.4 GHz); achieved counts the reference's fp32 FLOPs, "
-                        "so the split loop can exceed what fp32-input MFMAs could deliver"}
+           "peak_note": "achieved counts the reference's fp32 FLOPs (SURVEY 8(d) config 5: 2 d^3 + 2 d^2 + 2 d N per row, x3 with "
+                        "the backward); the products run as three-way bf16 splits = 6 bf16 MFMAs per fp32 MFMA-equivalent, so "
+                        "the roof of the unit that executes is the dense bf16 rate / 6 = 416.7 TFLOP/s of fp32 work (the fp32-"
+                        "input MFMA pipe's 157.3 TFLOP/s applies with HW_GEMM_SPLIT=0).  The kernels execute fewer FLOPs than "
+                        "that count (one matrix per distinct relation instead of per row), which is why mfma_util, the cycle "
+                        "fraction the matrix pipes are busy, is reported next to it"}
+    peak = res["peak"]
     for mode, mult in (("forward", 1), ("forward_backward", 3)):
         def step(i):
             m.zero_grad(set_to_none=True)
@@ -716,7 +795,8 @@ def leg_tucker(D, args):
         torch.cuda.synchronize()
         ms = ea.elapsed_time(eb) / reps
         res[mode] = {"ms": ms, "achieved": flops_fwd * mult / (ms * 1e-3) / 1e12,
-                     "frac": flops_fwd * mult / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                     "frac": flops_fwd * mult / (ms * 1e-3) / 1e12 / peak,
+                     "frac_of_fp32_input_mfma_peak": flops_fwd * mult / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
     # full-size parity, outside the timed region: one matrix per distinct relation (the engine's default) against the
     # reference's per-row mm(r, W) on the same batch and dropout stream -- the same loss, bit for bit
     def loss_with(shared):
@@ -855,6 +935,12 @@ def main():
             tm, tp = D.reduce(pg["ms_per_step"], "max"), D.reduce(pg["paths_per_step"], "sum")
             pg.update(value=tp / (tm * 1e-3), ms_per_step=tm, paths_per_step=tp, n_gpus=D.world)
         out["pgpr"] = pg
+    if not args.no_cafe and D.world == 1:
+        # "PGPR / CAFE beam-search traversal": the CAFE program executor on the same graph (bench_cafe.py)
+        import bench_cafe
+
+        torch.cuda.empty_cache()
+        guarded("cafe", lambda: bench_cafe.run(D.dev, n_users=256, cpu_users=(2 if not args.no_cpu_baseline else 0)))
     if args.workload == "sharded" and "value" in out.get("sharded", {}):
         sh = out["sharded"]
         out["replica_configs1"] = {k: out[k] for k in ("metric", "value", "unit", "ms_per_step", "config")}
@@ -863,6 +949,9 @@ def main():
                    config={"workload": "configs[3]: ComplEx dim=256, Yelp2018-shaped KG, user/entity tables row-sharded",
                            "parallelism": sh["parallelism"], "global_batch_triples": sh["batch_per_rank"]["triples"] * D.world})
     if D.rank == 0:
+        if os.environ.get("HW_BENCH_LAUNCH_LOG"):
+            with open(os.environ["HW_BENCH_LAUNCH_LOG"], "w") as f:
+                json.dump(LAUNCH_LOG, f, indent=1)
         print(json.dumps(out))
     D.close()
 

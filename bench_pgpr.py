@@ -70,12 +70,18 @@ def make_model(dev, dropout="reference"):
 
 
 def algorithmic_bytes(m, res, hops):
-    """SURVEY.md §8(d) config 3, summed over the parent rows of every hop of one search:
-    CSR slice deg * 8  +  (deg > max_acts: candidate rows deg * d * 4)  +  state gather 4 * d * 4  +  probs act_dim * 4
-    +  children min(k, n_acts) * 12.  `res` must come from beam_search_device(..., keep_buffers=True)."""
+    """Bytes THIS algorithm must move for one search, summed over the parent rows of every hop:
+        CSR slice                       deg * 8          (int32 relation + int32 neighbour per edge)
+        trim scores of over-full rows   deg * 16         (two float64 table entries per candidate instead of SURVEY's
+                                                          deg * d * 4 gathered rows: the float64 trim tables u.U[n],
+                                                          (u + r_ui).E[n], R[r].E[n] are precomputed per batch)
+        first policy layer              n_parts * H1 * 4 (one 2 KB slot-table row per state slot; 4 at state_history 1)
+        children                        min(k, n_acts) * 60   (48-byte path record + 3 float32 hop values)
+    `res` must come from beam_search_device(..., keep_buffers=True).  Returns (total, per-hop list)."""
     g, buf = m.graph, res.buffers
     nr = res.n_rows_per_hop.cpu().numpy()
-    d, total = m.embedding_size, 0
+    n_parts, h1 = 2 + 2 * m.state_history, m.hidden_sizes[0]
+    total, per_hop = 0, []
     for hop, k in enumerate(hops):
         n = int(nr[hop])
         rec = buf["paths"][hop][:n].long()
@@ -87,12 +93,15 @@ def algorithmic_bytes(m, res, hops):
         deg = g.ptr[gid + 1] - g.ptr[gid]
         # n_acts of this hop is overwritten by later hops in the shared buffer: children are bounded by k and by deg + 1
         kids = torch.minimum(torch.full_like(deg, k), torch.minimum(deg + 1, torch.full_like(deg, m.act_dim)))
-        per_row = deg * 8 + torch.where(deg > m.max_acts, deg * d * 4, torch.zeros_like(deg)) + 4 * d * 4 + m.act_dim * 4 + kids * 12
-        total += int(per_row.sum().item())
-    return total
+        per_row = deg * 8 + torch.where(deg > m.max_acts, deg * 16, torch.zeros_like(deg)) + n_parts * h1 * 4 + kids * 60
+        b = int(per_row.sum().item())
+        per_hop.append({"rows": n, "bytes": b})
+        total += b
+    return total, per_hop
 
 
-def run(dev, n_users=32, steps=5, warmup=1, cpu_users=0, rank=0):
+def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5):
+    """steps = 0: as many searches as fill `min_seconds` of timed work (at least 5)."""
     kg, ds, m = make_model(dev)
     rng = np.random.default_rng(100 + rank)
     expanded = 0
@@ -100,36 +109,68 @@ def run(dev, n_users=32, steps=5, warmup=1, cpu_users=0, rank=0):
     def batch(i):
         return torch.from_numpy(rng.integers(1, kg.n_users, n_users)).to(dev)
 
-    for i in range(warmup):
+    for i in range(max(warmup, 1)):
         res = m.beam_search_device(batch(i))
         torch.cuda.synchronize()
+    if steps <= 0:
+        t0 = time.perf_counter()
+        m.beam_search_device(batch(0))
+        torch.cuda.synchronize()
+        steps = max(5, int(np.ceil(min_seconds / max(time.perf_counter() - t0, 1e-4))))
+    user_batches = [batch(i) for i in range(steps)]  # ids resident on the device before the clock starts
     counts = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        res = m.beam_search_device(batch(i))
+        res = m.beam_search_device(user_batches[i])
         counts.append(res.n_rows_per_hop)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     expanded = int(sum(int(c[1:].sum().item()) for c in counts))
-    # byte accounting on one more (untimed) search of the same size
+    # byte accounting and per-stage times on more (untimed) searches of the same size
     res = m.beam_search_device(batch(steps), keep_buffers=True)
-    abytes = algorithmic_bytes(m, res, HOPS)
+    abytes, per_hop = algorithmic_bytes(m, res, HOPS)
     del res
+    stage_ms = {}
+    n_probe = 5
+    for j in range(n_probe):
+        evs = []
+        m.beam_search_device(batch(steps + 1 + j), stage_events=evs)
+        torch.cuda.synchronize()
+        for (_, _, e0), (stage, hop, e1) in zip(evs[:-1], evs[1:]):
+            key = f"{stage}.hop{hop + 1}"
+            stage_ms[key] = stage_ms.get(key, 0.0) + e0.elapsed_time(e1) / n_probe
+    by_stage = {}
+    for k, v in stage_ms.items():
+        by_stage[k.split(".")[0]] = by_stage.get(k.split(".")[0], 0.0) + v
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("pgpr_search_bytes_per_search")
+        except Exception:
+            traffic = None
     ms = dt / steps * 1e3
     out = {
         "metric": "PGPR paths expanded per second (3-hop beam 64/64/64, d=100, max_acts=250)",
-        "value": expanded / dt, "unit": "paths/s", "users_per_step": n_users, "steps": steps,
+        "value": expanded / dt, "unit": "paths/s", "users_per_step": n_users, "steps": steps, "timed_seconds": dt,
         "ms_per_step": ms, "paths_per_step": expanded / steps,
         "graph": {"n_users": kg.n_users, "n_items": kg.n_items, "n_entities": kg.n_entities, "nnz": m.graph.nnz,
                   "max_degree": m.graph.max_degree},
+        "policy": ("one launch per hop (hw_pgpr_policy_fused)" if m.fused_policy else "three launches per hop (lookup, l2, actor)"),
         "roofline": {
             "bound": "hbm", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "frac": abytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_search": abytes, "traffic": None,
-            "note": "SURVEY §8(d) config 3 byte sum over the parent rows of all three hops (CSR slice + candidate rows of "
-                    "over-full nodes + state gather + probs + children) / wall time of the whole search (21 launches).  The "
-                    "search is not one bandwidth-bound kernel: 35-40 % of it is the policy MLP's GEMMs and the rest is "
-                    "L2-gather / issue bound (DESIGN.md §4), so this fraction is a reported figure, not a target",
+            "frac": abytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_search": abytes, "traffic": traffic,
+            "per_hop": per_hop,
+            "stage_ms": {k: round(v, 4) for k, v in sorted(by_stage.items())},
+            "stage_ms_by_hop": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
+            "note": "bytes this algorithm must move (CSR slice deg * 8 + 2 float64 trim-score lookups per candidate of an "
+                    "over-full row + one 2 KB slot-table row per state slot + 60 B per child; bench_pgpr.algorithmic_bytes) / "
+                    "wall time of the whole search.  The search is not one bandwidth-bound kernel: the policy network is "
+                    "MFMA / issue bound and the action kernels are L2-gather bound (DESIGN.md §4), so this fraction is a "
+                    "reported figure, not a target.  stage_ms: HIP events between the stages of a search (5 untimed "
+                    "searches); per-kernel durations: profiles/r3/pgpr_kernel_stats_*.csv; traffic: fabric-side bytes of all "
+                    "kernels of one search from the FETCH_SIZE / WRITE_SIZE passes",
         },
     }
     if cpu_users > 0:
@@ -178,7 +219,7 @@ def run(dev, n_users=32, steps=5, warmup=1, cpu_users=0, rank=0):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--users", type=int, default=64)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=0, help="0: enough searches for 0.5 s of timed work")
     ap.add_argument("--cpu-users", type=int, default=0)
     a = ap.parse_args()
     print(json.dumps(run(torch.device("cuda", 0), a.users, a.steps, 1, a.cpu_users)))

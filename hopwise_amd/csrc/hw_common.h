@@ -75,8 +75,9 @@ struct SamplerArgs {
     const int64_t* keys;
     int64_t n_key_space, value_num;
     uint64_t seed, offset;
-    int words;  // bitmap words per wave = ceil(value_num / 32)
+    int words;  // bitmap words per wave = ceil(value_num / 32); 0: value space beyond the bitmap, membership by binary search
 };
+constexpr int SAMPLER_STAGE_IDS = 1024;  // words == 0: a key's sorted used slice is staged in LDS (4 KB: 8 blocks per CU stay resident) when it has at most this many ids
 constexpr int SAMPLER_MAX_ATTEMPTS_FUSED = 1 << 16;
 
 // Self-adversarial loss folded into the sampled grouped scorer (hw_kge_score_grouped_sampled_selfadv): the block that scores

@@ -214,9 +214,11 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         P.mlp_layer(buf["x2"], self.actor.weight, self.actor.bias, buf["logits"], n_rows, rmax, False)
 
     @torch.no_grad()
-    def beam_search_device(self, users, hops=None, drops=None, keep_trace=False, keep_buffers=False):
+    def beam_search_device(self, users, hops=None, drops=None, keep_trace=False, keep_buffers=False, stage_events=None):
         """Expand ``users`` (int64 tensor on the device) hop by hop; returns a :class:`BeamResult` of leaf rows.
-        ``drops``: optional per hop (mask1 [rows, h0], mask2 [rows, h1]) multiplicative masks."""
+        ``drops``: optional per hop (mask1 [rows, h0], mask2 [rows, h1]) multiplicative masks.
+        ``stage_events``: a list that receives (stage, hop, HIP event) marks on the launch stream after every stage of
+        every hop (bench_pgpr's per-stage times; nothing is recorded when None)."""
         hops = list(self.beam_search_hop if hops is None else hops)
         if not 1 <= len(hops) <= 3:
             raise ValueError("beam_search_hop must have 1..3 entries (paths hold at most 4 nodes)")
@@ -232,6 +234,14 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         P.init_paths(users, buf["paths"][0], buf["probs"][0], nr[0:1])
         score_user, score_entity = P.user_scores(g, U64, E64, R64, users, self._user_vec())  # float64 trim tables
         trace = []
+
+        def mark(stage, hop):
+            if stage_events is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                stage_events.append((stage, hop, ev))
+
+        mark("start", -1)
         for hop, k in enumerate(hops):
             rmax = buf["rows"][hop]
             paths, probs, n_rows = buf["paths"][hop], buf["probs"][hop], nr[hop : hop + 1]
@@ -242,11 +252,15 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 P.state(g, U32, E32, R32, self.state_history, paths, n_rows, rmax, buf["state"])
             P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, rmax, self.max_acts,
                       self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"])
+            mark("actions", hop)
             self._policy_logits(buf, n_rows, rmax, drops, hop, paths if lookup else None)
+            mark("policy", hop)
             P.policy_topk(buf["logits"], self.act_dim, buf["n_acts"], n_rows, rmax, k, buf["tk_idx"], buf["tk_val"])
+            mark("topk", hop)
             P.expand(g, paths, probs, buf["acts"], self.act_dim, buf["n_acts"], n_rows, rmax, buf["tk_idx"],
                      buf["tk_val"], k, buf["offsets"], buf["paths"][hop + 1], buf["probs"][hop + 1],
                      nr[hop + 1 : hop + 2], buf["rows"][hop + 1])
+            mark("expand", hop)
             if keep_trace:
                 n = int(n_rows.item())
                 trace.append(dict(acts=buf["acts"][:n].clone(), n_acts=buf["n_acts"][:n].clone(),
