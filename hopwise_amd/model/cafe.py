@@ -39,7 +39,7 @@ class RelationModule(nn.Module):
         self.fc1 = nn.Linear(embedding_size * 2, 256)
         self.bn1 = ops.BatchNorm1d(256)
         self.fc2 = nn.Linear(256, embedding_size)
-        self.dropout = ops.Dropout(0.5, 2020)
+        self.dropout = ops.Dropout(0.5, 2020, stream="cafe." + info["name"])
 
     def forward(self, inputs):  # cafe.py:656-667
         eh_vec, user_vec = inputs
@@ -58,7 +58,7 @@ class DeepRelationModule(nn.Module):
         self.fc2 = nn.Linear(256, n)
         self.bn2 = ops.BatchNorm1d(n)
         self.fc3 = nn.Linear(n, embedding_size)
-        self.dropout = ops.Dropout(0.5, 2020) if use_dropout else None
+        self.dropout = ops.Dropout(0.5, 2020, stream="cafe." + info["name"]) if use_dropout else None
 
     def forward(self, inputs):  # cafe.py:686-699; the three Linear layers run on the MFMA GEMM
         eh_vec, user_vec = inputs
@@ -126,8 +126,9 @@ def build_layout(metapaths):
     return root
 
 
-class CAFE(KnowledgeRecommender, ExplainableRecommender):
+class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
     input_type = InputType.USERWISE
+    other_parameter_name = ["_dropout_calls"]  # the relation modules' mask streams resume with the checkpoint
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)

@@ -505,7 +505,7 @@ class TransR(KnowledgeRecommender):
                                       None, self.n_relations - 1, 0, self.n_items, k, history_index, True, 0.0)
 
 
-class TuckER(KnowledgeRecommender):
+class TuckER(ops.DropoutCounters, KnowledgeRecommender):
     """TuckER 1-vs-all scorer (tucker.py:21-172) on the fp32 matrix cores.
 
     Same parameters / state_dict keys as the reference (``user_embedding`` has n_users + n_items rows, ``weights`` is
@@ -517,7 +517,8 @@ class TuckER(KnowledgeRecommender):
     hidden_dropout1 and the sigmoid + BCE with its gradient are fused kernels (csrc/tucker.hip); BatchNorm1d and the two
     [B, d] dropouts run on csrc/batchnorm.hip (ops.BatchNorm1d / ops.Dropout, same state_dict keys)."""
 
-    other_parameter_name = ["_drop_calls"]  # Philox offset of hidden_dropout1: saved with the checkpoint (trainer.py:296-304)
+    # Philox offsets of hidden_dropout1 and of the two [B, d] dropouts: saved with the checkpoint (trainer.py:296-304)
+    other_parameter_name = ["_drop_calls", "_dropout_calls"]
 
     input_type = InputType.PAIRWISE
 
@@ -557,7 +558,10 @@ class TuckER(KnowledgeRecommender):
         fm = self.forced_masks[side] if self.forced_masks is not None else (None, None, None)
         h = ops.embedding(self.user_embedding.weight if side == "rec" else self.entity_embedding.weight, h_idx)
         x = self._drop(self.input_dropout, self.bn0(h), fm[0])
-        if self.share_relation_matrices and h_idx.numel() > 0:
+        n_rel = self.relation_embedding.weight.shape[0]
+        # the relation-set form holds n_relations [d, d] matrices (and their gradient): only while that is no more than the
+        # reference's own [B, d, d] -- a KG with thousands of relations and a small batch takes the per-row product below
+        if self.share_relation_matrices and h_idx.numel() > 0 and (side == "rec" or n_rel <= h_idx.numel()):
             # mm(r, W) has one distinct row per distinct relation: ONE on the rec side (every row carries [UI-Relation],
             # self._ui) and n_relations at most on the kg side, against B = 2048 rows.  Form those few [d, d] matrices once
             # ([n_rel, d] x [d, d^2] instead of [B, d] x [d, d^2], forward and twice backward) and let each batch row pick
@@ -565,7 +569,9 @@ class TuckER(KnowledgeRecommender):
             if side == "rec":
                 rows, index = ops.embedding(self.relation_embedding.weight, r_idx[:1]), None
             else:
-                rows, index = self.relation_embedding.weight, r_idx
+                # the contraction kernels index the matrix set with this id unchecked: clamp it (one tiny launch) the way
+                # the embedding gather clamps a bad relation id on the per-row path
+                rows, index = self.relation_embedding.weight, r_idx.clamp(0, n_rel - 1)
             w_set = ops.matmul_nn(rows, self.weights.view(d, d * d)).view(-1, d, d)
             if fm[1] is None and self.training and self.hidden_dropout1.p > 0:
                 self._drop_calls += 1
@@ -644,7 +650,7 @@ class _PadEmbedding(torch.autograd.Function):
         return gt, None, None
 
 
-class ConvE(KnowledgeRecommender):
+class ConvE(ops.DropoutCounters, KnowledgeRecommender):
     """ConvE 1-vs-all scorer (conve.py:21-190): the head and relation rows are reshaped to [d1, d2] images, stacked,
     convolved with 32 3x3 filters, projected back to d and multiplied with every row of the entity table.
 
@@ -657,6 +663,8 @@ class ConvE(KnowledgeRecommender):
     The convolution (csrc/conv.hip), the two BatchNorm2d layers (csrc/batchnorm.hip), the two dense products and sigmoid +
     BCE are HIP, and so are BatchNorm1d and the element-wise dropouts (ops.BatchNorm1d / ops.Dropout); only the channel-wise
     Dropout2d is torch's."""
+
+    other_parameter_name = ["_dropout_calls"]  # mask streams of inp_drop / hidden_drop resume with the checkpoint
 
     input_type = InputType.PAIRWISE
 
@@ -753,7 +761,7 @@ class ConvE(KnowledgeRecommender):
         raise AttributeError("'ConvE' object has no attribute 'entities_embeddings'")
 
 
-class ConvKB(KnowledgeRecommender):
+class ConvKB(ops.DropoutCounters, KnowledgeRecommender):
     """ConvKB (convkb.py:24-160): the (h, r, t) rows form a [d, 3] matrix that goes through BatchNorm2d(1), T filters of
     shape (kernel_size, 3), BatchNorm2d(T), ReLU, dropout and a bias-free Linear to one score.
 
@@ -764,6 +772,8 @@ class ConvKB(KnowledgeRecommender):
     reference's order (convkb.py:131-134).  The convolution and the Linear run on csrc/conv.hip and the MFMA GEMM, the
     softplus means on the BCE kernel, the BatchNorm2d layers on csrc/batchnorm.hip; dropout / the tiny norms are torch.  No full-sort methods exist in
     the reference."""
+
+    other_parameter_name = ["_dropout_calls"]
 
     input_type = InputType.PAIRWISE
 

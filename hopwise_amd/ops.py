@@ -1042,19 +1042,20 @@ class _DropoutFn(torch.autograd.Function):
 
 
 class Dropout(torch.nn.Dropout):
-    """nn.Dropout drawn from a device Philox stream keyed by (seed, rank) with one offset per call (distribution-equal to
-    torch's, reproducible per seed).  ``state_dict`` is empty like nn.Dropout's; the call counter rides in the owning
-    model's ``other_parameter`` when it lists one."""
+    """nn.Dropout drawn from a device Philox stream keyed by (seed, rank, stream id) with one offset per call
+    (distribution-equal to torch's, reproducible per seed).  ``state_dict`` is empty like nn.Dropout's (reference
+    checkpoints load strictly); the call counters ride in the owning model's ``other_parameter`` through
+    :class:`DropoutCounters`.  ``stream``: an integer, or a string (e.g. the relation name of a CAFE module) hashed to
+    one -- never a process-global counter, so the masks of a model do not depend on what was built before it."""
 
-    _next_stream = 0
-
-    def __init__(self, p=0.5, seed=2020, stream=None):
+    def __init__(self, p=0.5, seed=2020, stream=0):
         super().__init__(p)
         from .utils import seed_for_rank
 
-        if stream is None:  # one Philox key per module instance, in construction order
-            stream = 1000 + Dropout._next_stream
-            Dropout._next_stream += 1
+        if isinstance(stream, str):
+            import zlib
+
+            stream = 1000 + zlib.crc32(stream.encode())
         self._seed = (seed_for_rank(seed) + 0x632BE59BD9B4E019 * (int(stream) + 1)) & 0xFFFFFFFFFFFFFFFF
         self.calls = 0
 
@@ -1067,6 +1068,23 @@ class Dropout(torch.nn.Dropout):
             return super().forward(x)
         self.calls += 1
         return _DropoutFn.apply(x, self.p, self._seed, self.calls)
+
+
+class DropoutCounters:
+    """Model mixin: ``_dropout_calls`` = {module path: calls} of every :class:`Dropout` below the model.  Listed in the
+    model's ``other_parameter_name`` it travels with the reference trainer's checkpoint (trainer.py:296-304), so a resumed
+    run continues every mask stream where it stopped instead of replaying it from call 1."""
+
+    @property
+    def _dropout_calls(self):
+        return {n: int(m.calls) for n, m in self.named_modules() if isinstance(m, Dropout)}
+
+    @_dropout_calls.setter
+    def _dropout_calls(self, counters):
+        mods = dict(self.named_modules())
+        for n, c in (counters or {}).items():
+            if isinstance(mods.get(n), Dropout):
+                mods[n].calls = int(c)
 
 
 class LinearAct(torch.autograd.Function):

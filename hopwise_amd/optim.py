@@ -219,14 +219,22 @@ class FusedAdam(torch.optim.Optimizer):
         return out
 
     def step(self, closure=None):
-        pre, post = self._optimizer_step_pre_hooks, self._optimizer_step_post_hooks
-        if pre:
-            for hook in list(pre.values()):
-                hook(self, (closure,) if closure is not None else (), {})
+        # torch's profile_hook_step wrapper is skipped (it costs ~10 us of Python per step); the hooks it would run are
+        # not: the process-global optimizer step hooks first, then this instance's, as torch.optim.Optimizer orders them
+        from torch.optim import optimizer as _topt
+
+        args = (closure,) if closure is not None else ()
+        g_pre = getattr(_topt, "_global_optimizer_pre_hooks", None)
+        g_post = getattr(_topt, "_global_optimizer_post_hooks", None)
+        for hooks in (g_pre, self._optimizer_step_pre_hooks):
+            if hooks:
+                for hook in list(hooks.values()):
+                    hook(self, args, {})
         loss = self._step(closure)
-        if post:
-            for hook in list(post.values()):
-                hook(self, (closure,) if closure is not None else (), {})
+        for hooks in (self._optimizer_step_post_hooks, g_post):
+            if hooks:
+                for hook in list(hooks.values()):
+                    hook(self, args, {})
         return loss
 
     @torch.no_grad()

@@ -13,9 +13,14 @@ One lookup (forward), with no host read anywhere on the way (SURVEY.md §8(e) ro
     all_to_all_single                  ONE float message per peer with every table's rows; the receive buffer holds the
                                        T compact tables (table t starts t * cap rows in; overlapping views, no copy)
 
-`cap` is a fixed per-owner capacity (ceil(n / P * capacity_factor) + 64, at most min(n, rows per shard)), so message
-sizes never depend on data and nothing is read back; an owner asked for more than `cap` distinct rows raises a
-device flag that :meth:`RowShardedKGE.check_overflow` (called one step late, from a pinned copy) turns into an error.
+`cap` is a fixed per-owner capacity (ceil(n / P * capacity_factor) + 64, at most min(n, rows per shard)) with n = the
+lookup's `max_ids` -- a number fixed per kind of lookup and IDENTICAL ON EVERY RANK (RowShardedKGE freezes it at the first
+batch of a kind as the maximum over ranks, or takes it from its `max_ids` argument): equal-split all-to-alls need equal
+message sizes on all ranks, and a ragged last batch must not change them.  Message sizes therefore never depend on data and
+nothing is read back on the good path.  An owner asked for more than `cap` distinct rows raises a device flag; the step's
+loss then comes back NaN (decided on the device: the reference trainer's `_check_nan` stops before backward,
+trainer.py:337-339), `sync_grads` checks the flag before any optimizer step can apply the clamped rows, and the evaluation
+entry points check it before returning.
 The fused scorers then run unchanged on the compact tables with remapped ids, so the kernels never see the
 sharding.  Backward is the mirror image: compact row-grads --all_to_all--> hw_shard_scatter_add into the owner's
 gradient shard.  xGMI is point-to-point (7 links per GPU): all-to-all uses all links at once; there is no ring
@@ -118,10 +123,14 @@ class _Plan:
     """Routing of one lookup, shared by every table looked up with the same ids.  Device-resident; no host sync.
     One int32 message per peer carries the count and the local rows ([P, 1 + cap])."""
 
-    def __init__(self, ids, n_rows, group, factor, overflow, n_tables):
+    def __init__(self, ids, n_rows, group, factor, overflow, n_tables, max_ids=None):
         rank, P = world(group)
         self.group, self.P, self.T = group, P, int(n_tables)
-        self.cap = capacity(ids.numel(), n_rows, P, factor)
+        n_cap = ids.numel() if max_ids is None else int(max_ids)
+        if ids.numel() > n_cap:
+            raise ValueError(f"row-sharded lookup of {ids.numel()} ids exceeds max_ids = {n_cap}: the exchange capacity is "
+                             "sized from max_ids on every rank (pad or split the batch, or build with a larger max_ids)")
+        self.cap = capacity(n_cap, n_rows, P, factor)
         plan = _shard_ops["plan"] or ops.shard_plan
         self.inv, self.send_meta = plan(ids, n_rows, P, self.cap, overflow, self.T)
         if _exchange(P):
@@ -201,13 +210,14 @@ class _ShardedLookup(torch.autograd.Function):
         return (None, *outs)
 
 
-def sharded_lookup(shards, ids, n_rows, group=None, capacity_factor=1.25, overflow=None):
+def sharded_lookup(shards, ids, n_rows, group=None, capacity_factor=1.25, overflow=None, max_ids=None):
     """Rows of the row-sharded tables ``shards`` (same sharding, e.g. re/im; ``n_rows`` = rows of the full table) for
     ``ids``.  Returns (compact tables tuple (views of one [P * T * cap, d] buffer), inverse map shaped like ids, overflow
-    flag tensor)."""
+    flag tensor).  ``max_ids``: the id count the exchange capacity is sized from -- it MUST be the same on every rank
+    (default: this call's ids.numel(), i.e. callers guarantee equal batch sizes); fewer ids than that are fine."""
     if overflow is None:
         overflow = torch.zeros(1, dtype=torch.int32, device=ids.device)
-    plan = _Plan(ids, n_rows, group, capacity_factor, overflow, len(shards))
+    plan = _Plan(ids, n_rows, group, capacity_factor, overflow, len(shards), max_ids)
     return _ShardedLookup.apply(plan, *shards), plan.inv, overflow
 
 
@@ -233,8 +243,13 @@ class RowShardedKGE(nn.Module):
     Evaluation shards the candidate tails instead: every rank scores the same queries
     against its own rows, keeps a local top-k, and ``merge_topk`` ranks the k * P candidates."""
 
-    def __init__(self, model, group=None, capacity_factor=1.25):
+    def __init__(self, model, group=None, capacity_factor=1.25, max_ids=None):
+        """``max_ids``: optional {"train_entity": n, "train_user": n, "eval_rec": n, "eval_kg": n} -- the largest id count
+        of each kind of lookup, identical on every rank (e.g. 5 * train_batch_size entity ids per training step).  Kinds
+        not given are frozen at their first batch as the maximum over ranks (one all-reduce, once); later batches may be
+        smaller (a ragged last batch) but not larger."""
         super().__init__()
+        self._max_ids = dict(max_ids or {})
         self.group = group
         self.rank, self.P = world(group)
         self.model = model
@@ -297,16 +312,32 @@ class RowShardedKGE(nn.Module):
             self._ovf_host.copy_(self._overflow, non_blocking=True)
             self._ovf_event.record()
 
-    def _lookup(self, names, ids, n_rows):
-        return sharded_lookup(self._shards(names), ids, n_rows, self.group, self.capacity_factor, self._flag(ids.device))[:2]
+    def _frozen_max_ids(self, kind, n):
+        """The id count lookups of ``kind`` size their messages from: given at construction, or frozen at the first batch
+        as the maximum over ranks (ranks may see different first batches; the all-to-alls need one size)."""
+        m = self._max_ids.get(kind)
+        if m is None:
+            m = int(n)
+            if _exchange(self.P):
+                t = torch.tensor([m], dtype=torch.int64)
+                if dist.get_backend(self.group) == "nccl":  # RCCL reduces device tensors
+                    t = t.to(self._shards(self.model.ENTITY_TABLES)[0].device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                m = int(t.item())
+            self._max_ids[kind] = m
+        return m
+
+    def _lookup(self, names, ids, n_rows, kind):
+        return sharded_lookup(self._shards(names), ids, n_rows, self.group, self.capacity_factor, self._flag(ids.device),
+                              self._frozen_max_ids(kind, ids.numel()))[:2]
 
     def calculate_loss(self, interaction):
         m = self.model
         self.check_overflow(wait=False)  # the previous call's flag: its copy landed long ago, no stall
         keys = (m.ITEM_ID, m.NEG_ITEM_ID, m.HEAD_ENTITY_ID, m.TAIL_ENTITY_ID, m.NEG_TAIL_ENTITY_ID)
         ent_ids = torch.cat([interaction[k].reshape(-1) for k in keys])
-        ent_rows, ent_inv = self._lookup(m.ENTITY_TABLES, ent_ids, self.n_entities)
-        usr_rows, usr_inv = self._lookup(m.USER_TABLES, interaction[m.USER_ID], self.n_users)
+        ent_rows, ent_inv = self._lookup(m.ENTITY_TABLES, ent_ids, self.n_entities, "train_entity")
+        usr_rows, usr_inv = self._lookup(m.USER_TABLES, interaction[m.USER_ID], self.n_users, "train_user")
         self._post_overflow_copy()
         pi, ni, h, t, nt = torch.split(ent_inv, [interaction[k].numel() for k in keys])
         remapped = {m.USER_ID: usr_inv, m.ITEM_ID: pi, m.NEG_ITEM_ID: ni, m.HEAD_ENTITY_ID: h,
@@ -317,23 +348,40 @@ class RowShardedKGE(nn.Module):
         finally:
             self._compact = None
         loss = sum(losses) if isinstance(losses, tuple) else losses
+        # an overflowed lookup clamped ids into the compact tables: this step's loss is NaN (decided on the device, no stall),
+        # which the trainer's NaN check turns into an error before backward (trainer.py:337-339)
+        flag = self._overflow.to(loss.device)
+        loss = loss + torch.where(flag > 0, torch.full((1,), float("nan"), device=loss.device),
+                                  torch.zeros(1, device=loss.device)).sum().to(loss.dtype)
         return _GradScale.apply(loss, 1.0 / self.P) if self.P > 1 else loss
 
     def sync_grads(self):
-        """Sum the replicated parameters' gradients over ranks (each already carries the 1 / P of the loss average)."""
+        """Sum the replicated parameters' gradients over ranks (each already carries the 1 / P of the loss average): ONE
+        all-reduce of the flattened gradients (xGMI wants few, large collectives).  Checks the overflow flag first -- this
+        runs between backward and the optimizer step, so a step whose lookups were clamped is never applied."""
+        self.check_overflow(wait=True)
         if not _exchange(self.P):
             return
-        for n, p in self.named_parameters():
-            if p.grad is not None and not n.startswith("shard_"):
-                all_reduce_sum(p.grad, self.group)
+        grads = [p.grad for n, p in self.named_parameters() if p.grad is not None and not n.startswith("shard_")]
+        if not grads:
+            return
+        if len(grads) == 1:
+            all_reduce_sum(grads[0], self.group)
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        all_reduce_sum(flat, self.group)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off : off + g.numel()].view_as(g))
+            off += g.numel()
 
     # -- evaluation: tails sharded, queries replicated (every rank passes the SAME interaction) ----------------------------
     def _queries(self, interaction, kg):
         m = self.model
         if kg:
-            rows, inv = self._lookup(m.ENTITY_TABLES, interaction[m.HEAD_ENTITY_ID], self.n_entities)
+            rows, inv = self._lookup(m.ENTITY_TABLES, interaction[m.HEAD_ENTITY_ID], self.n_entities, "eval_kg")
             return rows, inv, interaction[m.RELATION_ID], 0
-        rows, inv = self._lookup(m.USER_TABLES, interaction[m.USER_ID], self.n_users)
+        rows, inv = self._lookup(m.USER_TABLES, interaction[m.USER_ID], self.n_users, "eval_rec")
         return rows, inv, None, m._rec_rel_full_sort()
 
     def _local_cols(self, kg):
@@ -361,7 +409,9 @@ class RowShardedKGE(nn.Module):
             pad = int(k) - kk
             val = torch.cat([val, torch.full((val.shape[0], pad), float("-inf"), device=val.device)], 1)
             gid = torch.cat([gid, torch.full((gid.shape[0], pad), n, dtype=gid.dtype, device=gid.device)], 1)
-        return merge_topk(val, gid, int(k), self.group)
+        out = merge_topk(val, gid, int(k), self.group)
+        self.check_overflow(wait=True)  # an overflowed query lookup scored the wrong rows: never return those
+        return out
 
     @torch.no_grad()
     def _full_sort(self, interaction, kg):
@@ -370,6 +420,7 @@ class RowShardedKGE(nn.Module):
         n, n_loc = self._local_cols(kg)
         local = (_shard_ops["full_sort"] or ops.kge_full_sort)(m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx, r_fixed,
                                   0, n_loc, m.margin).view(-1, n_loc)
+        self.check_overflow(wait=True)
         if not _exchange(self.P):
             return local
         B, width = local.shape[0], local_rows(n, 0, self.P)

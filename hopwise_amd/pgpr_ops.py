@@ -348,7 +348,9 @@ def cafe_collect(raw, leaf_nodes_np, n_items, max_rec):
     )
     seen = int(overflow.item())  # the records are about to be copied to the host anyway
     if seen:
-        raise RuntimeError(f"hw_cafe_collect: a user has {seen} leaf paths, more than the 4096 one workgroup ranks")
+        raise RuntimeError(f"hw_cafe_collect: a user has {seen} leaf paths, more than the 4096 one workgroup ranks in LDS "
+                           "(manual_topk 5 gives 125 per metapath: more than 32 metapaths).  Run the users of such a layout in "
+                           "several run_program calls over subsets of the metapaths, or lower manual_topk")
     return results, rec
 
 

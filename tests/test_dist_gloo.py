@@ -224,6 +224,45 @@ def _worker(rank, world_size, port, tmp):
         finally:
             par.capacity = _orig_cap
 
+        # ---- 2d. overflow never reaches the optimizer: every id owned by rank 0 (id % P == 0), capacity sized for a spread ----
+        skew = par.RowShardedKGE(_StubModel(tables, nU, nE, nI), capacity_factor=1.0)
+        _orig_cap = par.capacity
+        par.capacity = lambda n, rows, P, f: 3
+        try:
+            b0 = batch(rank)
+            for k in ("item_id", "neg_item_id", "head_id", "tail_id", "neg_tail_id"):
+                b0[k] = (b0[k] // world_size) * world_size  # all owned by rank 0
+            b0["item_id"] = b0["item_id"].clamp(max=((nI - 1) // world_size) * world_size)
+            loss = skew.calculate_loss(b0)
+            assert torch.isnan(loss).item()  # decided by the device flag: the trainer's NaN check stops here
+            loss.backward()
+            with pytest.raises(RuntimeError, match="capacity"):
+                skew.sync_grads()  # ... and a caller that ignores the loss is stopped before its optimizer step
+        finally:
+            par.capacity = _orig_cap
+
+        # ---- 2e. ranks with different batch sizes (a ragged last batch): the message sizes come from max_ids, not from the
+        #          local batch, so the equal-split all-to-alls still line up -----------------------------------------------
+        ragged = par.RowShardedKGE(_StubModel(tables, nU, nE, nI), max_ids={"train_entity": 5 * 12, "train_user": 9})
+        def cut(b, n_rec, n_kg):
+            return {k: (v[:n_rec] if k in ("user_id", "item_id", "neg_item_id") else v[:n_kg]) for k, v in b.items()}
+        sizes = [(9 - 2 * r, 12 - 3 * r) for r in range(world_size)]
+        ref2 = _StubModel(tables, nU, nE)
+        ref2_loss = sum(ref2.calculate_loss(cut(batch(r), *sizes[r])) for r in range(world_size)) / world_size
+        ref2_loss.backward()
+        l2 = ragged.calculate_loss(cut(batch(rank), *sizes[rank]))
+        l2.backward()
+        ragged.sync_grads()
+        for n in _StubModel.USER_TABLES + _StubModel.ENTITY_TABLES:
+            assert torch.allclose(getattr(ragged, "shard_" + n).grad, getattr(ref2, n).weight.grad[rank::world_size], atol=1e-6), n
+        assert torch.allclose(ragged.model.relation_embedding.weight.grad, ref2.relation_embedding.weight.grad, atol=1e-6)
+        with pytest.raises(ValueError, match="max_ids"):  # a LARGER batch than max_ids is refused before any collective
+            par.sharded_lookup((sa.detach(), sb.detach()), ids, N, max_ids=ids.numel() - 1)
+        # without max_ids the first batch freezes the maximum over ranks (rank 0 has the larger batch here)
+        auto = par.RowShardedKGE(_StubModel(tables, nU, nE, nI))
+        auto.calculate_loss(cut(batch(rank), *sizes[rank]))
+        assert auto._max_ids["train_user"] == 9 and auto._max_ids["train_entity"] == 2 * 9 + 3 * 12
+
         # ---- 3. global top-k merge ---------------------------------------------------------------------------
         rng = np.random.default_rng(5)
         scores = rng.standard_normal((4, 40)).astype(np.float32)
@@ -251,6 +290,70 @@ def _worker(rank, world_size, port, tmp):
     finally:
         par.set_shard_ops()
         dist.destroy_process_group()
+
+
+def _worker8(rank, world_size, port, tmp):
+    """The control flow of `bench.py --gpus 8 --workload sharded` before it meets RCCL: eight ranks, Yelp2018 row counts,
+    Zipf-skewed ids (hot entities), the per-rank batch of the bench leg -- loss and every gradient shard against the
+    unsharded model, no overflow at the default capacity factor, sharded full sort exact."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    torch.set_num_threads(1)
+    from hopwise_amd import parallel as par
+
+    par.set_shard_ops(plan=_cpu_plan, gather=_cpu_gather, scatter_add=_cpu_scatter_add, full_sort=_cpu_full_sort,
+                      full_sort_topk=_cpu_full_sort_topk, topk=_cpu_topk)
+    try:
+        nU, nI, nE, nR, dim, B = 45920, 45539, 90962, 44, 4, 512
+        rng = np.random.default_rng(7)
+        tables = {k: rng.standard_normal(((nU if k.startswith("user") else nR if k.startswith("rel") else nE), dim)).astype(np.float32) * 0.3
+                  for k in okge.table_names("RotatE")}
+
+        def zipf(g, n, size):  # rank-frequency ~ 1 / rank over [1, n)
+            return np.minimum((g.zipf(1.3, size) - 1) % (n - 1) + 1, n - 1)
+
+        def batch(r):
+            g = np.random.default_rng(500 + r)
+            return {k: torch.from_numpy(v.astype(np.int64)) for k, v in dict(
+                user_id=zipf(g, nU, B), item_id=zipf(g, nI, B), neg_item_id=g.integers(1, nI, B),
+                head_id=zipf(g, nE, B), relation_id=g.integers(1, nR - 1, B), tail_id=zipf(g, nE, B),
+                neg_tail_id=g.integers(1, nE, B)).items()}
+
+        ref = _StubModel(tables, nU, nE)
+        ref_loss = sum(ref.calculate_loss(batch(r)) for r in range(world_size)) / world_size
+        ref_loss.backward()
+        sharded = par.RowShardedKGE(_StubModel(tables, nU, nE, nI), max_ids={"train_entity": 5 * B, "train_user": B})
+        loss = sharded.calculate_loss(batch(rank))
+        assert torch.isfinite(loss).item()
+        loss.backward()
+        sharded.sync_grads()  # raises on overflow
+        for n in _StubModel.USER_TABLES + _StubModel.ENTITY_TABLES:
+            want = getattr(ref, n).weight.grad[rank::world_size]
+            assert torch.allclose(getattr(sharded, "shard_" + n).grad, want, atol=1e-5), n
+        assert torch.allclose(sharded.model.relation_embedding.weight.grad, ref.relation_embedding.weight.grad, atol=1e-5)
+        lt = loss.detach().clone()
+        dist.all_reduce(lt)
+        assert abs(lt.item() / world_size - ref_loss.item()) < 1e-5
+        # evaluation: 6 users against all 45 539 items, top-10 equal to the unsharded ranking
+        full = _StubModel(tables, nU, nE, nI)
+        users = torch.tensor([3, 1, 45919, 3, 9, 20000])
+        H, R, T = full._tables("rec")
+        want = _rotate_scores(H, R, T, users, None, full._rec_rel_full_sort(), 0, nI, 1.0)
+        want[:, 0] = -np.inf
+        rv, ri = okge.topk_desc(want.detach().numpy(), 10)
+        tv, ti = sharded.full_sort_topk({"user_id": users}, 10, None, kg=False)
+        assert np.array_equal(ti.numpy(), ri) and np.array_equal(tv.numpy(), rv)
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        par.set_shard_ops()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world_size_8_gloo_yelp_shape_zipf(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(8))
 
 
 @pytest.mark.timeout(300)
