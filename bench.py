@@ -885,8 +885,52 @@ def leg_reference_layout(D, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 300
     res["forward_backward_adam_graph_replay"] = {"ms": dt * 1e3, "triples_per_s": 4 * B / dt}
+    del gstep
+    # what a drop-in user gets under hopwise's own trainer: driver.graphed_trainer(<Trainer class>)._train_epoch over an
+    # epoch of such batches, against the reference's loop (zero_grad / calculate_loss / .item() / backward / step per batch,
+    # trainer.py:208-268) on the same model -- a minimal base class stands in for hopwise's Trainer on this box
+    from hopwise_amd.driver import graphed_trainer
+
+    class _Base:  # the attributes and the loop of Trainer._train_epoch that matter here
+        def __init__(self, config, model):
+            self.config, self.model, self.device = config, model, dev
+            self.optimizer = FusedAdam(model.parameters(), lr=config["learning_rate"])
+            self.clip_grad_norm = None
+
+        def _check_nan(self, loss):
+            if torch.isnan(loss):
+                raise ValueError("Training loss is nan")
+
+        def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+            self.model.train()
+            total = None
+            for inter in train_data:
+                self.optimizer.zero_grad()
+                loss = self.model.calculate_loss(inter)
+                total = loss.item() if total is None else total + loss.item()
+                self._check_nan(loss)
+                loss.backward()
+                self.optimizer.step()
+            return total
+
+    class _Batch(dict):
+        def to(self, device):
+            return self
+
+    epoch = [_Batch(it) for _ in range(200)]
+    cfg = {"learning_rate": 1e-3, "learner": "adam", "single_spec": True}
+    for name, cls in (("reference_loop", _Base), ("graphed_trainer", graphed_trainer(_Base))):
+        tr = cls(cfg, m)
+        tr._train_epoch(epoch[:20], 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr._train_epoch(epoch, 1)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / len(epoch)
+        res["trainer_epoch_" + name] = {"ms_per_step": dt * 1e3, "triples_per_s": 4 * B / dt}
+        del tr
     res["note"] = "eager steps are host-bound; BASELINE.md's CPU probe of the reference: 0.52 M triples/s forward, 0.24 M forward+backward"
-    del gstep, m, opt
+    del m, opt
     torch.cuda.empty_cache()
     return res
 

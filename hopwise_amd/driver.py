@@ -178,6 +178,83 @@ def train_epoch_graphed(model, batches, optimizer, clip_grad_norm=None, device=N
     return (float(total.item()) if total is not None else 0.0), step
 
 
+def graphed_trainer(base):
+    """Class factory for the drop-in: ``class Trainer(graphed_trainer(hopwise.trainer.KGTrainer)): pass`` (or the class
+    returned by ``get_trainer``) trains a pairwise KGE model of this package with each steady-state step replayed from one
+    HIP graph -- zero_grad, calculate_loss, backward, clip, Adam in one launch of the graph instead of ~20 launches issued
+    by Python (RotatE, the reference's own batch of 8 192 triples: 0.26 ms eager -> 0.12 ms).
+
+    What it changes against Trainer._train_epoch (trainer.py:208-268), and nothing else:
+      * the optimizer becomes :class:`hopwise_amd.optim.FusedAdam` with the trainer's learning rate and weight decay when the
+        configured learner is adam (torch's Adam rule, state names and state_dict layout: checkpoints stay interchangeable);
+      * the per-batch ``loss.item()`` (a host sync per step) is gone: the epoch's loss is summed on the device and read once,
+        so the NaN check (trainer.py:337-339) fires at the end of the epoch instead of at the offending batch;
+      * a batch whose shapes differ from the captured one (the ragged last batch) runs eagerly, as the base class would.
+    Anything the graph cannot hold falls back to the base class for the whole epoch: a custom ``loss_func``, AMP, DDP
+    (``single_spec`` false), a model that keeps per-step host state (TuckER / ConvE / ConvKB / PGPR / CAFE)."""
+
+    # KGTrainer._train_epoch picks the loader state and then calls super()._train_epoch (trainer.py:647-666): the replayed
+    # loop has to sit BELOW it, in the place of Trainer._train_epoch.  So the override lives in a class derived from the
+    # root that defines _train_epoch, and the result inherits (base, that class): C3 puts it between the two.
+    root = [c for c in base.__mro__ if "_train_epoch" in c.__dict__][-1]
+
+    class _Core(root):
+        _graph_step = None
+
+        def __init__(self, config, model):
+            super().__init__(config, model)
+            learner = str(config["learner"]).lower() if "learner" in config else "adam"
+            if learner == "adam" and all(p.is_cuda for p in model.parameters()):
+                from .optim import FusedAdam
+
+                wd = config["weight_decay"] if "weight_decay" in config else 0.0
+                self.optimizer = FusedAdam(model.parameters(), lr=config["learning_rate"], weight_decay=wd or 0.0)
+
+        def _graph_safe(self, loss_func):
+            if loss_func is not None or getattr(self, "enable_amp", False) or getattr(self, "enable_scaler", False):
+                return False
+            if "single_spec" in self.config and not self.config["single_spec"]:
+                return False
+            if type(self.model).__name__ in GraphedTrainStep.REFUSED:
+                return False
+            return all(g.get("capturable", False) for g in self.optimizer.param_groups)
+
+        def _make_step(self, interaction):
+            return GraphedTrainStep(self.model, self.optimizer, interaction, getattr(self, "clip_grad_norm", None))
+
+        def _eager_step(self, interaction):
+            self.optimizer.zero_grad()
+            losses = self.model.calculate_loss(interaction)
+            loss = sum(losses) if isinstance(losses, tuple) else losses
+            loss.backward()
+            if getattr(self, "clip_grad_norm", None):
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), **self.clip_grad_norm)
+            self.optimizer.step()
+            return loss.detach()
+
+        def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+            if not self._graph_safe(loss_func):
+                return super()._train_epoch(train_data, epoch_idx, loss_func=loss_func, show_progress=show_progress)
+            self.model.train()
+            total = None
+            for batch_interaction in train_data:
+                interaction = batch_interaction.to(self.device)
+                if self._graph_step is None:
+                    self._graph_step = self._make_step(interaction)
+                loss = self._graph_step(interaction) if self._graph_step.matches(interaction) else self._eager_step(interaction)
+                total = loss.clone() if total is None else total + loss
+            if total is None:
+                return None
+            self._check_nan(total)
+            return float(total.item())
+
+    if base is root:
+        Graphed = type("Graphed" + base.__name__, (_Core,), {})
+    else:
+        Graphed = type("Graphed" + base.__name__, (base, _Core), {})
+    return Graphed
+
+
 @torch.no_grad()
 def full_sort_topk(model, interaction, history_index=None, k=10, kg=False):
     """Scores -> mask -> top-k on the device.  Returns (values [B, k], indices [B, k], masked scores [B, N])."""

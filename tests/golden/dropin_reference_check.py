@@ -88,7 +88,71 @@ def main():
         if name in ("PGPR", "CAFE"):
             rec["batch"] = {k: [list(v.shape), str(v.dtype)] for k, v in next(iter(train_data)).interaction.items()}
         out["models"][name] = rec
+    out["graphed_trainer"] = graphed_trainer_protocol(yaml)
     print("DROPIN_JSON " + json.dumps(out))
+
+
+def graphed_trainer_protocol(yaml):
+    """hopwise_amd.driver.graphed_trainer(KGTrainer) against KGTrainer itself, on the reference's fixture with the reference's
+    OWN TransE on the CPU: the mixin's epoch loop (device-side loss sum, one NaN check, eager fallback for the ragged last
+    batch) must leave the same parameters and report the same epoch loss as Trainer._train_epoch.  HIP graphs need a GPU, so
+    the captured step is replaced by a stand-in that runs the same four calls eagerly -- the loop around it is what is
+    checked here; the capture itself is checked on the GPU (tests/test_gpu_driver.py)."""
+    import copy
+
+    import torch
+    from hopwise.config import Config
+    from hopwise.data import create_dataset, data_preparation
+    from hopwise.utils import get_model, get_trainer, init_seed
+
+    from hopwise_amd.driver import graphed_trainer
+
+    cfg = {"data_path": os.path.join(REF, "tests/test_data"), "train_batch_size": 256, "epochs": 1, "embedding_size": 8,
+           "train_neg_sample_args": {"distribution": "uniform", "sample_num": 1, "alpha": 1.0, "dynamic": False,
+                                     "candidate_num": 0}}
+    res = {}
+    runs = {}
+    for kind in ("base", "graphed"):
+        config = Config(model="TransE", dataset="test", config_file_list=[yaml], config_dict=cfg)
+        init_seed(config["seed"], config["reproducibility"])
+        dataset = create_dataset(config)
+        train_data, valid_data, test_data = data_preparation(config, dataset)
+        init_seed(config["seed"], config["reproducibility"])
+        model = get_model("TransE")(config, train_data.dataset)
+        base = get_trainer(config["MODEL_TYPE"], config["model"])
+        cls = base
+        if kind == "graphed":
+            class _StandIn:  # GraphedTrainStep's interface with an eager body
+                def __init__(self, trainer, example):
+                    self.t, self.shapes = trainer, {k: tuple(v.shape) for k, v in example.interaction.items()}
+                    self.calls = 0
+
+                def matches(self, inter):
+                    return all(tuple(inter[k].shape) == s for k, s in self.shapes.items())
+
+                def __call__(self, inter):
+                    self.calls += 1
+                    return self.t._eager_step(inter)
+
+            class cls(graphed_trainer(base)):  # noqa: N801
+                def _graph_safe(self, loss_func):
+                    return loss_func is None
+
+                def _make_step(self, interaction):
+                    return _StandIn(self, interaction)
+
+        trainer = cls(config, model)
+        res[kind + "_class"] = type(trainer).__name__ if kind == "base" else [c.__name__ for c in type(trainer).__mro__[:3]]
+        res[kind + "_optimizer"] = type(trainer.optimizer).__name__
+        loss = trainer._train_epoch(train_data, 0)
+        runs[kind] = (float(loss) if not isinstance(loss, tuple) else float(sum(loss)),
+                      copy.deepcopy({k: v.detach().clone() for k, v in model.state_dict().items()}))
+        if kind == "graphed":
+            res["replayed_steps"] = trainer._graph_step.calls
+            res["epoch_len"] = len(train_data)
+    res["loss_base"], res["loss_graphed"] = runs["base"][0], runs["graphed"][0]
+    res["max_param_diff"] = max(float((runs["base"][1][k] - runs["graphed"][1][k]).abs().max()) for k in runs["base"][1])
+    return res
 
 
 if __name__ == "__main__":

@@ -72,3 +72,15 @@ def test_reference_loader_batch_is_what_the_model_indexes(report, name):
     # no CPU fallback: a CPU batch is refused, not scored (RuntimeError from the ctypes binding, NotImplementedError from
     # the dispatcher when the registered ops are loaded: no CPU kernel exists)
     assert rec["cpu_loss"] in ("RuntimeError", "NotImplementedError")
+
+
+def test_graphed_trainer_mixin_follows_the_reference_epoch(report):
+    """driver.graphed_trainer(KGTrainer): same epoch loss and same parameters after an epoch as KGTrainer._train_epoch on the
+    reference fixture (reference TransE on the CPU, the captured step replaced by an eager stand-in -- the capture itself
+    is tested on the GPU); the ragged last batch takes the eager path."""
+    g = report["graphed_trainer"]
+    assert g["graphed_class"][0].startswith("cls") or "Graphed" in " ".join(g["graphed_class"])
+    assert g["base_class"] == "KGTrainer" and g["graphed_class"][1] == "GraphedKGTrainer"
+    assert abs(g["loss_base"] - g["loss_graphed"]) <= 1e-5 * abs(g["loss_base"])
+    assert g["max_param_diff"] <= 1e-6
+    assert 0 < g["replayed_steps"] <= g["epoch_len"]

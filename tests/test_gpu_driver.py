@@ -120,3 +120,68 @@ def test_graphed_train_step_equals_eager(model_name):
         np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=5e-4, err_msg=k)
     with pytest.raises(ValueError):
         GraphedTrainStep(graphed, torch.optim.Adam(graphed.parameters()), batches[0])
+
+
+def test_graphed_trainer_mixin_equals_the_plain_loop():
+    """driver.graphed_trainer(<a Trainer>) -- the two-line drop-in of INTEGRATION.md -- replays the steady-state steps from
+    one HIP graph, runs the ragged last batch eagerly, and ends an epoch with the plain loop's loss and parameters.  (Its
+    loop is checked against hopwise's own KGTrainer in tests/test_dropin_reference.py, where hopwise is importable.)"""
+    import copy
+
+    import hopwise_amd.model as M
+    from hopwise_amd.driver import graphed_trainer
+    from hopwise_amd.optim import FusedAdam
+
+    dev = torch.device("cuda", 0)
+    nU, nI, nE, nR, nb = 300, 200, 900, 7, 512
+    torch.manual_seed(5)
+    plain_m = M.RotatE(make_config(dev, 64, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
+    graph_m = copy.deepcopy(plain_m)
+    rng = np.random.default_rng(1)
+
+    class Batch(dict):
+        def to(self, device):
+            return self
+
+    def batch(n):
+        return Batch({k: torch.from_numpy(rng.integers(1, hi, n)).to(dev) for k, hi in (
+            ("user_id", nU), ("item_id", nI), ("neg_item_id", nI), ("head_id", nE), ("relation_id", nR - 1),
+            ("tail_id", nE), ("neg_tail_id", nE))})
+
+    epoch = [batch(nb) for _ in range(5)] + [batch(77)]  # ragged last batch
+
+    class Base:
+        def __init__(self, config, model):
+            self.config, self.model, self.device, self.clip_grad_norm = config, model, dev, None
+            self.optimizer = FusedAdam(model.parameters(), lr=config["learning_rate"])
+
+        def _check_nan(self, loss):
+            if torch.isnan(loss):
+                raise ValueError("Training loss is nan")
+
+        def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+            self.model.train()
+            total = 0.0
+            for inter in train_data:
+                self.optimizer.zero_grad()
+                loss = (loss_func or self.model.calculate_loss)(inter)
+                total += loss.item()
+                self._check_nan(loss)
+                loss.backward()
+                self.optimizer.step()
+            return total
+
+    cfg = {"learning_rate": 1e-3, "learner": "adam", "single_spec": True}
+    plain, graphed = Base(cfg, plain_m), graphed_trainer(Base)(cfg, graph_m)
+    assert type(graphed).__name__ == "GraphedBase" and isinstance(graphed.optimizer, FusedAdam)
+    # GraphedTrainStep's constructor runs two warm-up steps on its example batch: give the plain loop the same start
+    plain._train_epoch([epoch[0], epoch[0]], 0)
+    for ep in range(2):
+        lp = plain._train_epoch(epoch, ep)
+        lg = graphed._train_epoch(epoch, ep)
+        np.testing.assert_allclose(lg, lp, rtol=2e-4)
+    assert graphed._graph_step is not None
+    for (k, a), (_, c) in zip(plain_m.state_dict().items(), graph_m.state_dict().items()):
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=0, atol=5e-4, err_msg=k)
+    # a custom loss function is not captured: the base loop runs
+    assert graphed._train_epoch(epoch[:1], 2, loss_func=graph_m.calculate_loss) > 0
