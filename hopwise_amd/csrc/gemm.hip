@@ -254,16 +254,24 @@ __global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_
     if constexpr (SPLIT) {
         constexpr int PA = SplitImg<A_KC>::PLANE, PB = SplitImg<B_KC>::PLANE, OA = SplitImg<A_KC>::OPERAND;
         uint8_t* const img = reinterpret_cast<uint8_t*>(lds);
-        f32x4 ra[2], rb[2];
-        fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra);
-        fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin, rb);
-        put_tile_split<A_KC, false>(ra, k_end, k_begin, img);
-        put_tile_split<B_KC, false>(rb, k_end, k_begin, img + OA);
+        // TWO k-tiles of register prefetch (r?[0] / r?[1] alternate): one k-step of MFMAs is 768 cycles, an operand tile that
+        // misses L2 (the long-K backward products stream dS from HBM; the score product's table tiles come from the Infinity
+        // Cache) is ~2 000 away, and the co-resident blocks of a CU run in lockstep -- with one tile of look-ahead they all
+        // sat in the same s_waitcnt.  Measured on the pre-split experiment (operands as bf16 plane images, same loop): 2.37 ->
+        // 2.08 ms on the TuckER forward.
+        f32x4 ra[2][2], rb[2][2];
+        fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra[0]);
+        fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin, rb[0]);
+        fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin + BK, ra[1]);
+        fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin + BK, rb[1]);
+        put_tile_split<A_KC, false>(ra[0], k_end, k_begin, img);
+        put_tile_split<B_KC, false>(rb[0], k_end, k_begin, img + OA);
         __syncthreads();
-        int cur = 0;
-        for (int k0 = k_begin; k0 < k_end; k0 += BK, cur ^= 1) {
-            fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + BK, ra);  // clamped past the end, stored as zeros
-            fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + BK, rb);
+        // one k-step: multiply LDS stage `cur`, store the tile held in (na, nb) = k0 + BK to the other stage, refill (fa_, fb_)
+        // with k0 + 2 BK (clamped past the end, stored as zeros)
+        auto kstep = [&](int k0, int cur, f32x4 (&na)[2], f32x4 (&nb)[2], f32x4 (&fa_)[2], f32x4 (&fb_)[2]) {
+            fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + 2 * BK, fa_);
+            fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + 2 * BK, fb_);
             __builtin_amdgcn_sched_barrier(0);
             const uint8_t* Ai = img + cur * SPLIT_STAGE;
             const uint8_t* Bi = Ai + OA;
@@ -289,14 +297,20 @@ __global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_
             __builtin_amdgcn_sched_barrier(0);
             uint8_t* An = img + (cur ^ 1) * SPLIT_STAGE;
             if (k0 + 2 * BK <= k_end) {  // block-uniform: the next tile is a whole one
-                put_tile_split<A_KC, true>(ra, k_end, k0 + BK, An);
-                put_tile_split<B_KC, true>(rb, k_end, k0 + BK, An + OA);
+                put_tile_split<A_KC, true>(na, k_end, k0 + BK, An);
+                put_tile_split<B_KC, true>(nb, k_end, k0 + BK, An + OA);
             } else {
-                put_tile_split<A_KC, false>(ra, k_end, k0 + BK, An);
-                put_tile_split<B_KC, false>(rb, k_end, k0 + BK, An + OA);
+                put_tile_split<A_KC, false>(na, k_end, k0 + BK, An);
+                put_tile_split<B_KC, false>(nb, k_end, k0 + BK, An + OA);
             }
             __syncthreads();
+        };
+        int k0 = k_begin;
+        for (; k0 + BK < k_end; k0 += 2 * BK) {  // two steps per trip: stages and register sets are fixed in each half
+            kstep(k0, 0, ra[1], rb[1], ra[0], rb[0]);
+            kstep(k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
         }
+        if (k0 < k_end) kstep(k0, 0, ra[1], rb[1], ra[0], rb[0]);
     } else if (pipe) {
         f32x4 ra[2], rb[2];
         fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra);

@@ -208,16 +208,29 @@ __device__ __forceinline__ int clamp_row(int64_t id, int64_t n, int32_t* oob) {
 }
 
 // ---- sigmoid + BCELoss element (tucker.py:83,124-125), shared by tucker.hip and the GEMM's fused epilogue ------------
-// One element of the loss / gradient.  Hardware exp / log (v_exp_f32, v_log_f32): the kernel is transcendental-bound
-// (one exp, two logs, one divide per element over ~3e8 elements), not bandwidth-bound, with the libm sequences.
+// One element of the loss / gradient.  The kernel that calls this is transcendental-bound (~3e8 elements per TuckER side),
+// so the element is written with ONE exp, ONE log and ONE reciprocal on the hardware units (v_exp_f32 / v_log_f32 /
+// v_rcp_f32) instead of the literal sequence sigmoid -> log(p), log(1 - p) (one exp, two logs, one reciprocal):
+//     e = exp(-|x|),  r = 1 / (1 + e),  p = sigmoid(x) = x >= 0 ? r : e r
+//     -log(1 - p) = softplus(x) = max(x, 0) + log(1 + e),   -log(p) = softplus(x) - x
+//     loss = t (-log p) + (1 - t)(-log(1 - p))
+// torch.nn.BCELoss clamps both logs at -100, and the reference feeds it a float32 sigmoid: p rounds to exactly 1 for
+// x > 16.6355 (1 + 2^-24 rounds to 1), where log(1 - p) = log(0) clamps to -100, and exp(-x) overflows for x < -88.72, where
+// p = 0 and log(p) clamps to -100.  Both saturations are reproduced; between them the softplus form is the exact value the
+// reference's float32 log(1 - p) approximates (its 1 - p carries a relative rounding error of up to 2^-24 / (1 - p): 3e-4
+// at x = 8, 3 % at x = 14).
 __device__ __forceinline__ float bce_elem(float x, float t, float inv_numel, float* p_out, float* g_out) {
-    const float p = __fdividef(1.f, 1.f + __expf(-x));
-    const float lp = fmaxf(__logf(p), -100.f), l1p = fmaxf(__logf(1.f - p), -100.f);
+    const float e = __expf(-fabsf(x));
+    const float r = __fdividef(1.f, 1.f + e);
+    const float p = x >= 0.f ? r : e * r;
+    const float sp = fmaxf(x, 0.f) + __logf(1.f + e);        // -log(1 - p)
+    const float nl1p = x > 16.635532f ? 100.f : fminf(sp, 100.f);
+    const float nlp = x < -88.72283f ? 100.f : fminf(sp - x, 100.f);
     const float pq = (1.f - p) * p;
     *p_out = p;
     // (p - t) / max(pq, 1e-12) * pq: the quotient and the product cancel unless pq was clamped -- one reciprocal fewer
     *g_out = (pq >= 1e-12f ? p - t : (p - t) * (pq * 1e12f)) * inv_numel;
-    return -(t * lp + (1.f - t) * l1p);
+    return t * nlp + (1.f - t) * nl1p;
 }
 
 // Flat float4 sweep over the [n_rows, n_cols] matrix (rows are not 16-byte aligned when n_cols is odd, the flat buffer

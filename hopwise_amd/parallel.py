@@ -283,7 +283,11 @@ class RowShardedKGE(nn.Module):
         return self._overflow
 
     def check_overflow(self, wait=True):
-        """Raise if an earlier lookup asked one owner for more distinct rows than the exchange capacity."""
+        """Raise if a lookup asked one owner for more distinct rows than the exchange capacity.
+        wait=False: only what has already landed in the pinned copy (no stall at all);
+        wait="lookups": wait for the pinned copy posted right after the LAST lookups (the routing kernels run at the very
+        start of a step, so the host waits for those few microseconds of device work, not for the step);
+        wait=True: additionally read the device flag itself (a full stream sync: tests, end of a run)."""
         if self._overflow is None:
             return
         if self._overflow.is_cuda:
@@ -292,9 +296,12 @@ class RowShardedKGE(nn.Module):
                     return
                 seen = int(self._overflow.item())
             else:
-                self._ovf_event.synchronize()
-                seen = int(self._ovf_host.item())
-                if wait:
+                if wait or self._ovf_event.query():
+                    self._ovf_event.synchronize()
+                    seen = int(self._ovf_host.item())
+                else:
+                    seen = 0
+                if wait is True:
                     seen = max(seen, int(self._overflow.item()))
         else:
             seen = int(self._overflow.item())
@@ -358,8 +365,9 @@ class RowShardedKGE(nn.Module):
     def sync_grads(self):
         """Sum the replicated parameters' gradients over ranks (each already carries the 1 / P of the loss average): ONE
         all-reduce of the flattened gradients (xGMI wants few, large collectives).  Checks the overflow flag first -- this
-        runs between backward and the optimizer step, so a step whose lookups were clamped is never applied."""
-        self.check_overflow(wait=True)
+        runs between backward and the optimizer step, so a step whose lookups were clamped is never applied (the wait is for
+        the pinned copy posted right after this step's routing kernels, not for the step)."""
+        self.check_overflow(wait="lookups")
         if not _exchange(self.P):
             return
         grads = [p.grad for n, p in self.named_parameters() if p.grad is not None and not n.startswith("shard_")]
@@ -380,8 +388,10 @@ class RowShardedKGE(nn.Module):
         m = self.model
         if kg:
             rows, inv = self._lookup(m.ENTITY_TABLES, interaction[m.HEAD_ENTITY_ID], self.n_entities, "eval_kg")
+            self._post_overflow_copy()
             return rows, inv, interaction[m.RELATION_ID], 0
         rows, inv = self._lookup(m.USER_TABLES, interaction[m.USER_ID], self.n_users, "eval_rec")
+        self._post_overflow_copy()
         return rows, inv, None, m._rec_rel_full_sort()
 
     def _local_cols(self, kg):
@@ -410,7 +420,7 @@ class RowShardedKGE(nn.Module):
             val = torch.cat([val, torch.full((val.shape[0], pad), float("-inf"), device=val.device)], 1)
             gid = torch.cat([gid, torch.full((gid.shape[0], pad), n, dtype=gid.dtype, device=gid.device)], 1)
         out = merge_topk(val, gid, int(k), self.group)
-        self.check_overflow(wait=True)  # an overflowed query lookup scored the wrong rows: never return those
+        self.check_overflow(wait="lookups")  # an overflowed query lookup scored the wrong rows: never return those
         return out
 
     @torch.no_grad()
@@ -420,7 +430,7 @@ class RowShardedKGE(nn.Module):
         n, n_loc = self._local_cols(kg)
         local = (_shard_ops["full_sort"] or ops.kge_full_sort)(m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx, r_fixed,
                                   0, n_loc, m.margin).view(-1, n_loc)
-        self.check_overflow(wait=True)
+        self.check_overflow(wait="lookups")
         if not _exchange(self.P):
             return local
         B, width = local.shape[0], local_rows(n, 0, self.P)
