@@ -706,7 +706,7 @@ def leg_sharded(D, args):
             "bytes_per_step_per_rank": xbytes,
             "xgmi_GBps_per_gpu_over_step": xbytes / (dt / n_steps) / 1e9,
             "collectives_per_step": "6 all-to-alls (per lookup -- entity ids, user ids -- one int32 [count, rows] message, one "
-                                    "float message with both tables' rows forward, one with their gradients backward) + 1 "
+                                    "float message with both tables' rows forward, one with their gradients backward) + "
                                     "ONE all-reduce of the flattened replicated (relation) gradients" if P > 1 else "none (P = 1: the exchange is the identity)",
         },
         "table_bytes_per_rank": 2 * (nU + nE) * Dm * 4 / P, "scaling": "weak", "parallelism": f"row-sharded x{P}",
