@@ -357,9 +357,11 @@ class RowShardedKGE(nn.Module):
         loss = sum(losses) if isinstance(losses, tuple) else losses
         # an overflowed lookup clamped ids into the compact tables: this step's loss is NaN (decided on the device, no stall),
         # which the trainer's NaN check turns into an error before backward (trainer.py:337-339)
-        flag = self._overflow.to(loss.device)
-        loss = loss + torch.where(flag > 0, torch.full((1,), float("nan"), device=loss.device),
-                                  torch.zeros(1, device=loss.device)).sum().to(loss.dtype)
+        consts = self.__dict__.get("_nan_consts")
+        if consts is None or consts[0].device != loss.device:
+            consts = self.__dict__["_nan_consts"] = (torch.full((1,), float("nan"), device=loss.device, dtype=loss.dtype),
+                                                     torch.zeros(1, device=loss.device, dtype=loss.dtype))
+        loss = loss + torch.where(self._overflow.to(loss.device) > 0, consts[0], consts[1])[0]
         return _GradScale.apply(loss, 1.0 / self.P) if self.P > 1 else loss
 
     def sync_grads(self):
