@@ -115,10 +115,13 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
                                                                    const int32_t* __restrict__ paths,
                                                                    const int32_t* __restrict__ n_rows_ptr, PfDrop dr,
                                                                    float* __restrict__ logits, int64_t ld) {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * PF_CHUNK];
+    constexpr int PF_STAGES = 2;
+    // ONE __shared__ object: a second one beside an array that direct-to-LDS loads write makes hipcc wait vmcnt(0) before the
+    // first ds_read of every k-step (cdna_hip_programming.md, 'Projection GEMM at M = 256' item 4(a))
+    __shared__ __attribute__((aligned(16))) uint8_t lds[PF_STAGES * PF_CHUNK + (1024 + PF_H2) * 4];
     // the two hidden biases: read per chunk inside the MFMA shadow, where a global load would have to be waited for with a
     // vmcnt that also drains the weight prefetch issued before it (vector-memory operations return in order)
-    __shared__ __attribute__((aligned(16))) float bias_lds[1024 + PF_H2];
+    float* const bias_lds = reinterpret_cast<float*>(lds + PF_STAGES * PF_CHUNK);
     const int n_rows = n_rows_ptr[0];
     const int row0 = blockIdx.x * PF_ROWS;
     if (row0 >= n_rows) return;
@@ -174,11 +177,17 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     // ---- weight chunk pipeline: global -> registers -> LDS stage (q & 1) ----
     pf_u32x4 wreg[12];
     auto w_fetch = [&](int q) {
+#ifdef PF_ABL_NO_W
+        return;
+#endif
         const pf_u32x4* s = reinterpret_cast<const pf_u32x4*>(planes + (size_t)q * PF_CHUNK);
 #pragma unroll
         for (int i = 0; i < 12; ++i) wreg[i] = s[tid + 256 * i];
     };
     auto w_put = [&](int q) {
+#ifdef PF_ABL_NO_W
+        return;
+#endif
         pf_u32x4* d = reinterpret_cast<pf_u32x4*>(lds + (q & 1) * PF_CHUNK);
 #pragma unroll
         for (int i = 0; i < 12; ++i) d[tid + 256 * i] = wreg[i];
@@ -195,6 +204,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) xm[u][i] = f32x4{1.f, 1.f, 1.f, 1.f};
     auto x_fetch = [&](int c, f32x4 (&xq)[NPARTS][4], f32x4 (&mq)[4]) {
+#ifdef PF_ABL_NO_X
+        return;
+#endif
         const int k0 = PF_KC * c + 16 * g;
 #pragma unroll
         for (int q = 0; q < NPARTS; ++q)
@@ -209,6 +221,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     // `fresh`: chunk c starts a new 128-element Philox block of this row (c % 4 == 0: H1 % 128 == 0) -- known at compile time
     // in the unrolled loop, so the region stays one basic block
     auto x_finish = [&](int c, int cu, const f32x4 (&xq)[NPARTS][4], const f32x4 (&mq)[4], pf_bf16x8 (&out)[2][3]) {
+#ifdef PF_ABL_NO_X
+        return;
+#endif
         // c: chunk (clamped, addresses only); cu = chunk & 3 as the unrolled loop knows it: word cu of the row's current
         // Philox block holds this chunk's 32 keep bits, this lane's 16 at bit 16 g; a new block every fourth chunk
         const int k0 = PF_KC * c + 16 * g;
@@ -247,6 +262,16 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 
     // one chunk of matrix work: acc[T] += W[chunk] (rows 32 T ..) . B operands, T = 0..7, both k-steps
     auto mma_chunk = [&](const uint8_t* stage, f32x16 (&acc)[8], const pf_bf16x8 (&bop)[2][3]) {
+#ifdef PF_ABL_NO_MMA  // timing experiment: one FMA per (tile, step) instead of six MFMAs, operands still read
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const pf_u32x4 w = *reinterpret_cast<const pf_u32x4*>(stage + pf_off(32 * i + b, 2 * g + t));
+                acc[i][0] = fmaf(__uint_as_float(w.x), __uint_as_float(__builtin_bit_cast(pf_u32x4, bop[t][0]).x), acc[i][0]);
+            }
+        return;
+#endif
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -294,7 +319,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
             mma_chunk(lds + (u & 1) * PF_CHUNK, acc2, xb[u & 1]);
             __builtin_amdgcn_sched_barrier(0);
             w_put(c + 1);
+#ifndef PF_ABL_NO_SYNC
             __syncthreads();
+#endif
         }
     }
 
@@ -342,7 +369,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         __builtin_amdgcn_sched_barrier(0);
         if (T + 1 < 8) {
             w_put(q + 1);
+#ifndef PF_ABL_NO_SYNC
             __syncthreads();
+#endif
         }
     }
 
