@@ -48,7 +48,7 @@ def _read(path):
 
 @pytest.fixture(scope="session", autouse=True)
 def _box_fingerprint():
-    """Which machine and card a GPU run was on, appended to gpurun_out/box_id.jsonl.  The round-2 wrong-gradient episode
+    """Which machine and card a GPU run was on, one file per session under gpurun_out/box_id/.  The round-2 wrong-gradient episode
      was confined to one box lease and nothing in the logs says which box: a recurrence should."""
     import json
     import socket
@@ -72,8 +72,11 @@ def _box_fingerprint():
                 v = _read(os.path.join(card, knob))
                 if v is not None:
                     rec.setdefault("cards", {}).setdefault(os.path.basename(os.path.dirname(card)), {})[knob] = v
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "box_id.jsonl"), "a") as f:
+        # one file per session: gpurun merges the box's gpurun_out/ into the local one file by file, so a single appended file
+        # would only ever hold the last call
+        out = os.path.join(ROOT, "gpurun_out", "box_id")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, time.strftime("%Y%m%d_%H%M%S") + f"_{os.getpid()}.json"), "w") as f:
             f.write(json.dumps(rec) + "\n")
     except Exception:  # a fingerprint must never fail a run
         pass

@@ -17,6 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_STAMP = __import__("time").strftime("%Y%m%d_%H%M%S")
 
 
 def dev():
@@ -39,10 +40,10 @@ def _pieces(bad_mask_row_major, dim):
 
 
 def _report(name, record):
-    out = os.path.join(ROOT, "gpurun_out")
+    out = os.path.join(ROOT, "gpurun_out", "atomics_stress")  # one file per process: merged back call by call
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "atomics_stress.jsonl"), "a") as f:
+        with open(os.path.join(out, f"{_STAMP}_{os.getpid()}.jsonl"), "a") as f:
             f.write(json.dumps(dict(test=name, **record)) + "\n")
     except OSError:
         pass
