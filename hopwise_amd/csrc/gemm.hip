@@ -13,6 +13,8 @@
 // read (lane l -> row l & 31, k = l >> 5) is a conflict-free ds_read_b32 and M/N-contiguous operands are staged with
 // ds_write_b128.  Two blocks fit a CU, which hides one block's staging behind the other's MFMA burst.
 // Epilogue: + bias[n], ELU, multiplicative dropout (explicit mask or Philox keep-1/2), all optional.
+#include <type_traits>
+
 #include "hw_common.h"
 
 namespace hw {
@@ -162,32 +164,35 @@ __device__ __forceinline__ int split_off(int r, int half) { return r * 32 + ((ha
 // registers of fetch_tile<KC> -> the three plane images of one operand.  KC: rows f >> 2, four consecutive k at (f & 3) * 4;
 // k-major: k = f >> 5, four consecutive rows at (f & 31) * 4.  FULL: the whole k-tile lies below K (no zeroing).
 template <bool KC, bool FULL>
-__device__ __forceinline__ void put_tile_split(const f32x4 (&v)[2], int K, int k0, uint8_t* __restrict__ img) {
+__device__ __forceinline__ void put_piece_split(const f32x4& v, int i, int K, int k0, uint8_t* __restrict__ img) {
     const int tid = threadIdx.x;
     constexpr int PLANE = SplitImg<KC>::PLANE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int f = tid + 256 * i;
-        float x0, x1, x2, x3;
-        uint8_t* dst;
-        if constexpr (KC) {
-            const int r = f >> 2, kq = (f & 3) * 4, kg = k0 + kq;
-            x0 = FULL || kg < K ? v[i].x : 0.f, x1 = FULL || kg + 1 < K ? v[i].y : 0.f;
-            x2 = FULL || kg + 2 < K ? v[i].z : 0.f, x3 = FULL || kg + 3 < K ? v[i].w : 0.f;
-            dst = img + split_off(r, kq >> 3) + ((kq & 4) << 1);
-        } else {
-            const int k = f >> 5, rq = (f & 31) * 4;
-            const bool live = FULL || k0 + k < K;
-            x0 = live ? v[i].x : 0.f, x1 = live ? v[i].y : 0.f, x2 = live ? v[i].z : 0.f, x3 = live ? v[i].w : 0.f;
-            dst = img + split_km_off(k, rq);
-        }
-        uint32_t h0, m0, l0, h1, m1, l1;
-        split_pair(x0, x1, h0, m0, l0);
-        split_pair(x2, x3, h1, m1, l1);
-        *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
-        *reinterpret_cast<uint2*>(dst + PLANE) = uint2{m0, m1};
-        *reinterpret_cast<uint2*>(dst + 2 * PLANE) = uint2{l0, l1};
+    const int f = tid + 256 * i;
+    float x0, x1, x2, x3;
+    uint8_t* dst;
+    if constexpr (KC) {
+        const int r = f >> 2, kq = (f & 3) * 4, kg = k0 + kq;
+        x0 = FULL || kg < K ? v.x : 0.f, x1 = FULL || kg + 1 < K ? v.y : 0.f;
+        x2 = FULL || kg + 2 < K ? v.z : 0.f, x3 = FULL || kg + 3 < K ? v.w : 0.f;
+        dst = img + split_off(r, kq >> 3) + ((kq & 4) << 1);
+    } else {
+        const int k = f >> 5, rq = (f & 31) * 4;
+        const bool live = FULL || k0 + k < K;
+        x0 = live ? v.x : 0.f, x1 = live ? v.y : 0.f, x2 = live ? v.z : 0.f, x3 = live ? v.w : 0.f;
+        dst = img + split_km_off(k, rq);
     }
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split_pair(x0, x1, h0, m0, l0);
+    split_pair(x2, x3, h1, m1, l1);
+    *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+    *reinterpret_cast<uint2*>(dst + PLANE) = uint2{m0, m1};
+    *reinterpret_cast<uint2*>(dst + 2 * PLANE) = uint2{l0, l1};
+}
+
+template <bool KC, bool FULL>
+__device__ __forceinline__ void put_tile_split(const f32x4 (&v)[2], int K, int k0, uint8_t* __restrict__ img) {
+    put_piece_split<KC, FULL>(v[0], 0, K, k0, img);
+    put_piece_split<KC, FULL>(v[1], 1, K, k0, img);
 }
 
 // the MFMA fragment (k = 8 h .. 8 h + 7 of tile row lane & 31, h = lane >> 5) of the 32-row tile that starts at `base`
@@ -218,8 +223,28 @@ struct GemmBce {
     float* loss_partial;
 };
 
+// Epilogue: one wave's 32-row x 64-column slab (accumulator tiles [ti][0], [ti][1]) leaves through a wave-private 8 KB LDS
+// image so that the global stores are dwordx4 -- 4 rows x 256 contiguous bytes per instruction instead of 2 rows x 128 as
+// dword stores straight from the accumulator layout (64 store instructions per lane and tile; the store tail was 0.19 ms of
+// the score product's 0.85, tools/gemm_abl).  LDS executes a wave's instructions in order: no wait between the write and the
+// read-back, none before the next slab overwrites the image.
+__device__ __forceinline__ void store_slab_via_lds(float* __restrict__ slab, const float (&v)[2][16], float* __restrict__ crow,
+                                                   int64_t ld, int lane) {
+    const int c = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) slab[((rg & 3) + 8 * (rg >> 2) + 4 * g) * 64 + tj * 32 + c] = v[tj][rg];
+    const int r = lane >> 4, q = (lane & 15) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(&slab[(pass * 4 + r) * 64 + q]);
+        *reinterpret_cast<f32x4*>(crow + (size_t)(pass * 4 + r) * ld + q) = x;
+    }
+}
+
 template <bool A_KC, bool B_KC, int ACT, bool SPLIT = false>
-__global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+__global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
                                                           float* __restrict__ C, int64_t ldc,
                                                           const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
@@ -256,9 +281,7 @@ __global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_
         uint8_t* const img = reinterpret_cast<uint8_t*>(lds);
         // TWO k-tiles of register prefetch (r?[0] / r?[1] alternate): one k-step of MFMAs is 768 cycles, an operand tile that
         // misses L2 (the long-K backward products stream dS from HBM; the score product's table tiles come from the Infinity
-        // Cache) is ~2 000 away, and the co-resident blocks of a CU run in lockstep -- with one tile of look-ahead they all
-        // sat in the same s_waitcnt.  Measured on the pre-split experiment (operands as bf16 plane images, same loop): 2.37 ->
-        // 2.08 ms on the TuckER forward.
+        // Cache) is ~2 000 away.  Four tiles of look-ahead measured the same as two (tools/gemm_abl, round 3).
         f32x4 ra[2][2], rb[2][2];
         fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra[0]);
         fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin, rb[0]);
@@ -268,50 +291,90 @@ __global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_
         put_tile_split<B_KC, false>(rb[0], k_end, k_begin, img + OA);
         __syncthreads();
         // one k-step: multiply LDS stage `cur`, store the tile held in (na, nb) = k0 + BK to the other stage, refill (fa_, fb_)
-        // with k0 + 2 BK (clamped past the end, stored as zeros)
-        auto kstep = [&](int k0, int cur, f32x4 (&na)[2], f32x4 (&nb)[2], f32x4 (&fa_)[2], f32x4 (&fb_)[2]) {
+        // with k0 + 2 BK (clamped past the end, stored as zeros).  The conversion of the next tile is cut into its four
+        // register pieces and placed BETWEEN the wave's own MFMA groups, and the scheduler is told to keep that order: with
+        // the phases apart (24 MFMAs, then the conversion) the parts of the score product ADDED UP -- MFMA 0.40 + conversion
+        // 0.23 + fragment reads 0.19 + output stores 0.28 ms of a 1.03 ms launch (tools/gemm_abl) -- although two other waves
+        // share the SIMD; interleaved it runs 0.83 ms (the backward products 1.02 -> 0.79, 1.08 -> 0.83).  Measured and not kept:
+        // fragment sets double-buffered across a mid-step barrier at two blocks per CU (0.98 / 0.83 / 0.88 ms), split-K with
+        // interleaved instead of contiguous k-ranges, one-time start offsets between co-resident blocks (no change).
+        auto kstep = [&](auto full_tag, int k0, int cur, f32x4 (&na)[2], f32x4 (&nb)[2], f32x4 (&fa_)[2], f32x4 (&fb_)[2]) {
+            constexpr bool FULL = decltype(full_tag)::value;  // the next tile is a whole one: no zeroing
+#ifndef GEMM_ABL_NO_FETCH  // timing ablations (tools/gemm_abl): never defined in the product build
             fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + 2 * BK, fa_);
             fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + 2 * BK, fb_);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             const uint8_t* Ai = img + cur * SPLIT_STAGE;
             const uint8_t* Bi = Ai + OA;
+            uint8_t* An = img + (cur ^ 1) * SPLIT_STAGE;
             bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
+#ifdef GEMM_ABL_NO_READ
+                    fa[t][p] = fb[t][p] = __builtin_bit_cast(bf16x8, f32x4{(float)lane, (float)t, (float)p, (float)cur});
+#else
                     fa[t][p] = read_frag_split<A_KC>(Ai + p * PA, wm + 32 * t, lane);
                     fb[t][p] = read_frag_split<B_KC>(Bi + p * PB, wn + 32 * t, lane);
+#endif
                 }
             // smallest terms first; the four accumulators alternate so that no MFMA waits for the one before it
+#ifdef GEMM_ABL_NO_MMA
+#define HW_SPLIT_TERM(PA_, PB_)                                                                                      \
+    _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)               \
+        asm volatile("" ::"v"(fa[ti][PA_]), "v"(fb[tj][PB_]));
+#else
 #define HW_SPLIT_TERM(PA_, PB_)                                                                                      \
     _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)               \
         acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ti][PA_], fb[tj][PB_], acc[ti][tj], 0, 0, 0);
+#endif
+#ifdef GEMM_ABL_NO_PUT
+#define HW_PIECE(KC_, V_, I_, OFF_) asm volatile("" ::"v"(V_), "v"(An));
+#else
+#define HW_PIECE(KC_, V_, I_, OFF_) put_piece_split<KC_, FULL>(V_, I_, k_end, k0 + BK, An + OFF_);
+#endif
             HW_SPLIT_TERM(1, 1)
+            HW_PIECE(A_KC, na[0], 0, 0)
             HW_SPLIT_TERM(2, 0)
+            HW_PIECE(A_KC, na[1], 1, 0)
             HW_SPLIT_TERM(0, 2)
+            HW_PIECE(B_KC, nb[0], 0, OA)
             HW_SPLIT_TERM(1, 0)
+            HW_PIECE(B_KC, nb[1], 1, OA)
             HW_SPLIT_TERM(0, 1)
             HW_SPLIT_TERM(0, 0)
-#undef HW_SPLIT_TERM
-            __builtin_amdgcn_sched_barrier(0);
-            uint8_t* An = img + (cur ^ 1) * SPLIT_STAGE;
-            if (k0 + 2 * BK <= k_end) {  // block-uniform: the next tile is a whole one
-                put_tile_split<A_KC, true>(na, k_end, k0 + BK, An);
-                put_tile_split<B_KC, true>(nb, k_end, k0 + BK, An + OA);
-            } else {
-                put_tile_split<A_KC, false>(na, k_end, k0 + BK, An);
-                put_tile_split<B_KC, false>(nb, k_end, k0 + BK, An + OA);
+            // the scheduler's order: per MFMA up to four vector instructions of the conversion, every other one an LDS store
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#undef HW_SPLIT_TERM
+#undef HW_PIECE
+#ifndef GEMM_ABL_NO_SYNC
             __syncthreads();
+#endif
         };
+        const std::true_type whole{};
+        const std::false_type ragged{};
         int k0 = k_begin;
-        for (; k0 + BK < k_end; k0 += 2 * BK) {  // two steps per trip: stages and register sets are fixed in each half
-            kstep(k0, 0, ra[1], rb[1], ra[0], rb[0]);
-            kstep(k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
+        // two steps per trip (stages and register sets are fixed in each half); the trips whose two stored tiles are whole
+        // ones run without a branch inside the loop, the last one or two steps take the zeroing form
+        for (; k0 + 3 * BK <= k_end; k0 += 2 * BK) {
+            kstep(whole, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+            kstep(whole, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
         }
-        if (k0 < k_end) kstep(k0, 0, ra[1], rb[1], ra[0], rb[0]);
-    } else if (pipe) {
+        if (k0 + BK < k_end) {
+            kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+            kstep(ragged, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
+            k0 += 2 * BK;
+        }
+        if (k0 < k_end) kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+    } else if (pipe & 1) {
         f32x4 ra[2], rb[2];
         fetch_tile<A_KC>(A, lda, M, k_end, m0, k_begin, ra);
         fetch_tile<B_KC>(B, ldb, N, k_end, n0, k_begin, rb);
@@ -365,33 +428,96 @@ __global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_
     }
     // C/D map of a 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if constexpr (ACT == 3) {
+        // 64 elements per lane: this epilogue is as many VALU cycles as the k-loop is MFMA cycles unless it is kept lean.  A
+        // 16-element group whose |x| all lie below 16 (block-uniform interior tile, wave-uniform vote) takes the form without
+        // BCELoss's clamps and without per-element predicates -- 3 transcendentals + ~12 VALU per element; any other group
+        // keeps the general element with its bounds tests.
         float loss = 0.f;
+        const bool interior = m0 + BM <= M && n0 + BN <= N;
+#ifdef GEMM_NO_LDS_EPI
+        const bool via_lds = false;
+#else
+        const bool via_lds = interior && (pipe & 2);
+#endif
+        float* const slab = lds + wave * 2048;  // every loop ended with a barrier: no wave still reads the tiles
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < 2; ++ti) {
+            const int gm0 = m0 + wm + ti * 32 + 4 * (lane >> 5);
+            float gv[2][16];
+            bool fast[2];
 #pragma unroll
             for (int tj = 0; tj < 2; ++tj) {
                 const int gn = n0 + wn + tj * 32 + (lane & 31);
                 const bool col_ok = gn < N;
                 const float bv = (bias && col_ok) ? bias[gn] : 0.f;
                 const float t = (bce.flag && col_ok) ? fmaf(bce.scale, (float)bce.flag[gn], bce.add) : bce.add;
+                float x[16], mx = 0.f;
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
-                    const int gm = m0 + wm + ti * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-                    float pv, gv;
-                    const float l = bce_elem(acc[ti][tj][rg] + bv, t, bce.inv_numel, &pv, &gv);
-                    if (gm < M && col_ok) {
-                        loss += l;
-                        C[(size_t)gm * ldc + gn] = gv;
+                    x[rg] = acc[ti][tj][rg] + bv;
+                    mx = fmaxf(mx, fabsf(x[rg]));
+                }
+                fast[tj] = interior && __builtin_amdgcn_ballot_w64(!(mx <= 16.f)) == 0;  // NaN fails the test: general element
+                if (fast[tj]) {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) loss += bce_elem_unclamped(x[rg], t, bce.inv_numel, &gv[tj][rg]);
+                } else {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int gm = gm0 + (rg & 3) + 8 * (rg >> 2);
+                        float pv;
+                        const float l = bce_elem(x[rg], t, bce.inv_numel, &pv, &gv[tj][rg]);
+                        if (gm < M && col_ok) loss += l;
                     }
                 }
             }
+            if (via_lds) {
+                store_slab_via_lds(slab, gv, C + (size_t)(m0 + wm + ti * 32) * ldc + n0 + wn, ldc, lane);
+            } else {
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const int gn = n0 + wn + tj * 32 + (lane & 31);
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int gm = gm0 + (rg & 3) + 8 * (rg >> 2);
+                        if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = gv[tj][rg];
+                    }
+                }
+            }
+        }
         loss = group_sum<64>(loss);
-        float* red = lds;  // every loop ends with a barrier: no wave still reads the tiles
+        float* red = lds + 8192;  // past the four slabs
         if (lane == 0) red[wave] = loss;
         __syncthreads();
         if (tid == 0) bce.loss_partial[blockIdx.x + gridDim.x * blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
         return;
     }
+#ifndef GEMM_ABL_NO_STORE
+    if ((pipe & 2) && drop_mode == 0 && m0 + BM <= M && n0 + BN <= N) {  // interior tile, 16-byte rows: dwordx4 stores
+        float* const slab = lds + wave * 2048;  // every loop ended with a barrier: no wave still reads the tiles
+        float* const dst = partial ? partial + (size_t)blockIdx.z * m_max * N : C;
+        const int64_t ld = partial ? (int64_t)N : ldc;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            float v[2][16];
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const float bv = (bias && !partial) ? bias[n0 + wn + tj * 32 + (lane & 31)] : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    float x = acc[ti][tj][rg] + bv;
+                    if (!partial) {
+                        if (ACT == 1) x = x > 0.f ? x : expm1f(x);
+                        if (ACT == 2) x = fmaxf(x, 0.f);
+                    }
+                    v[tj][rg] = x;
+                }
+            }
+            store_slab_via_lds(slab, v, dst + (size_t)(m0 + wm + ti * 32) * ld + n0 + wn, ld, lane);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -433,6 +559,9 @@ __global__ __launch_bounds__(256, SPLIT ? (A_KC && B_KC ? 3 : 2) : 2) void gemm_
                     if (drop_mode == 1) v *= drop_mask[(size_t)gm * N + gn];
                     else if (quad_drop) v = ((keep16 >> rg) & 1u) ? v * 2.f : 0.f;
                     else if (drop_mode == 2) v = (philox_bits(seed, offset, (uint64_t)gm * N + gn) & 1u) ? v * 2.f : 0.f;
+#ifdef GEMM_ABL_NO_STORE
+                    if (v == 123.456f)
+#endif
                     C[(size_t)gm * ldc + gn] = v;
                 }
             }
@@ -669,10 +798,13 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     const char* pe = getenv("HW_GEMM_PIPE");
     // the pipelined loop needs 16-byte loads on both operands and at least one float4 along each inner extent
     // (a K-contiguous operand is fetched along k, whatever its row count; a k-major one along its rows)
-    const int pipe = (pe ? atoi(pe) : 1) && va && vb && k >= 4 && (a_kc || m_max >= 4) && (b_kc || n >= 4);
+    const int pipe1 = (pe ? atoi(pe) : 1) && va && vb && k >= 4 && (a_kc || m_max >= 4) && (b_kc || n >= 4);
+    // bit 1: the output rows take 16-byte stores (interior tiles leave through the LDS transposition of the epilogue)
+    const int vc = splits > 1 ? ((((uintptr_t)partial) & 15) == 0 && (n % 4) == 0) : aligned16(c, ldc);
+    const int pipe = pipe1 | (vc << 1);
     // 16-byte aligned operands: the three-way bf16 split on the bf16 matrix pipes (HW_GEMM_SPLIT=0: the exact-FMA loop)
     const char* se = getenv("HW_GEMM_SPLIT");
-    const bool split = pipe && (se ? atoi(se) != 0 : true);
+    const bool split = pipe1 && (se ? atoi(se) != 0 : true);
 #define GO(AK, BK_, EL)                                                                                                  \
     do {                                                                                                                 \
         if (split)                                                                                                       \
@@ -690,6 +822,17 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
         else if (act == 2) GO(AK, BK_, 2); \
         else GO(AK, BK_, 0);               \
     } while (0)
+#ifdef GEMM_ABL_ONLY  // experiment builds: one instantiation per operand layout (seconds instead of a minute of hipcc)
+    if (split && act == 3 && a_kc && b_kc) {
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true, 3, true>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial, pipe, bce);
+        return HW_OK;
+    }
+    if (!split || act != 0) return HW_ERR_UNSUPPORTED;
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true, 0, true>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial, pipe, bce);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false, 0, true>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial, pipe, bce);
+    else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, false, 0, true>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset, va, vb, k_len, partial, pipe, bce);
+    else return HW_ERR_UNSUPPORTED;
+#else
     if (act == 3) {  // fused BCE epilogue: x . E^T only, never split
         if (!(a_kc && b_kc) || splits != 1) return HW_ERR_UNSUPPORTED;
         GO(true, true, 3);
@@ -697,6 +840,7 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     else if (a_kc && !b_kc) GO3(true, false);
     else if (!a_kc && !b_kc) GO3(false, false);
     else GO3(false, true);
+#endif
 #undef GO3
 #undef GO
     if (splits > 1) {
