@@ -182,6 +182,13 @@ SIGNATURES = {
     "hw_tucker_contract_shared_grad": (
         C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_uint64,
                   C.c_uint64, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
+    "hw_tucker_keep_words": (C.c_int64, [C.c_int64, C.c_int32]),
+    "hw_tucker_contract_shared_keep": (
+        C.c_int, [c_f32p, c_f32p, c_i64p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, c_f32p, C.c_void_p,
+                  C.c_void_p]),
+    "hw_tucker_contract_shared_grad_keep": (
+        C.c_int, [c_f32p, c_f32p, c_i64p, c_i64p, C.c_int64, C.c_void_p, c_f32p, C.c_int64, C.c_int32, C.c_float, c_f32p,
+                  c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "hw_tucker_contract_dropout_grad": (
         C.c_int,
         [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_float, C.c_uint64, C.c_uint64, c_f32p, c_f32p, C.c_void_p],

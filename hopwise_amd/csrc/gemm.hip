@@ -300,8 +300,10 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         // interleaved instead of contiguous k-ranges, one-time start offsets between co-resident blocks (no change).
         auto kstep = [&](auto full_tag, int k0, int cur, f32x4 (&na)[2], f32x4 (&nb)[2], f32x4 (&fa_)[2], f32x4 (&fb_)[2]) {
             constexpr bool FULL = decltype(full_tag)::value;  // the next tile is a whole one: no zeroing
-#ifndef GEMM_ABL_NO_FETCH  // timing ablations (tools/gemm_abl): never defined in the product build
+#if !defined(GEMM_ABL_NO_FETCH) && !defined(GEMM_ABL_NO_FETCH_A)  // timing ablations (tools/gemm_abl): never in the product
             fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + 2 * BK, fa_);
+#endif
+#if !defined(GEMM_ABL_NO_FETCH) && !defined(GEMM_ABL_NO_FETCH_B)
             fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + 2 * BK, fb_);
 #endif
             __builtin_amdgcn_sched_barrier(0);
@@ -700,7 +702,17 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int gm = (int)(i / N), gn = (int)(i % N);
         float v = 0.f;
-        for (int z = 0; z < splits; ++z) v += partial[((size_t)z * m_max + gm) * N + gn];
+        const float* __restrict__ pz = partial + (size_t)gm * N + gn;
+        const size_t zs = (size_t)m_max * N;
+        int z = 0;
+        for (; z + 8 <= splits; z += 8) {  // eight loads in flight, the additions in the same fixed order as one by one
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = pz[(size_t)(z + u) * zs];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; z < splits; ++z) v += pz[(size_t)z * zs];
         v += bias ? bias[gn] : 0.f;
         if (ACT == 1) v = v > 0.f ? v : expm1f(v);
         if (ACT == 2) v = fmaxf(v, 0.f);
@@ -714,7 +726,15 @@ __global__ __launch_bounds__(256) void gemm_bce_finish_kernel(const float* __res
                                                               float* __restrict__ loss) {
     __shared__ float red[4];
     float v = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) v += partial[i];  // fixed order: deterministic
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < n; i += 8 * 256) {  // fixed order (deterministic), eight loads in flight
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = partial[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; i < n; i += 256) v += partial[i];
     v = group_sum<64>(v);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();

@@ -29,6 +29,12 @@ __device__ __forceinline__ float keep_scale(uint32_t word, float p, float inv_ke
     return (float)(word >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
 }
 
+// MODE 3: the keep flags written by the forward (see tucker_contract_fwd_kernel) -- nibble of (b, q, j)
+__device__ __forceinline__ uint32_t keep_nibble(const float* __restrict__ mask, int b, int nq, int q, int d, int j) {
+    const uint32_t* __restrict__ kb = reinterpret_cast<const uint32_t*>(mask);
+    return (kb[((size_t)b * ((nq + 7) >> 3) + (q >> 3)) * d + j] >> (4 * (q & 7))) & 15u;
+}
+
 // out[b, j] = sum_i x[b, i] * w[b, i, j] * m[b, i, j]; MODE 0: no mask, 1: mask tensor (0 or 1/(1-p)), 2: Philox
 template <int MODE>
 __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* __restrict__ x,
@@ -36,8 +42,12 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
                                                                   const float* __restrict__ mask, int d, float drop_p,
                                                                   uint64_t seed, uint64_t offset,
                                                                   float* __restrict__ out, int64_t w_stride,
-                                                                  const int64_t* __restrict__ w_index) {
+                                                                  const int64_t* __restrict__ w_index,
+                                                                  uint32_t* __restrict__ keep_out) {
     const int b = blockIdx.x;
+    // keep_out (MODE 2, nullable): the keep flags of this call, 4 bits per (quad of rows q, column j) -- bit k = row 4 q + k --
+    // eight quads per word, word ((b * ceil(nq / 8)) + (q >> 3)) * d + j.  The three backward kernels read them (MODE 3)
+    // instead of evaluating the same Philox blocks again: the [B, d, d] dropout is Philox-bound (82 M draws per side).
     // w_stride = d * d with w_index == NULL: the reference's [B, d, d] tensor; with w_index: matrix w_index[b] of a small
     // set (one per relation); w_stride = 0: one [d, d] matrix shared by the whole batch
     const float* __restrict__ wb = w + (size_t)(w_index ? w_index[b] : b) * w_stride;
@@ -48,9 +58,20 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
     for (int j = threadIdx.x; j < d; j += 256) {
         float acc = 0.f;
         if constexpr (MODE == 2) {
+            uint32_t kw = 0u;
+            const int nq8 = (nq + 7) >> 3;
             for (int q = 0; q < nq; ++q) {
                 uint32_t rw[4];
                 philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+                if (keep_out) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        kw |= (keep_scale(rw[k], drop_p, inv_keep) != 0.f ? 1u : 0u) << (4 * (q & 7) + k);
+                    if ((q & 7) == 7 || q == nq - 1) {
+                        keep_out[((size_t)b * nq8 + (q >> 3)) * d + j] = kw;
+                        kw = 0u;
+                    }
+                }
                 if (4 * q + 3 < d) {  // full quad: the four row loads are issued together (no test between load and use)
                     float wv[4];
 #pragma unroll
@@ -100,7 +121,9 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
         for (int k = 0; k < 4; ++k) xi[k] = 4 * q + k < d ? x[(size_t)b * d + 4 * q + k] : 0.f;
         for (int j = lane; j < d; j += 64) {
             uint32_t rw[4] = {0u, 0u, 0u, 0u};
+            uint32_t nib = 0u;
             if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+            if constexpr (MODE == 3) nib = keep_nibble(mask, b, nq, q, d, j);
             const float gj = gob[j];
             if (4 * q + 3 < d) {  // full quad: loads first, no test between a load and its use
                 float wv[4], mv[4];
@@ -110,6 +133,7 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
                     mv[k] = 1.f;
                     if constexpr (MODE == 1) mv[k] = mb[(size_t)(4 * q + k) * d + j];
                     if constexpr (MODE == 2) mv[k] = keep_scale(rw[k], drop_p, inv_keep);
+                    if constexpr (MODE == 3) mv[k] = (nib >> k) & 1u ? inv_keep : 0.f;
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -126,6 +150,7 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
                 float m = 1.f;
                 if constexpr (MODE == 1) m = mb[(size_t)i * d + j];
                 if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
+                if constexpr (MODE == 3) m = (nib >> k) & 1u ? inv_keep : 0.f;
                 const float g = gj * m;
                 acc[k] = fmaf(g, wb[(size_t)i * d + j], acc[k]);
                 if (gw) gw[(size_t)b * d * d + (size_t)i * d + j] = xi[k] * g;
@@ -157,7 +182,9 @@ __global__ __launch_bounds__(256) void tucker_gw_shared_kernel(const float* __re
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int64_t b = b0; b < b1; ++b) {
             uint32_t rw[4] = {0u, 0u, 0u, 0u};
+            uint32_t nib = 0u;
             if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+            if constexpr (MODE == 3) nib = keep_nibble(mask, (int)b, nq, q, d, j);
             const float gj = go[(size_t)b * d + j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -165,6 +192,7 @@ __global__ __launch_bounds__(256) void tucker_gw_shared_kernel(const float* __re
                 float m = 1.f;
                 if constexpr (MODE == 1) m = mask[((size_t)b * d + i) * d + j];
                 if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
+                if constexpr (MODE == 3) m = (nib >> k) & 1u ? inv_keep : 0.f;
                 acc[k] = fmaf(x[(size_t)b * d + i] * m, gj, acc[k]);
             }
         }
@@ -208,7 +236,9 @@ __global__ __launch_bounds__(256) void tucker_gw_indexed_kernel(const float* __r
             }
             if (s == s1) break;
             uint32_t rw[4] = {0u, 0u, 0u, 0u};
+            uint32_t nib = 0u;
             if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
+            if constexpr (MODE == 3) nib = keep_nibble(mask, (int)b, nq, q, d, j);
             const float gj = go[(size_t)b * d + j];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -216,6 +246,7 @@ __global__ __launch_bounds__(256) void tucker_gw_indexed_kernel(const float* __r
                 float m = 1.f;
                 if constexpr (MODE == 1) m = mask[((size_t)b * d + i) * d + j];
                 if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
+                if constexpr (MODE == 3) m = (nib >> k) & 1u ? inv_keep : 0.f;
                 acc[k] = fmaf(x[(size_t)b * d + i] * m, gj, acc[k]);
             }
         }
@@ -309,22 +340,25 @@ using namespace hw;
 
 static int contract_launch(int mode, const float* x, const float* w, const float* mask, const float* gout, int64_t batch,
                            int32_t dim, float drop_p, uint64_t seed, uint64_t offset, float* out, float* gx, float* gw,
-                           bool backward, void* stream, bool shared_w = false, const int64_t* w_index = nullptr) {
+                           bool backward, void* stream, bool shared_w = false, const int64_t* w_index = nullptr,
+                           uint32_t* keep_out = nullptr) {
     const int64_t w_stride = (shared_w && !w_index) ? 0 : (int64_t)dim * dim;
     if (!x || !w || batch < 0 || dim < 1 || batch > INT32_MAX) return HW_ERR_INVALID_ARG;
-    if (mode == 2 && !(drop_p >= 0.f && drop_p < 1.f)) return HW_ERR_INVALID_ARG;
+    if ((mode == 2 || mode == 3) && !(drop_p >= 0.f && drop_p < 1.f)) return HW_ERR_INVALID_ARG;
+    if (mode == 3 && (!backward || !mask)) return HW_ERR_INVALID_ARG;
     if (backward ? !gout : !out) return HW_ERR_INVALID_ARG;
     if (batch == 0) return HW_OK;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
-#define FWD(M) hipLaunchKernelGGL((tucker_contract_fwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, dim, drop_p, seed, offset, out, w_stride, w_index)
+#define FWD(M) hipLaunchKernelGGL((tucker_contract_fwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, dim, drop_p, seed, offset, out, w_stride, w_index, keep_out)
 #define BWD(M) hipLaunchKernelGGL((tucker_contract_bwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, gout, dim, drop_p, seed, offset, gx, gw, w_stride, w_index)
     if (!backward) {
         if (mode == 2) FWD(2);
         else if (mode == 1) FWD(1);
         else FWD(0);
     } else {
-        if (mode == 2) BWD(2);
+        if (mode == 3) BWD(3);
+        else if (mode == 2) BWD(2);
         else if (mode == 1) BWD(1);
         else BWD(0);
     }
@@ -366,17 +400,15 @@ extern "C" int64_t hw_tucker_contract_shared_workspace_floats(int64_t batch, int
     return batch < 0 || dim < 1 ? 0 : ((batch + TGW_CHUNK - 1) / TGW_CHUNK) * (int64_t)dim * dim;
 }
 
-extern "C" int hw_tucker_contract_shared_grad(const float* x, const float* w, const int64_t* w_index,
-                                              const int64_t* order, int64_t n_mats, const float* mask, const float* gout,
-                                              int64_t batch, int32_t dim, float drop_p, uint64_t seed, uint64_t offset,
-                                              float* gx, float* gw, float* workspace, int64_t workspace_floats,
-                                              void* stream) {
-    const int mode = mask ? 1 : (drop_p > 0.f ? 2 : 0);
+static int shared_grad(int mode, const float* x, const float* w, const int64_t* w_index, const int64_t* order,
+                       int64_t n_mats, const float* mask, const float* gout, int64_t batch, int32_t dim, float drop_p,
+                       uint64_t seed, uint64_t offset, float* gx, float* gw, float* workspace, int64_t workspace_floats,
+                       void* stream) {
     if (!x || !w || !gout || batch < 0 || dim < 1 || batch > INT32_MAX || n_mats < 1) return HW_ERR_INVALID_ARG;
     if (w_index && gw && !order) return HW_ERR_INVALID_ARG;
     if (batch == 0) return HW_OK;
     if (gx) {
-        const int rc = contract_launch(mode, x, w, mask, gout, batch, dim, mode == 2 ? drop_p : 0.f, seed, offset, nullptr,
+        const int rc = contract_launch(mode, x, w, mask, gout, batch, dim, mode >= 2 ? drop_p : 0.f, seed, offset, nullptr,
                                        gx, nullptr, true, stream, true, w_index);
         if (rc) return rc;
     }
@@ -385,11 +417,12 @@ extern "C" int hw_tucker_contract_shared_grad(const float* x, const float* w, co
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)((dim + 3) / 4), (unsigned)chunks);
-    const float p = mode == 2 ? drop_p : 0.f;
+    const float p = mode >= 2 ? drop_p : 0.f;
     if (w_index) {  // one matrix per relation: atomic flushes into gw (zeroed here)
         if (hipMemsetAsync(gw, 0, (size_t)n_mats * n * sizeof(float), st) != hipSuccess) return HW_ERR_LAUNCH;
 #define GWI(M) hipLaunchKernelGGL((tucker_gw_indexed_kernel<M>), grid, dim3(256), 0, st, x, mask, gout, order, w_index, n_mats, batch, dim, p, seed, offset, gw)
-        if (mode == 2) GWI(2);
+        if (mode == 3) GWI(3);
+        else if (mode == 2) GWI(2);
         else if (mode == 1) GWI(1);
         else GWI(0);
 #undef GWI
@@ -397,7 +430,8 @@ extern "C" int hw_tucker_contract_shared_grad(const float* x, const float* w, co
     }
     if (!workspace || workspace_floats < chunks * n) return HW_ERR_WORKSPACE;
 #define GWS(M) hipLaunchKernelGGL((tucker_gw_shared_kernel<M>), grid, dim3(256), 0, st, x, mask, gout, batch, dim, p, seed, offset, workspace)
-    if (mode == 2) GWS(2);
+    if (mode == 3) GWS(3);
+    else if (mode == 2) GWS(2);
     else if (mode == 1) GWS(1);
     else GWS(0);
 #undef GWS
@@ -405,6 +439,36 @@ extern "C" int hw_tucker_contract_shared_grad(const float* x, const float* w, co
     if (rg > 2048) rg = 2048;
     hipLaunchKernelGGL(tucker_gw_reduce_kernel, dim3((unsigned)rg), dim3(256), 0, st, workspace, (int)chunks, n, gw);
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_tucker_contract_shared_grad(const float* x, const float* w, const int64_t* w_index,
+                                              const int64_t* order, int64_t n_mats, const float* mask, const float* gout,
+                                              int64_t batch, int32_t dim, float drop_p, uint64_t seed, uint64_t offset,
+                                              float* gx, float* gw, float* workspace, int64_t workspace_floats,
+                                              void* stream) {
+    return shared_grad(mask ? 1 : (drop_p > 0.f ? 2 : 0), x, w, w_index, order, n_mats, mask, gout, batch, dim, drop_p, seed,
+                       offset, gx, gw, workspace, workspace_floats, stream);
+}
+
+extern "C" int64_t hw_tucker_keep_words(int64_t batch, int32_t dim) {
+    return batch < 0 || dim < 1 ? 0 : batch * ((((int64_t)dim + 3) / 4 + 7) / 8) * dim;
+}
+
+extern "C" int hw_tucker_contract_shared_keep(const float* x, const float* w, const int64_t* w_index, int64_t batch,
+                                              int32_t dim, float drop_p, uint64_t seed, uint64_t offset, float* out,
+                                              uint32_t* keep, void* stream) {
+    if (!keep || !(drop_p > 0.f)) return HW_ERR_INVALID_ARG;
+    return contract_launch(2, x, w, nullptr, nullptr, batch, dim, drop_p, seed, offset, out, nullptr, nullptr, false, stream,
+                           true, w_index, keep);
+}
+
+extern "C" int hw_tucker_contract_shared_grad_keep(const float* x, const float* w, const int64_t* w_index,
+                                                   const int64_t* order, int64_t n_mats, const uint32_t* keep,
+                                                   const float* gout, int64_t batch, int32_t dim, float drop_p, float* gx,
+                                                   float* gw, float* workspace, int64_t workspace_floats, void* stream) {
+    if (!keep || !(drop_p > 0.f)) return HW_ERR_INVALID_ARG;
+    return shared_grad(3, x, w, w_index, order, n_mats, reinterpret_cast<const float*>(keep), gout, batch, dim, drop_p, 0, 0,
+                       gx, gw, workspace, workspace_floats, stream);
 }
 
 extern "C" int64_t hw_tucker_bce_workspace_floats(void) { return TB_BLOCKS; }

@@ -1306,19 +1306,30 @@ class TuckerContractShared(torch.autograd.Function):
         if mask is not None:
             mask = _dev(mask, torch.float32, "mask").contiguous()
         out = torch.empty((B, d), dtype=torch.float32, device=x.device)
-        check(lib.hw_tucker_contract_shared(_ptr(x), _ptr(w), _ptr(index), _ptr(mask), B, d, float(p), C.c_uint64(seed),
-                                            C.c_uint64(offset), _ptr(out), _stream()), "hw_tucker_contract_shared")
-        ctx.args = (float(p), int(seed), int(offset), index is not None, mask is not None)
-        ctx.save_for_backward(x, w, *([index] if index is not None else []), *([mask] if mask is not None else []))
+        keep = None
+        if mask is None and p > 0 and (x.requires_grad or w.requires_grad):
+            # the backward reads the forward's keep flags (4 bits per quad of rows and column) instead of drawing the
+            # 4 x 10^7 Philox blocks three more times
+            keep = torch.empty(int(lib.hw_tucker_keep_words(B, d)), dtype=torch.int32, device=x.device)
+            check(lib.hw_tucker_contract_shared_keep(_ptr(x), _ptr(w), _ptr(index), B, d, float(p), C.c_uint64(seed),
+                                                     C.c_uint64(offset), _ptr(out), _ptr(keep), _stream()),
+                  "hw_tucker_contract_shared_keep")
+        else:
+            check(lib.hw_tucker_contract_shared(_ptr(x), _ptr(w), _ptr(index), _ptr(mask), B, d, float(p), C.c_uint64(seed),
+                                                C.c_uint64(offset), _ptr(out), _stream()), "hw_tucker_contract_shared")
+        ctx.args = (float(p), int(seed), int(offset), index is not None, mask is not None, keep is not None)
+        ctx.save_for_backward(x, w, *([index] if index is not None else []), *([mask] if mask is not None else []),
+                              *([keep] if keep is not None else []))
         return out
 
     @staticmethod
     def backward(ctx, go):
         lib = _lib.load()
-        p, seed, offset, has_index, has_mask = ctx.args
+        p, seed, offset, has_index, has_mask, has_keep = ctx.args
         saved = list(ctx.saved_tensors)
         x, w = saved[0], saved[1]
         index = saved[2] if has_index else None
+        keep = saved.pop() if has_keep else None
         mask = saved[-1] if has_mask else None
         B, d = x.shape
         go = go.contiguous()
@@ -1332,6 +1343,11 @@ class TuckerContractShared(torch.autograd.Function):
                 ws = torch.empty(n_ws, dtype=torch.float32, device=x.device)
             else:
                 order = torch.argsort(index, stable=True)  # 2048 ids: rows grouped by matrix
+        if keep is not None:
+            check(lib.hw_tucker_contract_shared_grad_keep(_ptr(x), _ptr(w), _ptr(index), _ptr(order), w.shape[0], _ptr(keep),
+                                                          _ptr(go), B, d, p, _ptr(gx), _ptr(gw), _ptr(ws), n_ws, _stream()),
+                  "hw_tucker_contract_shared_grad_keep")
+            return gx, gw, None, None, None, None, None
         check(lib.hw_tucker_contract_shared_grad(_ptr(x), _ptr(w), _ptr(index), _ptr(order), w.shape[0], _ptr(mask), _ptr(go),
                                                  B, d, p, C.c_uint64(seed), C.c_uint64(offset), _ptr(gx), _ptr(gw), _ptr(ws),
                                                  n_ws, _stream()), "hw_tucker_contract_shared_grad")

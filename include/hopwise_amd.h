@@ -405,6 +405,18 @@ int hw_tucker_contract_shared_grad(const float* x, const float* w, const int64_t
                                    int64_t n_mats, const float* mask, const float* gout, int64_t batch, int32_t dim,
                                    float drop_p, uint64_t seed, uint64_t offset, float* gx, float* gw, float* workspace,
                                    int64_t workspace_floats, void* stream);
+/* The Philox form with the keep flags kept: the [batch, d, d] dropout of tucker.py:76 draws 4 x 10^7 Philox blocks per side
+ * and call, and the gradient call would draw them three more times (gx, gw and, on the kg side, the per-relation gw).
+ * *_keep writes the flags of the forward (`keep`: hw_tucker_keep_words(batch, dim) uint32 words -- 4 bits per (quad of rows,
+ * column), 1.4 bytes per 16 mask elements) and *_grad_keep reads them.  Same masks, same results as the (seed, offset)
+ * entry points bit for bit. */
+int64_t hw_tucker_keep_words(int64_t batch, int32_t dim);
+int hw_tucker_contract_shared_keep(const float* x, const float* w, const int64_t* w_index, int64_t batch, int32_t dim,
+                                   float drop_p, uint64_t seed, uint64_t offset, float* out, uint32_t* keep, void* stream);
+int hw_tucker_contract_shared_grad_keep(const float* x, const float* w, const int64_t* w_index, const int64_t* order,
+                                        int64_t n_mats, const uint32_t* keep, const float* gout, int64_t batch, int32_t dim,
+                                        float drop_p, float* gx, float* gw, float* workspace, int64_t workspace_floats,
+                                        void* stream);
 
 /* sigmoid + nn.BCELoss(mean) against target[b, c] = target_scale * pos_flag[c] + target_add (tucker.py:111-125:
  * the union-of-the-batch multi-hot with label smoothing).  pred / glogits nullable.  workspace:

@@ -245,3 +245,43 @@ def test_shared_relation_matrices_equal_per_row_product(d, B):
             ref = q.grad.cpu().numpy()
             np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=3e-4, atol=3e-6 * (np.abs(ref).max() + 1e-12) + 1e-9,
                                        err_msg=f"{mode}:{k}")
+
+
+@pytest.mark.parametrize("d,B,n_mats", [(200, 33, 5), (24, 7, 1), (37, 65, 3)])
+def test_kept_dropout_flags_give_the_regenerated_masks(d, B, n_mats):
+    """hw_tucker_contract_shared_keep / _grad_keep (the forward stores its keep flags, the backward reads them) against
+    the (seed, offset) entry points that draw the Philox blocks again: same output, same gx bit for bit; gw (float atomics
+    per relation on the indexed side) to summation order."""
+    import ctypes as C
+
+    from hopwise_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(d)
+    x = torch.randn(B, d, generator=g).to(dev())
+    w = torch.randn(n_mats, d, d, generator=g).mul_(0.1).to(dev())
+    index = torch.randint(0, n_mats, (B,), generator=g).to(dev()) if n_mats > 1 else None
+    go = torch.randn(B, d, generator=g).to(dev())
+    res = []
+    for keep_path in (True, False):
+        xs, ws = x.clone().requires_grad_(keep_path), w.clone().requires_grad_(keep_path)
+        if keep_path:
+            out = ops.tucker_contract_shared(xs, ws, index, None, 0.4, 11, 3)
+            out.backward(go)
+            res.append((out.detach(), xs.grad, ws.grad))
+        else:  # no grad requested: the plain forward; the gradient through the regenerating entry point
+            out = ops.tucker_contract_shared(xs, ws, index, None, 0.4, 11, 3)
+            gx, gw = torch.empty_like(x), torch.empty_like(w)
+            order = torch.argsort(index, stable=True) if index is not None else None
+            n_ws = int(lib.hw_tucker_contract_shared_workspace_floats(B, d))
+            wsp = torch.empty(n_ws, device=dev())
+            ops.check(lib.hw_tucker_contract_shared_grad(ops._ptr(x), ops._ptr(w), ops._ptr(index), ops._ptr(order), n_mats, None,
+                                                         ops._ptr(go), B, d, 0.4, C.c_uint64(11), C.c_uint64(3), ops._ptr(gx), ops._ptr(gw), ops._ptr(wsp),
+                                                         n_ws, None), "hw_tucker_contract_shared_grad")
+            res.append((out, gx, gw))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    if index is None:
+        assert torch.equal(res[0][2], res[1][2])
+    else:
+        np.testing.assert_allclose(res[0][2].cpu().numpy(), res[1][2].cpu().numpy(), rtol=1e-5, atol=1e-6)
