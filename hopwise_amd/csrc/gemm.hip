@@ -462,7 +462,8 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
                 fast[tj] = interior && __builtin_amdgcn_ballot_w64(!(mx <= 16.f)) == 0;  // NaN fails the test: general element
                 if (fast[tj]) {
 #pragma unroll
-                    for (int rg = 0; rg < 16; ++rg) loss += bce_elem_unclamped(x[rg], t, bce.inv_numel, &gv[tj][rg]);
+                    for (int rg = 0; rg < 16; ++rg)
+                        loss += bce_elem_unclamped(x[rg], 1.f - t, t * bce.inv_numel, bce.inv_numel, &gv[tj][rg]);
                 } else {
 #pragma unroll
                     for (int rg = 0; rg < 16; ++rg) {
@@ -915,11 +916,13 @@ extern "C" int hw_gemm_f32_bce(const float* x, int64_t ldx, const float* table, 
     if (!x || !table || !g_out || !loss_out || !workspace || m < 1 || n < 1 || k < 1 || ldg < n || ldx < k || ldt < k)
         return HW_ERR_INVALID_ARG;
     if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
-    const int64_t blocks = hw_gemm_bce_workspace_floats(m, n);
-    if (workspace_floats < blocks || blocks > INT32_MAX) return HW_ERR_WORKSPACE;
+    const int64_t need = hw_gemm_bce_workspace_floats(m, n);
+    if (workspace_floats < need || need > INT32_MAX) return HW_ERR_WORKSPACE;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     GemmBce bce{pos_flag, target_scale, target_add, (float)(1.0 / ((double)m * (double)n)), workspace};
+    const int64_t tiles_m = (m + BM - 1) / BM;
+    const int64_t blocks = tiles_m * ((n + BN - 1) / BN);
     const int rc = launch_gemm(x, ldx, true, table, ldt, true, g_out, ldg, nullptr, m, n, k, bias, 3, nullptr, 0, 0, 0, nullptr,
                                0, st, bce);
     if (rc) return rc;

@@ -67,7 +67,9 @@ for rnd in range(6):
 A_ = a if akc else a.t()
 B_ = b.t() if bkc else b
 ref = A_.double() @ B_.double()
+ref_loss = None
 if BCE:
+    ref_loss = (torch.nn.functional.softplus(ref) - 0.0005 * ref).mean().item()
     ref = (torch.sigmoid(ref) - 0.0005) / (M * N)
 ref = ref.float()
 scale = ref.abs().max().item()
@@ -77,4 +79,5 @@ for n in names:
     run(loaded[n])
     torch.cuda.synchronize()
     err = (out - ref).abs().max().item() / scale
-    print(f"{n:10s} median {t[len(t) // 2]:7.3f} ms   min {t[0]:7.3f}   max |err| / max |c| = {err:.2e}", flush=True)
+    extra = "" if ref_loss is None else f"   loss {loss_out.item():.9f} (float64 {ref_loss:.9f})"
+    print(f"{n:10s} median {t[len(t) // 2]:7.3f} ms   min {t[0]:7.3f}   max |err| / max |c| = {err:.2e}{extra}", flush=True)
