@@ -263,8 +263,23 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
     float (*As)[LDT] = As2[0];
     float (*Bs)[LDT] = Bs2[0];
     const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    if (m0 >= M) return;
+    // Block coordinates.  pipe bit 2: XCD-aware order -- workgroups go to the 8 XCDs round-robin by linear id, so the blocks
+    // that read the SAME B tile (all row tiles of one column tile / one k-range) are renumbered onto ONE XCD: the tile then
+    // fills one L2 instead of eight (gridDim.y, or gridDim.z with split-K, is a multiple of 8 when the bit is set).
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (pipe & 4) {
+        const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned xcd = lin & 7u, j = lin >> 3;
+        bx = j % gridDim.x;
+        if (gridDim.z > 1) {
+            by = (j / gridDim.x) % gridDim.y;
+            bz = (j / (gridDim.x * gridDim.y)) * 8u + xcd;
+        } else {
+            by = (j / gridDim.x) * 8u + xcd;
+        }
+    }
+    const int m0 = bx * BM, n0 = by * BN;
+    if (m0 >= M || n0 >= N) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     f32x16 acc[2][2];
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
 
     // split-K: blockIdx.z owns k in [z * k_len, min(K, (z + 1) * k_len)); partial sums go to `partial[z]`
-    const int k_begin = blockIdx.z * k_len;
+    const int k_begin = bz * k_len;
     const int k_end = min(K, k_begin + k_len);
     if constexpr (SPLIT) {
         constexpr int PA = SplitImg<A_KC>::PLANE, PB = SplitImg<B_KC>::PLANE, OA = SplitImg<A_KC>::OPERAND;
@@ -492,13 +507,13 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         float* red = lds + 8192;  // past the four slabs
         if (lane == 0) red[wave] = loss;
         __syncthreads();
-        if (tid == 0) bce.loss_partial[blockIdx.x + gridDim.x * blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) bce.loss_partial[bx + gridDim.x * by] = (red[0] + red[1]) + (red[2] + red[3]);
         return;
     }
 #ifndef GEMM_ABL_NO_STORE
     if ((pipe & 2) && drop_mode == 0 && m0 + BM <= M && n0 + BN <= N) {  // interior tile, 16-byte rows: dwordx4 stores
         float* const slab = lds + wave * 2048;  // every loop ended with a barrier: no wave still reads the tiles
-        float* const dst = partial ? partial + (size_t)blockIdx.z * m_max * N : C;
+        float* const dst = partial ? partial + (size_t)bz * m_max * N : C;
         const int64_t ld = partial ? (int64_t)N : ldc;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -554,7 +569,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
             for (int rg = 0; rg < 16; ++rg) {
                 const int gm = m0 + wm + ti * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
                 if (gm < M && gn < N && partial) {
-                    partial[((size_t)blockIdx.z * m_max + gm) * N + gn] = acc[ti][tj][rg];
+                    partial[((size_t)bz * m_max + gm) * N + gn] = acc[ti][tj][rg];
                 } else if (gm < M && gn < N) {
                     float v = acc[ti][tj][rg] + bv;
                     if (ACT == 1) v = v > 0.f ? v : expm1f(v);
@@ -822,7 +837,20 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     const int pipe1 = (pe ? atoi(pe) : 1) && va && vb && k >= 4 && (a_kc || m_max >= 4) && (b_kc || n >= 4);
     // bit 1: the output rows take 16-byte stores (interior tiles leave through the LDS transposition of the epilogue)
     const int vc = splits > 1 ? ((((uintptr_t)partial) & 15) == 0 && (n % 4) == 0) : aligned16(c, ldc);
-    const int pipe = pipe1 | (vc << 1);
+    int pipe = pipe1 | (vc << 1);
+    {
+        // XCD-aware block order (see the kernel): worth it when many row tiles share a B tile; the y (or z) extent is padded to
+        // a multiple of 8, surplus blocks exit at once
+        const char* xe = getenv("HW_GEMM_XCD");
+        const bool on = xe ? atoi(xe) != 0 : true;
+        if (on && gm >= 2 && gm * gn * splits >= 512) {
+            if (splits > 1 && splits % 8 == 0) pipe |= 4;
+            else if (splits == 1 && gn >= 16) {
+                pipe |= 4;
+                grid.y = (unsigned)((gn + 7) / 8 * 8);
+            }
+        }
+    }
     // 16-byte aligned operands: the three-way bf16 split on the bf16 matrix pipes (HW_GEMM_SPLIT=0: the exact-FMA loop)
     const char* se = getenv("HW_GEMM_SPLIT");
     const bool split = pipe1 && (se ? atoi(se) != 0 : true);
