@@ -586,6 +586,200 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         }
 }
 
+// ---- wide tiles for the narrow-output products: 128 x 256 per block, 512 threads ------------------------------------------
+// The TuckER / ConvE backward products (dX = dS . E, dE = dS^T . x) have N = d = 200 output columns.  With 128-wide tiles two
+// blocks cover a row tile and BOTH stream the same dS tile; measured with everything but the matrix pipe and the global
+// loads removed, those launches already ran at their full 0.79 ms (matrix pipe alone: 0.45) at ~12 bytes per cycle and CU of
+// L1 fill -- the rate a CU sustains against far memory (MI355X_MICROARCH.md, 'prologue HBM burst').  One block per row tile
+// with all 256 columns reads dS once (-25 % bytes per MFMA), converts a quarter less per MFMA and meets half as many
+// barriers per MFMA.  Eight waves as 2 x 4, each 64 x 64 as above; LDS 2 x 36 KB; one block per CU (two waves per SIMD).
+// Plain epilogue only (split-K partials or C); same k-step as gemm_f32_kernel's split loop.
+constexpr int WBN = 256, WNT = 512, W_PB = WBN * 32;
+template <bool KC>
+__device__ __forceinline__ void fetch_b256(const float* __restrict__ X, int64_t ld, int rows, int K, int r0, int k0,
+                                           f32x4 (&v)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + WNT * i;
+        if constexpr (KC) {
+            const int r = f >> 2, kq = (f & 3) * 4;
+            const int gr = min(r0 + r, rows - 1), gk = min(k0 + kq, ((K + 3) & ~3) - 4);
+            v[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gr * ld + gk);
+        } else {
+            const int k = f >> 6, rq = (f & 63) * 4;
+            const int gk = min(k0 + k, K - 1), gr = min(r0 + rq, ((rows + 3) & ~3) - 4);
+            v[i] = *reinterpret_cast<const f32x4*>(X + (size_t)gk * ld + gr);
+        }
+    }
+}
+// k-major image of a 256-row operand: 512-byte k-rows, 64-byte chunks at chunk ^ (k & 3) as in split_km_off
+__device__ __forceinline__ int split_km_off256(int k, int col) { return k * 512 + ((col * 2) ^ ((k & 3) << 6)); }
+template <bool KC, bool FULL>
+__device__ __forceinline__ void put_piece_b256(const f32x4& v, int i, int K, int k0, uint8_t* __restrict__ img) {
+    const int f = threadIdx.x + WNT * i;
+    float x0, x1, x2, x3;
+    uint8_t* dst;
+    if constexpr (KC) {
+        const int r = f >> 2, kq = (f & 3) * 4, kg = k0 + kq;
+        x0 = FULL || kg < K ? v.x : 0.f, x1 = FULL || kg + 1 < K ? v.y : 0.f;
+        x2 = FULL || kg + 2 < K ? v.z : 0.f, x3 = FULL || kg + 3 < K ? v.w : 0.f;
+        dst = img + split_off(r, kq >> 3) + ((kq & 4) << 1);
+    } else {
+        const int k = f >> 6, rq = (f & 63) * 4;
+        const bool live = FULL || k0 + k < K;
+        x0 = live ? v.x : 0.f, x1 = live ? v.y : 0.f, x2 = live ? v.z : 0.f, x3 = live ? v.w : 0.f;
+        dst = img + split_km_off256(k, rq);
+    }
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split_pair(x0, x1, h0, m0, l0);
+    split_pair(x2, x3, h1, m1, l1);
+    *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
+    *reinterpret_cast<uint2*>(dst + W_PB) = uint2{m0, m1};
+    *reinterpret_cast<uint2*>(dst + 2 * W_PB) = uint2{l0, l1};
+}
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag_b256(const uint8_t* __restrict__ plane, int base, int lane) {
+    if constexpr (KC) {
+        return *reinterpret_cast<const bf16x8*>(plane + split_off(base + (lane & 31), lane >> 5));
+    } else {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const uint8_t* a = plane + split_km_off256(8 * (g >> 1) + q, base + 16 * (g & 1) + 4 * pp);
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * 512));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, both);
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __restrict__ A, int64_t lda,
+                                                                 const float* __restrict__ B, int64_t ldb,
+                                                                 float* __restrict__ C, int64_t ldc,
+                                                                 const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
+                                                                 int k_len, float* __restrict__ partial, int flags) {
+    constexpr int PA = SplitImg<A_KC>::PLANE, OA = SplitImg<A_KC>::OPERAND, STAGE = OA + 3 * W_PB;
+    __shared__ __attribute__((aligned(16))) uint8_t img[2 * STAGE];
+    const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
+    unsigned bx = blockIdx.x, bz = blockIdx.z;
+    if (flags & 4) {  // XCD-aware order: the row tiles of one k-range on one XCD (gridDim.z is a multiple of 8)
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.z;
+        bx = (lin >> 3) % gridDim.x;
+        bz = ((lin >> 3) / gridDim.x) * 8u + (lin & 7u);
+    }
+    const int m0 = bx * BM;
+    if (m0 >= M) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
+    const int k_begin = bz * k_len;
+    const int k_end = min(K, k_begin + k_len);
+    // this thread's one float4 of the A tile: the 256-thread mapping of fetch_tile with f = tid
+    auto fetch_a = [&](int k0, f32x4& v) {
+        if constexpr (A_KC) {
+            const int r = tid >> 2, kq = (tid & 3) * 4;
+            const int gr = min(m0 + r, M - 1), gk = min(k0 + kq, ((k_end + 3) & ~3) - 4);
+            v = *reinterpret_cast<const f32x4*>(A + (size_t)gr * lda + gk);
+        } else {
+            const int k = tid >> 5, rq = (tid & 31) * 4;
+            const int gk = min(k0 + k, k_end - 1), gr = min(m0 + rq, ((M + 3) & ~3) - 4);
+            v = *reinterpret_cast<const f32x4*>(A + (size_t)gk * lda + gr);
+        }
+    };
+    f32x4 ra[2], rb[2][2];
+    fetch_a(k_begin, ra[0]);
+    fetch_b256<B_KC>(B, ldb, N, k_end, 0, k_begin, rb[0]);
+    fetch_a(k_begin + BK, ra[1]);
+    fetch_b256<B_KC>(B, ldb, N, k_end, 0, k_begin + BK, rb[1]);
+    put_piece_split<A_KC, false>(ra[0], 0, k_end, k_begin, img);
+    put_piece_b256<B_KC, false>(rb[0][0], 0, k_end, k_begin, img + OA);
+    put_piece_b256<B_KC, false>(rb[0][1], 1, k_end, k_begin, img + OA);
+    __syncthreads();
+    auto kstep = [&](auto full_tag, int k0, int cur, f32x4& na, f32x4 (&nb)[2], f32x4& fa_, f32x4 (&fb_)[2]) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        fetch_a(k0 + 2 * BK, fa_);
+        fetch_b256<B_KC>(B, ldb, N, k_end, 0, k0 + 2 * BK, fb_);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint8_t* Ai = img + cur * STAGE;
+        const uint8_t* Bi = Ai + OA;
+        uint8_t* An = img + (cur ^ 1) * STAGE;
+        bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                fa[t][p] = read_frag_split<A_KC>(Ai + p * PA, wm + 32 * t, lane);
+                fb[t][p] = read_frag_b256<B_KC>(Bi + p * W_PB, wn + 32 * t, lane);
+            }
+#define HW_WTERM(PA_, PB_)                                                                                           \
+    _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)               \
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ti][PA_], fb[tj][PB_], acc[ti][tj], 0, 0, 0);
+        HW_WTERM(1, 1)
+        put_piece_split<A_KC, FULL>(na, 0, k_end, k0 + BK, An);
+        HW_WTERM(2, 0)
+        put_piece_b256<B_KC, FULL>(nb[0], 0, k_end, k0 + BK, An + OA);
+        HW_WTERM(0, 2)
+        put_piece_b256<B_KC, FULL>(nb[1], 1, k_end, k0 + BK, An + OA);
+        HW_WTERM(1, 0)
+        HW_WTERM(0, 1)
+        HW_WTERM(0, 0)
+#undef HW_WTERM
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    const std::true_type whole{};
+    const std::false_type ragged{};
+    int k0 = k_begin;
+    for (; k0 + 3 * BK <= k_end; k0 += 2 * BK) {
+        kstep(whole, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+        kstep(whole, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
+    }
+    if (k0 + BK < k_end) {
+        kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+        kstep(ragged, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
+        k0 += 2 * BK;
+    }
+    if (k0 < k_end) kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+    // epilogue: split-K partial [z][m_max][N] or C; dwordx4 through the LDS transposition where the slab is whole and aligned
+    float* const dst = partial ? partial + (size_t)bz * m_max * N : C;
+    const int64_t ld = partial ? (int64_t)N : ldc;
+    float* const slab = reinterpret_cast<float*>(img) + wave * 2048;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti) {
+        const int r0 = m0 + wm + ti * 32;
+        if ((flags & 2) && r0 + 32 <= M && wn + 64 <= N) {
+            float v[2][16];
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) v[tj][rg] = acc[ti][tj][rg];
+            store_slab_via_lds(slab, v, dst + (size_t)r0 * ld + wn, ld, lane);
+        } else {
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int gn = wn + tj * 32 + (lane & 31);
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int gm = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+                    if (gm < M && gn < N) dst[(size_t)gm * ld + gn] = acc[ti][tj][rg];
+                }
+            }
+        }
+    }
+}
+
 // ---- narrow-N variant: 192 < N <= 208 ------------------------------------------------------------------------------------
 // The TuckER / ConvE backward products have N = d = 200 output columns (dX = dS . E, dE = dS^T . x): 128-wide tiles pad
 // that to 256 and spend 22 % of the MFMA passes on zeros.  This kernel covers the whole row with 13 tiles of
@@ -801,6 +995,48 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
             else if (!a_kc && !b_kc) GON(false, false);
             else GON(false, true);
 #undef GON
+            if (splits > 1) {
+                int64_t rg = (m_max * n + 255) / 256;
+                if (rg > 4096) rg = 4096;
+                hipLaunchKernelGGL((gemm_splitk_reduce_kernel<0>), dim3((unsigned)rg), dim3(256), 0, st, partial, splits, m_rows,
+                                   (int)m_max, (int)n, c, ldc, bias, drop_mask, drop_mode, seed, offset);
+            }
+            return HW_OK;
+        }
+    }
+    {
+        // wide tiles (gemm_split_wide_kernel): plain products with 128 < N <= 256 on 16-byte aligned operands
+        const char* we = getenv("HW_GEMM_WIDE");
+        const char* se1 = getenv("HW_GEMM_SPLIT");
+        const char* pe1 = getenv("HW_GEMM_PIPE");
+        const bool on = (we ? atoi(we) != 0 : true) && (se1 ? atoi(se1) != 0 : true) && (pe1 ? atoi(pe1) != 0 : true);
+        if (on && act == 0 && !bias && drop_mode == 0 && n > BN && n <= WBN && aligned16(a, lda) && aligned16(b, ldb) && k >= 4 &&
+            (a_kc || m_max >= 4) && (a_kc || !b_kc)) {
+            const int64_t gmw = (m_max + BM - 1) / BM;
+            int splits = 1;
+            if (workspace && gmw < 128 && k >= 64 * BK) {  // one block per CU: 256 slots
+                int64_t want = (256 + gmw - 1) / gmw;
+                const int64_t kmax = k / (8 * BK);
+                if (want > kmax) want = kmax;
+                const int64_t fit = workspace_floats / (m_max * n);
+                if (want > fit) want = fit;
+                if (want >= 8) want = want / 8 * 8;  // a multiple of 8: the XCD-aware order
+                if (want > 1) splits = (int)want;
+            }
+            int k_len = (int)k;
+            if (splits > 1) {
+                k_len = (int)(((k + splits - 1) / splits + BK - 1) / BK * BK);
+                if ((k + k_len - 1) / k_len != splits) splits = (int)((k + k_len - 1) / k_len);
+            }
+            float* partial = splits > 1 ? workspace : nullptr;
+            const int vc = splits > 1 ? ((((uintptr_t)partial) & 15) == 0 && (n % 4) == 0) : aligned16(c, ldc);
+            const int flags = (vc << 1) | ((splits > 1 && splits % 8 == 0) ? 4 : 0);
+            dim3 grid((unsigned)gmw, 1, (unsigned)splits);
+#define GOW(AK, BK_) hipLaunchKernelGGL((gemm_split_wide_kernel<AK, BK_>), grid, dim3(WNT), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, k_len, partial, flags)
+            if (a_kc && b_kc) GOW(true, true);
+            else if (a_kc) GOW(true, false);
+            else GOW(false, false);
+#undef GOW
             if (splits > 1) {
                 int64_t rg = (m_max * n + 255) / 256;
                 if (rg > 4096) rg = 4096;
