@@ -594,6 +594,9 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
 // with all 256 columns reads dS once (-25 % bytes per MFMA), converts a quarter less per MFMA and meets half as many
 // barriers per MFMA.  Eight waves as 2 x 4, each 64 x 64 as above; LDS 2 x 36 KB; one block per CU (two waves per SIMD).
 // Plain epilogue only (split-K partials or C); same k-step as gemm_f32_kernel's split loop.
+#ifndef GEMM_WIDE_RING
+#define GEMM_WIDE_RING 2
+#endif
 constexpr int WBN = 256, WNT = 512, W_PB = WBN * 32;
 template <bool KC>
 __device__ __forceinline__ void fetch_b256(const float* __restrict__ X, int64_t ld, int rows, int K, int r0, int k0,
@@ -692,19 +695,24 @@ __global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __
             v = *reinterpret_cast<const f32x4*>(A + (size_t)gk * lda + gr);
         }
     };
-    f32x4 ra[2], rb[2][2];
-    fetch_a(k_begin, ra[0]);
-    fetch_b256<B_KC>(B, ldb, N, k_end, 0, k_begin, rb[0]);
-    fetch_a(k_begin + BK, ra[1]);
-    fetch_b256<B_KC>(B, ldb, N, k_end, 0, k_begin + BK, rb[1]);
+    // ring of WD register sets: the loads of tile j + WD are issued at the top of step j (WD = 4 measured the same as 2 on
+    // both backward products: the loop is paced by the CU's fill rate, not by the latency of a miss)
+    constexpr int WD = GEMM_WIDE_RING;
+    static_assert(WD == 2 || WD == 4, "ring depth");
+    f32x4 ra[WD], rb[WD][2];
+#pragma unroll
+    for (int d = 0; d < WD; ++d) {
+        fetch_a(k_begin + d * BK, ra[d]);
+        fetch_b256<B_KC>(B, ldb, N, k_end, 0, k_begin + d * BK, rb[d]);
+    }
     put_piece_split<A_KC, false>(ra[0], 0, k_end, k_begin, img);
     put_piece_b256<B_KC, false>(rb[0][0], 0, k_end, k_begin, img + OA);
     put_piece_b256<B_KC, false>(rb[0][1], 1, k_end, k_begin, img + OA);
     __syncthreads();
     auto kstep = [&](auto full_tag, int k0, int cur, f32x4& na, f32x4 (&nb)[2], f32x4& fa_, f32x4 (&fb_)[2]) {
         constexpr bool FULL = decltype(full_tag)::value;
-        fetch_a(k0 + 2 * BK, fa_);
-        fetch_b256<B_KC>(B, ldb, N, k_end, 0, k0 + 2 * BK, fb_);
+        fetch_a(k0 + WD * BK, fa_);
+        fetch_b256<B_KC>(B, ldb, N, k_end, 0, k0 + WD * BK, fb_);
         __builtin_amdgcn_sched_barrier(0);
         const uint8_t* Ai = img + cur * STAGE;
         const uint8_t* Bi = Ai + OA;
@@ -742,16 +750,31 @@ __global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __
     const std::true_type whole{};
     const std::false_type ragged{};
     int k0 = k_begin;
-    for (; k0 + 3 * BK <= k_end; k0 += 2 * BK) {
-        kstep(whole, k0, 0, ra[1], rb[1], ra[0], rb[0]);
-        kstep(whole, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
+    if constexpr (WD == 2) {
+        for (; k0 + 3 * BK <= k_end; k0 += 2 * BK) {
+            kstep(whole, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+            kstep(whole, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
+        }
+        if (k0 + BK < k_end) {
+            kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+            kstep(ragged, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
+            k0 += 2 * BK;
+        }
+        if (k0 < k_end) kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+    } else {
+        for (; k0 + 5 * BK <= k_end; k0 += 4 * BK) {
+            kstep(whole, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+            kstep(whole, k0 + BK, 1, ra[2], rb[2], ra[1], rb[1]);
+            kstep(whole, k0 + 2 * BK, 0, ra[3], rb[3], ra[2], rb[2]);
+            kstep(whole, k0 + 3 * BK, 1, ra[0], rb[0], ra[3], rb[3]);
+        }
+        for (; k0 < k_end; k0 += 4 * BK) {  // at most two trips: the last steps, in the zeroing form
+            kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
+            if (k0 + BK < k_end) kstep(ragged, k0 + BK, 1, ra[2], rb[2], ra[1], rb[1]);
+            if (k0 + 2 * BK < k_end) kstep(ragged, k0 + 2 * BK, 0, ra[3], rb[3], ra[2], rb[2]);
+            if (k0 + 3 * BK < k_end) kstep(ragged, k0 + 3 * BK, 1, ra[0], rb[0], ra[3], rb[3]);
+        }
     }
-    if (k0 + BK < k_end) {
-        kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
-        kstep(ragged, k0 + BK, 1, ra[0], rb[0], ra[1], rb[1]);
-        k0 += 2 * BK;
-    }
-    if (k0 < k_end) kstep(ragged, k0, 0, ra[1], rb[1], ra[0], rb[0]);
     // epilogue: split-K partial [z][m_max][N] or C; dwordx4 through the LDS transposition where the slab is whole and aligned
     float* const dst = partial ? partial + (size_t)bz * m_max * N : C;
     const int64_t ld = partial ? (int64_t)N : ldc;
