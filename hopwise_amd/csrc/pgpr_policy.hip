@@ -107,6 +107,10 @@ __device__ __forceinline__ float pf_elu(float x) {
     return x > 0.f ? x : u;
 }
 
+#ifndef PF_INTERLEAVE
+#define PF_INTERLEAVE 1
+#endif
+
 template <int NPARTS, int MODE>
 __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, const float* __restrict__ b1, int H1,
                                                                    const uint8_t* __restrict__ planes,
@@ -220,22 +224,30 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     pf_bf16x8 xb[2][2][3];  // B operands: [set][k-step][plane]
     // `fresh`: chunk c starts a new 128-element Philox block of this row (c % 4 == 0: H1 % 128 == 0) -- known at compile time
     // in the unrolled loop, so the region stays one basic block
-    auto x_finish = [&](int c, int cu, const f32x4 (&xq)[NPARTS][4], const f32x4 (&mq)[4], pf_bf16x8 (&out)[2][3]) {
-#ifdef PF_ABL_NO_X
-        return;
-#endif
+    // The finish of a chunk is cut in two pieces (k-step t = 0, 1: eight of the lane's sixteen values each) so that the main
+    // loop can place them BETWEEN the four MFMA groups of the chunk being multiplied: with one wave per SIMD only the wave's
+    // own instruction stream can fill the matrix pipe's shadow, and a finish issued as one block before (or after) the 96
+    // MFMAs was time added, not hidden (matrix work alone 1.70 ms, the rest alone 1.71, together 2.73: tools/pf_abl).
+    auto x_keep = [&](int c, int cu) -> uint32_t {
         // c: chunk (clamped, addresses only); cu = chunk & 3 as the unrolled loop knows it: word cu of the row's current
         // Philox block holds this chunk's 32 keep bits, this lane's 16 at bit 16 g; a new block every fourth chunk
-        const int k0 = PF_KC * c + 16 * g;
         uint32_t keep = 0xFFFFu;
         if constexpr (MODE == 3) {
             if (cu == 0) philox_bits4(dr.seed, dr.offset1, ((uint64_t)rowc * H1 + PF_KC * c) >> 7, pw);
             const uint32_t word = cu == 0 ? pw[0] : (cu == 1 ? pw[1] : (cu == 2 ? pw[2] : pw[3]));
             keep = (word >> (16 * g)) & 0xFFFFu;
         }
-        float e[16];
+        return keep;
+    };
+    auto x_piece = [&](int c, int t, uint32_t keep, const f32x4 (&xq)[NPARTS][4], const f32x4 (&mq)[4], pf_bf16x8 (&out)[2][3]) {
+#ifdef PF_ABL_NO_X
+        return;
+#endif
+        const int k0 = PF_KC * c + 16 * g;
+        float e[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = 2 * t + ii;
             f32x4 acc = *reinterpret_cast<const f32x4*>(bias_lds + k0 + 4 * i);
 #pragma unroll
             for (int q = 0; q < NPARTS; ++q) acc += xq[q][i];
@@ -246,20 +258,43 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
                 float x = pf_elu(v[j]);
                 if constexpr (MODE == 1) x *= mk[j];
                 else if constexpr (MODE == 3) x = ((keep >> (4 * i + j)) & 1u) ? x * 2.f : 0.f;
-                e[4 * i + j] = x;
+                e[4 * ii + j] = x;
             }
         }
+        uint32_t h[4], m[4], l[4];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            uint32_t h[4], m[4], l[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) pf_split_pair(e[8 * t + 2 * p], e[8 * t + 2 * p + 1], h[p], m[p], l[p]);
-            out[t][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{h[0], h[1], h[2], h[3]});
-            out[t][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{m[0], m[1], m[2], m[3]});
-            out[t][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{l[0], l[1], l[2], l[3]});
-        }
+        for (int p = 0; p < 4; ++p) pf_split_pair(e[2 * p], e[2 * p + 1], h[p], m[p], l[p]);
+        out[t][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{h[0], h[1], h[2], h[3]});
+        out[t][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{m[0], m[1], m[2], m[3]});
+        out[t][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{l[0], l[1], l[2], l[3]});
     };
-
+    auto x_finish = [&](int c, int cu, const f32x4 (&xq)[NPARTS][4], const f32x4 (&mq)[4], pf_bf16x8 (&out)[2][3]) {
+        const uint32_t keep = x_keep(c, cu);
+        x_piece(c, 0, keep, xq, mq, out);
+        x_piece(c, 1, keep, xq, mq, out);
+    };
+    // a quarter of a chunk's matrix work: k-step t, tiles T = 4 half .. 4 half + 3 (12 fragment reads, 24 MFMAs)
+    auto mma_group = [&](const uint8_t* stage, f32x16 (&acc)[8], const pf_bf16x8 (&bop)[2][3], int t, int half) {
+#ifdef PF_ABL_NO_MMA
+        return;
+#endif
+        pf_bf16x8 fa[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                fa[i][p] = *reinterpret_cast<const pf_bf16x8*>(stage + p * PF_PLANE + pf_off(32 * (4 * half + i) + b, 2 * g + t));
+#define PF_TERM(PA_, PB_)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[4 * half + i] =                                              \
+        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA_], bop[t][PB_], acc[4 * half + i], 0, 0, 0);
+        PF_TERM(1, 1)
+        PF_TERM(2, 0)
+        PF_TERM(0, 2)
+        PF_TERM(1, 0)
+        PF_TERM(0, 1)
+        PF_TERM(0, 0)
+#undef PF_TERM
+    };
     // one chunk of matrix work: acc[T] += W[chunk] (rows 32 T ..) . B operands, T = 0..7, both k-steps
     auto mma_chunk = [&](const uint8_t* stage, f32x16 (&acc)[8], const pf_bf16x8 (&bop)[2][3]) {
 #ifdef PF_ABL_NO_MMA  // timing experiment: one FMA per (tile, step) instead of six MFMAs, operands still read
@@ -275,25 +310,7 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                pf_bf16x8 fa[4][3];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        fa[i][p] = *reinterpret_cast<const pf_bf16x8*>(stage + p * PF_PLANE +
-                                                                       pf_off(32 * (4 * half + i) + b, 2 * g + t));
-#define PF_TERM(PA_, PB_)                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[4 * half + i] =                                              \
-        __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA_], bop[t][PB_], acc[4 * half + i], 0, 0, 0);
-                PF_TERM(1, 1)
-                PF_TERM(2, 0)
-                PF_TERM(0, 2)
-                PF_TERM(1, 0)
-                PF_TERM(0, 1)
-                PF_TERM(0, 0)
-#undef PF_TERM
-            }
+            for (int half = 0; half < 2; ++half) mma_group(stage, acc, bop, t, half);
     };
     f32x16 acc2[8];
 #pragma unroll
@@ -309,16 +326,37 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u;
-            w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
             // no test around the gathers (a load that leaves its block through a phi is waited for at the end of that
             // block, i.e. in front of the MFMAs): the last trips re-read the last chunk and throw the result away
             const int c2 = c + 2 < n2 ? c + 2 : n2 - 1, c1 = c + 1 < n2 ? c + 1 : n2 - 1;
+#if PF_INTERLEAVE
+            {
+                // ONE scheduling region per trip, in the order wanted: the weight loads of chunk c + 1 and the gathers of
+                // chunk c + 2 ride in the first MFMA groups, the finish of chunk c + 1 in the middle ones, the LDS stores
+                // of the weights (the other stage: every wave left it at the barrier that ended the previous trip) in the last.
+                // The compiler's own order inside the region is kept: sched_group_barrier patterns measured slower (2.82 vs 2.51 ms).
+                const uint8_t* st = lds + (u & 1) * PF_CHUNK;
+                const uint32_t keep = x_keep(c1, (u + 1) & 3);
+                mma_group(st, acc2, xb[u & 1], 0, 0);
+                w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
+                x_fetch(c2, xs[u & 1], xm[u & 1]);  // two chunks ahead; the finish of the previous trip emptied this buffer
+                x_piece(c1, 0, keep, xs[(u + 1) & 1], xm[(u + 1) & 1], xb[(u + 1) & 1]);
+                mma_group(st, acc2, xb[u & 1], 0, 1);
+                x_piece(c1, 1, keep, xs[(u + 1) & 1], xm[(u + 1) & 1], xb[(u + 1) & 1]);
+                mma_group(st, acc2, xb[u & 1], 1, 0);
+                w_put(c + 1);
+                mma_group(st, acc2, xb[u & 1], 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
             x_fetch(c2, xs[u & 1], xm[u & 1]);  // two chunks ahead; x_finish of the previous trip emptied this buffer
             __builtin_amdgcn_sched_barrier(0);
             x_finish(c1, (u + 1) & 3, xs[(u + 1) & 1], xm[(u + 1) & 1], xb[(u + 1) & 1]);
             mma_chunk(lds + (u & 1) * PF_CHUNK, acc2, xb[u & 1]);
             __builtin_amdgcn_sched_barrier(0);
             w_put(c + 1);
+#endif
 #ifndef PF_ABL_NO_SYNC
             __syncthreads();
 #endif
@@ -332,36 +370,69 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     uint32_t pw2[4] = {0u, 0u, 0u, 0u};
     pf_bf16x8 hb[2][2][3];
     // bias, ELU, dropout of the 16 values of tile T -> operand set; element (row, n): keep bit of idx = row * 256 + n
-    auto h_make = [&](int T, pf_bf16x8 (&out)[2][3]) {
+    auto h_word = [&](int T) -> uint32_t {
         uint32_t word = 0u;
         if constexpr (MODE == 3) {  // block (row * 256 + 32 T) >> 7 (new at T = 0, 4), word T & 3, bit n & 31
             const uint64_t idx0 = (uint64_t)rowc * PF_H2 + 32 * T;
             if ((T & 3) == 0) philox_bits4(dr.seed, dr.offset2, idx0 >> 7, pw2);
             word = (T & 3) == 0 ? pw2[0] : ((T & 3) == 1 ? pw2[1] : ((T & 3) == 2 ? pw2[2] : pw2[3]));
         }
-        float e[16];
+        return word;
+    };
+    // half h of tile T's sixteen values (v = 8 h .. 8 h + 7) -> operand planes of k-step h
+    auto h_piece = [&](int T, int h, uint32_t word, pf_bf16x8 (&out)[2][3]) {
+        float e[8];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
+        for (int vv = 0; vv < 8; ++vv) {
+            const int v = 8 * h + vv;
             const int nl = 8 * (v >> 2) + 4 * g + (v & 3);  // n - 32 T
             float x = pf_elu(acc2[T][v] + bias_lds[1024 + 32 * T + nl]);
             if constexpr (MODE == 1) x *= dr.mask2[(size_t)rowc * PF_H2 + 32 * T + nl];
             else if constexpr (MODE == 3) x = ((word >> nl) & 1u) ? x * 2.f : 0.f;
-            e[v] = x;
+            e[vv] = x;
         }
+        uint32_t hh[4], mm[4], ll[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            uint32_t hh[4], mm[4], ll[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) pf_split_pair(e[8 * h + 2 * p], e[8 * h + 2 * p + 1], hh[p], mm[p], ll[p]);
-            out[h][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{hh[0], hh[1], hh[2], hh[3]});
-            out[h][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{mm[0], mm[1], mm[2], mm[3]});
-            out[h][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{ll[0], ll[1], ll[2], ll[3]});
-        }
+        for (int p = 0; p < 4; ++p) pf_split_pair(e[2 * p], e[2 * p + 1], hh[p], mm[p], ll[p]);
+        out[h][0] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{hh[0], hh[1], hh[2], hh[3]});
+        out[h][1] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{mm[0], mm[1], mm[2], mm[3]});
+        out[h][2] = __builtin_bit_cast(pf_bf16x8, pf_u32x4{ll[0], ll[1], ll[2], ll[3]});
+    };
+    auto h_make = [&](int T, pf_bf16x8 (&out)[2][3]) {
+        const uint32_t word = h_word(T);
+        h_piece(T, 0, word, out);
+        h_piece(T, 1, word, out);
     };
     h_make(0, hb[0]);
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         const int q = n2 + T;
+#if PF_INTERLEAVE
+        {  // one scheduling region per trip, as in the hidden-layer loop
+            const uint8_t* st = lds + (q & 1) * PF_CHUNK;
+            mma_group(st, acc3, hb[T & 1], 0, 0);
+            if (T + 1 < 8) {
+                w_fetch(q + 1);
+                const uint32_t word = h_word(T + 1);
+                h_piece(T + 1, 0, word, hb[(T + 1) & 1]);
+                mma_group(st, acc3, hb[T & 1], 0, 1);
+                h_piece(T + 1, 1, word, hb[(T + 1) & 1]);
+                mma_group(st, acc3, hb[T & 1], 1, 0);
+                w_put(q + 1);
+                mma_group(st, acc3, hb[T & 1], 1, 1);
+            } else {
+                mma_group(st, acc3, hb[T & 1], 0, 1);
+                mma_group(st, acc3, hb[T & 1], 1, 0);
+                mma_group(st, acc3, hb[T & 1], 1, 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (T + 1 < 8) {
+#ifndef PF_ABL_NO_SYNC
+            __syncthreads();
+#endif
+        }
+#else
         if (T + 1 < 8) w_fetch(q + 1);
         __builtin_amdgcn_sched_barrier(0);
         if (T + 1 < 8) h_make(T + 1, hb[(T + 1) & 1]);
@@ -373,6 +444,7 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
             __syncthreads();
 #endif
         }
+#endif
     }
 
     // ---- logits: lane (b, g) holds actions a = 32 Ta + 8 (v >> 2) + 4 g + (v & 3) of its beam row ----
