@@ -83,3 +83,24 @@ def test_split_exact_on_bf16_representable_integers(monkeypatch):
         A = a.double() if akc else a.double().t()
         Bm = b.double().t() if bkc else b.double()
         assert torch.equal(ops.gemm(a, b, akc, bkc).double(), A @ Bm), (akc, bkc)
+
+
+@pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, False)])
+def test_wide_tiles_equal_the_128_wide_ones(monkeypatch, akc, bkc):
+    """gemm_split_wide_kernel (128 x 256 tiles, plain products with 128 < N <= 256) against gemm_f32_kernel on the same
+    operands: ragged M, N and K, a device-side row count, split-K over a long K, an output with padded rows."""
+    from hopwise_amd import ops
+
+    gen = torch.Generator(device=dev()).manual_seed(11)
+    rows = torch.tensor([200], dtype=torch.int32, device=dev())
+    for M, N, K, kw in ((257, 129, 50, {}), (300, 200, 203, dict(m_rows=rows)), (128, 256, 16, {}), (1000, 252, 4100, {})):
+        a = padded(gen, M, K, False) if akc else padded(gen, K, M, False)
+        b = padded(gen, N, K, False) if bkc else padded(gen, K, N, False)
+        outs = []
+        for wide in ("1", "0"):
+            monkeypatch.setenv("HW_GEMM_WIDE", wide)
+            out = torch.full((M, (N + 31) // 32 * 32), -7.0, device=dev())[:, :N]
+            outs.append(ops.gemm(a, b, akc, bkc, out=out, **kw))
+        torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5 * float(outs[1].abs().max()))
+        if "m_rows" in kw:
+            assert bool((outs[0][200:] == -7.0).all())
