@@ -657,13 +657,19 @@ __device__ __forceinline__ bf16x8 read_frag_b256(const uint8_t* __restrict__ pla
     }
 }
 
-template <bool A_KC, bool B_KC>
+// WM = 128: the tile above.  WM = 256 (K-contiguous A only): 256 x 256 per block, each wave 128 x 64 = eight accumulators --
+// for the products whose row tiles are few and whose K is long (dX = dS . E: 8 row tiles x 32 split-K ranges = 256 blocks):
+// L1 fill per MFMA another third lower (16 + 16 KB per 384 MFMAs against 8 + 16 KB per 192), four float4 converted per
+// thread and 48 MFMAs instead of three and 24, 18 fragment reads per 48 MFMAs instead of 12 per 24.  LDS 2 x 48 KB.
+template <bool A_KC, bool B_KC, int WM>
 __global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ B, int64_t ldb,
                                                                  float* __restrict__ C, int64_t ldc,
                                                                  const int32_t* __restrict__ m_ptr, int m_max, int N, int K,
                                                                  int k_len, float* __restrict__ partial, int flags) {
-    constexpr int PA = SplitImg<A_KC>::PLANE, OA = SplitImg<A_KC>::OPERAND, STAGE = OA + 3 * W_PB;
+    static_assert(WM == 128 || (WM == 256 && A_KC), "256-row tiles: K-contiguous A");
+    constexpr int TI = WM / 64, NA = WM / 128;                       // accumulator row tiles per wave, float4 of A per thread
+    constexpr int PA = WM == 128 ? SplitImg<A_KC>::PLANE : W_PB, OA = 3 * PA, STAGE = OA + 3 * W_PB;
     __shared__ __attribute__((aligned(16))) uint8_t img[2 * STAGE];
     const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
     unsigned bx = blockIdx.x, bz = blockIdx.z;
@@ -672,44 +678,58 @@ __global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __
         bx = (lin >> 3) % gridDim.x;
         bz = ((lin >> 3) / gridDim.x) * 8u + (lin & 7u);
     }
-    const int m0 = bx * BM;
+    const int m0 = bx * WM;
     if (m0 >= M) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
-    f32x16 acc[2][2];
+    const int wm = (wave >> 2) * (WM / 2), wn = (wave & 3) * 64;
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0};
     const int k_begin = bz * k_len;
     const int k_end = min(K, k_begin + k_len);
-    // this thread's one float4 of the A tile: the 256-thread mapping of fetch_tile with f = tid
-    auto fetch_a = [&](int k0, f32x4& v) {
-        if constexpr (A_KC) {
+    // this thread's float4s of the A tile (128 rows: the 256-thread mapping of fetch_tile with f = tid)
+    auto fetch_a = [&](int k0, f32x4 (&v)[NA]) {
+        if constexpr (WM == 256) {
+            fetch_b256<true>(A, lda, M, k_end, m0, k0, v);
+        } else if constexpr (A_KC) {
             const int r = tid >> 2, kq = (tid & 3) * 4;
             const int gr = min(m0 + r, M - 1), gk = min(k0 + kq, ((k_end + 3) & ~3) - 4);
-            v = *reinterpret_cast<const f32x4*>(A + (size_t)gr * lda + gk);
+            v[0] = *reinterpret_cast<const f32x4*>(A + (size_t)gr * lda + gk);
         } else {
             const int k = tid >> 5, rq = (tid & 31) * 4;
             const int gk = min(k0 + k, k_end - 1), gr = min(m0 + rq, ((M + 3) & ~3) - 4);
-            v = *reinterpret_cast<const f32x4*>(A + (size_t)gk * lda + gr);
+            v[0] = *reinterpret_cast<const f32x4*>(A + (size_t)gk * lda + gr);
         }
+    };
+    auto put_a = [&](auto full_tag, const f32x4& v, int i, int kt, uint8_t* dst) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        if constexpr (WM == 256) put_piece_b256<true, FULL>(v, i, k_end, kt, dst);
+        else put_piece_split<A_KC, FULL>(v, i, k_end, kt, dst);
+    };
+    auto read_a = [&](const uint8_t* plane, int base) -> bf16x8 {
+        if constexpr (WM == 256) return read_frag_b256<true>(plane, base, lane);
+        else return read_frag_split<A_KC>(plane, base, lane);
     };
     // ring of WD register sets: the loads of tile j + WD are issued at the top of step j (WD = 4 measured the same as 2 on
     // both backward products: the loop is paced by the CU's fill rate, not by the latency of a miss)
     constexpr int WD = GEMM_WIDE_RING;
     static_assert(WD == 2 || WD == 4, "ring depth");
-    f32x4 ra[WD], rb[WD][2];
+    const std::true_type whole{};
+    const std::false_type ragged{};
+    f32x4 ra[WD][NA], rb[WD][2];
 #pragma unroll
     for (int d = 0; d < WD; ++d) {
         fetch_a(k_begin + d * BK, ra[d]);
         fetch_b256<B_KC>(B, ldb, N, k_end, 0, k_begin + d * BK, rb[d]);
     }
-    put_piece_split<A_KC, false>(ra[0], 0, k_end, k_begin, img);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) put_a(ragged, ra[0][i], i, k_begin, img);
     put_piece_b256<B_KC, false>(rb[0][0], 0, k_end, k_begin, img + OA);
     put_piece_b256<B_KC, false>(rb[0][1], 1, k_end, k_begin, img + OA);
     __syncthreads();
-    auto kstep = [&](auto full_tag, int k0, int cur, f32x4& na, f32x4 (&nb)[2], f32x4& fa_, f32x4 (&fb_)[2]) {
+    auto kstep = [&](auto full_tag, int k0, int cur, f32x4 (&na)[NA], f32x4 (&nb)[2], f32x4 (&fa_)[NA], f32x4 (&fb_)[2]) {
         constexpr bool FULL = decltype(full_tag)::value;
         fetch_a(k0 + WD * BK, fa_);
         fetch_b256<B_KC>(B, ldb, N, k_end, 0, k0 + WD * BK, fb_);
@@ -717,29 +737,39 @@ __global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __
         const uint8_t* Ai = img + cur * STAGE;
         const uint8_t* Bi = Ai + OA;
         uint8_t* An = img + (cur ^ 1) * STAGE;
-        bf16x8 fa[2][3], fb[2][3];
+        bf16x8 fb[2][3];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                fa[t][p] = read_frag_split<A_KC>(Ai + p * PA, wm + 32 * t, lane);
-                fb[t][p] = read_frag_b256<B_KC>(Bi + p * W_PB, wn + 32 * t, lane);
-            }
-#define HW_WTERM(PA_, PB_)                                                                                           \
+            for (int p = 0; p < 3; ++p) fb[t][p] = read_frag_b256<B_KC>(Bi + p * W_PB, wn + 32 * t, lane);
+#define HW_WTERM(H_, PA_, PB_)                                                                                       \
     _Pragma("unroll") for (int ti = 0; ti < 2; ++ti) _Pragma("unroll") for (int tj = 0; tj < 2; ++tj)               \
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ti][PA_], fb[tj][PB_], acc[ti][tj], 0, 0, 0);
-        HW_WTERM(1, 1)
-        put_piece_split<A_KC, FULL>(na, 0, k_end, k0 + BK, An);
-        HW_WTERM(2, 0)
-        put_piece_b256<B_KC, FULL>(nb[0], 0, k_end, k0 + BK, An + OA);
-        HW_WTERM(0, 2)
-        put_piece_b256<B_KC, FULL>(nb[1], 1, k_end, k0 + BK, An + OA);
-        HW_WTERM(1, 0)
-        HW_WTERM(0, 1)
-        HW_WTERM(0, 0)
+        acc[2 * (H_) + ti][tj] =                                                                                     \
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ti][PA_], fb[tj][PB_], acc[2 * (H_) + ti][tj], 0, 0, 0);
+        // pass h: accumulator row tiles 2 h, 2 h + 1 (their A fragments live only inside the pass)
+#pragma unroll
+        for (int h = 0; h < TI / 2; ++h) {
+            bf16x8 fa[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) fa[t][p] = read_a(Ai + p * PA, wm + 64 * h + 32 * t);
+            HW_WTERM(h, 1, 1)
+            if (h == 0) put_a(full_tag, na[0], 0, k0 + BK, An);
+            else put_piece_b256<B_KC, FULL>(nb[1], 1, k_end, k0 + BK, An + OA);
+            HW_WTERM(h, 2, 0)
+            if (h == 0 && NA == 2) put_a(full_tag, na[NA - 1], NA - 1, k0 + BK, An);
+            if (h == 0 && NA == 1) put_piece_b256<B_KC, FULL>(nb[0], 0, k_end, k0 + BK, An + OA);
+            HW_WTERM(h, 0, 2)
+            if (h == 0 && NA == 2) put_piece_b256<B_KC, FULL>(nb[0], 0, k_end, k0 + BK, An + OA);
+            if (h == 0 && NA == 1) put_piece_b256<B_KC, FULL>(nb[1], 1, k_end, k0 + BK, An + OA);
+            HW_WTERM(h, 1, 0)
+            HW_WTERM(h, 0, 1)
+            HW_WTERM(h, 0, 0)
+        }
 #undef HW_WTERM
 #pragma unroll
-        for (int q = 0; q < 24; ++q) {
+        for (int q = 0; q < 12 * TI; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -747,8 +777,6 @@ __global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
-    const std::true_type whole{};
-    const std::false_type ragged{};
     int k0 = k_begin;
     if constexpr (WD == 2) {
         for (; k0 + 3 * BK <= k_end; k0 += 2 * BK) {
@@ -780,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_wide_kernel(const float* __
     const int64_t ld = partial ? (int64_t)N : ldc;
     float* const slab = reinterpret_cast<float*>(img) + wave * 2048;
 #pragma unroll
-    for (int ti = 0; ti < 2; ++ti) {
+    for (int ti = 0; ti < TI; ++ti) {
         const int r0 = m0 + wm + ti * 32;
         if ((flags & 2) && r0 + 32 <= M && wn + 64 <= N) {
             float v[2][16];
@@ -1035,7 +1063,11 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
         const bool on = (we ? atoi(we) != 0 : true) && (se1 ? atoi(se1) != 0 : true) && (pe1 ? atoi(pe1) != 0 : true);
         if (on && act == 0 && !bias && drop_mode == 0 && n > BN && n <= WBN && aligned16(a, lda) && aligned16(b, ldb) && k >= 4 &&
             (a_kc || m_max >= 4) && (a_kc || !b_kc)) {
-            const int64_t gmw = (m_max + BM - 1) / BM;
+            // 256-row tiles when the row tiles are few and K is long (split-K fills the chip either way), else 128
+            const char* te = getenv("HW_GEMM_TALL");
+            const bool tall = (te ? atoi(te) != 0 : true) && a_kc && workspace && m_max >= 1024 && m_max <= 8192 && k >= 256 * BK;
+            const int wmr = tall ? 256 : BM;
+            const int64_t gmw = (m_max + wmr - 1) / wmr;
             int splits = 1;
             if (workspace && gmw < 128 && k >= 64 * BK) {  // one block per CU: 256 slots
                 int64_t want = (256 + gmw - 1) / gmw;
@@ -1055,10 +1087,12 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
             const int vc = splits > 1 ? ((((uintptr_t)partial) & 15) == 0 && (n % 4) == 0) : aligned16(c, ldc);
             const int flags = (vc << 1) | ((splits > 1 && splits % 8 == 0) ? 4 : 0);
             dim3 grid((unsigned)gmw, 1, (unsigned)splits);
-#define GOW(AK, BK_) hipLaunchKernelGGL((gemm_split_wide_kernel<AK, BK_>), grid, dim3(WNT), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, k_len, partial, flags)
-            if (a_kc && b_kc) GOW(true, true);
-            else if (a_kc) GOW(true, false);
-            else GOW(false, false);
+#define GOW(AK, BK_, WM_) hipLaunchKernelGGL((gemm_split_wide_kernel<AK, BK_, WM_>), grid, dim3(WNT), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, k_len, partial, flags)
+            if (tall && b_kc) GOW(true, true, 256);
+            else if (tall) GOW(true, false, 256);
+            else if (a_kc && b_kc) GOW(true, true, 128);
+            else if (a_kc) GOW(true, false, 128);
+            else GOW(false, false, 128);
 #undef GOW
             if (splits > 1) {
                 int64_t rg = (m_max * n + 255) / 256;

@@ -93,7 +93,8 @@ def test_wide_tiles_equal_the_128_wide_ones(monkeypatch, akc, bkc):
 
     gen = torch.Generator(device=dev()).manual_seed(11)
     rows = torch.tensor([200], dtype=torch.int32, device=dev())
-    for M, N, K, kw in ((257, 129, 50, {}), (300, 200, 203, dict(m_rows=rows)), (128, 256, 16, {}), (1000, 252, 4100, {})):
+    for M, N, K, kw in ((257, 129, 50, {}), (300, 200, 203, dict(m_rows=rows)), (128, 256, 16, {}), (1000, 252, 4100, {}),
+                        (1100, 200, 4200, {}), (2048, 130, 4096 + 5, dict(m_rows=torch.tensor([1999], dtype=torch.int32, device=dev())))):
         a = padded(gen, M, K, False) if akc else padded(gen, K, M, False)
         b = padded(gen, N, K, False) if bkc else padded(gen, K, N, False)
         outs = []
@@ -103,4 +104,4 @@ def test_wide_tiles_equal_the_128_wide_ones(monkeypatch, akc, bkc):
             outs.append(ops.gemm(a, b, akc, bkc, out=out, **kw))
         torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-5 * float(outs[1].abs().max()))
         if "m_rows" in kw:
-            assert bool((outs[0][200:] == -7.0).all())
+            assert bool((outs[0][int(kw["m_rows"][0]):] == -7.0).all())
