@@ -1072,7 +1072,13 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
             // valid keys have the top bit set and are distinct; T = the k-th largest of them (all of them if fewer than k)
             uint32_t T = 0x80000000u;
             if (count_ge(T) > k) {
-                for (int bit = 30; bit >= 0; --bit) {
+                // no key has a bit set above the largest key's highest one: the search starts there (probabilities of a
+                // 250-way softmax leave the top ~8 mantissa bits of p + 1 clear, i.e. ~8 of the ~25 rounds)
+                uint32_t mk = max(max(key[0], key[1]), max(key[2], key[3]));
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, m, 64));
+                const int top = 31 - __builtin_clz((__builtin_amdgcn_readfirstlane(mk) & 0x7FFFFFFFu) | 1u);
+                for (int bit = top; bit >= 0; --bit) {
                     const uint32_t cand = T | (1u << bit);
                     const int c = count_ge(cand);
                     if (c >= k) T = cand;
