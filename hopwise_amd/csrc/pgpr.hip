@@ -1032,16 +1032,17 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            x[i] = x[i] == -INFINITY ? 0.f : expf(x[i] - mx);
+            x[i] = x[i] == -INFINITY ? 0.f : __expf(x[i] - mx);  // v_exp_f32: the ranking key keeps 23 bits of p + 1 anyway
             sum += x[i];
         }
         sum = group_sum<64>(sum);
+        const float inv_sum = 1.f / sum;  // one division per row
         uint32_t key[4];
         bool two = false;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int j = lane * 4 + i;
-            const float pr = x[i] / sum;
+            const float pr = x[i] * inv_sum;
             if (probs_out && j < act_dim) probs_out[(size_t)row * act_dim + j] = j < na ? pr : 0.f;
             const uint32_t bits = __float_as_uint(pr + 1.0f);  // [1, 2]: 0x3F800000 .. 0x40000000
             const bool valid = j < na && j < act_dim;
