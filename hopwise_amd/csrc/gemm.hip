@@ -315,13 +315,22 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         // interleaved instead of contiguous k-ranges, one-time start offsets between co-resident blocks (no change).
         auto kstep = [&](auto full_tag, int k0, int cur, f32x4 (&na)[2], f32x4 (&nb)[2], f32x4 (&fa_)[2], f32x4 (&fb_)[2]) {
             constexpr bool FULL = decltype(full_tag)::value;  // the next tile is a whole one: no zeroing
+            // the loads of tile k0 + 2 BK: at the top of the step behind a scheduling barrier -- or, when both operands are
+            // K-contiguous (the score products), after the first MFMA group inside the step's one region, with four
+            // load slots in the group pattern below (measured: -2 % there, +2 % on the k-major layouts)
+            constexpr bool FETCH_IN = A_KC && B_KC;
+            auto fetch_next = [&]() {
 #if !defined(GEMM_ABL_NO_FETCH) && !defined(GEMM_ABL_NO_FETCH_A)  // timing ablations (tools/gemm_abl): never in the product
-            fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + 2 * BK, fa_);
+                fetch_tile<A_KC>(A, lda, M, k_end, m0, k0 + 2 * BK, fa_);
 #endif
 #if !defined(GEMM_ABL_NO_FETCH) && !defined(GEMM_ABL_NO_FETCH_B)
-            fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + 2 * BK, fb_);
+                fetch_tile<B_KC>(B, ldb, N, k_end, n0, k0 + 2 * BK, fb_);
 #endif
-            __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (!FETCH_IN) {
+                fetch_next();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const uint8_t* Ai = img + cur * SPLIT_STAGE;
             const uint8_t* Bi = Ai + OA;
             uint8_t* An = img + (cur ^ 1) * SPLIT_STAGE;
@@ -353,6 +362,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
 #define HW_PIECE(KC_, V_, I_, OFF_) put_piece_split<KC_, FULL>(V_, I_, k_end, k0 + BK, An + OFF_);
 #endif
             HW_SPLIT_TERM(1, 1)
+            if constexpr (FETCH_IN) fetch_next();
             HW_PIECE(A_KC, na[0], 0, 0)
             HW_SPLIT_TERM(2, 0)
             HW_PIECE(A_KC, na[1], 1, 0)
@@ -367,6 +377,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
             for (int q = 0; q < 24; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (FETCH_IN && q >= 1 && q <= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
