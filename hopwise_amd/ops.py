@@ -1445,7 +1445,7 @@ class ScoreAllBceMean(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gemm(g, table, True, False) * gl  # [B, N] @ [N, d]
         if ctx.needs_input_grad[1]:
-            gw = gemm(g, x, False, False) * gl  # g^T [N, B] @ x [B, d]
+            gw = gemm(g, x * gl, False, False)  # g^T [N, B] @ (gl x) [B, d]: the scalar goes onto the SMALL operand
         if ctx.needs_input_grad[2]:
             gb = P.colsum(g) * gl
         return gx, gw, gb, None, None, None
