@@ -43,8 +43,12 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
                                                                   uint64_t seed, uint64_t offset,
                                                                   float* __restrict__ out, int64_t w_stride,
                                                                   const int64_t* __restrict__ w_index,
-                                                                  uint32_t* __restrict__ keep_out) {
-    const int b = blockIdx.x;
+                                                                  uint32_t* __restrict__ keep_out, int64_t batch) {
+    // one thread per (batch row, column), numbered flat over the batch: with a block per row, d = 200 filled three waves and an
+    // eighth of the fourth, and the kernel is bound by the Philox rounds its lanes execute (2 x 10^7 blocks per call)
+    const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (item >= batch * d) return;
+    const int b = (int)(item / d);
     // keep_out (MODE 2, nullable): the keep flags of this call, 4 bits per (quad of rows q, column j) -- bit k = row 4 q + k --
     // eight quads per word, word ((b * ceil(nq / 8)) + (q >> 3)) * d + j.  The three backward kernels read them (MODE 3)
     // instead of evaluating the same Philox blocks again: the [B, d, d] dropout is Philox-bound (82 M draws per side).
@@ -55,7 +59,8 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
     const float* __restrict__ xb = x + (size_t)b * d;
     const int nq = (d + 3) >> 2;
     const float inv_keep = 1.f / (1.f - drop_p);
-    for (int j = threadIdx.x; j < d; j += 256) {
+    {
+        const int j = (int)(item - (int64_t)b * d);
         float acc = 0.f;
         if constexpr (MODE == 2) {
             uint32_t kw = 0u;
@@ -114,6 +119,44 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
     const float* __restrict__ gob = go + (size_t)b * d;
     const int nq = (d + 3) >> 2;
     const float inv_keep = 1.f / (1.f - drop_p);
+    if constexpr (MODE == 3) {
+        // gx only, d <= 256 (the training step's call): the four column passes of a quad are unrolled with clamped columns, so
+        // that their 24 loads (flag word, go, four matrix rows) are in flight together -- as a loop over j the wave paid one
+        // memory round trip per pass (105 us per call for 164 MFLOP).  Same sums in the same order: a column past d adds 0.
+        if (!gw && d <= 256) {
+            const uint32_t* __restrict__ kb = reinterpret_cast<const uint32_t*>(mask);
+            const int nq8 = (nq + 7) >> 3;
+            for (int q = wave; q < nq; q += 4) {
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                uint32_t wd[4];
+                float gj[4], wv[4][4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int j = min(lane + 64 * it, d - 1);
+                    wd[it] = kb[((size_t)b * nq8 + (q >> 3)) * d + j];
+                    gj[it] = gob[j];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wv[it][k] = wb[(size_t)min(4 * q + k, d - 1) * d + j];
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const bool live = lane + 64 * it < d;
+                    const uint32_t nib = (wd[it] >> (4 * (q & 7))) & 15u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float g = live && ((nib >> k) & 1u) ? gj[it] * inv_keep : (live ? gj[it] * 0.f : 0.f);
+                        acc[k] = fmaf(g, wv[it][k], acc[k]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = group_sum<64>(acc[k]);
+                    if (gx && lane == 0 && 4 * q + k < d) gx[(size_t)b * d + 4 * q + k] = v;
+                }
+            }
+            return;
+        }
+    }
     for (int q = wave; q < nq; q += 4) {  // four consecutive rows i = 4q .. 4q + 3 per wave pass
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         float xi[4];
@@ -180,7 +223,8 @@ __global__ __launch_bounds__(256) void tucker_gw_shared_kernel(const float* __re
     const int64_t b0 = (int64_t)c * TGW_CHUNK, b1 = min(batch, b0 + TGW_CHUNK);
     for (int j = threadIdx.x; j < d; j += 256) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int64_t b = b0; b < b1; ++b) {
+#pragma unroll 4
+        for (int64_t b = b0; b < b1; ++b) {  // unrolled: the loads of four batch rows in flight, the sums in the same order
             uint32_t rw[4] = {0u, 0u, 0u, 0u};
             uint32_t nib = 0u;
             if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
@@ -216,40 +260,61 @@ __global__ __launch_bounds__(256) void tucker_gw_indexed_kernel(const float* __r
     const int nq = (d + 3) >> 2;
     const float inv_keep = 1.f / (1.f - drop_p);
     const int64_t s0 = (int64_t)c * TGW_CHUNK, s1 = min(batch, s0 + TGW_CHUNK);
+    const int n = (int)(s1 - s0);
+    // the chunk's (batch row, matrix) pairs once, in LDS: read per row inside the loop they were a chain of three dependent
+    // global loads (order -> w_index -> data) in front of every row's arithmetic
+    __shared__ int sb[TGW_CHUNK], sm[TGW_CHUNK];
+    if ((int)threadIdx.x < n) {
+        const int64_t bb = min(max(order[s0 + threadIdx.x], (int64_t)0), batch - 1);
+        sb[threadIdx.x] = (int)bb;
+        sm[threadIdx.x] = (int)min(max(w_index[bb], (int64_t)0), n_mats - 1);
+    }
+    __syncthreads();
     for (int j = threadIdx.x; j < d; j += 256) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        int64_t cur = -1;
-        for (int64_t s = s0; s <= s1; ++s) {
-            int64_t b = 0, mat = -1;
-            if (s < s1) {
-                b = min(max(order[s], (int64_t)0), batch - 1);
-                mat = min(max(w_index[b], (int64_t)0), n_mats - 1);
-            }
-            if (mat != cur) {  // uniform across the block: every thread walks the same rows
-                if (cur >= 0) {
+        int cur = -1;
+        auto flush = [&]() {
+            if (cur >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (4 * q + k < d) atomicAdd(gw + ((size_t)cur * d + 4 * q + k) * d + j, acc[k]);
+                for (int k = 0; k < 4; ++k)
+                    if (4 * q + k < d) atomicAdd(gw + ((size_t)cur * d + 4 * q + k) * d + j, acc[k]);
+            }
+            acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
+        };
+        for (int base = 0; base < n; base += 4) {  // four rows' loads in flight, their sums in row order
+            float gj[4], xm[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = sb[min(base + u, n - 1)];
+                uint32_t rw[4] = {0u, 0u, 0u, 0u};
+                uint32_t nib = 0u;
+                if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)bb * nq + q) * d + j, rw);
+                if constexpr (MODE == 3) nib = keep_nibble(mask, bb, nq, q, d, j);
+                gj[u] = go[(size_t)bb * d + j];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = min(4 * q + k, d - 1);
+                    float m = 1.f;
+                    if constexpr (MODE == 1) m = mask[((size_t)bb * d + i) * d + j];
+                    if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
+                    if constexpr (MODE == 3) m = (nib >> k) & 1u ? inv_keep : 0.f;
+                    xm[u][k] = x[(size_t)bb * d + i] * m;
                 }
-                acc[0] = acc[1] = acc[2] = acc[3] = 0.f;
-                cur = mat;
             }
-            if (s == s1) break;
-            uint32_t rw[4] = {0u, 0u, 0u, 0u};
-            uint32_t nib = 0u;
-            if constexpr (MODE == 2) philox_block(seed, offset, ((uint64_t)b * nq + q) * d + j, rw);
-            if constexpr (MODE == 3) nib = keep_nibble(mask, (int)b, nq, q, d, j);
-            const float gj = go[(size_t)b * d + j];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = min(4 * q + k, d - 1);
-                float m = 1.f;
-                if constexpr (MODE == 1) m = mask[((size_t)b * d + i) * d + j];
-                if constexpr (MODE == 2) m = keep_scale(rw[k], drop_p, inv_keep);
-                if constexpr (MODE == 3) m = (nib >> k) & 1u ? inv_keep : 0.f;
-                acc[k] = fmaf(x[(size_t)b * d + i] * m, gj, acc[k]);
+            for (int u = 0; u < 4; ++u) {
+                if (base + u < n) {  // uniform across the block: every thread walks the same rows
+                    const int mat = sm[base + u];
+                    if (mat != cur) {
+                        flush();
+                        cur = mat;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k] = fmaf(xm[u][k], gj[u], acc[k]);
+                }
             }
         }
+        flush();
     }
 }
 
@@ -350,7 +415,7 @@ static int contract_launch(int mode, const float* x, const float* w, const float
     if (batch == 0) return HW_OK;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
-#define FWD(M) hipLaunchKernelGGL((tucker_contract_fwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, dim, drop_p, seed, offset, out, w_stride, w_index, keep_out)
+#define FWD(M) hipLaunchKernelGGL((tucker_contract_fwd_kernel<M>), dim3((unsigned)((batch * dim + 255) / 256)), dim3(256), 0, st, x, w, mask, dim, drop_p, seed, offset, out, w_stride, w_index, keep_out, batch)
 #define BWD(M) hipLaunchKernelGGL((tucker_contract_bwd_kernel<M>), dim3((unsigned)batch), dim3(256), 0, st, x, w, mask, gout, dim, drop_p, seed, offset, gx, gw, w_stride, w_index)
     if (!backward) {
         if (mode == 2) FWD(2);
