@@ -148,6 +148,8 @@ __global__ __launch_bounds__(256) void bn1d_partial_kernel(const float* __restri
     if (c < C) {
         float mu = 0.f, rs = 0.f;
         if (MODE == 1) mu = mean[c], rs = rstd[c];
+        // (unrolled: the rows are 16 dependent-looking loads otherwise -- one round trip each; the sums keep their order)
+#pragma unroll 8
         for (int64_t n = n0 + ry; n < n1; n += 4) {
             if (MODE == 0) {
                 const float v = x[(size_t)n * C + c];
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict
     const int64_t n0 = (int64_t)s * per, n1 = min(N, n0 + per);
     double sa = 0.0, sb = 0.0;
     if (MODE != 2)
+#pragma unroll
         for (int q = 0; q < BN1_SPLITS; ++q) {
             sa += partial[((size_t)c * BN1_SPLITS + q) * 2];
             sb += partial[((size_t)c * BN1_SPLITS + q) * 2 + 1];
@@ -206,10 +209,12 @@ __global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict
             }
         }
         const float scale = rs * g, shift = (beta ? beta[c] : 0.f) - mu * rs * g;
+#pragma unroll 8
         for (int64_t n = n0 + ry; n < n1; n += 4) out[(size_t)n * C + c] = fmaf(x[(size_t)n * C + c], scale, shift);
     } else if (MODE == 2) {
         const float rs = 1.f / sqrtf(running_var[c] + eps), mu = running_mean[c];
         const float scale = rs * g, shift = (beta ? beta[c] : 0.f) - mu * rs * g;
+#pragma unroll 8
         for (int64_t n = n0 + ry; n < n1; n += 4) out[(size_t)n * C + c] = fmaf(x[(size_t)n * C + c], scale, shift);
     } else {
         if (s == 0 && ry == 0) {
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(256) void bn1d_apply_kernel(const float* __restrict
         if (!out) return;
         const float mu = save_mean[c], rs = save_rstd[c];
         const float k0 = g * rs, mdy = (float)(sa / cnt), mdyx = (float)(sb / cnt);
+#pragma unroll 8
         for (int64_t n = n0 + ry; n < n1; n += 4) {
             const float xh = (x[(size_t)n * C + c] - mu) * rs;
             out[(size_t)n * C + c] = k0 * (dy[(size_t)n * C + c] - mdy - xh * mdyx);
