@@ -266,29 +266,46 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         user_vec = self.user_embedding[users.to(dev)]
         d = user_vec.shape[1]
         vec_all = torch.zeros((max(total, 1), d), dtype=torch.float32, device=dev)
-        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        # every index column of stages 1 and 2 goes to the device in ONE copy (they were three pageable host-to-device copies
+        # per (level, relation) pair -- ~45 per call, each a stall of the launching thread in a leg that is host-bound)
+        et_of = np.array([m.et_name for m in mods])[rel_code] if total else np.zeros(0, "<U6")
+        plan, cols = [], []
         for dep in range(1, int(depth.max()) + 1 if total else 1):
-            src = torch.cat([user_vec, vec_all]) if dep > 1 else user_vec
             at_dep = depth == dep
-            for j, mod in enumerate(mods):
+            for j in range(len(mods)):
                 rows = np.nonzero(at_dep & (rel_code == j))[0]
-                if not len(rows):
-                    continue
-                eh = src.index_select(0, t(np.where(par_row[rows] < 0, row_b[rows], B + par_row[rows])))
-                uv = user_vec.index_select(0, t(row_b[rows]))
-                vec_all.index_copy_(0, t(rows), mod((eh, uv)).view(len(rows), -1))
+                if len(rows):
+                    plan.append((dep, j, len(rows)))
+                    cols += [np.where(par_row[rows] < 0, row_b[rows], B + par_row[rows]), row_b[rows], rows]
+        et_rows = [(et, np.nonzero(et_of == et)[0]) for et in np.unique(et_of)]
+        cols += [rs for _, rs in et_rows]
+        idx_all = (torch.from_numpy(np.ascontiguousarray(np.concatenate(cols), dtype=np.int64)).to(dev) if cols
+                   else torch.zeros(0, dtype=torch.int64, device=dev))
+        pos = 0
+
+        def take(n):
+            nonlocal pos
+            pos += n
+            return idx_all[pos - n : pos]
+
+        src, src_dep = user_vec, 1
+        for dep, j, n in plan:
+            if dep != src_dep:
+                src, src_dep = torch.cat([user_vec, vec_all]), dep
+            eh = src.index_select(0, take(n))
+            uv = user_vec.index_select(0, take(n))
+            vec_all.index_copy_(0, take(n), mods[j]((eh, uv)).view(n, -1))
         # 2) log-probabilities of every node over its tail vocabulary: one GEMM per entity type + row log_softmax
         width = max(self.n_users, self.n_entities)
         lp = torch.empty((max(total, 1), width), dtype=torch.float32, device=dev)
-        et_of = np.array([m.et_name for m in mods])[rel_code] if total else np.zeros(0, "<U6")
-        for et in np.unique(et_of):
-            rs = np.nonzero(et_of == et)[0]
+        for et, rs in et_rows:
+            rs_dev = take(len(rs))
             whole = len(rs) == total
-            sc = ops.gemm(vec_all if whole else vec_all.index_select(0, t(rs)), self.embeddings[str(et)])  # [n, d] @ E^T
+            sc = ops.gemm(vec_all if whole else vec_all.index_select(0, rs_dev), self.embeddings[str(et)])  # [n, d] @ E^T
             if whole:
                 P.log_softmax_rows(sc, out=lp[:, : self._vocab[str(et)]])
             else:
-                lp[t(rs), : self._vocab[str(et)]] = P.log_softmax_rows(sc)
+                lp[rs_dev, : self._vocab[str(et)]] = P.log_softmax_rows(sc)
         # 3) interpret
         nodes = np.zeros(total, P.CAFE_NODE_DTYPE)
         nodes["parent"], nodes["k"], nodes["is_leaf"], nodes["depth"] = par_i, k_of, is_leaf, depth
