@@ -445,6 +445,12 @@ __global__ __launch_bounds__(256) void cafe_collect_kernel(const hw_cafe_node* _
         const size_t s = (size_t)(slot0 + l_off[sl] + sr) * 3;
         rec_ids[o * 3 + 0] = ids[s], rec_ids[o * 3 + 1] = ids[s + 1], rec_ids[o * 3 + 2] = ids[s + 2];
     }
+    // a user with more leaf paths than the workgroup ranks (counted into `overflow`): its scores leave as NaN, so that a caller
+    // that keeps everything on the device and does not read the counter cannot consume a truncated ranking unnoticed
+    if (pre[n_leaves] > CAFE_MAX_ENTRIES) {
+        __syncthreads();
+        for (int i = tid; i < n_items; i += 256) res[i] = __builtin_nanf("");
+    }
 }
 
 extern "C" int hw_cafe_collect(const hw_cafe_node* nodes, const int32_t* node_ptr, const int64_t* slot_ptr,

@@ -383,16 +383,22 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         plus everything run_program derives from it (flattened program columns, leaf rows, record capacity)."""
         lay = self._layout()
         kids_of, nodes = lay["kids"], lay["nodes"]
-        ids, pars, queue = [], [], [(c, -1) for c in lay["root_kids"]]
-        while queue:
-            nid, par = queue.pop(0)
-            pos = len(ids)
-            ids.append(nid)
-            pars.append(par)
-            kids = kids_of[nid]
-            if len(kids) > 1:
-                kids = [kids[j] for j in self.rng.permutation(len(kids))]
-            queue.extend((k, pos) for k in kids)
+        # the queue IS the visiting order (nodes are appended in the order they will be popped): two flat lists and a cursor --
+        # this runs once per user of a batch and was half of run_program's host time as a pop(0) / tuple loop
+        ids = list(lay["root_kids"])
+        pars = [-1] * len(ids)
+        perm = self.rng.permutation
+        head = 0
+        while head < len(ids):
+            kids = kids_of[ids[head]]
+            n = len(kids)
+            if n > 1:
+                ids.extend([kids[j] for j in perm(n).tolist()])
+                pars.extend([head] * n)
+            elif n:
+                ids.append(kids[0])
+                pars.append(head)
+            head += 1
         key = tuple(ids)
         ent = lay["orders"].get(key)
         if ent is None:
@@ -422,6 +428,8 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
 
     def run_program_device(self, users, manual_topk=5):
         """run_program with everything left on the device: (scores [B, n_items] float32, record tensors, leaf chains).
+        Nothing here waits for the device: a user with more leaf paths than hw_cafe_collect ranks (4096) gets NaN scores and
+        rec["overflow"] holds the count (P.cafe_overflow_check(rec) raises on it; run_program does that after its copy).
         Per-user host work is one rng.permutation draw and one dictionary lookup: program columns, leaf rows and record
         capacities are cached per visiting order of the layout tree."""
         users = torch.as_tensor(users)
@@ -452,7 +460,7 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         raw = self._run_programs(users, None, None, grow_excluded=True, exclude=True, raw=True, flat=flat)
         leaf_nodes = np.stack([e["leaf_row"] for e in ents]) if B else np.full((0, max(len(leaves), 1)), -1, np.int32)
         max_rec = min(max([1] + [e["max_rec"] for e in ents]), self.n_items)
-        scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec)
+        scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec, check_overflow=False)
         return scores, rec, leaves, users_np
 
     def _leaf_chains_cached(self):
@@ -470,7 +478,9 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         the device records: the Python lists the reference's contract asks for are only built when somebody reads them
         (the ranking metrics of an evaluation never do)."""
         scores, rec, leaves, users_np = self.run_program_device(users, manual_topk)
-        return scores.cpu(), _LazyRecords(self, rec, leaves, users_np)
+        scores = scores.cpu()
+        P.cafe_overflow_check(rec)  # after the copy: the device work is over, the read costs nothing more
+        return scores, _LazyRecords(self, rec, leaves, users_np)
 
     def _records_to_lists(self, rec, leaves, users_np):
         cnt = rec["count"].cpu().numpy()

@@ -322,7 +322,16 @@ def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, g
     return ids, vals, counts
 
 
-def cafe_collect(raw, leaf_nodes_np, n_items, max_rec):
+def cafe_overflow_check(rec):
+    """Raise if hw_cafe_collect met a user with more leaf paths than it ranks (reads one int from the device: a sync)."""
+    seen = int(rec["overflow"].item())
+    if seen:
+        raise RuntimeError(f"hw_cafe_collect: a user has {seen} leaf paths, more than the 4096 one workgroup ranks in LDS "
+                           "(manual_topk 5 gives 125 per metapath: more than 32 metapaths).  Run the users of such a layout in "
+                           "several run_program calls over subsets of the metapaths, or lower manual_topk")
+
+
+def cafe_collect(raw, leaf_nodes_np, n_items, max_rec, check_overflow=True):
     """collect_results + ranking of run_program on the interpreter's device buffers (hw_cafe_collect).  ``raw``: what
     CAFE._run_programs(..., raw=True) returns; leaf_nodes_np int32 [n_tasks, n_leaves].  Returns (results [n_tasks, n_items]
     float32 on the device, dict of record tensors: item / score / leaf [n_tasks, max_rec], ids [n_tasks, max_rec, 3], count)."""
@@ -346,11 +355,11 @@ def cafe_collect(raw, leaf_nodes_np, n_items, max_rec):
                             _ptr(rec["ids"]), _ptr(rec["count"]), _ptr(overflow), _stream()),
         "hw_cafe_collect",
     )
-    seen = int(overflow.item())  # the records are about to be copied to the host anyway
-    if seen:
-        raise RuntimeError(f"hw_cafe_collect: a user has {seen} leaf paths, more than the 4096 one workgroup ranks in LDS "
-                           "(manual_topk 5 gives 125 per metapath: more than 32 metapaths).  Run the users of such a layout in "
-                           "several run_program calls over subsets of the metapaths, or lower manual_topk")
+    rec["overflow"] = overflow
+    # check_overflow=False (run_program_device): no device sync here -- the scores of an overflowing user are NaN, the counter
+    # travels with the records and cafe_overflow_check reads it when somebody copies results to the host anyway
+    if check_overflow:
+        cafe_overflow_check(rec)
     return results, rec
 
 
