@@ -267,3 +267,31 @@ def test_collect_kernel_against_restatement(n_leaves, cap, n_items, seed):
             ni = leaf_nodes[b, l]
             s0 = int(slot_ptr[b]) + int(ni) * cap + r
             assert np.array_equal(pid[b, j], ids[s0]), (b, j)
+
+
+def test_collect_overflow_is_never_silent():
+    """A user with more than 4096 leaf paths: hw_cafe_collect counts it; the checking call raises, the non-waiting call
+    (run_program_device's) leaves that user's scores NaN, the others untouched, and hands the counter on."""
+    from hopwise_amd import pgpr_ops as P
+
+    B, n_leaves, cap, n_items = 3, 40, 128, 500
+    nodes = np.zeros(B * n_leaves, P.CAFE_NODE_DTYPE)
+    nodes["depth"], nodes["cap"] = 1, cap
+    nodes["slot_off"] = np.tile(np.arange(n_leaves) * cap, B)
+    counts = np.full(B * n_leaves, 10, np.int32)
+    counts[n_leaves : 2 * n_leaves] = cap  # user 1: 40 x 128 = 5120 entries
+    rng = np.random.default_rng(0)
+    ids = rng.integers(0, n_items, (B * n_leaves * cap, 3)).astype(np.int32)
+    vals = -rng.random((B * n_leaves * cap, 3)).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev())
+    raw = dict(ids=t(ids), vals=t(vals), counts=t(counts), nodes=t(nodes.view(np.int32).reshape(-1, 10).copy()),
+               node_ptr=t(np.arange(B + 1, dtype=np.int32) * n_leaves), slot_ptr=t(np.arange(B + 1, dtype=np.int64) * n_leaves * cap))
+    leaf_nodes = np.tile(np.arange(n_leaves, dtype=np.int32), (B, 1))
+    with pytest.raises(RuntimeError, match="5120 leaf paths"):
+        P.cafe_collect(raw, leaf_nodes, n_items, n_items)
+    scores, rec = P.cafe_collect(raw, leaf_nodes, n_items, n_items, check_overflow=False)
+    s = scores.cpu().numpy()
+    assert np.isnan(s[1]).all() and not np.isnan(s[0]).any() and not np.isnan(s[2]).any()
+    assert int(rec["overflow"].item()) == 5120
+    with pytest.raises(RuntimeError):
+        P.cafe_overflow_check(rec)
