@@ -1112,8 +1112,13 @@ class LinearAct(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+_ACT_ARG = {0: False, 1: True, 2: "relu"}
+
+
 def linear_act(x, w, b, act=0):
     """act: 0 none, 1 ELU, 2 ReLU."""
+    if not torch.is_grad_enabled():  # inference: straight to the GEMM (an autograd.Function.apply costs ~8 us of host time,
+        return gemm(x.contiguous(), w.contiguous(), True, True, bias=b, elu=_ACT_ARG[int(act)])  # CAFE makes 40 per call)
     return LinearAct.apply(x, w, b, int(act))
 
 
