@@ -59,6 +59,14 @@ class CafeNode(C.Structure):
                 ("parent", "rel", "eh_is_entity", "k", "is_leaf", "lp_row", "depth", "vocab", "cap", "slot_off")]
 
 
+class CafeModule(C.Structure):
+    """hw_cafe_module (include/hopwise_amd.h): device pointers to one relation module's evaluation-mode parameters."""
+
+    _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "bn1_weight", "bn1_bias", "bn1_mean", "bn1_var", "w2", "b2", "bn2_weight",
+                                          "bn2_bias", "bn2_mean", "bn2_var", "w3", "b3")] + [
+        ("bn1_eps", C.c_float), ("bn2_eps", C.c_float), ("deep", C.c_int32), ("reserved", C.c_int32)]
+
+
 class KgeGrads(C.Structure):
     _fields_ = [("head", C.c_void_p * MAX_TABLES), ("rel", C.c_void_p * MAX_TABLES), ("tail", C.c_void_p * MAX_TABLES)]
 
@@ -336,6 +344,12 @@ SIGNATURES = {
         C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i32p, C.c_int64, c_i32p, C.c_int64, C.c_int32, C.c_int32, c_f32p,
                   C.c_int64, C.c_int64, c_i32p, C.c_void_p]),
     "hw_log_softmax_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_void_p]),
+    "hw_cafe_modules_workspace_floats": (C.c_int64, [C.c_int64, C.c_int32]),
+    "hw_cafe_modules_forward": (
+        C.c_int,
+        [C.POINTER(CafeModule), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int32, c_f32p, C.c_int64, C.c_int32, c_i64p,
+         c_i64p, c_i64p, c_f32p, c_f32p, C.c_int64, C.c_void_p],
+    ),
     "hw_cafe_collect": (
         C.c_int,
         [C.c_void_p, c_i32p, c_i64p, c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, c_i32p,

@@ -21,6 +21,8 @@ of the CSR (as in the reference, where they walk a dict graph); ``SymbolicNetwor
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -221,6 +223,31 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             np.bitwise_or.at(bits[i], pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
         return torch.from_numpy(bits.view(np.int32)).to(dev)
 
+    def _module_structs(self, mods, user_vec):
+        """ctypes table of the relation modules' parameters for hw_cafe_modules_forward, or None when the C++ loop does not
+        apply (training mode, gradients wanted, dropout patched by a test, non-fp32 / host tensors, embedding size % 4).
+        Pointers are read per call (an optimizer step may have replaced storage); nothing is copied."""
+        from .._lib import CafeModule
+
+        if (torch.is_grad_enabled() or self.training or not user_vec.is_cuda or user_vec.dtype != torch.float32
+                or user_vec.shape[1] % 4 or os.environ.get("HW_CAFE_MODULES", "1") == "0"):
+            return None
+        arr = (CafeModule * len(mods))()
+        for i, m in enumerate(mods):
+            deep = isinstance(m, DeepRelationModule)
+            ps = [m.fc1.weight, m.fc1.bias, m.bn1.weight, m.bn1.bias, m.bn1.running_mean, m.bn1.running_var, m.fc2.weight,
+                  m.fc2.bias] + ([m.bn2.weight, m.bn2.bias, m.bn2.running_mean, m.bn2.running_var, m.fc3.weight, m.fc3.bias]
+                                 if deep else [None] * 6)
+            if m.training or any(p is not None and (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous())
+                                 for p in ps) or m.bn1.running_mean is None:
+                return None
+            for name, p in zip(("w1", "b1", "bn1_weight", "bn1_bias", "bn1_mean", "bn1_var", "w2", "b2", "bn2_weight", "bn2_bias",
+                                "bn2_mean", "bn2_var", "w3", "b3"), ps):
+                setattr(arr[i], name, p.data_ptr() if p is not None else None)
+            arr[i].bn1_eps, arr[i].bn2_eps = float(m.bn1.eps), float(m.bn2.eps) if deep else 0.0
+            arr[i].deep = int(deep)
+        return arr
+
     @torch.no_grad()
     def _run_programs(self, users, programs, ks, grow_excluded, exclude, raw=False, flat=None):
         """programs[b] = list of (parent index, relation name) in execution order for user b; ks[b][i] = k of node i.
@@ -269,32 +296,44 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         # every index column of stages 1 and 2 goes to the device in ONE copy (they were three pageable host-to-device copies
         # per (level, relation) pair -- ~45 per call, each a stall of the launching thread in a leg that is host-bound)
         et_of = np.array([m.et_name for m in mods])[rel_code] if total else np.zeros(0, "<U6")
-        plan, cols = [], []
+        plan, c_eh, c_uv, c_row = [], [], [], []
         for dep in range(1, int(depth.max()) + 1 if total else 1):
             at_dep = depth == dep
             for j in range(len(mods)):
                 rows = np.nonzero(at_dep & (rel_code == j))[0]
                 if len(rows):
                     plan.append((dep, j, len(rows)))
-                    cols += [np.where(par_row[rows] < 0, row_b[rows], B + par_row[rows]), row_b[rows], rows]
+                    c_eh.append(np.where(par_row[rows] < 0, row_b[rows], B + par_row[rows]))
+                    c_uv.append(row_b[rows])
+                    c_row.append(rows)
         et_rows = [(et, np.nonzero(et_of == et)[0]) for et in np.unique(et_of)]
-        cols += [rs for _, rs in et_rows]
+        cols = c_eh + c_uv + c_row + [rs for _, rs in et_rows]  # three columns over all groups, then the stage-2 row lists
         idx_all = (torch.from_numpy(np.ascontiguousarray(np.concatenate(cols), dtype=np.int64)).to(dev) if cols
                    else torch.zeros(0, dtype=torch.int64, device=dev))
-        pos = 0
+        offs = np.cumsum([0] + [n for _, _, n in plan])
+        n_idx = int(offs[-1])
+        eh_all, uv_all, row_all = idx_all[:n_idx], idx_all[n_idx : 2 * n_idx], idx_all[2 * n_idx : 3 * n_idx]
+        pos = 3 * n_idx
 
         def take(n):
             nonlocal pos
             pos += n
             return idx_all[pos - n : pos]
 
-        src, src_dep = user_vec, 1
-        for dep, j, n in plan:
-            if dep != src_dep:
-                src, src_dep = torch.cat([user_vec, vec_all]), dep
-            eh = src.index_select(0, take(n))
-            uv = user_vec.index_select(0, take(n))
-            vec_all.index_copy_(0, take(n), mods[j]((eh, uv)).view(n, -1))
+        structs = self._module_structs(mods, user_vec) if plan else None
+        if structs is not None:
+            # evaluation, fp32 on the device: the whole (level, relation) loop from one host call (csrc/cafe_modules.hip: the
+            # same GEMM / batch-norm launches, issued from C++; bit-identical to the loop below)
+            P.cafe_modules_forward(structs, [j for _, j, _ in plan], offs, user_vec, eh_all, uv_all, row_all, vec_all)
+        else:
+            src, src_dep = user_vec, 1
+            for g, (dep, j, n) in enumerate(plan):
+                if dep != src_dep:
+                    src, src_dep = torch.cat([user_vec, vec_all]), dep
+                o = int(offs[g])
+                eh = src.index_select(0, eh_all[o : o + n])
+                uv = user_vec.index_select(0, uv_all[o : o + n])
+                vec_all.index_copy_(0, row_all[o : o + n], mods[j]((eh, uv)).view(n, -1))
         # 2) log-probabilities of every node over its tail vocabulary: one GEMM per entity type + row log_softmax
         width = max(self.n_users, self.n_entities)
         lp = torch.empty((max(total, 1), width), dtype=torch.float32, device=dev)

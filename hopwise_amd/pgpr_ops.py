@@ -322,6 +322,22 @@ def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, g
     return ids, vals, counts
 
 
+def cafe_modules_forward(mod_structs, group_mod, group_ptr, user_vec, eh_idx, uv_idx, out_rows, vec_all):
+    """hw_cafe_modules_forward: every (level, relation) module application of a run_program call from one host call.
+    mod_structs: ctypes array of _lib.CafeModule; group_mod / group_ptr: host sequences; index columns and vectors on the device."""
+    lib = _lib.load()
+    n_groups = len(group_mod)
+    gm = (C.c_int32 * max(n_groups, 1))(*[int(x) for x in group_mod])
+    gp = (C.c_int64 * (n_groups + 1))(*[int(x) for x in group_ptr])
+    d = user_vec.shape[1]
+    max_rows = max([gp[g + 1] - gp[g] for g in range(n_groups)] + [0])
+    n_ws = int(lib.hw_cafe_modules_workspace_floats(max_rows, d))
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=user_vec.device)
+    check(lib.hw_cafe_modules_forward(mod_structs, gm, gp, n_groups, _ptr(user_vec), user_vec.shape[0], d, _ptr(eh_idx),
+                                      _ptr(uv_idx), _ptr(out_rows), _ptr(vec_all), _ptr(ws), n_ws, _stream()),
+          "hw_cafe_modules_forward")
+
+
 def cafe_overflow_check(rec):
     """Raise if hw_cafe_collect met a user with more leaf paths than it ranks (reads one int from the device: a sync)."""
     seen = int(rec["overflow"].item())

@@ -595,6 +595,30 @@ int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const
                     int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
                     int32_t* out_count, const int64_t* slot_ptr, void* stream);
 
+/* One relation module of SymbolicNetwork in evaluation mode (cafe.py:645-699): device pointers to the parameters of
+ * RelationModule (deep = 0: fc1 [256, 2d], bn1, fc2 [d, 256], residual + eh_vec) or DeepRelationModule (deep = 1: fc1
+ * [256, 2d], bn1, fc2 [2d, 256], residual + feature, bn2 [2d], fc3 [d, 2d]).  Weights are nn.Linear layouts [out, in]. */
+typedef struct {
+    const float *w1, *b1, *bn1_weight, *bn1_bias, *bn1_mean, *bn1_var;
+    const float *w2, *b2, *bn2_weight, *bn2_bias, *bn2_mean, *bn2_var;
+    const float *w3, *b3;
+    float bn1_eps, bn2_eps;
+    int32_t deep, reserved;
+} hw_cafe_module;
+
+/* The module applications of one run_program call (the per-(level, relation) loop around `module((eh_vec, user_vec))` of
+ * MetaProgramExecutor, cafe.py:807-835) from one host call.  Group g applies module mods[group_mod[g]] to rows
+ * group_ptr[g] .. group_ptr[g + 1] of the index columns: input = [ eh | user_vec[uv_idx] ] with eh = user_vec[eh_idx] when
+ * eh_idx < n_user_rows, else vec_all[eh_idx - n_user_rows]; the result row goes to vec_all[out_rows].  Groups run in order
+ * (a level reads what the levels before it wrote).  mods / group_mod / group_ptr are HOST arrays, the rest device memory;
+ * dim % 4 == 0; workspace: hw_cafe_modules_workspace_floats(largest group, dim) floats.  The launches are hw_gemm_f32 and
+ * hw_batchnorm1d_forward(training = 0) themselves: results equal the module-by-module path bit for bit. */
+int64_t hw_cafe_modules_workspace_floats(int64_t max_rows, int32_t dim);
+int hw_cafe_modules_forward(const hw_cafe_module* mods, const int32_t* group_mod, const int64_t* group_ptr, int32_t n_groups,
+                            const float* user_vec, int64_t n_user_rows, int32_t dim, const int64_t* eh_idx,
+                            const int64_t* uv_idx, const int64_t* out_rows, float* vec_all, float* workspace,
+                            int64_t workspace_floats, void* stream);
+
 /* collect_results + the ranking loop of run_program (cafe.py:417-441, :859-867) on hw_cafe_execute's output, one user
  * per task: entries = the paths of the task's leaf nodes in `leaf_nodes` order (int32 [n_tasks, n_leaves], node index
  * inside the task, -1 = absent), score = product of the path's float32 log-probs left to right.  Per item the entry with

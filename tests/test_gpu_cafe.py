@@ -295,3 +295,22 @@ def test_collect_overflow_is_never_silent():
     assert int(rec["overflow"].item()) == 5120
     with pytest.raises(RuntimeError):
         P.cafe_overflow_check(rec)
+
+
+def test_module_loop_in_cpp_equals_the_python_loop(monkeypatch):
+    """hw_cafe_modules_forward (every (level, relation) module application of a run_program call issued from C++) against
+    the module-by-module torch loop: same kernels in the same order, so scores and records are equal bit for bit."""
+    z, orc, m = build()
+    users = torch.from_numpy(z["users"])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HW_CAFE_MODULES", mode)
+        scores, rec, leaves, _ = m.run_program_device(users)
+        out[mode] = (scores.cpu(), {k: v.cpu() for k, v in rec.items()})
+    assert torch.equal(out["1"][0].nan_to_num(-1e30), out["0"][0].nan_to_num(-1e30))
+    for k in ("count", "item", "score", "leaf", "ids"):
+        assert torch.equal(out["1"][1][k], out["0"][1][k]), k
+    # and the C++ loop really ran: the struct table exists for this model in evaluation mode
+    monkeypatch.setenv("HW_CAFE_MODULES", "1")
+    with torch.no_grad():
+        assert m._module_structs([m._module(n) for n in sorted(m.relation_info)], m.user_embedding) is not None
