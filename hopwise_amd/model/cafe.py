@@ -34,6 +34,36 @@ from ..utils import InputType
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
 
 
+class _Packed:
+    """Integer host arrays (int64 / int32, any shape) -> one int64 buffer -> ONE host-to-device copy -> typed views."""
+
+    def __init__(self):
+        self.parts, self.meta, self.off = [], {}, 0
+
+    def add(self, name, arr):
+        a = np.ascontiguousarray(arr)
+        flat = a.reshape(-1)
+        if a.dtype == np.int32:
+            if flat.size & 1:
+                flat = np.concatenate([flat, np.zeros(1, np.int32)])
+            words = flat.view(np.int64)
+        else:
+            words = flat.astype(np.int64, copy=False)
+        self.meta[name] = (self.off, words.size, a.dtype == np.int32, a.shape)
+        self.parts.append(words)
+        self.off += words.size
+
+    def to(self, dev):
+        buf = torch.from_numpy(np.concatenate(self.parts) if self.parts else np.zeros(0, np.int64)).to(dev)
+        out = {}
+        for name, (off, n, is32, shape) in self.meta.items():
+            t = buf[off : off + n]
+            if is32:
+                t = t.view(torch.int32)[: int(np.prod(shape))]
+            out[name] = t.view(shape) if len(shape) != 1 else t
+        return out
+
+
 class RelationModule(nn.Module):
     def __init__(self, embedding_size, info):
         super().__init__()
@@ -192,7 +222,7 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             self.__dict__["_module_table"] = tab
         return tab[relation]
 
-    def _excluded_bits(self, users_np, exclude):
+    def _excluded_bits(self, users_np, exclude, users_dev=None):
         """Bitset [B, words] of the ids excluded at leaves: the user's train positives without the 0 padding for the
         executor (cafe.py:421-422), nothing for infer_with_path -- there the reference subtracts a torch tensor from a
         set of ints (cafe.py:606-607), which removes nothing because tensor elements hash by identity.
@@ -214,7 +244,9 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             table = self.__dict__["_excluded_table"] = torch.from_numpy(
                 bits.view(np.int32).reshape(pos.shape[0], self._bit_words)).to(dev)
         if table is not None:
-            return table.index_select(0, torch.from_numpy(np.asarray(users_np, np.int64)).to(dev)).contiguous()
+            if users_dev is None:
+                users_dev = torch.from_numpy(np.asarray(users_np, np.int64)).to(dev)
+            return table.index_select(0, users_dev).contiguous()
         bits = np.zeros((len(users_np), self._bit_words), np.uint32)
         for i, u in enumerate(users_np):
             pos = self.positives[int(u)]
@@ -290,8 +322,7 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         slot_ptr = np.concatenate([[0], cum[node_ptr[1:] - 1]]) if total else np.zeros(B + 1, np.int64)
         slot_off = cum - cap - slot_ptr[row_b]
         # 1) node vectors, level by level, one module call per (level, relation) over all users
-        user_vec = self.user_embedding[users.to(dev)]
-        d = user_vec.shape[1]
+        d = self.user_embedding.shape[1]
         vec_all = torch.zeros((max(total, 1), d), dtype=torch.float32, device=dev)
         # every index column of stages 1 and 2 goes to the device in ONE copy (they were three pageable host-to-device copies
         # per (level, relation) pair -- ~45 per call, each a stall of the launching thread in a leg that is host-bound)
@@ -307,9 +338,27 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
                     c_uv.append(row_b[rows])
                     c_row.append(rows)
         et_rows = [(et, np.nonzero(et_of == et)[0]) for et in np.unique(et_of)]
-        cols = c_eh + c_uv + c_row + [rs for _, rs in et_rows]  # three columns over all groups, then the stage-2 row lists
-        idx_all = (torch.from_numpy(np.ascontiguousarray(np.concatenate(cols), dtype=np.int64)).to(dev) if cols
-                   else torch.zeros(0, dtype=torch.int64, device=dev))
+        # the interpreter's node table (host-only inputs: built here so that it rides in the same copy)
+        nodes = np.zeros(total, P.CAFE_NODE_DTYPE)
+        nodes["parent"], nodes["k"], nodes["is_leaf"], nodes["depth"] = par_i, k_of, is_leaf, depth
+        nodes["rel"] = np.array([self.relation2rid[n] for n in names], np.int64)[rel_code] if total else 0
+        nodes["eh_is_entity"] = np.array([int(m.eh_name == "entity") for m in mods], np.int64)[rel_code] if total else 0
+        nodes["vocab"] = np.array([self._vocab[m.et_name] for m in mods], np.int64)[rel_code] if total else 0
+        nodes["lp_row"], nodes["cap"], nodes["slot_off"] = np.arange(total), cap, slot_off
+        # ONE host-to-device copy per call: the index columns of stages 1 and 2 (three columns over all groups, then the
+        # stage-2 row lists), the user ids, the node table and its pointers, the collector's leaf rows.  Each used to be its
+        # own pageable copy (~0.2 ms of the launching thread apiece, eight of them) in a leg that is bound by the host.
+        pk = _Packed()
+        pk.add("idx", np.concatenate(c_eh + c_uv + c_row + [rs for _, rs in et_rows]) if plan or et_rows else np.zeros(0, np.int64))
+        pk.add("users", np.asarray(users_np, np.int64))
+        pk.add("nodes", nodes.view(np.int32).reshape(-1, 10))
+        pk.add("node_ptr", np.asarray(node_ptr, np.int32))
+        pk.add("slot_ptr", np.asarray(slot_ptr, np.int64))
+        if flat is not None and "leaf_nodes" in flat:
+            pk.add("leaf_nodes", np.ascontiguousarray(flat["leaf_nodes"], np.int32))
+        on_dev = pk.to(dev)
+        idx_all, users_dev = on_dev["idx"], on_dev["users"]
+        user_vec = self.user_embedding[users_dev]
         offs = np.cumsum([0] + [n for _, _, n in plan])
         n_idx = int(offs[-1])
         eh_all, uv_all, row_all = idx_all[:n_idx], idx_all[n_idx : 2 * n_idx], idx_all[2 * n_idx : 3 * n_idx]
@@ -346,19 +395,13 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             else:
                 lp[rs_dev, : self._vocab[str(et)]] = P.log_softmax_rows(sc)
         # 3) interpret
-        nodes = np.zeros(total, P.CAFE_NODE_DTYPE)
-        nodes["parent"], nodes["k"], nodes["is_leaf"], nodes["depth"] = par_i, k_of, is_leaf, depth
-        nodes["rel"] = np.array([self.relation2rid[n] for n in names], np.int64)[rel_code] if total else 0
-        nodes["eh_is_entity"] = np.array([int(m.eh_name == "entity") for m in mods], np.int64)[rel_code] if total else 0
-        nodes["vocab"] = np.array([self._vocab[m.et_name] for m in mods], np.int64)[rel_code] if total else 0
-        nodes["lp_row"], nodes["cap"], nodes["slot_off"] = np.arange(total), cap, slot_off
-        excl = self._excluded_bits(users_np, exclude)
-        users_dev = users.to(dev, torch.int64).contiguous()
+        excl = self._excluded_bits(users_np, exclude, users_dev)
         ids, vals, counts, nodes_dev, node_ptr_dev, slot_ptr_dev = P.cafe_execute(
-            self.graph, nodes, node_ptr, users_dev, lp, excl, grow_excluded, slot_ptr, int(slot_ptr[-1]), keep_tables=True)
+            self.graph, nodes, node_ptr, users_dev, lp, excl, grow_excluded, slot_ptr, int(slot_ptr[-1]), keep_tables=True,
+            on_device=(on_dev["nodes"], on_dev["node_ptr"], on_dev["slot_ptr"]))
         if raw:
             return dict(ids=ids, vals=vals, counts=counts, nodes=nodes_dev, node_ptr=node_ptr_dev, slot_ptr=slot_ptr_dev,
-                        cap=cap, node_ptr_np=node_ptr)
+                        cap=cap, node_ptr_np=node_ptr, leaf_nodes=on_dev.get("leaf_nodes"))
         ids, vals, counts = ids.cpu().numpy(), vals.cpu().numpy(), counts.cpu().numpy()
         out = []
         for b in range(B):
@@ -496,10 +539,12 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
                     par_i=np.concatenate([e["par_i"] for e in ents]) if B else np.zeros(0, np.int64),
                     rel_code=np.concatenate([e["rel_code"] for e in ents]) if B else np.zeros(0, np.int64), names=names)
         flat["k_of"] = np.full(len(flat["par_i"]), manual_topk, np.int64)
-        raw = self._run_programs(users, None, None, grow_excluded=True, exclude=True, raw=True, flat=flat)
         leaf_nodes = np.stack([e["leaf_row"] for e in ents]) if B else np.full((0, max(len(leaves), 1)), -1, np.int32)
+        flat["leaf_nodes"] = leaf_nodes  # rides in _run_programs' one host-to-device copy
+        raw = self._run_programs(users, None, None, grow_excluded=True, exclude=True, raw=True, flat=flat)
         max_rec = min(max([1] + [e["max_rec"] for e in ents]), self.n_items)
-        scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec, check_overflow=False)
+        scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec, check_overflow=False,
+                                     leaf_nodes_dev=raw.get("leaf_nodes"))
         return scores, rec, leaves, users_np
 
     def _leaf_chains_cached(self):

@@ -299,14 +299,17 @@ def log_softmax_rows(x, n_cols=None, out=None):
 
 
 def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, grow_excluded, slot_ptr_np, n_slots,
-                 keep_tables=False):
+                 keep_tables=False, on_device=None):
     """Run the program interpreter.  nodes_np: structured array of CafeNode fields; returns (ids [n_slots, 3] int32,
     vals [n_slots, 3] float32, counts [n_nodes] int32) on the device."""
     lib = _lib.load()
     dev = users.device
-    nodes = torch.from_numpy(nodes_np.view(np.int32).reshape(-1, 10).copy()).to(dev)
-    node_ptr = torch.from_numpy(np.asarray(node_ptr_np, np.int32)).to(dev)
-    slot_ptr = torch.from_numpy(np.asarray(slot_ptr_np, np.int64)).to(dev)
+    if on_device is not None:  # (nodes [n, 10] int32, node_ptr int32, slot_ptr int64) already copied by the caller
+        nodes, node_ptr, slot_ptr = on_device
+    else:
+        nodes = torch.from_numpy(nodes_np.view(np.int32).reshape(-1, 10).copy()).to(dev)
+        node_ptr = torch.from_numpy(np.asarray(node_ptr_np, np.int32)).to(dev)
+        slot_ptr = torch.from_numpy(np.asarray(slot_ptr_np, np.int64)).to(dev)
     ids = torch.zeros((max(n_slots, 1), 3), dtype=torch.int32, device=dev)
     vals = torch.zeros((max(n_slots, 1), 3), dtype=torch.float32, device=dev)
     counts = torch.zeros(max(len(nodes_np), 1), dtype=torch.int32, device=dev)
@@ -347,14 +350,15 @@ def cafe_overflow_check(rec):
                            "several run_program calls over subsets of the metapaths, or lower manual_topk")
 
 
-def cafe_collect(raw, leaf_nodes_np, n_items, max_rec, check_overflow=True):
+def cafe_collect(raw, leaf_nodes_np, n_items, max_rec, check_overflow=True, leaf_nodes_dev=None):
     """collect_results + ranking of run_program on the interpreter's device buffers (hw_cafe_collect).  ``raw``: what
     CAFE._run_programs(..., raw=True) returns; leaf_nodes_np int32 [n_tasks, n_leaves].  Returns (results [n_tasks, n_items]
     float32 on the device, dict of record tensors: item / score / leaf [n_tasks, max_rec], ids [n_tasks, max_rec, 3], count)."""
     lib = _lib.load()
     dev = raw["ids"].device
     n_tasks, n_leaves = leaf_nodes_np.shape
-    leaf_nodes = torch.from_numpy(np.ascontiguousarray(leaf_nodes_np, np.int32)).to(dev)
+    leaf_nodes = (leaf_nodes_dev if leaf_nodes_dev is not None
+                  else torch.from_numpy(np.ascontiguousarray(leaf_nodes_np, np.int32)).to(dev))
     best = torch.empty((n_tasks, n_items), dtype=torch.int64, device=dev)
     last = torch.empty((n_tasks, n_items), dtype=torch.int32, device=dev)
     results = torch.empty((n_tasks, n_items), dtype=torch.float32, device=dev)
