@@ -181,44 +181,71 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
                 const int last = nd.parent < 0 ? uid : p_ids[(size_t)pp * 3 + depth - 2];
                 // adjacency of (the RELATION's head type, last) under nd.rel: the lookup type comes from the relation,
                 // not from the node (cafe.py:603 kg_mask.get_ids(module.eh_name, path[-1], ...))
-                int lo = 0, hi = 0;
                 long long base = 0;
+                int deg = 0;
                 const int64_t n_type = nd.eh_is_entity ? g.n_entities : g.n_users;
                 if (last >= 0 && last < n_type) {
                     const int64_t gid = nd.eh_is_entity ? (int64_t)g.n_users + last : last;
-                    const int64_t a = g.ptr[gid], b = g.ptr[gid + 1];
-                    int64_t l = a, h = b;
-                    while (l < h) {  // first edge with rel >= nd.rel
-                        const int64_t m = (l + h) >> 1;
-                        if (g.rel[m] < nd.rel) l = m + 1;
-                        else h = m;
-                    }
-                    lo = (int)(l - a);
-                    h = b;
-                    while (l < h) {  // first edge with rel > nd.rel
-                        const int64_t m = (l + h) >> 1;
-                        if (g.rel[m] <= nd.rel) l = m + 1;
-                        else h = m;
-                    }
-                    hi = (int)(l - a);
-                    base = a;
+                    base = g.ptr[gid];
+                    deg = (int)(g.ptr[gid + 1] - base);
                 }
-                sh_lo = lo, sh_hi = hi, sh_base = base;
+                sh_base = base, sh_hi = deg;
+            }
+            __syncthreads();
+            {
+                // the relation's segment [lo, hi) of the (relation, destination)-sorted adjacency: lo = edges with a smaller
+                // relation, hi = edges with a relation <= nd.rel, counted by the whole block in one sweep of independent loads
+                // (two binary searches by one thread were ~14 dependent loads = 6-8 us per parent path, ~80 paths per user)
+                const int deg = sh_hi;
+                const int32_t* __restrict__ rl = g.rel + sh_base;
+                int lt = 0, le = 0;
+                for (int e = tid; e < deg; e += 256) {
+                    const int r = rl[e];
+                    lt += r < nd.rel;
+                    le += r <= nd.rel;
+                }
+                uint64_t both = ((uint64_t)(uint32_t)lt << 32) | (uint32_t)le;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) both += __shfl_xor(both, m, 64);
+                __syncthreads();  // every thread has read sh_hi
+                if ((tid & 63) == 0) red[tid >> 6] = both;
+                __syncthreads();
+                if (tid == 0) {
+                    const uint64_t t = (red[0] + red[1]) + (red[2] + red[3]);
+                    sh_lo = (int)(t >> 32), sh_hi = (int)(t & 0xffffffffu);
+                }
             }
             __syncthreads();
             const int lo = sh_lo, hi = sh_hi;
             const int32_t* __restrict__ dst = g.dst + sh_base;
             const int first = n_out;
             uint64_t bound = ~0ull;
+            // candidate key of adjacency slot e (0: not a candidate).  Neither the visited nor the excluded set changes
+            // during a parent's k rounds (its picks are entered after them), so a slot's key is the same in every round.
+            auto slot_key = [&](int e) -> uint64_t {
+                const int id = dst[e];
+                if (e > lo && dst[e - 1] == id) return 0ull;  // set(): the adjacency keeps multiplicity
+                if (id < 0 || id >= nd.vocab) return 0ull;
+                if ((vis[id >> 5] >> (id & 31)) & 1u) return 0ull;
+                if (nd.is_leaf && ((excl[id >> 5] >> (id & 31)) & 1u)) return 0ull;
+                return lp_key(lp[id], (uint32_t)id);
+            };
+            // this thread's first four slots are gathered ONCE and kept for all rounds (segments of up to 1 024 edges: almost
+            // all of them); the rounds used to gather every slot again, k times per parent path
+            constexpr int CK = 4;
+            uint64_t ck[CK];
+#pragma unroll
+            for (int i = 0; i < CK; ++i) {
+                const int e = lo + tid + 256 * i;
+                ck[i] = e < hi ? slot_key(e) : 0ull;
+            }
             for (int r = 0; r < nd.k && n_out < nd.cap; ++r) {
                 uint64_t best = 0;
-                for (int e = lo + tid; e < hi; e += 256) {
-                    const int id = dst[e];
-                    if (e > lo && dst[e - 1] == id) continue;  // set(): the adjacency keeps multiplicity
-                    if (id < 0 || id >= nd.vocab) continue;
-                    if ((vis[id >> 5] >> (id & 31)) & 1u) continue;
-                    if (nd.is_leaf && ((excl[id >> 5] >> (id & 31)) & 1u)) continue;
-                    const uint64_t key = lp_key(lp[id], (uint32_t)id);
+#pragma unroll
+                for (int i = 0; i < CK; ++i)
+                    if (ck[i] < bound && ck[i] > best) best = ck[i];
+                for (int e = lo + tid + 256 * CK; e < hi; e += 256) {
+                    const uint64_t key = slot_key(e);
                     if (key < bound && key > best) best = key;
                 }
 #pragma unroll
