@@ -175,10 +175,15 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
         float* c_vals = out_vals + (slot0 + nd.slot_off) * 3;
         const float* __restrict__ lp = logprobs + (size_t)nd.lp_row * lp_ld;
         int n_out = 0;
+        int pfx_id[2] = {0, 0};  // thread 0: the parent path's ids / values, read once per parent (depth - 1 <= 2 of them)
+        float pfx_v[2] = {0.f, 0.f};
         for (int pp = 0; pp < n_parent && n_out < nd.cap; ++pp) {
             if (tid == 0) {
                 // thread 0 is the only reader of what thread 0 wrote earlier in this launch (parent paths)
-                const int last = nd.parent < 0 ? uid : p_ids[(size_t)pp * 3 + depth - 2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (j < depth - 1) pfx_id[j] = p_ids[(size_t)pp * 3 + j], pfx_v[j] = p_vals[(size_t)pp * 3 + j];
+                const int last = nd.parent < 0 ? uid : pfx_id[depth == 3 ? 1 : 0];
                 // adjacency of (the RELATION's head type, last) under nd.rel: the lookup type comes from the relation,
                 // not from the node (cafe.py:603 kg_mask.get_ids(module.eh_name, path[-1], ...))
                 long long base = 0;
@@ -265,12 +270,14 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
                         const int id = (int)(~(uint32_t)(w & 0xffffffffu));
                         int32_t* q = c_ids + (size_t)n_out * 3;
                         float* v = c_vals + (size_t)n_out * 3;
-                        for (int j = 0; j < depth - 1; ++j) {
-                            q[j] = p_ids[(size_t)pp * 3 + j];
-                            v[j] = p_vals[(size_t)pp * 3 + j];
-                        }
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            if (j < depth - 1) q[j] = pfx_id[j], v[j] = pfx_v[j];
                         q[depth - 1] = id;
-                        v[depth - 1] = lp[id];
+                        // the log-probability back out of the key (lp_key's map is a bijection on float bits): no load in
+                        // the one-thread section every round waits for
+                        const uint32_t uu = (uint32_t)(w >> 32);
+                        v[depth - 1] = __uint_as_float((uu & 0x80000000u) ? (uu & 0x7fffffffu) : ~uu);
                     }
                 }
                 __syncthreads();
