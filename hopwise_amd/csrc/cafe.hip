@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
     __shared__ uint32_t excl[CAFE_BIT_WORDS];
     __shared__ int counts[CAFE_MAX_NODES];
     __shared__ uint64_t red[4];
-    __shared__ uint64_t sh_win;
+    __shared__ uint64_t red2[2][4];
     __shared__ int sh_lo, sh_hi;
     __shared__ long long sh_base;
     const int task = blockIdx.x;
@@ -223,10 +223,9 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
             __syncthreads();
             const int lo = sh_lo, hi = sh_hi;
             const int32_t* __restrict__ dst = g.dst + sh_base;
-            const int first = n_out;
             uint64_t bound = ~0ull;
-            // candidate key of adjacency slot e (0: not a candidate).  Neither the visited nor the excluded set changes
-            // during a parent's k rounds (its picks are entered after them), so a slot's key is the same in every round.
+            // candidate key of adjacency slot e (0: not a candidate).  During a parent's k rounds the visited / excluded sets
+            // only gain that parent's own picks, which the rounds exclude through `bound` anyway: a slot's key can be taken once.
             auto slot_key = [&](int e) -> uint64_t {
                 const int id = dst[e];
                 if (e > lo && dst[e - 1] == id) return 0ull;  // set(): the adjacency keeps multiplicity
@@ -258,43 +257,34 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
                     const uint64_t o = __shfl_xor(best, m, 64);
                     best = o > best ? o : best;
                 }
+                // ONE barrier per round: the four wave maxima go to the round's half of a double buffer and every thread takes
+                // their maximum itself (the other half was last read before the barrier of the round before this one)
+                if ((tid & 63) == 0) red2[r & 1][tid >> 6] = best;
                 __syncthreads();
-                if ((tid & 63) == 0) red[tid >> 6] = best;
-                __syncthreads();
-                if (tid == 0) {
-                    uint64_t w = red[0];
+                uint64_t w = red2[r & 1][0];
 #pragma unroll
-                    for (int i = 1; i < 4; ++i) w = red[i] > w ? red[i] : w;
-                    sh_win = w;
-                    if (w != 0) {
-                        const int id = (int)(~(uint32_t)(w & 0xffffffffu));
-                        int32_t* q = c_ids + (size_t)n_out * 3;
-                        float* v = c_vals + (size_t)n_out * 3;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            if (j < depth - 1) q[j] = pfx_id[j], v[j] = pfx_v[j];
-                        q[depth - 1] = id;
-                        // the log-probability back out of the key (lp_key's map is a bijection on float bits): no load in
-                        // the one-thread section every round waits for
-                        const uint32_t uu = (uint32_t)(w >> 32);
-                        v[depth - 1] = __uint_as_float((uu & 0x80000000u) ? (uu & 0x7fffffffu) : ~uu);
-                    }
-                }
-                __syncthreads();
-                const uint64_t w = sh_win;
+                for (int i = 1; i < 4; ++i) w = red2[r & 1][i] > w ? red2[r & 1][i] : w;
                 if (w == 0) break;
-                bound = w;
-                ++n_out;
-            }
-            // this parent's picks become visited (and, at executor leaves, excluded) before the next parent
-            if (tid == 0) {
-                for (int i = first; i < n_out; ++i) {
-                    const int id = c_ids[(size_t)i * 3 + depth - 1];
+                if (tid == 0) {
+                    const int id = (int)(~(uint32_t)(w & 0xffffffffu));
+                    int32_t* q = c_ids + (size_t)n_out * 3;
+                    float* v = c_vals + (size_t)n_out * 3;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (j < depth - 1) q[j] = pfx_id[j], v[j] = pfx_v[j];
+                    q[depth - 1] = id;
+                    // the log-probability back out of the key (lp_key's map is a bijection on float bits): no load here
+                    const uint32_t uu = (uint32_t)(w >> 32);
+                    v[depth - 1] = __uint_as_float((uu & 0x80000000u) ? (uu & 0x7fffffffu) : ~uu);
+                    // the pick becomes visited (and, at executor leaves, excluded) for the parents after this one.  Entering it
+                    // now is equivalent: this parent's later rounds exclude it through `bound` already
                     vis[id >> 5] |= 1u << (id & 31);
                     if (nd.is_leaf && grow_excluded) excl[id >> 5] |= 1u << (id & 31);
                 }
+                bound = w;
+                ++n_out;
             }
-            __syncthreads();
+            __syncthreads();  // the picks' bits are in place before the next parent's candidates are gathered
         }
         if (tid == 0) {
             counts[ni - n0] = n_out;
