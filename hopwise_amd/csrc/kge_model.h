@@ -89,6 +89,7 @@ struct Scorer {
     using R = Row<G, NE, VEC>;
 
     R q[MT::NQ];
+    static constexpr bool SPLIT_BUILD = MODEL != HW_RESCAL && MODEL != HW_HOLE;  // build() = issue() + fold()
 
     // Load the head / relation rows of one (h, r) pair and fold them into the query.
     // KEEP = true additionally returns the raw rows (the gradient kernel needs them).
@@ -178,12 +179,34 @@ struct Scorer {
             }
             return;
         }
-        R hh[MT::NH], rr[MT::NR];
+        if constexpr (SPLIT_BUILD) {
+            R hh[MT::NH], rr[MT::NR];
+            issue(d, h, r, gl, hh, rr);
+            fold<KEEP>(d.dim, gl, hh, rr, hraw, rraw);
+        }
+    }
+
+    // build() in two halves for the models whose query is an element-wise fold of the head and relation rows: issue() only
+    // starts the row loads, fold() consumes them.  A kernel with other memory round trips ahead of its tail loop (the fused
+    // sampler's key -> slice -> ids chain) puts those between the two, so that the rows travel under them.
+    __device__ __forceinline__ void issue(const hw_kge_desc& d, int h, int r, int gl, R (&hh)[MT::NH], R (&rr)[MT::NR]) {
         const size_t ho = (size_t)h * d.dim, ro = (size_t)r * d.dim;
 #pragma unroll
-        for (int k = 0; k < MT::NH; ++k) hh[k].load(d.head[k] + ho, d.dim, gl);
+        for (int k = 0; k < MT::NH; ++k) hh[k].load_raw(d.head[k] + ho, d.dim, gl);
 #pragma unroll
-        for (int k = 0; k < MT::NR; ++k) rr[k].load(d.rel[k] + ro, d.dim, gl);
+        for (int k = 0; k < MT::NR; ++k) rr[k].load_raw(d.rel[k] + ro, d.dim, gl);
+    }
+    template <bool KEEP>
+    __device__ __forceinline__ void fold(int dim, int gl, R (&hh)[MT::NH], R (&rr)[MT::NR], R* hraw, R* rraw) {
+        // the zeroing half of Row::load: padding slots of the raw loads hold copies of valid data
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const bool valid = R::slot_valid(i, dim, gl);
+#pragma unroll
+            for (int k = 0; k < MT::NH; ++k) hh[k].v[i] = valid ? hh[k].v[i] : 0.f;
+#pragma unroll
+            for (int k = 0; k < MT::NR; ++k) rr[k].v[i] = valid ? rr[k].v[i] : 0.f;
+        }
         float red = 0.f;  // TransH: sum of the norm vector; TransD: h . h_vec
         if constexpr (MODEL == HW_TRANSH || MODEL == HW_TRANSD) {
 #pragma unroll

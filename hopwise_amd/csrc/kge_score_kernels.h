@@ -46,7 +46,7 @@ __device__ __forceinline__ void selfadv_finish_block(const float* __restrict__ g
 
 constexpr int LOSS_MAX_TAILS = 1024;
 template <int MODEL, int G, int NE, bool VEC, int U, bool SAMPLE = false, bool LOSS = false>
-__global__ __launch_bounds__(256) void kge_score_grouped_kernel(
+__global__ __launch_bounds__(256, (SAMPLE && NE <= 4) ? 8 : 1) void kge_score_grouped_kernel(
     hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
     int64_t* t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
     float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob, SamplerArgs sa, SelfAdvArgs la = SelfAdvArgs{}) {
@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
 
     const int lane = threadIdx.x & (HW_WAVE - 1);
     const int sub = lane / G, gl = lane % G;
-    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + (threadIdx.x / HW_WAVE);
+    // the wave's number read from lane 0: task, group, split, the group's ids and slice bounds and every row base derived
+    // from them are then scalars for the compiler too (scalar loads, SGPRs) instead of 64 equal lanes of vector registers
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x / HW_WAVE);
     if (task >= n_groups * S) return;  // wave-uniform
     if constexpr (SAMPLE && LOSS) {
         // chained launches: block 0 (all four waves live: S == 4) first adds the group terms the previous launch on this
@@ -70,13 +72,44 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
     }
     const int64_t b = task / S;
     const int s = (int)(task % S);
+    // EARLY (fused sampler, element-wise queries): the launch is ONE generation of blocks that all start together, so every
+    // memory round trip ahead of the tail loop is a stretch in which the chip fetches nothing.  The sampler's chain (key ->
+    // slice bounds -> slice ids) and the query's chain (h, r ids -> rows) are independent: their loads are issued side by
+    // side and the rows are folded into the query after the slice is staged -- four dependent trips ahead of the first tail
+    // row instead of six.
+    constexpr bool EARLY = SAMPLE && SC::SPLIT_BUILD;
+    // POS_FIRST (fused loss: S == 4, the block is one group): the positive (column 0) is scored ahead of the loop by every
+    // wave from the early loads (wave 0 writes it) and the waves share the negatives, j = 1 + 4 q + s.  With 1 + 256 tails
+    // dealt j = 4 q + s, wave 0 owned a 65th tail: a second chunk -- one more Philox draw, one more exposed round trip and
+    // three dummy rows -- at the end of every block of the launch.
+    constexpr bool POS_FIRST = SAMPLE && LOSS && SC::SPLIT_BUILD;
+    bool bad = false;
+    int h = 0, r = 0;
+    SC sc;
+    R hh[EARLY ? MT::NH : 1], rr[EARLY ? MT::NR : 1], tpos[POS_FIRST ? MT::NT : 1];
     uint32_t* bits = nullptr;
     bool bad_key = false;
     int64_t ulo = 0, uhi = 0;  // the key's slice of the used-set CSR
     if constexpr (SAMPLE) {
         const int64_t key = sa.keys[b];
+        int64_t hid = 0, rid = 0, pid = 0;
+        if constexpr (EARLY) hid = h_idx[b], rid = r_idx ? r_idx[b] : r_fixed;
+        if constexpr (POS_FIRST) pid = t_idx[b * tsb];
         bad_key = key < 0 || key >= sa.n_key_space;
-        if (!bad_key) ulo = sa.used_ptr[key], uhi = sa.used_ptr[key + 1];
+        // branch-free (a load under a divergent branch is waited for on the spot, and with it everything issued before it)
+        const int64_t kk = bad_key ? 0 : key;
+        ulo = sa.used_ptr[kk], uhi = sa.used_ptr[kk + 1];
+        if constexpr (EARLY) {
+            h = clamp_row_flag(hid, d.n_head, bad);
+            r = clamp_row_flag(rid, d.n_rel, bad);
+            sc.issue(d, h, r, gl, hh, rr);
+        }
+        if constexpr (POS_FIRST) {
+            const int tp = clamp_row_flag(pid, d.n_tail, bad);
+#pragma unroll
+            for (int kx = 0; kx < MT::NT; ++kx) tpos[kx].load_raw(d.tail[kx] + (size_t)tp * d.dim, d.dim, gl);
+        }
+        if (bad_key) ulo = uhi = 0;
         // sa.words == 0: a value space beyond the LDS bitmap (> 65 536 ids: Yelp2018's entities, HBM-sized tables); the
         // draws then test membership by binary search in the key's sorted slice, as hw_neg_sample's generic kernel does
         if (sa.words > 0 && S == 4) {
@@ -136,19 +169,38 @@ __global__ __launch_bounds__(256) void kge_score_grouped_kernel(
         return a < uhi && sa.used_idx[a] == id;
     };
 
-    bool bad = false;
-    const int h = clamp_row_flag(h_idx[b], d.n_head, bad);
-    const int r = clamp_row_flag(r_idx ? r_idx[b] : r_fixed, d.n_rel, bad);
-    SC sc;
-    sc.template build<false>(d, h, r, gl, nullptr, nullptr);
+    if constexpr (EARLY) {
+        sc.template fold<false>(d.dim, gl, hh, rr, nullptr, nullptr);
+    } else {
+        h = clamp_row_flag(h_idx[b], d.n_head, bad);
+        r = clamp_row_flag(r_idx ? r_idx[b] : r_fixed, d.n_rel, bad);
+        sc.template build<false>(d, h, r, gl, nullptr, nullptr);
+    }
 
     const int64_t* __restrict__ tb = t_idx + b * tsb;
     float* __restrict__ ob = out + b * osb;
+    if constexpr (POS_FIRST) {
+        // the positive: slot 0 of a four-row reduction whose other slots are zero (x + 0 is exact: the score a loop trip
+        // would have produced, whatever slot it had there)
+        float p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = 0.f;
+        float aux = 0.f;
+        if constexpr (MT::TWO_PASS) aux = group_sum<G>(sc.template pre<true>(tpos, d.dim, gl));
+        p[0] = sc.template partial<true>(tpos, d.eps, d.dim, gl, aux);
+        int which;
+        const float tot = group_reduce_multi<G, U>(p, gl, which);
+        if (s == 0 && sub == 0 && which == 0 && (gl & (G / U - 1)) == 0) {
+            const float sv = SC::finalize(tot, d.margin);
+            ob[0] = sv;
+            sh_scores[0] = sv;
+        }
+    }
 
     // This wave's tails, in processing order: q = 0, 1, ... -> j(q) = ((q / NS) * S + s) * NS + q % NS.
     // Lane l prefetches the id of tail q = chunk * 64 + l (one coalesced-ish load per 64 tails, off the
     // critical path), the row loads then pick their id with a cross-lane read.
-    auto j_of = [&](int q) { return ((q / NS) * S + s) * NS + (q % NS); };
+    auto j_of = [&](int q) { return ((q / NS) * S + s) * NS + (q % NS) + (POS_FIRST ? 1 : 0); };
     for (int q0 = 0; j_of(q0) < ntail; q0 += HW_WAVE) {  // wave-uniform: j_of is monotone in q for q % NS == 0
         const int jq = j_of(q0 + lane);
         int tpre = 0;
