@@ -15,6 +15,12 @@
 
 namespace hw {
 
+// The wave's number inside its block, read from lane 0: a scalar for the compiler too.  Everything derived from it (the row or
+// task a wave works on, that row's ids, bounds and base addresses) then lives in SGPRs and is fetched by scalar loads instead
+// of 64 equal lanes of vector registers and vector loads (fused RotatE scorer: 79 -> 61 VGPRs from this alone).
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One 32-bit word of the Philox4x32-10 stream keyed by `seed`: word idx & 3 of block (idx >> 2, offset).
@@ -325,6 +331,38 @@ inline RowShape row_shape(int dim, bool allow_vec) {
         s.NE = dim <= 64 ? 1 : (dim <= 256 ? 4 : 16);
     }
     return s;
+}
+
+// Stream-ordered fill of a buffer with a byte value, as a KERNEL launch (what hipMemsetAsync is for, without being one).
+// Why not hipMemsetAsync: a training step captured in a HIP graph turns it into a memset node, and on this stack a replayed
+// memset node was seen to run out of order with the kernel nodes around it -- the relation-replica scratch of
+// hw_kge_grad_grouped (zeroed, accumulated into, reduced) came back with the bytes of an EARLIER kernel's temporaries that
+// shared its pool block, once in ~6 processes and then at a fixed replay (tools/ref_layout_stress.py --graph --poison:
+// relation row NaN at replay 67 / 77).  A kernel node is ordered like every other kernel of the capture.
+// bytes must be a multiple of 4 (every caller fills float / int32 / 64-bit arrays).
+static __global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t v) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if ((((uintptr_t)p) & 15) == 0) {
+        uint4* __restrict__ p4 = reinterpret_cast<uint4*>(p);
+        const size_t n4 = n_words >> 2;
+        for (size_t q = i; q < n4; q += stride) p4[q] = uint4{v, v, v, v};
+        for (size_t q = (n4 << 2) + i; q < n_words; q += stride) p[q] = v;
+        return;
+    }
+    for (; i < n_words; i += stride) p[i] = v;
+}
+
+inline hipError_t fill_bytes_async(void* p, int byte_value, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes & 3) return hipErrorInvalidValue;
+    const uint32_t b = (uint32_t)(byte_value & 0xff), v = b | (b << 8) | (b << 16) | (b << 24);
+    const size_t n_words = bytes >> 2;
+    size_t blocks = (n_words / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n_words, v);
+    return hipGetLastError();
 }
 
 }  // namespace hw

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void kge_grad_grouped_kernel(
     using R = Row<G, NE, false>;
 
     const int gl = threadIdx.x & (HW_WAVE - 1);
-    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + (threadIdx.x / HW_WAVE);
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + wave_in_block();
     if (task >= n_groups * S) return;
     const int64_t b = task / S;
     const int s = (int)(task % S);
@@ -377,7 +377,7 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     float* replicas =
         (!gq && desc->model != HW_RESCAL && !r_idx && rel_workspace && grads->rel[0] && n_tasks >= 256) ? rel_workspace
                                                                                                           : nullptr;
-    if (replicas) (void)hipMemsetAsync(replicas, 0, sizeof(float) * REL_REPLICAS * n_rel_tab * rel_row_len, st);
+    if (replicas) (void)hw::fill_bytes_async(replicas, 0, sizeof(float) * REL_REPLICAS * n_rel_tab * rel_row_len, st);
 #define CALL(MODEL, NE_)                                                                                           \
     hipLaunchKernelGGL((kge_grad_grouped_kernel<MODEL, NE_>), dim3((unsigned)n_blocks), dim3(256), 0, st, *desc,     \
                        *grads, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, g,          \

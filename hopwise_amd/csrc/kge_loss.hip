@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void self_adv_kernel(const float* __restrict__
                                                        float alpha, float inv_b, float* __restrict__ gsc,
                                                        float* __restrict__ group_loss) {
     const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave_in_block();
     if (b >= n_groups) return;
     const float* __restrict__ row = sc + b * n_cols;
     float mx = -INFINITY;

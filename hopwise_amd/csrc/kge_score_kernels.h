@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, (SAMPLE && NE <= 4) ? 8 : 1) void kge_score_gr
     const int sub = lane / G, gl = lane % G;
     // the wave's number read from lane 0: task, group, split, the group's ids and slice bounds and every row base derived
     // from them are then scalars for the compiler too (scalar loads, SGPRs) instead of 64 equal lanes of vector registers
-    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + __builtin_amdgcn_readfirstlane(threadIdx.x / HW_WAVE);
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + wave_in_block();
     if (task >= n_groups * S) return;  // wave-uniform
     if constexpr (SAMPLE && LOSS) {
         // chained launches: block 0 (all four waves live: S == 4) first adds the group terms the previous launch on this
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void kge_score_grouped_xcd_kernel(
     __shared__ int sel_j[4][128];
 
     const int lane = threadIdx.x & (HW_WAVE - 1);
-    const int wave = threadIdx.x / HW_WAVE;
+    const int wave = wave_in_block();
     const int sub = lane / G, gl = lane % G;
     const int part = blockIdx.x & 7;
     const int64_t b = (int64_t)(blockIdx.x >> 3) * 4 + wave;
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void kge_full_sort_kernel(
     const int sub = lane / G, gl = lane % G;
     const int n_hb = (n_heads + HB - 1) / HB;
     const int64_t n_chunks = (hi - lo + chunk - 1) / chunk;
-    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + (threadIdx.x / HW_WAVE);
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HW_WAVE) + wave_in_block();
     if (task >= n_chunks * n_hb) return;
     const int hb = (int)(task % n_hb);
     const int64_t c = task / n_hb;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void kge_full_sort_topk_kernel(
     __shared__ float lds_sc[4][HB][FS_SUB];
 
     const int lane = threadIdx.x & (HW_WAVE - 1);
-    const int wave = threadIdx.x / HW_WAVE;
+    const int wave = wave_in_block();
     const int sub = lane / G, gl = lane % G;
     const int n_hb = (n_heads + HB - 1) / HB;
     const int64_t task = (int64_t)blockIdx.x * 4 + wave;
@@ -931,7 +931,7 @@ static int full_sort_topk_impl(const hw_kge_desc* desc, const int64_t* h_idx, co
     const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
     hipStream_t st = (hipStream_t)stream;
     HW_CLEAR_ERR();
-    (void)hipMemsetAsync(bits, 0, (size_t)n_heads * words * 4, st);
+    (void)hw::fill_bytes_async(bits, 0, (size_t)n_heads * words * 4, st);
     if (n_hist > 0)
         hipLaunchKernelGGL(build_mask_bits_kernel, dim3((unsigned)((n_hist + 255) / 256)), dim3(256), 0, st, hist_rows,
                            hist_cols, n_hist, n_heads, n, words, bits);

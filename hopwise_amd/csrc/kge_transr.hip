@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void project_rows_grad_e_kernel(const float* _
                                                                   const float* __restrict__ gp, float* __restrict__ ge) {
     using R = Row<64, NE, false>;
     const int gl = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = (int64_t)blockIdx.x * 4 + wave_in_block();
     if (i >= n) return;
     const int r = clamp_row(r_idx ? r_idx[i] : r_fixed, n_rel, nullptr);
     const int e = clamp_row(e_idx[i], n_rows_table, nullptr);

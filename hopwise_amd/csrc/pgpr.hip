@@ -36,7 +36,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 
 // exclusive scan over the block; `total` = block sum.  `wsum` is 4 ints of LDS.
 __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int& total) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = wave_in_block(), lane = threadIdx.x & 63;
     const int inc = wave_incl_scan(v);
     __syncthreads();
     if (lane == 63) wsum[w] = inc;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
     const int act_dim = max_acts + 1;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * 4 + wave_in_block(); row < n_rows; row += gridDim.x * 4) {
         PathRec rec;
         rec.load(paths, row);
         const int uid = rec.uid, len = rec.len;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
     const int act_dim = max_acts + 1;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int it = blockIdx.x * 4 + (threadIdx.x >> 6); it < n_rows; it += gridDim.x * 4) {
+    for (int it = blockIdx.x * 4 + wave_in_block(); it < n_rows; it += gridDim.x * 4) {
         const int row = list ? list[it] : it;
         if (n_acts[row] >= 0) continue;  // wave-uniform: finished by the first pass
         PathRec rec;
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void pgpr_layer1_lookup_kernel(L1Tables t, con
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int t = 0; t < L1_MAX_H / 256; ++t) kept[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int chunk = blockIdx.x * 4 + (threadIdx.x >> 6); chunk * run < n_rows; chunk += gridDim.x * 4) {
+    for (int chunk = blockIdx.x * 4 + wave_in_block(); chunk * run < n_rows; chunk += gridDim.x * 4) {
         for (int row_v = chunk * run; row_v < min(n_rows, (chunk + 1) * run); ++row_v) {
             // the path record in one go, through the scalar unit (the row index is wave-uniform; saying so lets the compiler
             // use s_load): indexing the record by a length read from it would chain three memory round trips per row
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(256) void policy_topk_kernel(const float* __restric
                                                           float* __restrict__ probs_out) {
     const int n_rows = n_rows_ptr[0];
     const int lane = threadIdx.x & 63;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * 4 + wave_in_block(); row < n_rows; row += gridDim.x * 4) {
         const int na = n_acts[row];
         const float* __restrict__ lr = logits + (size_t)row * ld;
         float x[NPL];
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
                                                                float* __restrict__ probs_out) {
     const int n_rows = n_rows_ptr[0];
     const int lane = threadIdx.x & 63;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += gridDim.x * 4) {
+    for (int row = blockIdx.x * 4 + wave_in_block(); row < n_rows; row += gridDim.x * 4) {
         const int na = n_acts[row];
         const float* __restrict__ lr = logits + (size_t)row * ld;
         float x[4];
@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const
     __shared__ __attribute__((aligned(16))) int rec_lds[4][64 * PATH_INTS];
     __shared__ float prob_lds[4][64 * 3];
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_in_block();
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     const int64_t n_iter = (total + 63) / 64;
     for (int64_t it = (int64_t)blockIdx.x * 4 + w; it < n_iter; it += (int64_t)gridDim.x * 4) {  // wave-uniform trips
@@ -1266,7 +1266,7 @@ extern "C" int hw_pgpr_init_paths(const int64_t* users, int64_t n_users_in_batch
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int n = (int)n_users_in_batch;
-    if (probs && n > 0) (void)hipMemsetAsync(probs, 0, sizeof(float) * 3 * (size_t)n, st);
+    if (probs && n > 0) (void)hw::fill_bytes_async(probs, 0, sizeof(float) * 3 * (size_t)n, st);
     hipLaunchKernelGGL(pgpr_init_paths_kernel, dim3(n > 0 ? (n + 255) / 256 : 1), dim3(256), 0, st, users, n, paths,
                        n_rows);
     return HW_LAUNCH_RC();
@@ -1357,7 +1357,7 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_u
     const int32_t* lists[3] = {nullptr, nullptr, nullptr};
     const int32_t* lens[3] = {nullptr, nullptr, nullptr};
     if (work) {
-        (void)hipMemsetAsync(work, 0, 4 * sizeof(int32_t), st);
+        (void)hw::fill_bytes_async(work, 0, 4 * sizeof(int32_t), st);
         for (int c = 0; c < 3; ++c) lists[c] = work + 4 + (int64_t)c * max_rows, lens[c] = work + c;
     }
     {

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(float* __restrict__ table, int64_t n_table, int dim,
                                                                const int64_t* __restrict__ idx, int64_t n,
                                                                const float* __restrict__ src) {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = wave_in_block(), lane = threadIdx.x & 63;
     for (int64_t i = (int64_t)blockIdx.x * 4 + w; i < n; i += (int64_t)gridDim.x * 4) {
         const int64_t r = idx[i];
         if (r < 0 || r >= n_table) continue;

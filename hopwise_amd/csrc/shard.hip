@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void shard_mark_kernel(const int64_t* __restri
 
 // block-wide exclusive scan of one int per thread (1024 threads = 16 waves); returns the exclusive prefix, total in `sum`
 __device__ __forceinline__ int block_exclusive_scan(int v, int* lds16, int& sum) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_in_block();
     int incl = v;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -151,7 +151,7 @@ extern "C" int hw_shard_plan(const int64_t* ids, int64_t n, int64_t n_rows, int3
     uint32_t* bitmap = (uint32_t*)workspace;
     int32_t* prefix = (int32_t*)(bitmap + seg_words * n_ranks);
     HW_CLEAR_ERR();
-    if (hipMemsetAsync(bitmap, 0, seg_words * n_ranks * sizeof(uint32_t), st) != hipSuccess) return HW_ERR_LAUNCH;
+    if (hw::fill_bytes_async(bitmap, 0, seg_words * n_ranks * sizeof(uint32_t), st) != hipSuccess) return HW_ERR_LAUNCH;
     int64_t grid = (n + 255) / 256;
     if (grid > 4096) grid = 4096;
     if (n > 0)

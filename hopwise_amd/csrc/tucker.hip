@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
                                                                   float* __restrict__ gx, float* __restrict__ gw,
                                                                   int64_t w_stride, const int64_t* __restrict__ w_index) {
     const int b = blockIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = wave_in_block(), lane = threadIdx.x & 63;
     const float* __restrict__ wb = w + (size_t)(w_index ? w_index[b] : b) * w_stride;
     const float* __restrict__ mb = MODE == 1 ? mask + (size_t)b * d * d : nullptr;
     const float* __restrict__ gob = go + (size_t)b * d;
@@ -484,7 +484,7 @@ static int shared_grad(int mode, const float* x, const float* w, const int64_t* 
     const dim3 grid((unsigned)((dim + 3) / 4), (unsigned)chunks);
     const float p = mode >= 2 ? drop_p : 0.f;
     if (w_index) {  // one matrix per relation: atomic flushes into gw (zeroed here)
-        if (hipMemsetAsync(gw, 0, (size_t)n_mats * n * sizeof(float), st) != hipSuccess) return HW_ERR_LAUNCH;
+        if (hw::fill_bytes_async(gw, 0, (size_t)n_mats * n * sizeof(float), st) != hipSuccess) return HW_ERR_LAUNCH;
 #define GWI(M) hipLaunchKernelGGL((tucker_gw_indexed_kernel<M>), grid, dim3(256), 0, st, x, mask, gout, order, w_index, n_mats, batch, dim, p, seed, offset, gw)
         if (mode == 3) GWI(3);
         else if (mode == 2) GWI(2);
