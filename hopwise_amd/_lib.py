@@ -350,6 +350,11 @@ SIGNATURES = {
         [C.POINTER(CafeModule), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.c_int32, c_f32p, C.c_int64, C.c_int32, c_i64p,
          c_i64p, c_i64p, c_f32p, c_f32p, C.c_int64, C.c_void_p],
     ),
+    "hw_cafe_modules_forward_fused": (
+        C.c_int,
+        [C.POINTER(CafeModule), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32, c_f32p, C.c_int64,
+         C.c_int32, c_i64p, c_i64p, c_i64p, c_f32p, C.c_void_p],
+    ),
     "hw_cafe_collect": (
         C.c_int,
         [C.c_void_p, c_i32p, c_i64p, c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, c_i32p,

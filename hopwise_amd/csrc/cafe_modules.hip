@@ -53,6 +53,128 @@ __global__ __launch_bounds__(256) void cafe_scatter_rows_kernel(const float* __r
     }
 }
 
+// ---- the fused form: ONE launch per level ---------------------------------------------------------------------------------
+// A module application is a 2d -> 256 -> (2d ->) d perceptron over ~256 rows: 60 MFLOP.  As GEMM / batch-norm / glue launches
+// it is 8 launches of 5-25 us per (level, relation) group -- ~100 launches and ~1.1 ms of a 2.0 ms run_program call, none of
+// them doing more than waiting for its own first loads.  Here a block takes CF_R rows of one group through the whole module
+// with the activations in LDS (transposed: [column][row], so that a k-step reads its CF_R inputs as two broadcast
+// ds_read_b128) and one output column per thread; the weights are read in the TRANSPOSED layout [in, out] (one coalesced
+// 1 KB row per k-step, L2-resident: 0.5 MB per module), which the caller prepares once per weight version.  Groups of one
+// level are independent (they read node vectors of earlier levels only): one launch covers up to CF_MAXG of them.
+// Arithmetic: fp32 FMA chains in k order (the loop path runs the products as three-way bf16 splits on the matrix pipes; both
+// are fp32-level, they differ in summation order), batch norm as fmaf(x, rs g, beta - mu rs g) like hw_batchnorm1d_forward.
+constexpr int CF_R = 8, CF_MAXG = 8, CF_H = 256;
+
+struct CfLevel {
+    int32_t n_groups;
+    int32_t blk0[CF_MAXG + 1];  // first block of each group
+    int64_t r0[CF_MAXG], n[CF_MAXG];
+    hw_cafe_module mod[CF_MAXG];
+};
+
+// acc[r] += sum_k act[k][r] * wt[k * ldw + c] over k < K (act: LDS [K][CF_R])
+__device__ __forceinline__ void cf_dot(const float (*act)[CF_R], int K, const float* __restrict__ wt, int ldw, int c,
+                                       float (&acc)[CF_R]) {
+    int k = 0;
+    for (; k + 4 <= K; k += 4) {
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = wt[(size_t)(k + u) * ldw + c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&act[k + u][0]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&act[k + u][4]);
+            acc[0] = fmaf(a0.x, w[u], acc[0]), acc[1] = fmaf(a0.y, w[u], acc[1]);
+            acc[2] = fmaf(a0.z, w[u], acc[2]), acc[3] = fmaf(a0.w, w[u], acc[3]);
+            acc[4] = fmaf(a1.x, w[u], acc[4]), acc[5] = fmaf(a1.y, w[u], acc[5]);
+            acc[6] = fmaf(a1.z, w[u], acc[6]), acc[7] = fmaf(a1.w, w[u], acc[7]);
+        }
+    }
+    for (; k < K; ++k) {
+        const float w = wt[(size_t)k * ldw + c];
+#pragma unroll
+        for (int r = 0; r < CF_R; ++r) acc[r] = fmaf(act[k][r], w, acc[r]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cafe_level_kernel(CfLevel L, const float* __restrict__ user_vec, int64_t n_user_rows, int d,
+                                                         const int64_t* __restrict__ eh_idx, const int64_t* __restrict__ uv_idx,
+                                                         const int64_t* __restrict__ out_rows, float* vec_all) {
+    __shared__ __attribute__((aligned(16))) float xT[CF_H][CF_R], h1T[CF_H][CF_R], h2T[CF_H][CF_R];
+    int g = 0;
+    while (g + 1 < L.n_groups && (int)blockIdx.x >= L.blk0[g + 1]) ++g;  // block-uniform
+    const hw_cafe_module& m = L.mod[g];
+    const int64_t rb = L.r0[g] + (int64_t)((int)blockIdx.x - L.blk0[g]) * CF_R;
+    const int64_t left = L.r0[g] + L.n[g] - rb;
+    const int nr = left < CF_R ? (int)left : CF_R;
+    const int tid = threadIdx.x, d2 = 2 * d;
+    // feature[r] = [ eh(r) | uv(r) ], transposed into LDS; rows past the group's end are zero
+    // (vec_all is not __restrict__: other blocks of this launch write rows of it -- rows no block of this level reads)
+    for (int i = tid; i < CF_R * d2; i += 256) {
+        const int r = i / d2, c = i - r * d2;
+        float v = 0.f;
+        if (r < nr) {
+            if (c < d) {
+                const int64_t e = eh_idx[rb + r];
+                v = e < n_user_rows ? user_vec[e * d + c] : vec_all[(e - n_user_rows) * d + c];
+            } else {
+                v = user_vec[uv_idx[rb + r] * d + (c - d)];
+            }
+        }
+        xT[c][r] = v;
+    }
+    __syncthreads();
+    {  // fc1 + ReLU, bn1 (evaluation): 256 columns, one per thread
+        const int c = tid;
+        float acc[CF_R];
+        const float b = m.b1[c];
+#pragma unroll
+        for (int r = 0; r < CF_R; ++r) acc[r] = b;
+        cf_dot(xT, d2, m.w1, CF_H, c, acc);
+        const float rs = 1.f / sqrtf(m.bn1_var[c] + m.bn1_eps), gm = m.bn1_weight ? m.bn1_weight[c] : 1.f;
+        const float scale = rs * gm, shift = (m.bn1_bias ? m.bn1_bias[c] : 0.f) - m.bn1_mean[c] * rs * gm;
+#pragma unroll
+        for (int r = 0; r < CF_R; ++r) h1T[c][r] = fmaf(fmaxf(acc[r], 0.f), scale, shift);
+    }
+    __syncthreads();
+    if (m.deep) {
+        if (tid < d2) {  // relu(fc2(x) + feature), bn2
+            const int c = tid;
+            float acc[CF_R];
+            const float b = m.b2[c];
+#pragma unroll
+            for (int r = 0; r < CF_R; ++r) acc[r] = b;
+            cf_dot(h1T, CF_H, m.w2, d2, c, acc);
+            const float rs = 1.f / sqrtf(m.bn2_var[c] + m.bn2_eps), gm = m.bn2_weight ? m.bn2_weight[c] : 1.f;
+            const float scale = rs * gm, shift = (m.bn2_bias ? m.bn2_bias[c] : 0.f) - m.bn2_mean[c] * rs * gm;
+#pragma unroll
+            for (int r = 0; r < CF_R; ++r) h2T[c][r] = fmaf(fmaxf(acc[r] + xT[c][r], 0.f), scale, shift);
+        }
+        __syncthreads();
+        if (tid < d) {  // fc3 -> the node's vector
+            const int c = tid;
+            float acc[CF_R];
+            const float b = m.b3[c];
+#pragma unroll
+            for (int r = 0; r < CF_R; ++r) acc[r] = b;
+            cf_dot(h2T, d2, m.w3, d, c, acc);
+#pragma unroll
+            for (int r = 0; r < CF_R; ++r)
+                if (r < nr) vec_all[out_rows[rb + r] * d + c] = acc[r];
+        }
+    } else if (tid < d) {  // fc2(x) + eh
+        const int c = tid;
+        float acc[CF_R];
+        const float b = m.b2[c];
+#pragma unroll
+        for (int r = 0; r < CF_R; ++r) acc[r] = b;
+        cf_dot(h1T, CF_H, m.w2, d, c, acc);
+#pragma unroll
+        for (int r = 0; r < CF_R; ++r)
+            if (r < nr) vec_all[out_rows[rb + r] * d + c] = acc[r] + xT[c][r];
+    }
+}
+
 static unsigned grid_for(int64_t n) {
     int64_t g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -136,5 +258,45 @@ extern "C" int hw_cafe_modules_forward(const hw_cafe_module* mods, const int32_t
         if (rc) return rc;
     }
     (void)d1;
+    return HW_OK;
+}
+
+extern "C" int hw_cafe_modules_forward_fused(const hw_cafe_module* mods, const int32_t* group_mod, const int64_t* group_ptr,
+                                             const int32_t* group_level, int32_t n_groups, const float* user_vec,
+                                             int64_t n_user_rows, int32_t dim, const int64_t* eh_idx, const int64_t* uv_idx,
+                                             const int64_t* out_rows, float* vec_all, void* stream) {
+    if (!mods || !group_mod || !group_ptr || !group_level || n_groups < 0 || !user_vec || !eh_idx || !uv_idx || !out_rows ||
+        !vec_all || dim < 1)
+        return HW_ERR_INVALID_ARG;
+    if (2 * dim > CF_H) return HW_ERR_UNSUPPORTED;  // one output column per thread: the caller takes the launch-per-layer path
+    hipStream_t st = (hipStream_t)stream;
+    int g = 0;
+    while (g < n_groups) {
+        CfLevel L{};
+        int blocks = 0;
+        const int level = group_level[g];
+        while (g < n_groups && group_level[g] == level && L.n_groups < CF_MAXG) {
+            const int64_t n = group_ptr[g + 1] - group_ptr[g];
+            if (n < 0) return HW_ERR_INVALID_ARG;
+            const hw_cafe_module& m = mods[group_mod[g]];
+            if (!m.w1 || !m.b1 || !m.w2 || !m.b2 || !m.bn1_mean || !m.bn1_var ||
+                (m.deep && (!m.w3 || !m.b3 || !m.bn2_mean || !m.bn2_var)))
+                return HW_ERR_INVALID_ARG;
+            if (n > 0) {
+                if (blocks + (n + CF_R - 1) / CF_R > INT32_MAX) return HW_ERR_INVALID_ARG;
+                const int q = L.n_groups++;
+                L.blk0[q] = blocks, L.r0[q] = group_ptr[g], L.n[q] = n, L.mod[q] = m;
+                blocks += (int)((n + CF_R - 1) / CF_R);
+                L.blk0[q + 1] = blocks;
+            }
+            ++g;
+        }
+        if (blocks == 0) continue;
+        HW_CLEAR_ERR();
+        hipLaunchKernelGGL(cafe_level_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L, user_vec, n_user_rows, (int)dim, eh_idx,
+                           uv_idx, out_rows, vec_all);
+        const int rc = HW_LAUNCH_RC();
+        if (rc) return rc;
+    }
     return HW_OK;
 }

@@ -255,10 +255,23 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             np.bitwise_or.at(bits[i], pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
         return torch.from_numpy(bits.view(np.int32)).to(dev)
 
-    def _module_structs(self, mods, user_vec):
+    def _transposed(self, w):
+        """[in, out] copy of an nn.Linear weight for hw_cafe_modules_forward_fused, cached per (storage, version): made once
+        per weight version (evaluation reads the same weights call after call; an optimizer step bumps the version)."""
+        cache = self.__dict__.setdefault("_wt_cache", {})
+        key = id(w)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == (w.data_ptr(), w._version):
+            return hit[1]
+        wt = w.detach().t().contiguous()
+        cache[key] = ((w.data_ptr(), w._version), wt)
+        return wt
+
+    def _module_structs(self, mods, user_vec, transposed=False):
         """ctypes table of the relation modules' parameters for hw_cafe_modules_forward, or None when the C++ loop does not
         apply (training mode, gradients wanted, dropout patched by a test, non-fp32 / host tensors, embedding size % 4).
-        Pointers are read per call (an optimizer step may have replaced storage); nothing is copied."""
+        Pointers are read per call (an optimizer step may have replaced storage); nothing is copied -- except with
+        ``transposed`` (the fused form): w1 / w2 / w3 then address cached [in, out] copies (:meth:`_transposed`)."""
         from .._lib import CafeModule
 
         if (torch.is_grad_enabled() or self.training or not user_vec.is_cuda or user_vec.dtype != torch.float32
@@ -275,6 +288,8 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
                 return None
             for name, p in zip(("w1", "b1", "bn1_weight", "bn1_bias", "bn1_mean", "bn1_var", "w2", "b2", "bn2_weight", "bn2_bias",
                                 "bn2_mean", "bn2_var", "w3", "b3"), ps):
+                if transposed and p is not None and name in ("w1", "w2", "w3"):
+                    p = self._transposed(p)
                 setattr(arr[i], name, p.data_ptr() if p is not None else None)
             arr[i].bn1_eps, arr[i].bn2_eps = float(m.bn1.eps), float(m.bn2.eps) if deep else 0.0
             arr[i].deep = int(deep)
@@ -369,8 +384,21 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             pos += n
             return idx_all[pos - n : pos]
 
-        structs = self._module_structs(mods, user_vec) if plan else None
-        if structs is not None:
+        # HW_CAFE_MODULES: 2 (default) = one fused launch per level (cafe_level_kernel: fp32 FMA chains, equal to the others to
+        # fp32 rounding); 1 = the GEMM / batch-norm launches of the loop below issued from C++ (bit-identical to it); 0 = the
+        # loop below
+        mode = os.environ.get("HW_CAFE_MODULES", "2")
+        structs, done = None, False
+        if plan and mode == "2" and 2 * user_vec.shape[1] <= 256:
+            structs = self._module_structs(mods, user_vec, transposed=True)
+            if structs is not None:
+                done = P.cafe_modules_forward_fused(structs, [j for _, j, _ in plan], offs, [dep for dep, _, _ in plan], user_vec,
+                                                    eh_all, uv_all, row_all, vec_all)
+        if not done:
+            structs = self._module_structs(mods, user_vec) if plan else None
+        if done:
+            pass
+        elif structs is not None:
             # evaluation, fp32 on the device: the whole (level, relation) loop from one host call (csrc/cafe_modules.hip: the
             # same GEMM / batch-norm launches, issued from C++; bit-identical to the loop below)
             P.cafe_modules_forward(structs, [j for _, j, _ in plan], offs, user_vec, eh_all, uv_all, row_all, vec_all)

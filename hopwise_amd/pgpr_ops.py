@@ -341,6 +341,22 @@ def cafe_modules_forward(mod_structs, group_mod, group_ptr, user_vec, eh_idx, uv
           "hw_cafe_modules_forward")
 
 
+def cafe_modules_forward_fused(mod_structs, group_mod, group_ptr, group_level, user_vec, eh_idx, uv_idx, out_rows, vec_all):
+    """hw_cafe_modules_forward_fused: one launch per level; ``mod_structs`` carries TRANSPOSED weights.  Returns False when the
+    library refuses the shape (2 * dim > 256): the caller then takes hw_cafe_modules_forward."""
+    lib = _lib.load()
+    n_groups = len(group_mod)
+    gm = (C.c_int32 * max(n_groups, 1))(*[int(x) for x in group_mod])
+    gp = (C.c_int64 * (n_groups + 1))(*[int(x) for x in group_ptr])
+    gl = (C.c_int32 * max(n_groups, 1))(*[int(x) for x in group_level])
+    rc = lib.hw_cafe_modules_forward_fused(mod_structs, gm, gp, gl, n_groups, _ptr(user_vec), user_vec.shape[0], user_vec.shape[1],
+                                           _ptr(eh_idx), _ptr(uv_idx), _ptr(out_rows), _ptr(vec_all), _stream())
+    if rc == -2:  # HW_ERR_UNSUPPORTED
+        return False
+    check(rc, "hw_cafe_modules_forward_fused")
+    return True
+
+
 def cafe_overflow_check(rec):
     """Raise if hw_cafe_collect met a user with more leaf paths than it ranks (reads one int from the device: a sync)."""
     seen = int(rec["overflow"].item())

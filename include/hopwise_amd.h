@@ -619,6 +619,17 @@ int hw_cafe_modules_forward(const hw_cafe_module* mods, const int32_t* group_mod
                             const int64_t* uv_idx, const int64_t* out_rows, float* vec_all, float* workspace,
                             int64_t workspace_floats, void* stream);
 
+/* The same module applications with ONE launch per level (csrc/cafe_modules.hip, cafe_level_kernel): a block takes eight rows
+ * of a group through the whole module with the activations in LDS.  Differences to hw_cafe_modules_forward: the weight
+ * pointers of `mods` (w1, w2, w3) address TRANSPOSED copies [in, out] (prepared by the caller once per weight version);
+ * group_level[g] (host, non-decreasing) is the depth of group g's nodes -- groups of one level only read node vectors of
+ * earlier levels and share a launch; no workspace.  2 * dim <= 256, else HW_ERR_UNSUPPORTED.  Products are fp32 FMA chains
+ * in k order (the launch-per-layer form runs them as three-way bf16 splits): equal to it to fp32 rounding, not bit for bit. */
+int hw_cafe_modules_forward_fused(const hw_cafe_module* mods, const int32_t* group_mod, const int64_t* group_ptr,
+                                  const int32_t* group_level, int32_t n_groups, const float* user_vec, int64_t n_user_rows,
+                                  int32_t dim, const int64_t* eh_idx, const int64_t* uv_idx, const int64_t* out_rows,
+                                  float* vec_all, void* stream);
+
 /* collect_results + the ranking loop of run_program (cafe.py:417-441, :859-867) on hw_cafe_execute's output, one user
  * per task: entries = the paths of the task's leaf nodes in `leaf_nodes` order (int32 [n_tasks, n_leaves], node index
  * inside the task, -1 = absent), score = product of the path's float32 log-probs left to right.  Per item the entry with

@@ -303,13 +303,18 @@ def test_module_loop_in_cpp_equals_the_python_loop(monkeypatch):
     z, orc, m = build()
     users = torch.from_numpy(z["users"])
     out = {}
-    for mode in ("1", "0"):
+    for mode in ("2", "1", "0"):
         monkeypatch.setenv("HW_CAFE_MODULES", mode)
         scores, rec, leaves, _ = m.run_program_device(users)
         out[mode] = (scores.cpu(), {k: v.cpu() for k, v in rec.items()})
     assert torch.equal(out["1"][0].nan_to_num(-1e30), out["0"][0].nan_to_num(-1e30))
     for k in ("count", "item", "score", "leaf", "ids"):
         assert torch.equal(out["1"][1][k], out["0"][1][k]), k
+    # the fused form (one launch per level, fp32 FMA chains instead of the split GEMM): same items and paths, scores to fp32
+    # rounding of the module outputs
+    for k in ("count", "item", "leaf", "ids"):
+        assert torch.equal(out["2"][1][k], out["0"][1][k]), k
+    torch.testing.assert_close(out["2"][0].nan_to_num(-1e30), out["0"][0].nan_to_num(-1e30), rtol=2e-5, atol=2e-5)
     # and the C++ loop really ran: the struct table exists for this model in evaluation mode
     monkeypatch.setenv("HW_CAFE_MODULES", "1")
     with torch.no_grad():
