@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/hopwise_amd.h"
 
@@ -355,6 +356,10 @@ static __global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __rest
 
 inline hipError_t fill_bytes_async(void* p, int byte_value, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
+    // HW_FILL_MEMSET=1: the hipMemsetAsync this function replaced, kept as a switch so that the replay failure can be shown
+    // with and without it on one tree (tools/ref_layout_stress.py); read once per translation unit
+    static const bool use_memset = [] { const char* e = getenv("HW_FILL_MEMSET"); return e && e[0] == '1'; }();
+    if (use_memset) return hipMemsetAsync(p, byte_value, bytes, st);
     if (bytes & 3) return hipErrorInvalidValue;
     const uint32_t b = (uint32_t)(byte_value & 0xff), v = b | (b << 8) | (b << 16) | (b << 24);
     const size_t n_words = bytes >> 2;

@@ -19,7 +19,9 @@ def test_library_has_no_memset_nodes():
             + glob.glob(os.path.join(ROOT, "hopwise_amd", "csrc", "*.cpp")):
         src = open(f).read()
         code = "\n".join(ln.split("//")[0] for ln in src.splitlines())
-        assert "hipMemsetAsync(" not in code and "hipMemset(" not in code, f
+        # the one call left is the HW_FILL_MEMSET=1 diagnostic switch inside hw::fill_bytes_async itself
+        allowed = 1 if f.endswith("hw_common.h") else 0
+        assert code.count("hipMemsetAsync(") == allowed and "hipMemset(" not in code, f
 
 
 @pytest.mark.gpu
