@@ -342,7 +342,10 @@ extern "C" int hw_cafe_level_loss_grad(const float* logits, int64_t ld, int64_t 
 // its own).  Here: entry e = (leaf ordinal, row) in leaf order; pass 1 takes per item the max of key(score, e) = (orderable
 // score, ~e) and the max of e (global atomics on this user's [n_items] rows); pass 2 keeps the winners' keys in LDS and sorts
 // them (bitonic, descending: score desc, entry asc = the reference's emission order); pass 3 writes one record per winner.
-constexpr int CAFE_MAX_ENTRIES = 4096;
+// The LDS sort holds the WINNERS only (one entry per distinct item reached, compacted): 8 192 keys = 64 KB of dynamic LDS.
+// The reference's executor keeps 5 per node (manual_topk, cafe.py:790), i.e. at most 125 paths per leaf: with the 64 leaves
+// this kernel takes, a user has at most 8 000 entries -- the winner limit cannot be reached under the reference's settings.
+constexpr int CAFE_MAX_WINNERS = 8192;
 constexpr int CAFE_MAX_LEAVES = 64;
 
 __device__ __forceinline__ uint32_t orderable(float s) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(256) void cafe_collect_kernel(const hw_cafe_node* _
                                                            float* __restrict__ rec_score, int32_t* __restrict__ rec_leaf,
                                                            int32_t* __restrict__ rec_ids, int32_t* __restrict__ rec_count,
                                                            int32_t* __restrict__ overflow) {
-    __shared__ unsigned long long keys[CAFE_MAX_ENTRIES];
+    extern __shared__ unsigned long long keys[];  // CAFE_MAX_WINNERS
     __shared__ int pre[CAFE_MAX_LEAVES + 1];
     __shared__ int l_off[CAFE_MAX_LEAVES], l_dep[CAFE_MAX_LEAVES];
     __shared__ int n_win;
@@ -393,12 +396,9 @@ __global__ __launch_bounds__(256) void cafe_collect_kernel(const hw_cafe_node* _
         }
         pre[n_leaves] = acc;
         n_win = 0;
-        if (acc > CAFE_MAX_ENTRIES) atomicMax(overflow, acc);
     }
     __syncthreads();
-    const int n = min(pre[n_leaves], CAFE_MAX_ENTRIES);
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
+    const int n = pre[n_leaves];
     auto entry = [&](int e, int& item, float& score, int& leaf, int& row) {
         int l = 0;
         while (l + 1 < n_leaves && pre[l + 1] <= e) ++l;
@@ -421,22 +421,27 @@ __global__ __launch_bounds__(256) void cafe_collect_kernel(const hw_cafe_node* _
         }
     }
     __syncthreads();
-    for (int e = tid; e < np2; e += 256) {
-        unsigned long long k = 0ull;
-        if (e < n) {
-            int item, leaf, row;
-            float score;
-            entry(e, item, score, leaf, row);
-            if (item >= 0 && item < n_items && score > -INFINITY) {
-                const unsigned long long mine = ((unsigned long long)orderable(score) << 32) | (0xFFFFFFFFu - (uint32_t)e);
-                if (__hip_atomic_load(best + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine) {
-                    k = mine;
-                    atomicAdd(&n_win, 1);
-                }
+    // the winners, compacted (any order: the keys are distinct, the sort below fixes the order)
+    for (int e = tid; e < n; e += 256) {
+        int item, leaf, row;
+        float score;
+        entry(e, item, score, leaf, row);
+        if (item >= 0 && item < n_items && score > -INFINITY) {
+            const unsigned long long mine = ((unsigned long long)orderable(score) << 32) | (0xFFFFFFFFu - (uint32_t)e);
+            if (__hip_atomic_load(best + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine) {
+                const int pos = atomicAdd(&n_win, 1);
+                if (pos < CAFE_MAX_WINNERS) keys[pos] = mine;
             }
         }
-        keys[e] = k;
     }
+    __syncthreads();
+    const int n_win_all = n_win;
+    const bool too_many = n_win_all > CAFE_MAX_WINNERS;  // block-uniform
+    if (too_many && tid == 0) atomicMax(overflow, n_win_all);
+    const int m = too_many ? CAFE_MAX_WINNERS : n_win_all;
+    int np2 = 1;
+    while (np2 < m) np2 <<= 1;
+    for (int i = m + tid; i < np2; i += 256) keys[i] = 0ull;
     __syncthreads();
     for (int size = 2; size <= np2; size <<= 1) {  // bitonic sort, descending
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(256) void cafe_collect_kernel(const hw_cafe_node* _
             __syncthreads();
         }
     }
-    const int nw = min(n_win, max_rec);
+    const int nw = min(m, max_rec);
     if (tid == 0) rec_count[task] = nw;
     for (int j = tid; j < nw; j += 256) {
         const int e = (int)(0xFFFFFFFFu - (uint32_t)(keys[j] & 0xFFFFFFFFull));
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(256) void cafe_collect_kernel(const hw_cafe_node* _
     }
     // a user with more leaf paths than the workgroup ranks (counted into `overflow`): its scores leave as NaN, so that a caller
     // that keeps everything on the device and does not read the counter cannot consume a truncated ranking unnoticed
-    if (pre[n_leaves] > CAFE_MAX_ENTRIES) {
+    if (too_many) {
         __syncthreads();
         for (int i = tid; i < n_items; i += 256) res[i] = __builtin_nanf("");
     }
@@ -489,7 +494,11 @@ extern "C" int hw_cafe_collect(const hw_cafe_node* nodes, const int32_t* node_pt
     if (n_leaves > CAFE_MAX_LEAVES) return HW_ERR_UNSUPPORTED;
     if (n_tasks == 0) return HW_OK;
     HW_CLEAR_ERR();
-    hipLaunchKernelGGL(cafe_collect_kernel, dim3((unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, nodes, node_ptr,
+    constexpr size_t key_bytes = (size_t)CAFE_MAX_WINNERS * sizeof(unsigned long long);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(cafe_collect_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)key_bytes);
+    if (attr != hipSuccess) return HW_ERR_LAUNCH;
+    hipLaunchKernelGGL(cafe_collect_kernel, dim3((unsigned)n_tasks), dim3(256), key_bytes, (hipStream_t)stream, nodes, node_ptr,
                        slot_ptr, ids, vals, counts, leaf_nodes, (int)n_leaves, (int)n_items,
                        (unsigned long long*)best_ws, last_ws, results, (int)max_rec, rec_item, rec_score, rec_leaf, rec_ids,
                        rec_count, overflow);

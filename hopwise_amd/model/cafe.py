@@ -538,7 +538,7 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
 
     def run_program_device(self, users, manual_topk=5):
         """run_program with everything left on the device: (scores [B, n_items] float32, record tensors, leaf chains).
-        Nothing here waits for the device: a user with more leaf paths than hw_cafe_collect ranks (4096) gets NaN scores and
+        Nothing here waits for the device: a user whose paths reach more distinct items than hw_cafe_collect ranks (8 192) gets NaN scores and
         rec["overflow"] holds the count (P.cafe_overflow_check(rec) raises on it; run_program does that after its copy).
         Per-user host work is one rng.permutation draw and one dictionary lookup: program columns, leaf rows and record
         capacities are cached per visiting order of the layout tree."""

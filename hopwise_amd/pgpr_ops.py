@@ -358,12 +358,13 @@ def cafe_modules_forward_fused(mod_structs, group_mod, group_ptr, group_level, u
 
 
 def cafe_overflow_check(rec):
-    """Raise if hw_cafe_collect met a user with more leaf paths than it ranks (reads one int from the device: a sync)."""
+    """Raise if hw_cafe_collect met a user whose paths reach more distinct items than it ranks (reads one int from the device:
+    a sync).  Out of reach with the reference's manual_topk = 5 (at most 125 paths per leaf, 64 leaves: 8 000 entries)."""
     seen = int(rec["overflow"].item())
     if seen:
-        raise RuntimeError(f"hw_cafe_collect: a user has {seen} leaf paths, more than the 4096 one workgroup ranks in LDS "
-                           "(manual_topk 5 gives 125 per metapath: more than 32 metapaths).  Run the users of such a layout in "
-                           "several run_program calls over subsets of the metapaths, or lower manual_topk")
+        raise RuntimeError(f"hw_cafe_collect: a user's paths reach {seen} distinct items, more than the 8192 one workgroup "
+                           "ranks in LDS (manual_topk 5 gives at most 125 paths per metapath).  Lower manual_topk, or run the "
+                           "users of such a layout in several run_program calls over subsets of the metapaths")
 
 
 def cafe_collect(raw, leaf_nodes_np, n_items, max_rec, check_overflow=True, leaf_nodes_dev=None):

@@ -637,7 +637,9 @@ int hw_cafe_modules_forward_fused(const hw_cafe_module* mods, const int32_t* gro
  * reference's inst[item]); emission order = score descending, entry ascending.  results [n_tasks, n_items] (-inf where
  * nothing is written); records rec_* [n_tasks, max_rec] (item, score, leaf ordinal of the attached path, its 3 ids) and
  * rec_count [n_tasks].  best_ws uint64 / last_ws int32 [n_tasks, n_items] scratch.  *overflow (zero it first) = the
- * largest entry count seen when a task has more than 4096 entries (its output is then truncated). */
+ * largest count of distinct items reached by one task when that exceeds the 8 192 winners one workgroup ranks in LDS (the
+ * task's scores then leave as NaN); with the reference's 5 paths per node and the 64 leaves accepted here a task has at most
+ * 8 000 entries, so the limit is out of reach under the reference's settings. */
 int hw_cafe_collect(const hw_cafe_node* nodes, const int32_t* node_ptr, const int64_t* slot_ptr, const int32_t* ids,
                     const float* vals, const int32_t* counts, const int32_t* leaf_nodes, int64_t n_tasks, int32_t n_leaves,
                     int32_t n_items, uint64_t* best_ws, int32_t* last_ws, float* results, int32_t max_rec,

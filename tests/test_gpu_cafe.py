@@ -270,31 +270,51 @@ def test_collect_kernel_against_restatement(n_leaves, cap, n_items, seed):
 
 
 def test_collect_overflow_is_never_silent():
-    """A user with more than 4096 leaf paths: hw_cafe_collect counts it; the checking call raises, the non-waiting call
-    (run_program_device's) leaves that user's scores NaN, the others untouched, and hands the counter on."""
+    """A user whose leaf paths reach more than 8192 distinct items (out of reach with the reference's 5 paths per node):
+    hw_cafe_collect counts it; the checking call raises, the non-waiting call (run_program_device's) leaves that user's
+    scores NaN, the others untouched, and hands the counter on.  A user with 5120 leaf paths -- beyond the 4096 ENTRIES the
+    kernel ranked before it compacted the winners -- is ranked like any other."""
     from hopwise_amd import pgpr_ops as P
+    from oracle import cafe as oc
 
-    B, n_leaves, cap, n_items = 3, 40, 128, 500
+    B, n_leaves, cap, n_items = 3, 64, 256, 30000
     nodes = np.zeros(B * n_leaves, P.CAFE_NODE_DTYPE)
     nodes["depth"], nodes["cap"] = 1, cap
     nodes["slot_off"] = np.tile(np.arange(n_leaves) * cap, B)
     counts = np.full(B * n_leaves, 10, np.int32)
-    counts[n_leaves : 2 * n_leaves] = cap  # user 1: 40 x 128 = 5120 entries
+    counts[n_leaves : 2 * n_leaves] = cap  # user 1: 64 x 256 = 16384 entries over distinct items
+    counts[2 * n_leaves : 2 * n_leaves + 40] = 128  # user 2: 40 x 128 + 24 x 10 = 5360 entries
     rng = np.random.default_rng(0)
     ids = rng.integers(0, n_items, (B * n_leaves * cap, 3)).astype(np.int32)
+    ids[n_leaves * cap : 2 * n_leaves * cap, 0] = rng.permutation(n_items)[: n_leaves * cap]  # user 1: all distinct
     vals = -rng.random((B * n_leaves * cap, 3)).astype(np.float32)
     t = lambda a: torch.from_numpy(a).to(dev())
+    slot_ptr = np.arange(B + 1, dtype=np.int64) * n_leaves * cap
     raw = dict(ids=t(ids), vals=t(vals), counts=t(counts), nodes=t(nodes.view(np.int32).reshape(-1, 10).copy()),
-               node_ptr=t(np.arange(B + 1, dtype=np.int32) * n_leaves), slot_ptr=t(np.arange(B + 1, dtype=np.int64) * n_leaves * cap))
+               node_ptr=t(np.arange(B + 1, dtype=np.int32) * n_leaves), slot_ptr=t(slot_ptr))
     leaf_nodes = np.tile(np.arange(n_leaves, dtype=np.int32), (B, 1))
-    with pytest.raises(RuntimeError, match="5120 leaf paths"):
+    with pytest.raises(RuntimeError, match="16384 distinct items"):
         P.cafe_collect(raw, leaf_nodes, n_items, n_items)
     scores, rec = P.cafe_collect(raw, leaf_nodes, n_items, n_items, check_overflow=False)
     s = scores.cpu().numpy()
     assert np.isnan(s[1]).all() and not np.isnan(s[0]).any() and not np.isnan(s[2]).any()
-    assert int(rec["overflow"].item()) == 5120
+    assert int(rec["overflow"].item()) == 16384
     with pytest.raises(RuntimeError):
         P.cafe_overflow_check(rec)
+    # users 0 and 2 against the numpy restatement
+    cnt = rec["count"].cpu().numpy()
+    item, score, leaf = (rec[k].cpu().numpy() for k in ("item", "score", "leaf"))
+    for b in (0, 2):
+        entries = []
+        for l in range(n_leaves):
+            c = int(counts[b * n_leaves + l])
+            s0 = int(slot_ptr[b]) + l * cap
+            entries.append((ids[s0 : s0 + c, :1], vals[s0 : s0 + c, :1]))
+        res, out = oc.collect_records(entries, n_items)
+        assert np.array_equal(s[b], res), b
+        assert cnt[b] == len(out), (b, cnt[b], len(out))
+        for j, (it, sc, l, r) in enumerate(out):
+            assert item[b, j] == it and score[b, j] == sc and leaf[b, j] == l, (b, j)
 
 
 def test_module_loop_in_cpp_equals_the_python_loop(monkeypatch):
