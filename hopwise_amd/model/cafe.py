@@ -277,14 +277,34 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         if (torch.is_grad_enabled() or self.training or not user_vec.is_cuda or user_vec.dtype != torch.float32
                 or user_vec.shape[1] % 4 or os.environ.get("HW_CAFE_MODULES", "1") == "0"):
             return None
-        arr = (CafeModule * len(mods))()
-        for i, m in enumerate(mods):
+        # the table of the previous call is reused while every parameter / buffer is the same object at the same address and
+        # version (evaluation calls run_program again and again on unchanged weights; building the table was 0.2 ms of a
+        # 1.3 ms call).  Parameters are read through the modules' own dictionaries: nn.Module.__getattr__ costs ~1 us a name.
+        per_mod = []
+        for m in mods:
+            if m.training:
+                return None
+            mm = m._modules
             deep = isinstance(m, DeepRelationModule)
-            ps = [m.fc1.weight, m.fc1.bias, m.bn1.weight, m.bn1.bias, m.bn1.running_mean, m.bn1.running_var, m.fc2.weight,
-                  m.fc2.bias] + ([m.bn2.weight, m.bn2.bias, m.bn2.running_mean, m.bn2.running_var, m.fc3.weight, m.fc3.bias]
-                                 if deep else [None] * 6)
-            if m.training or any(p is not None and (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous())
-                                 for p in ps) or m.bn1.running_mean is None:
+            fc1, bn1, fc2 = mm["fc1"], mm["bn1"], mm["fc2"]
+            ps = [fc1._parameters["weight"], fc1._parameters["bias"], bn1._parameters["weight"], bn1._parameters["bias"],
+                  bn1._buffers["running_mean"], bn1._buffers["running_var"], fc2._parameters["weight"], fc2._parameters["bias"]]
+            if deep:
+                bn2, fc3 = mm["bn2"], mm["fc3"]
+                ps += [bn2._parameters["weight"], bn2._parameters["bias"], bn2._buffers["running_mean"],
+                       bn2._buffers["running_var"], fc3._parameters["weight"], fc3._parameters["bias"]]
+            else:
+                ps += [None] * 6
+            per_mod.append((deep, ps, m))
+        sig = tuple((id(p), p.data_ptr(), p._version) if p is not None else None for _, ps, _ in per_mod for p in ps)
+        cache = self.__dict__.setdefault("_struct_cache", {})
+        hit = cache.get(bool(transposed))
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        arr = (CafeModule * len(mods))()
+        for i, (deep, ps, m) in enumerate(per_mod):
+            if any(p is not None and (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous())
+                   for p in ps) or ps[4] is None:
                 return None
             for name, p in zip(("w1", "b1", "bn1_weight", "bn1_bias", "bn1_mean", "bn1_var", "w2", "b2", "bn2_weight", "bn2_bias",
                                 "bn2_mean", "bn2_var", "w3", "b3"), ps):
@@ -293,6 +313,7 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
                 setattr(arr[i], name, p.data_ptr() if p is not None else None)
             arr[i].bn1_eps, arr[i].bn2_eps = float(m.bn1.eps), float(m.bn2.eps) if deep else 0.0
             arr[i].deep = int(deep)
+        cache[bool(transposed)] = (sig, arr)
         return arr
 
     @torch.no_grad()

@@ -1,0 +1,47 @@
+"""CAFE's visiting orders: the batched draw (_bfs_orders: one rng.permuted call when the layout tree has a single branching
+node) against the per-user walk (_bfs_order: rng.permutation at every branching node, cafe.py:807-808) -- same orders, same
+generator state afterwards; trees with several branching nodes keep the per-user walk."""
+import numpy as np
+
+from hopwise_amd.model.cafe import CAFE
+
+
+def _stub(metapaths, seed):
+    m = object.__new__(CAFE)  # only the layout helpers are exercised: no tables, no device
+    m.__dict__["metapaths"] = metapaths
+    m.__dict__["rng"] = np.random.default_rng(seed)
+    return m
+
+
+def _orders(ents):
+    return [(e["par_i"].tolist(), list(e["rel_names"])) for e in ents]
+
+
+def test_single_branching_node_batched_draw_equals_the_per_user_walk():
+    mps = [[(None, "user"), ("watched", "entity"), (f"rel{j}", "entity"), (f"rel{j}", "entity")] for j in range(6)]
+    a, b = _stub(mps, 5), _stub(mps, 5)
+    seq = [a._bfs_order() for _ in range(300)]
+    bat = b._bfs_orders(300)
+    assert b._layout()["fast"]["on"]
+    assert _orders(seq) == _orders(bat)
+    assert a.rng.bit_generator.state == b.rng.bit_generator.state
+    # and again on the warmed caches, from the state both generators are in now
+    assert _orders([a._bfs_order() for _ in range(50)]) == _orders(b._bfs_orders(50))
+    assert a.rng.random() == b.rng.random()
+
+
+def test_several_branching_nodes_keep_the_per_user_walk():
+    mps = [[(None, "user"), ("watched", "entity"), ("rel0", "entity")], [(None, "user"), ("watched", "entity"), ("rel1", "entity")],
+           [(None, "user"), ("mentions", "word"), ("rel2", "entity")], [(None, "user"), ("mentions", "word"), ("rel3", "entity")]]
+    a, b = _stub(mps, 9), _stub(mps, 9)
+    seq = [a._bfs_order() for _ in range(100)]
+    bat = b._bfs_orders(100)
+    assert not b._layout()["fast"]["on"]
+    assert _orders(seq) == _orders(bat) and a.rng.bit_generator.state == b.rng.bit_generator.state
+
+
+def test_no_branching_node_draws_nothing():
+    mps = [[(None, "user"), ("watched", "entity"), ("rel0", "entity")]]
+    a = _stub(mps, 1)
+    before = a.rng.bit_generator.state
+    assert len({id(e) for e in a._bfs_orders(10)}) == 1 and a.rng.bit_generator.state == before
