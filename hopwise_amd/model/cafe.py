@@ -532,8 +532,11 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
                     same = False
                 if same:
                     fast.update(on=True, n=n, base=np.tile(np.arange(n), (1, 1)), weights=n ** np.arange(n, dtype=np.int64),
-                                by_code={})
-        if not fast["on"] or B == 0:
+                                by_code={}, bitgen=type(self.rng.bit_generator))
+        # the check above vouches for ONE kind of generator: a caller that swaps self.rng (the bench's parity leg installs an
+        # identity "rng", tests install seeded ones) gets the batched draw only for that kind, the per-user walk otherwise
+        if (not fast["on"] or B == 0 or not isinstance(self.rng, np.random.Generator)
+                or type(self.rng.bit_generator) is not fast["bitgen"]):
             return [self._bfs_order() for _ in range(B)]
         n = fast["n"]
         perms = self.rng.permuted(np.tile(fast["base"], (B, 1)), axis=1)

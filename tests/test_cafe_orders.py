@@ -45,3 +45,22 @@ def test_no_branching_node_draws_nothing():
     a = _stub(mps, 1)
     before = a.rng.bit_generator.state
     assert len({id(e) for e in a._bfs_orders(10)}) == 1 and a.rng.bit_generator.state == before
+
+
+def test_a_swapped_rng_of_another_kind_takes_the_per_user_walk():
+    """bench_cafe's parity leg replaces model.rng by an object that only has permutation(): the batched draw must not be used."""
+    class Identity:
+        def permutation(self, n):
+            return np.arange(n)
+
+    mps = [[(None, "user"), ("watched", "entity"), (f"rel{j}", "entity")] for j in range(4)]
+    m = _stub(mps, 3)
+    m._bfs_orders(8)
+    assert m._layout()["fast"]["on"]
+    m.__dict__["rng"] = Identity()
+    ents = m._bfs_orders(5)
+    assert len({id(e) for e in ents}) == 1 and ents[0]["rel_names"] == ["watched", "rel0", "rel1", "rel2", "rel3"]
+    m.__dict__["rng"] = np.random.Generator(np.random.MT19937(4))  # another bit generator than the one that was checked
+    ref = _stub(mps, 0)
+    ref.__dict__["rng"] = np.random.Generator(np.random.MT19937(4))
+    assert _orders(m._bfs_orders(40)) == _orders([ref._bfs_order() for _ in range(40)])

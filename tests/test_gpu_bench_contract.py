@@ -32,7 +32,7 @@ def test_default_legs_at_a_tiny_size():
     assert r["configs1_launch"]["bound"] == "l2" and r["configs1_launch"]["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "triples/s"
-    for leg in ("sharded", "tucker", "reference_layout", "pgpr"):
+    for leg in ("sharded", "tucker", "reference_layout", "pgpr", "cafe"):
         assert leg in d and "error" not in d[leg], (leg, d[leg].get("error"))
     assert d["sharded"]["parity"] and abs(d["sharded"]["parity"]["sharded_loss"] - d["sharded"]["parity"]["plain_loss"]) < 1e-5
     assert d["tucker"]["parity"]["loss_relation_sets"] == d["tucker"]["parity"]["loss_per_row_product"]

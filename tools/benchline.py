@@ -13,7 +13,9 @@ for leg in ("tucker", "pgpr", "cafe", "sharded"):
     v = line.get(leg)
     if not v:
         continue
-    if leg == "tucker":
+    if "error" in v:
+        print("%s ERROR %s" % (leg, v["error"]))
+    elif leg == "tucker":
         print("tucker fwd %.3f ms  fwd+bwd %.3f ms" % (v["forward"]["ms"], v["forward_backward"]["ms"]))
     else:
         print("%s ms_per_step %.3f value %.4g" % (leg, v["ms_per_step"], v["value"]))
