@@ -83,6 +83,7 @@ struct SamplerArgs {
     int64_t n_key_space, value_num;
     uint64_t seed, offset;
     int words;  // bitmap words per wave = ceil(value_num / 32); 0: value space beyond the bitmap, membership by binary search
+    int stagger;  // fused scorer: issue priority by co-resident block during the draws (kge_score_kernels.h)
 };
 constexpr int SAMPLER_STAGE_IDS = 1024;  // words == 0: a key's sorted used slice is staged in LDS (4 KB: 8 blocks per CU stay resident) when it has at most this many ids
 constexpr int SAMPLER_MAX_ATTEMPTS_FUSED = 1 << 16;

@@ -4,6 +4,12 @@
 
 using namespace hw;
 
+// HW_SCORER_STAGGER=0: the fused sampler + scorer without its issue-priority stagger (read once)
+static int scorer_stagger() {
+    static const int on = [] { const char* e = getenv("HW_SCORER_STAGGER"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on;
+}
+
 extern "C" int hw_kge_score_grouped(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx,
                                     int64_t r_fixed, const int64_t* t_idx, int64_t t_stride_b, int64_t t_stride_j,
                                     int64_t n_groups, int64_t n_tail_per_group, float* out, int64_t o_stride_b,
@@ -25,7 +31,7 @@ extern "C" int hw_kge_score_grouped_sampled(const hw_kge_desc* desc, const int64
     if (HW_FAMILY_OF(desc->model) != 0) return HW_ERR_UNSUPPORTED;  // caller: sample, then score
     SamplerArgs sa;
     sa.used_ptr = used_ptr, sa.used_idx = used_idx, sa.keys = keys, sa.n_key_space = n_key_space;
-    sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = value_num <= 65536 ? (int)((value_num + 31) / 32) : 0;  // 0: no LDS bitmap, binary search in the sorted used slice
+    sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = value_num <= 65536 ? (int)((value_num + 31) / 32) : 0, sa.stagger = scorer_stagger();  // 0: no LDS bitmap, binary search in the sorted used slice
     return score_grouped_impl<0>(desc, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, n_tail_per_group,
                                  out, o_stride_b, o_stride_j, oob_counter, stream, &sa);
 }
@@ -45,7 +51,7 @@ static int selfadv_launch(const hw_kge_desc* desc, const int64_t* h_idx, const i
     if (HW_FAMILY_OF(desc->model) != 0) return HW_ERR_UNSUPPORTED;
     SamplerArgs sa;
     sa.used_ptr = used_ptr, sa.used_idx = used_idx, sa.keys = keys, sa.n_key_space = n_key_space;
-    sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = value_num <= 65536 ? (int)((value_num + 31) / 32) : 0;  // 0: no LDS bitmap, binary search in the sorted used slice
+    sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = value_num <= 65536 ? (int)((value_num + 31) / 32) : 0, sa.stagger = scorer_stagger();  // 0: no LDS bitmap, binary search in the sorted used slice
     SelfAdvArgs la;
     la.alpha = alpha, la.inv_b = 1.0f / (float)n_groups, la.group_loss = group_loss_ws, la.loss_out = loss_out;
     if (prev_group_loss) la.prev_group_loss = prev_group_loss, la.prev_loss_out = prev_loss_out, la.prev_n = (int)prev_n_groups;

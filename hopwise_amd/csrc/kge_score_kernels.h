@@ -72,6 +72,19 @@ __global__ __launch_bounds__(256, (SAMPLE && NE <= 4) ? 8 : 1) void kge_score_gr
     }
     const int64_t b = task / S;
     const int s = (int)(task % S);
+    if constexpr (SAMPLE) {
+        // The eight waves a SIMD holds belong to eight blocks that start together and all spend their first ~1 000 cycles of
+        // issue on Philox rounds (v_mul_hi / v_mul_lo at quarter rate) before any tail row is requested: ~3.5 us in which the
+        // chip fetches nothing.  Issue priority by co-resident block (blocks b, b + 256, ... share a CU) lets them finish the
+        // draws one after the other instead of together, so the first waves' row loads travel under the others' draws.
+        // HW_SCORER_STAGGER=0 (host) launches without it.
+        if (sa.stagger) {  // s_setprio takes an immediate
+            const unsigned cls = (blockIdx.x >> 8) & 3u;
+            if (cls == 0) __builtin_amdgcn_s_setprio(3);
+            else if (cls == 1) __builtin_amdgcn_s_setprio(2);
+            else if (cls == 2) __builtin_amdgcn_s_setprio(1);
+        }
+    }
     // EARLY (fused sampler, element-wise queries): the launch is ONE generation of blocks that all start together, so every
     // memory round trip ahead of the tail loop is a stretch in which the chip fetches nothing.  The sampler's chain (key ->
     // slice bounds -> slice ids) and the query's chain (h, r ids -> rows) are independent: their loads are issued side by
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(256, (SAMPLE && NE <= 4) ? 8 : 1) void kge_score_gr
             }
             tpre = clamp_row_flag(id, d.n_tail, bad);
         }
+        if constexpr (SAMPLE) __builtin_amdgcn_s_setprio(0);
 #pragma unroll 1
         for (int k = 0; k < HW_WAVE / NS; k += U) {  // k counts rows of NS tails inside the chunk
             if (j_of(q0 + k * NS) >= ntail) break;   // wave-uniform
