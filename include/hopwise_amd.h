@@ -619,7 +619,9 @@ int hw_cafe_modules_forward(const hw_cafe_module* mods, const int32_t* group_mod
                             const int64_t* uv_idx, const int64_t* out_rows, float* vec_all, float* workspace,
                             int64_t workspace_floats, void* stream);
 
-/* The same module applications with ONE launch per level (csrc/cafe_modules.hip, cafe_level_kernel): a block takes eight rows
+/* The same module applications (MetaProgramExecutor's `module((eh_vec, user_vec))` per node, cafe.py:807-835, over the
+ * RelationModule / DeepRelationModule forwards of cafe.py:645-699) with ONE launch per level (csrc/cafe_modules.hip,
+ * cafe_level_kernel): a block takes eight rows
  * of a group through the whole module with the activations in LDS.  Differences to hw_cafe_modules_forward: the weight
  * pointers of `mods` (w1, w2, w3) address TRANSPOSED copies [in, out] (prepared by the caller once per weight version);
  * group_level[g] (host, non-decreasing) is the depth of group g's nodes -- groups of one level only read node vectors of
