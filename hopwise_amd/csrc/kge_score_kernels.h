@@ -45,8 +45,16 @@ __device__ __forceinline__ void selfadv_finish_block(const float* __restrict__ g
 }
 
 constexpr int LOSS_MAX_TAILS = 1024;
+// 8 waves per SIMD (<= 64 VGPRs: the 2048 blocks of a launch resident as one generation, like the plain scorer) is asked of
+// the compiler only where it costs no scratch: whole-row shapes (G = 64) with one load unit per table.  ComplEx's fused-loss
+// form would spill one register there and the short-row shapes 2-11 (tools/kernel_regs.sh kge_score): they keep the
+// compiler's own allocation (67-88 VGPRs, 5-7 waves per SIMD).
+template <int MODEL, int G, int NE, bool SAMPLE, bool LOSS>
+constexpr int grouped_min_waves() {
+    return (SAMPLE && NE <= 4 && G == 64 && !(MODEL == HW_COMPLEX && LOSS)) ? 8 : 1;
+}
 template <int MODEL, int G, int NE, bool VEC, int U, bool SAMPLE = false, bool LOSS = false>
-__global__ __launch_bounds__(256, (SAMPLE && NE <= 4) ? 8 : 1) void kge_score_grouped_kernel(
+__global__ __launch_bounds__(256, (grouped_min_waves<MODEL, G, NE, SAMPLE, LOSS>())) void kge_score_grouped_kernel(
     hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
     int64_t* t_idx, int64_t tsb, int64_t tsj, int64_t n_groups, int ntail, int S,
     float* __restrict__ out, int64_t osb, int64_t osj, int32_t* oob, SamplerArgs sa, SelfAdvArgs la = SelfAdvArgs{}) {
