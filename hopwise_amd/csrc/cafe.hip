@@ -33,6 +33,46 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
     for (int c = threadIdx.x; c < n_cols; c += 256) o[c] = (r[c] - m) - ls;
 }
 
+// The same row with its values held in registers between the three passes (NPT per thread, column c = tid + 256 i as above):
+// the row is read once instead of three times.  Per-thread order of the maximum and of the sum, the wave butterflies and the
+// four-way combination are those of log_softmax_rows_kernel: results are equal bit for bit.  n_cols <= 256 NPT.
+template <int NPT>
+__global__ __launch_bounds__(256) void log_softmax_rows_reg_kernel(const float* __restrict__ x, int64_t ld, int n_cols,
+                                                                   float* __restrict__ y, int64_t ldy) {
+    __shared__ float red[4];
+    const float* __restrict__ r = x + (size_t)blockIdx.x * ld;
+    float* __restrict__ o = y + (size_t)blockIdx.x * ldy;
+    float v[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        v[i] = r[c < n_cols ? c : n_cols - 1];  // unconditional: all loads of the row in flight together
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+        if ((int)threadIdx.x + 256 * i < n_cols) m = fmaxf(m, v[i]);
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i)
+        if ((int)threadIdx.x + 256 * i < n_cols) s += expf(v[i] - m);
+    s = group_sum<64>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float ls = logf((red[0] + red[1]) + (red[2] + red[3]));
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < n_cols) o[c] = (v[i] - m) - ls;
+    }
+}
+
 // ---- training: cross entropy over one level's vocabulary + the ranking term (cafe.py:541-553) -------------------------
 // Per row: lse = logsumexp(logits), ce = lse - logits[target]; rank = sigmoid(logits[neg] - logits[pos]) (the two
 // log-softmax values differ from the logits by the same lse).  Row results go to row_ws [2, n_rows]; a second
@@ -304,8 +344,15 @@ extern "C" int hw_log_softmax_rows(const float* x, int64_t ld, int64_t n_rows, i
         return HW_ERR_INVALID_ARG;
     if (n_rows == 0) return HW_OK;
     HW_CLEAR_ERR();
-    hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, x, ld,
-                       (int)n_cols, y, ldy);
+    if (n_cols <= 256 * 16)
+        hipLaunchKernelGGL(log_softmax_rows_reg_kernel<16>, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, x, ld,
+                           (int)n_cols, y, ldy);
+    else if (n_cols <= 256 * 64)
+        hipLaunchKernelGGL(log_softmax_rows_reg_kernel<64>, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, x, ld,
+                           (int)n_cols, y, ldy);
+    else
+        hipLaunchKernelGGL(log_softmax_rows_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, x, ld,
+                           (int)n_cols, y, ldy);
     return HW_LAUNCH_RC();
 }
 
