@@ -53,8 +53,30 @@ class _Packed:
         self.parts.append(words)
         self.off += words.size
 
+    # Pinned staging, four slots used in turn: a copy from pageable memory makes the launching thread wait until the stream
+    # has drained (the previous call's kernels), which ties the host to the device once the host is the faster of the two; from
+    # pinned memory the copy is one more stream operation.  A slot is rewritten only after the copy issued from it four calls
+    # earlier has completed (its event).
+    _SLOTS, _ring, _next = 4, {}, {}
+
     def to(self, dev):
-        buf = torch.from_numpy(np.concatenate(self.parts) if self.parts else np.zeros(0, np.int64)).to(dev)
+        n = self.off
+        if n == 0 or not torch.cuda.is_available() or torch.device(dev).type != "cuda":
+            buf = torch.from_numpy(np.concatenate(self.parts) if self.parts else np.zeros(0, np.int64)).to(dev)
+        else:
+            key = torch.device(dev).index
+            ring = _Packed._ring.setdefault(key, [None] * _Packed._SLOTS)
+            i = _Packed._next.get(key, 0)
+            _Packed._next[key] = (i + 1) % _Packed._SLOTS
+            slot = ring[i]
+            if slot is not None:
+                slot[1].synchronize()
+            if slot is None or slot[0].numel() < n:
+                slot = ring[i] = [torch.empty(max(2 * n, 1 << 14), dtype=torch.int64, pin_memory=True), torch.cuda.Event()]
+            np.concatenate(self.parts, out=slot[0].numpy()[:n])
+            buf = torch.empty(n, dtype=torch.int64, device=dev)
+            buf.copy_(slot[0][:n], non_blocking=True)
+            slot[1].record()
         out = {}
         for name, (off, n, is32, shape) in self.meta.items():
             t = buf[off : off + n]
@@ -550,6 +572,54 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             out.append(ent)
         return out
 
+    def _derive_order(self, e, manual_topk, leaves, code):
+        """What run_program needs of a visiting order beyond the order itself: relation codes, the program row of every
+        leaf chain, the record capacity (product of k along each leaf's chain)."""
+        if "rel_code" not in e:
+            e["rel_code"] = np.fromiter((code[n] for n in e["rel_names"]), np.int64, len(e["rel_names"]))
+            index_of_chain = {_chain_of(e["order"], i): i for i in range(len(e["order"]))}
+            e["leaf_row"] = np.asarray([index_of_chain.get(chain, -1) for chain in leaves] or [-1], np.int32)
+        if e.get("topk") != manual_topk:  # capacity of a node = product of k along its chain
+            cap = np.ones(len(e["order"]), np.int64)
+            for i, (par, _, _) in enumerate(e["order"]):
+                cap[i] = manual_topk * (cap[par] if par >= 0 else 1)
+            sel = e["leaf_row"][e["leaf_row"] >= 0]
+            e["topk"], e["max_rec"] = manual_topk, int(cap[sel].sum())
+
+    def _order_tables(self, B, manual_topk, leaves, code):
+        """Single branching node with at most 7 children (<= 5 040 visiting orders): every order enumerated once, its columns
+        stacked into [n_orders, L] tables; a batch is then ONE permuted draw (as in :meth:`_bfs_orders`), one searchsorted
+        from permutation codes to table rows and a gather per column -- no per-user Python at all.  Returns (order index per
+        user, tables) or None when the layout / generator does not qualify (the caller walks the users then)."""
+        lay = self._layout()
+        if "fast" not in lay:
+            self._bfs_orders(0)  # decides lay["fast"]
+        fast = lay["fast"]
+        if (not fast["on"] or B == 0 or fast["n"] > 7 or not isinstance(self.rng, np.random.Generator)
+                or type(self.rng.bit_generator) is not fast["bitgen"]):
+            return None
+        n = fast["n"]
+        tabs = fast.setdefault("tables", {})
+        T = tabs.get(manual_topk)
+        if T is None:
+            import itertools
+
+            rows = np.asarray(list(itertools.permutations(range(n))), np.int64)
+            codes = rows @ fast["weights"]
+            ents = []
+            for row, c in zip(rows, codes.tolist()):
+                ent = fast["by_code"].get(c)
+                if ent is None:
+                    ent = fast["by_code"][c] = self._bfs_order(perm=lambda k, row=row: row)
+                self._derive_order(ent, manual_topk, leaves, code)
+                ents.append(ent)
+            srt = np.argsort(codes)
+            T = tabs[manual_topk] = dict(
+                codes=codes[srt], par=np.stack([ents[i]["par_i"] for i in srt]), rel=np.stack([ents[i]["rel_code"] for i in srt]),
+                leaf=np.stack([ents[i]["leaf_row"] for i in srt]), max_rec=np.asarray([ents[i]["max_rec"] for i in srt], np.int64))
+        perms = self.rng.permuted(np.tile(fast["base"], (B, 1)), axis=1)
+        return np.searchsorted(T["codes"], perms @ fast["weights"]), T
+
     def _bfs_order(self, perm=None):
         """One visiting order of the executor (children of a node in self.rng.permutation order, cafe.py:807-808; the
         draws happen per call, exactly as before) -> its cache entry: the order as (parent index, relation, node) triples
@@ -611,31 +681,31 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         users_np = users.cpu().numpy()
         B = len(users_np)
         leaves = self._leaf_chains_cached()
-        ents = self._bfs_orders(B)
         names = self.__dict__.get("_all_rel_names")
         if names is None:
             names = self.__dict__["_all_rel_names"] = sorted(self.relation_info)
             self.__dict__["_rel_code_of"] = {n: j for j, n in enumerate(names)}
         code = self.__dict__["_rel_code_of"]
-        for e in {id(e): e for e in ents}.values():
-            if "rel_code" not in e:
-                e["rel_code"] = np.fromiter((code[n] for n in e["rel_names"]), np.int64, len(e["rel_names"]))
-                index_of_chain = {_chain_of(e["order"], i): i for i in range(len(e["order"]))}
-                e["leaf_row"] = np.asarray([index_of_chain.get(chain, -1) for chain in leaves] or [-1], np.int32)
-            if e.get("topk") != manual_topk:  # capacity of a node = product of k along its chain
-                cap = np.ones(len(e["order"]), np.int64)
-                for i, (par, _, _) in enumerate(e["order"]):
-                    cap[i] = manual_topk * (cap[par] if par >= 0 else 1)
-                sel = e["leaf_row"][e["leaf_row"] >= 0]
-                e["topk"], e["max_rec"] = manual_topk, int(cap[sel].sum())
-        flat = dict(lens=np.fromiter((len(e["par_i"]) for e in ents), np.int64, B),
-                    par_i=np.concatenate([e["par_i"] for e in ents]) if B else np.zeros(0, np.int64),
-                    rel_code=np.concatenate([e["rel_code"] for e in ents]) if B else np.zeros(0, np.int64), names=names)
+        got = self._order_tables(B, manual_topk, leaves, code)
+        if got is not None:  # the usual layout: columns gathered from the per-order tables
+            oid, T = got
+            flat = dict(lens=np.full(B, T["par"].shape[1], np.int64), par_i=T["par"][oid].ravel(),
+                        rel_code=T["rel"][oid].ravel(), names=names)
+            leaf_nodes = T["leaf"][oid]
+            max_rec_all = int(T["max_rec"][oid].max())
+        else:
+            ents = self._bfs_orders(B)
+            for e in {id(e): e for e in ents}.values():
+                self._derive_order(e, manual_topk, leaves, code)
+            flat = dict(lens=np.fromiter((len(e["par_i"]) for e in ents), np.int64, B),
+                        par_i=np.concatenate([e["par_i"] for e in ents]) if B else np.zeros(0, np.int64),
+                        rel_code=np.concatenate([e["rel_code"] for e in ents]) if B else np.zeros(0, np.int64), names=names)
+            leaf_nodes = np.stack([e["leaf_row"] for e in ents]) if B else np.full((0, max(len(leaves), 1)), -1, np.int32)
+            max_rec_all = max([1] + [e["max_rec"] for e in ents])
         flat["k_of"] = np.full(len(flat["par_i"]), manual_topk, np.int64)
-        leaf_nodes = np.stack([e["leaf_row"] for e in ents]) if B else np.full((0, max(len(leaves), 1)), -1, np.int32)
         flat["leaf_nodes"] = leaf_nodes  # rides in _run_programs' one host-to-device copy
         raw = self._run_programs(users, None, None, grow_excluded=True, exclude=True, raw=True, flat=flat)
-        max_rec = min(max([1] + [e["max_rec"] for e in ents]), self.n_items)
+        max_rec = min(max(1, max_rec_all), self.n_items)
         scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec, check_overflow=False,
                                      leaf_nodes_dev=raw.get("leaf_nodes"))
         return scores, rec, leaves, users_np

@@ -64,3 +64,25 @@ def test_a_swapped_rng_of_another_kind_takes_the_per_user_walk():
     ref = _stub(mps, 0)
     ref.__dict__["rng"] = np.random.Generator(np.random.MT19937(4))
     assert _orders(m._bfs_orders(40)) == _orders([ref._bfs_order() for _ in range(40)])
+
+
+def test_order_tables_give_the_columns_of_the_per_user_walk():
+    mps = [[(None, "user"), ("watched", "entity"), (f"rel{j}", "entity"), (f"rel{j}", "entity")] for j in range(5)]
+    a, b = _stub(mps, 11), _stub(mps, 11)
+    names = sorted({mp[i][0] for mp in mps for i in range(1, len(mp))})
+    code = {n: j for j, n in enumerate(names)}
+    leaves = a._leaf_chains()
+    ents = a._bfs_orders(200)
+    for e in ents:
+        a._derive_order(e, 5, leaves, code)
+    oid, T = b._order_tables(200, 5, leaves, code)
+    assert T["par"].shape[0] == 120 and a.rng.bit_generator.state == b.rng.bit_generator.state
+    assert np.array_equal(T["par"][oid], np.stack([e["par_i"] for e in ents]))
+    assert np.array_equal(T["rel"][oid], np.stack([e["rel_code"] for e in ents]))
+    assert np.array_equal(T["leaf"][oid], np.stack([e["leaf_row"] for e in ents]))
+    assert T["max_rec"][oid].tolist() == [e["max_rec"] for e in ents]
+    # another k: its own tables; layouts that do not qualify: None
+    assert b._order_tables(3, 2, leaves, code)[1]["max_rec"][0] != T["max_rec"][0]
+    c = _stub([[(None, "user"), ("watched", "entity"), ("rel0", "entity")], [(None, "user"), ("watched", "entity"), ("rel1", "entity")],
+               [(None, "user"), ("mentions", "word"), ("rel2", "entity")], [(None, "user"), ("mentions", "word"), ("rel3", "entity")]], 2)
+    assert c._order_tables(4, 5, c._leaf_chains(), {}) is None
