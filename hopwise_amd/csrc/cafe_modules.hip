@@ -72,29 +72,32 @@ struct CfLevel {
     hw_cafe_module mod[CF_MAXG];
 };
 
-// acc[r] += sum_k act[k][r] * wt[k * ldw + c] over k < K (act: LDS [K][CF_R])
+// acc[r] += sum_k act[k][r] * wt[k * ldw + c] over k < K (act: LDS [K][CF_R]), in k order.  The weight loads of U k-steps
+// are issued together: the loop is paced by the latency of its L2-resident weight rows, not by their bandwidth (4 in flight:
+// 65 us per level launch; 16: see DESIGN.md A16).
+template <int U>
+__device__ __forceinline__ void cf_dot_steps(const float (*act)[CF_R], int k, const float* __restrict__ wt, int ldw, int c,
+                                             float (&acc)[CF_R]) {
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = wt[(size_t)(k + u) * ldw + c];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(&act[k + u][0]);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(&act[k + u][4]);
+        acc[0] = fmaf(a0.x, w[u], acc[0]), acc[1] = fmaf(a0.y, w[u], acc[1]);
+        acc[2] = fmaf(a0.z, w[u], acc[2]), acc[3] = fmaf(a0.w, w[u], acc[3]);
+        acc[4] = fmaf(a1.x, w[u], acc[4]), acc[5] = fmaf(a1.y, w[u], acc[5]);
+        acc[6] = fmaf(a1.z, w[u], acc[6]), acc[7] = fmaf(a1.w, w[u], acc[7]);
+    }
+}
+
 __device__ __forceinline__ void cf_dot(const float (*act)[CF_R], int K, const float* __restrict__ wt, int ldw, int c,
                                        float (&acc)[CF_R]) {
     int k = 0;
-    for (; k + 4 <= K; k += 4) {
-        float w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = wt[(size_t)(k + u) * ldw + c];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&act[k + u][0]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&act[k + u][4]);
-            acc[0] = fmaf(a0.x, w[u], acc[0]), acc[1] = fmaf(a0.y, w[u], acc[1]);
-            acc[2] = fmaf(a0.z, w[u], acc[2]), acc[3] = fmaf(a0.w, w[u], acc[3]);
-            acc[4] = fmaf(a1.x, w[u], acc[4]), acc[5] = fmaf(a1.y, w[u], acc[5]);
-            acc[6] = fmaf(a1.z, w[u], acc[6]), acc[7] = fmaf(a1.w, w[u], acc[7]);
-        }
-    }
-    for (; k < K; ++k) {
-        const float w = wt[(size_t)k * ldw + c];
-#pragma unroll
-        for (int r = 0; r < CF_R; ++r) acc[r] = fmaf(act[k][r], w, acc[r]);
-    }
+    for (; k + 16 <= K; k += 16) cf_dot_steps<16>(act, k, wt, ldw, c, acc);
+    for (; k + 4 <= K; k += 4) cf_dot_steps<4>(act, k, wt, ldw, c, acc);
+    for (; k < K; ++k) cf_dot_steps<1>(act, k, wt, ldw, c, acc);
 }
 
 __global__ __launch_bounds__(256) void cafe_level_kernel(CfLevel L, const float* __restrict__ user_vec, int64_t n_user_rows, int d,
