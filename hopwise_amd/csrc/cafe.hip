@@ -180,6 +180,7 @@ __device__ __forceinline__ bool bit_get(const uint32_t* b, int i) { return (b[i 
 
 constexpr int CAFE_BIT_WORDS = 8192;  // 262 144 ids per LDS bitmap (2 x 32 KiB)
 constexpr int CAFE_MAX_NODES = 128;
+constexpr int CAFE_PCHUNK = 128;  // parent paths whose adjacency bounds are looked up together
 
 __global__ __launch_bounds__(256) void cafe_execute_kernel(
     hw_pgpr_graph g, const hw_cafe_node* __restrict__ nodes, const int32_t* __restrict__ node_ptr,
@@ -190,10 +191,10 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
     __shared__ uint32_t vis[CAFE_BIT_WORDS];
     __shared__ uint32_t excl[CAFE_BIT_WORDS];
     __shared__ int counts[CAFE_MAX_NODES];
-    __shared__ uint64_t red[4];
     __shared__ uint64_t red2[2][4];
-    __shared__ int sh_lo, sh_hi;
-    __shared__ long long sh_base;
+    __shared__ long long pt_base[CAFE_PCHUNK];  // parent table (see the node loop)
+    __shared__ int pt_deg[CAFE_PCHUNK], pt_lo[CAFE_PCHUNK], pt_hi[CAFE_PCHUNK], pt_id[CAFE_PCHUNK][2];
+    __shared__ float pt_v[CAFE_PCHUNK][2];
     const int task = blockIdx.x;
     const int tid = threadIdx.x;
     const int uid = (int)users[task];
@@ -215,54 +216,61 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
         float* c_vals = out_vals + (slot0 + nd.slot_off) * 3;
         const float* __restrict__ lp = logprobs + (size_t)nd.lp_row * lp_ld;
         int n_out = 0;
-        int pfx_id[2] = {0, 0};  // thread 0: the parent path's ids / values, read once per parent (depth - 1 <= 2 of them)
+        int pfx_id[2] = {0, 0};  // this parent path's ids / values (depth - 1 <= 2 of them)
         float pfx_v[2] = {0.f, 0.f};
         for (int pp = 0; pp < n_parent && n_out < nd.cap; ++pp) {
-            if (tid == 0) {
-                // thread 0 is the only reader of what thread 0 wrote earlier in this launch (parent paths)
+            const int ps = pp % CAFE_PCHUNK;
+            if (ps == 0) {
+                // Parent table of the next CAFE_PCHUNK parent paths, built by the whole block in two sweeps of independent
+                // loads: (A) thread t reads parent pp + t's ids / values and the bounds of its tail's adjacency; (B) wave w
+                // counts, for parents w, w + 4, ..., the edges below / up to nd.rel = the relation's segment [lo, hi) of the
+                // (relation, destination)-sorted adjacency.  Per parent path this used to be two dependent trips by thread 0
+                // plus a block-wide sweep and three barriers: ~1.7 of the ~2.7 us a parent path cost, ~180 paths per user.
+                // The parent paths were written by thread 0 of THIS block before the barrier that ended their node: visible.
+                __syncthreads();  // the previous chunk's table is no longer read
+                const int chunk_n = min(CAFE_PCHUNK, n_parent - pp);
+                if (tid < chunk_n) {
+                    const int q = pp + tid;
+                    int ids[2] = {0, 0};
+                    float vs[2] = {0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (j < depth - 1) pfx_id[j] = p_ids[(size_t)pp * 3 + j], pfx_v[j] = p_vals[(size_t)pp * 3 + j];
-                const int last = nd.parent < 0 ? uid : pfx_id[depth == 3 ? 1 : 0];
-                // adjacency of (the RELATION's head type, last) under nd.rel: the lookup type comes from the relation,
-                // not from the node (cafe.py:603 kg_mask.get_ids(module.eh_name, path[-1], ...))
-                long long base = 0;
-                int deg = 0;
-                const int64_t n_type = nd.eh_is_entity ? g.n_entities : g.n_users;
-                if (last >= 0 && last < n_type) {
-                    const int64_t gid = nd.eh_is_entity ? (int64_t)g.n_users + last : last;
-                    base = g.ptr[gid];
-                    deg = (int)(g.ptr[gid + 1] - base);
+                    for (int j = 0; j < 2; ++j)
+                        if (j < depth - 1) ids[j] = p_ids[(size_t)q * 3 + j], vs[j] = p_vals[(size_t)q * 3 + j];
+                    const int last = nd.parent < 0 ? uid : ids[depth == 3 ? 1 : 0];
+                    // adjacency of (the RELATION's head type, last) under nd.rel: the lookup type comes from the relation,
+                    // not from the node (cafe.py:603 kg_mask.get_ids(module.eh_name, path[-1], ...))
+                    long long base = 0;
+                    int deg = 0;
+                    const int64_t n_type = nd.eh_is_entity ? g.n_entities : g.n_users;
+                    if (last >= 0 && last < n_type) {
+                        const int64_t gid = nd.eh_is_entity ? (int64_t)g.n_users + last : last;
+                        base = g.ptr[gid];
+                        deg = (int)(g.ptr[gid + 1] - base);
+                    }
+                    pt_base[tid] = base, pt_deg[tid] = deg;
+                    pt_id[tid][0] = ids[0], pt_id[tid][1] = ids[1], pt_v[tid][0] = vs[0], pt_v[tid][1] = vs[1];
                 }
-                sh_base = base, sh_hi = deg;
-            }
-            __syncthreads();
-            {
-                // the relation's segment [lo, hi) of the (relation, destination)-sorted adjacency: lo = edges with a smaller
-                // relation, hi = edges with a relation <= nd.rel, counted by the whole block in one sweep of independent loads
-                // (two binary searches by one thread were ~14 dependent loads = 6-8 us per parent path, ~80 paths per user)
-                const int deg = sh_hi;
-                const int32_t* __restrict__ rl = g.rel + sh_base;
-                int lt = 0, le = 0;
-                for (int e = tid; e < deg; e += 256) {
-                    const int r = rl[e];
-                    lt += r < nd.rel;
-                    le += r <= nd.rel;
-                }
-                uint64_t both = ((uint64_t)(uint32_t)lt << 32) | (uint32_t)le;
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) both += __shfl_xor(both, m, 64);
-                __syncthreads();  // every thread has read sh_hi
-                if ((tid & 63) == 0) red[tid >> 6] = both;
                 __syncthreads();
-                if (tid == 0) {
-                    const uint64_t t = (red[0] + red[1]) + (red[2] + red[3]);
-                    sh_lo = (int)(t >> 32), sh_hi = (int)(t & 0xffffffffu);
+                for (int t = tid >> 6; t < chunk_n; t += 4) {  // wave-uniform
+                    const int deg = pt_deg[t];
+                    const int32_t* __restrict__ rl = g.rel + pt_base[t];
+                    int lt = 0, le = 0;
+                    for (int e = tid & 63; e < deg; e += 64) {
+                        const int r = rl[e];
+                        lt += r < nd.rel;
+                        le += r <= nd.rel;
+                    }
+                    uint64_t both = ((uint64_t)(uint32_t)lt << 32) | (uint32_t)le;
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) both += __shfl_xor(both, m, 64);
+                    if ((tid & 63) == 0) pt_lo[t] = (int)(both >> 32), pt_hi[t] = (int)(both & 0xffffffffu);
                 }
+                __syncthreads();
             }
-            __syncthreads();
-            const int lo = sh_lo, hi = sh_hi;
-            const int32_t* __restrict__ dst = g.dst + sh_base;
+            pfx_id[0] = pt_id[ps][0], pfx_id[1] = pt_id[ps][1], pfx_v[0] = pt_v[ps][0], pfx_v[1] = pt_v[ps][1];
+            const long long p_base = pt_base[ps];
+            const int lo = pt_lo[ps], hi = pt_hi[ps];
+            const int32_t* __restrict__ dst = g.dst + p_base;
             uint64_t bound = ~0ull;
             // candidate key of adjacency slot e (0: not a candidate).  During a parent's k rounds the visited / excluded sets
             // only gain that parent's own picks, which the rounds exclude through `bound` anyway: a slot's key can be taken once.
