@@ -178,40 +178,6 @@ __device__ __forceinline__ uint64_t lp_key(float v, uint32_t id) {
 
 __device__ __forceinline__ bool bit_get(const uint32_t* b, int i) { return (b[i >> 5] >> (i & 31)) & 1u; }
 
-// Wave-wide maximum / sum of a 64-bit value per lane without the LDS crossbar: four DPP steps inside each 16-lane row (quad_perm,
-// quad_perm, row_half_mirror, row_mirror: two moves, a compare and two selects per step), then the four row results through
-// v_readlane.  A __shfl_xor of a 64-bit value is two ds_bpermute round trips; the six dependent steps of a butterfly measured
-// ~1 400 cycles per selection round of the interpreter, 56 % of the kernel (cycle stamps).  Whole wave active.
-template <int CTRL>
-__device__ __forceinline__ uint64_t dpp_mov_u64(uint64_t v) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane_const) {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_const);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_const);
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
-    uint64_t o;
-    o = dpp_mov_u64<0xB1>(v), v = o > v ? o : v;
-    o = dpp_mov_u64<0x4E>(v), v = o > v ? o : v;
-    o = dpp_mov_u64<0x141>(v), v = o > v ? o : v;
-    o = dpp_mov_u64<0x140>(v), v = o > v ? o : v;
-    const uint64_t a = readlane_u64(v, 0), b = readlane_u64(v, 16), c = readlane_u64(v, 32), d = readlane_u64(v, 48);
-    const uint64_t ab = a > b ? a : b, cd = c > d ? c : d;
-    return ab > cd ? ab : cd;
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
-    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
-           __builtin_amdgcn_readlane(v, 48);
-}
-
 constexpr int CAFE_BIT_WORDS = 8192;  // 262 144 ids per LDS bitmap (2 x 32 KiB)
 constexpr int CAFE_MAX_NODES = 128;
 constexpr int CAFE_PCHUNK = 128;  // parent paths whose adjacency bounds are looked up together

@@ -125,6 +125,63 @@ __device__ __forceinline__ float dpp_group_sum(float v) {
     return v;
 }
 
+// Wave-wide maximum / sum of a 64-bit value per lane without the LDS crossbar: four DPP steps inside each 16-lane row (quad_perm,
+// quad_perm, row_half_mirror, row_mirror: two moves, a compare and two selects per step), then the four row results through
+// v_readlane.  A __shfl_xor of a 64-bit value is two ds_bpermute round trips; the six dependent steps of a butterfly measured
+// ~1 400 cycles per selection round of the interpreter, 56 % of the kernel (cycle stamps).  Maxima only: a sum taken this way adds in another order than group_sum's.  Whole wave active.
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_mov_u64(uint64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane_const) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_const);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_const);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+    uint64_t o;
+    o = dpp_mov_u64<0xB1>(v), v = o > v ? o : v;
+    o = dpp_mov_u64<0x4E>(v), v = o > v ? o : v;
+    o = dpp_mov_u64<0x141>(v), v = o > v ? o : v;
+    o = dpp_mov_u64<0x140>(v), v = o > v ? o : v;
+    const uint64_t a = readlane_u64(v, 0), b = readlane_u64(v, 16), c = readlane_u64(v, 32), d = readlane_u64(v, 48);
+    const uint64_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false), v = o > v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false), v = o > v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false), v = o > v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false), v = o > v ? o : v;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
 // ---- sub-wave sum over G lanes (G power of two, 1..64); every lane gets the total ----
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {

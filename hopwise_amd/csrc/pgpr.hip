@@ -886,8 +886,7 @@ __global__ __launch_bounds__(256) void policy_topk_kernel(const float* __restric
             x[i] = (j < na && j < act_dim) ? lr[j] : -INFINITY;
             mx = fmaxf(mx, x[i]);
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        mx = wave_max_f32(mx);
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NPL; ++i) {
@@ -911,11 +910,7 @@ __global__ __launch_bounds__(256) void policy_topk_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < NPL; ++i)
                 if (key[i] < bound && key[i] > best) best = key[i];
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                const uint64_t o = __shfl_xor(best, m, 64);
-                best = o > best ? o : best;
-            }
+            best = wave_max_u64(best);
             if (lane == 0) {
                 const int idx = (int)(~(uint32_t)(best & 0xffffffffu));
                 const bool ok = best != 0 && idx < na;
@@ -1027,8 +1022,7 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
             x[i] = (j < na && j < act_dim) ? x[i] : -INFINITY;
             mx = fmaxf(mx, x[i]);
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        mx = wave_max_f32(mx);
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1076,8 +1070,7 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
                 // no key has a bit set above the largest key's highest one: the search starts there (probabilities of a
                 // 250-way softmax leave the top ~8 mantissa bits of p + 1 clear, i.e. ~8 of the ~25 rounds)
                 uint32_t mk = max(max(key[0], key[1]), max(key[2], key[3]));
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, m, 64));
+                mk = wave_max_u32(mk);
                 const int top = 31 - __builtin_clz((__builtin_amdgcn_readfirstlane(mk) & 0x7FFFFFFFu) | 1u);
                 for (int bit = top; bit >= 0; --bit) {
                     const uint32_t cand = T | (1u << bit);
