@@ -339,3 +339,46 @@ def test_module_loop_in_cpp_equals_the_python_loop(monkeypatch):
     monkeypatch.setenv("HW_CAFE_MODULES", "1")
     with torch.no_grad():
         assert m._module_structs([m._module(n) for n in sorted(m.relation_info)], m.user_embedding) is not None
+
+
+def test_shallow_relation_modules_fused_equals_the_python_loop(monkeypatch):
+    """RelationModule (deep_module = False: fc1 -> bn1 -> fc2 + eh, cafe.py:645-667) has no reference golden here; the three
+    forms of the module loop must agree on it as they do on the deep one: C++ launch-per-layer == Python loop bit for bit,
+    fused one-launch-per-level == them to fp32 rounding with the same items and paths.  Batch-norm statistics are perturbed
+    so that the evaluation-mode affine is not the identity."""
+    from hopwise_amd.model import CAFE
+
+    z, orc, rid, ui = load()
+    ds = FakeKGDataset(int(z["n_users"]), int(z["n_items"]), int(z["n_entities"]), len(rid), int(z["ui_relation"]),
+                       z["inter_users"], z["inter_items"], z["heads"], z["rels"], z["tails"], z["positives"],
+                       z["user_emb"], z["entity_emb"], np.zeros((len(rid), z["user_emb"].shape[1]), np.float32))
+    ds.ui_relation = ui
+    ds.field2token_id = {"relation_id": dict(rid)}
+    metapaths = [[[None, "user"]] + [[str(r), "entity"] for r in mp] for mp in z["metapaths"]]
+    cfg = dict(FIELDS, device=dev(), path_constraint=metapaths, rank_weight=10.0, deep_module=False, use_dropout=True,
+               topk_candidates=10, sample_size=500, topk_paths=int(z["topk_paths"]), max_user_trials=50, load_embeddings=True)
+    torch.manual_seed(3)
+    m = CAFE(cfg, ds).to(dev())
+    g = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        for rel in sorted(m.relation_info):
+            mod = m._module(rel)
+            assert not hasattr(mod, "fc3")
+            mod.bn1.running_mean.copy_(torch.randn(mod.bn1.running_mean.shape, generator=g) * 0.1)
+            mod.bn1.running_var.copy_(torch.rand(mod.bn1.running_var.shape, generator=g) + 0.5)
+            mod.bn1.weight.copy_(torch.rand(mod.bn1.weight.shape, generator=g) + 0.5)
+            mod.bn1.bias.copy_(torch.randn(mod.bn1.bias.shape, generator=g) * 0.1)
+    m.eval()
+    users = torch.from_numpy(z["users"])
+    out = {}
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("HW_CAFE_MODULES", mode)
+        m.rng = np.random.default_rng(11)
+        scores, rec, leaves, _ = m.run_program_device(users)
+        out[mode] = (scores.cpu(), {k: v.cpu() for k, v in rec.items()})
+    assert torch.equal(out["1"][0].nan_to_num(-1e30), out["0"][0].nan_to_num(-1e30))
+    for k in ("count", "item", "leaf", "ids"):
+        assert torch.equal(out["1"][1][k], out["0"][1][k]), k
+        assert torch.equal(out["2"][1][k], out["0"][1][k]), k
+    assert int(out["0"][1]["count"].sum()) > 0
+    torch.testing.assert_close(out["2"][0].nan_to_num(-1e30), out["0"][0].nan_to_num(-1e30), rtol=2e-5, atol=2e-5)
