@@ -77,4 +77,25 @@ def test_graph_replay_with_eager_work_between_replays_stays_finite_and_tracks_th
         diff = (p1.detach() - p0.detach()).abs()
         assert float(diff.mean()) < 2e-4, (n, float(diff.mean()))
         assert float((diff > 2e-2).float().mean()) < 1e-3, (n, float((diff > 2e-2).float().mean()))
-    assert abs(float(loss1) - float(loss0)) < 2e-3 * abs(float(loss0))
+    assert abs(float(loss1.detach()) - float(loss0.detach())) < 2e-3 * abs(float(loss0.detach()))
+
+
+@pytest.mark.gpu
+def test_fill_kernel_on_unaligned_and_odd_sized_buffers():
+    """hw::fill_bytes_async through an entry point that fills a caller's buffer (hw_pgpr_init_paths zeroes probs [3 n]): a
+    probs view that starts 4 bytes off a 16-byte boundary (the kernel's dword path) and lengths that are not multiples of
+    four words (the tail of its 16-byte path); the words around the view must stay untouched."""
+    from hopwise_amd import pgpr_ops as P
+
+    dev = torch.device("cuda", 0)
+    for n, off in ((1, 0), (5, 0), (7, 1), (33, 3), (1000, 1), (4096, 2)):
+        users = torch.arange(1, n + 1, device=dev, dtype=torch.int64)
+        paths = torch.zeros((n, P.ROW_INTS), dtype=torch.int32, device=dev)
+        backing = torch.full((3 * n + 8,), 7.0, device=dev)
+        probs = backing[off : off + 3 * n]
+        n_rows = torch.zeros(1, dtype=torch.int32, device=dev)
+        P.init_paths(users, paths, probs, n_rows)
+        torch.cuda.synchronize()
+        assert int(n_rows.item()) == n
+        assert bool((backing[off : off + 3 * n] == 0).all()), (n, off)
+        assert bool((backing[:off] == 7).all()) and bool((backing[off + 3 * n :] == 7).all()), (n, off)
