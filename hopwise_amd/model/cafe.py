@@ -381,7 +381,8 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         slot_off = cum - cap - slot_ptr[row_b]
         # 1) node vectors, level by level, one module call per (level, relation) over all users
         d = self.user_embedding.shape[1]
-        vec_all = torch.zeros((max(total, 1), d), dtype=torch.float32, device=dev)
+        # every node row is written by its (level, relation) group before anything reads it (the groups partition the nodes)
+        vec_all = torch.empty((max(total, 1), d), dtype=torch.float32, device=dev)
         # every index column of stages 1 and 2 goes to the device in ONE copy (they were three pageable host-to-device copies
         # per (level, relation) pair -- ~45 per call, each a stall of the launching thread in a leg that is host-bound)
         et_of = np.array([m.et_name for m in mods])[rel_code] if total else np.zeros(0, "<U6")
