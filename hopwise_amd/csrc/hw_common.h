@@ -393,12 +393,14 @@ inline RowShape row_shape(int dim, bool allow_vec) {
 }
 
 // Stream-ordered fill of a buffer with a byte value, as a KERNEL launch (what hipMemsetAsync is for, without being one).
-// Why not hipMemsetAsync: a training step captured in a HIP graph turns it into a memset node, and on this stack a replayed
-// memset node was seen to run out of order with the kernel nodes around it -- the relation-replica scratch of
-// hw_kge_grad_grouped (zeroed, accumulated into, reduced) came back with the bytes of an EARLIER kernel's temporaries that
-// shared its pool block, once in ~6 processes and then at a fixed replay (tools/ref_layout_stress.py --graph --poison:
-// relation row NaN at replay 67 / 77).  A kernel node is ordered like every other kernel of the capture.
-// bytes must be a multiple of 4 (every caller fills float / int32 / 64-bit arrays).
+// Why not hipMemsetAsync: a training step captured in a HIP graph turns it into a memset NODE, and on this stack a memset
+// node writes its captured value on the FIRST launch of the instantiated graph only -- from the second launch on it fills
+// the destination with a 16-byte pattern read from runtime staging memory that has been reused since (the byte count of
+// the fill, a 1 and an address-like word: tools/memset_pattern_probe.py shows it in one process, every replay after the
+// first; profiles/r4/memset_pattern_probe*.json).  Viewed as floats that pattern is mostly denormals, which is why the
+// relation-replica scratch of hw_kge_grad_grouped (zeroed, accumulated into, reduced) only OCCASIONALLY came back visibly
+// wrong.  A kernel node carries its arguments in the graph and has no such state.
+// Any size and alignment: unaligned head and tail bytes are written singly, the body as 16-byte or 4-byte words.
 static __global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __restrict__ p, size_t n_words, uint32_t v) {
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -412,19 +414,30 @@ static __global__ __launch_bounds__(256) void fill_words_kernel(uint32_t* __rest
     for (; i < n_words; i += stride) p[i] = v;
 }
 
+static __global__ __launch_bounds__(64) void fill_edge_bytes_kernel(uint8_t* __restrict__ head, int n_head,
+                                                                   uint8_t* __restrict__ tail, int n_tail, uint8_t b) {
+    const int t = threadIdx.x;
+    if (t < n_head) head[t] = b;
+    if (t < n_tail) tail[t] = b;
+}
+
 inline hipError_t fill_bytes_async(void* p, int byte_value, size_t bytes, hipStream_t st) {
     if (bytes == 0) return hipSuccess;
-    // HW_FILL_MEMSET=1: the hipMemsetAsync this function replaced, kept as a switch so that the replay failure can be shown
-    // with and without it on one tree (tools/ref_layout_stress.py); read once per translation unit
-    static const bool use_memset = [] { const char* e = getenv("HW_FILL_MEMSET"); return e && e[0] == '1'; }();
-    if (use_memset) return hipMemsetAsync(p, byte_value, bytes, st);
-    if (bytes & 3) return hipErrorInvalidValue;
+    if (!p) return hipErrorInvalidValue;
     const uint32_t b = (uint32_t)(byte_value & 0xff), v = b | (b << 8) | (b << 16) | (b << 24);
-    const size_t n_words = bytes >> 2;
-    size_t blocks = (n_words / 4 + 255) / 256;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n_words, v);
+    uint8_t* base = (uint8_t*)p;
+    size_t n_head = (size_t)((4 - ((uintptr_t)base & 3)) & 3);  // bytes up to the first 4-byte boundary
+    if (n_head > bytes) n_head = bytes;
+    const size_t n_words = (bytes - n_head) >> 2, n_tail = bytes - n_head - (n_words << 2);
+    if (n_head || n_tail)
+        hipLaunchKernelGGL(fill_edge_bytes_kernel, dim3(1), dim3(64), 0, st, base, (int)n_head,
+                           base + n_head + (n_words << 2), (int)n_tail, (uint8_t)b);
+    if (n_words) {
+        size_t blocks = (n_words / 4 + 255) / 256;
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)(base + n_head), n_words, v);
+    }
     return hipGetLastError();
 }
 

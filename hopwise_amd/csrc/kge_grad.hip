@@ -377,7 +377,8 @@ extern "C" int hw_kge_grad_grouped(const hw_kge_desc* desc, const hw_kge_grads* 
     float* replicas =
         (!gq && desc->model != HW_RESCAL && !r_idx && rel_workspace && grads->rel[0] && n_tasks >= 256) ? rel_workspace
                                                                                                           : nullptr;
-    if (replicas) (void)hw::fill_bytes_async(replicas, 0, sizeof(float) * REL_REPLICAS * n_rel_tab * rel_row_len, st);
+    if (replicas && hw::fill_bytes_async(replicas, 0, sizeof(float) * REL_REPLICAS * n_rel_tab * rel_row_len, st) != hipSuccess)
+        return HW_ERR_LAUNCH;
 #define CALL(MODEL, NE_)                                                                                           \
     hipLaunchKernelGGL((kge_grad_grouped_kernel<MODEL, NE_>), dim3((unsigned)n_blocks), dim3(256), 0, st, *desc,     \
                        *grads, h_idx, r_idx, r_fixed, t_idx, t_stride_b, t_stride_j, n_groups, ntail, S, g,          \

@@ -953,7 +953,7 @@ static int full_sort_topk_impl(const hw_kge_desc* desc, const int64_t* h_idx, co
     const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
     hipStream_t st = (hipStream_t)stream;
     HW_CLEAR_ERR();
-    (void)hw::fill_bytes_async(bits, 0, (size_t)n_heads * words * 4, st);
+    if (hw::fill_bytes_async(bits, 0, (size_t)n_heads * words * 4, st) != hipSuccess) return HW_ERR_LAUNCH;
     if (n_hist > 0)
         hipLaunchKernelGGL(build_mask_bits_kernel, dim3((unsigned)((n_hist + 255) / 256)), dim3(256), 0, st, hist_rows,
                            hist_cols, n_hist, n_heads, n, words, bits);

@@ -1259,7 +1259,7 @@ extern "C" int hw_pgpr_init_paths(const int64_t* users, int64_t n_users_in_batch
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int n = (int)n_users_in_batch;
-    if (probs && n > 0) (void)hw::fill_bytes_async(probs, 0, sizeof(float) * 3 * (size_t)n, st);
+    if (probs && n > 0 && hw::fill_bytes_async(probs, 0, sizeof(float) * 3 * (size_t)n, st) != hipSuccess) return HW_ERR_LAUNCH;
     hipLaunchKernelGGL(pgpr_init_paths_kernel, dim3(n > 0 ? (n + 255) / 256 : 1), dim3(256), 0, st, users, n, paths,
                        n_rows);
     return HW_LAUNCH_RC();
@@ -1350,7 +1350,7 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_u
     const int32_t* lists[3] = {nullptr, nullptr, nullptr};
     const int32_t* lens[3] = {nullptr, nullptr, nullptr};
     if (work) {
-        (void)hw::fill_bytes_async(work, 0, 4 * sizeof(int32_t), st);
+        if (hw::fill_bytes_async(work, 0, 4 * sizeof(int32_t), st) != hipSuccess) return HW_ERR_LAUNCH;
         for (int c = 0; c < 3; ++c) lists[c] = work + 4 + (int64_t)c * max_rows, lens[c] = work + c;
     }
     {

@@ -225,10 +225,11 @@ extern "C" int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_em
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)n_batch;
     const int64_t cells = n_batch * (int64_t)graph->n_items;
-    (void)hw::fill_bytes_async(best_ws, 0, sizeof(uint64_t) * (size_t)cells, st);
-    (void)hw::fill_bytes_async(sel_leaf, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st);
-    (void)hw::fill_bytes_async(sel_item, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st);
-    (void)hw::fill_bytes_async(sel_score, 0, sizeof(double) * (size_t)n_batch * kmax, st);
+    if (hw::fill_bytes_async(best_ws, 0, sizeof(uint64_t) * (size_t)cells, st) != hipSuccess ||
+        hw::fill_bytes_async(sel_leaf, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st) != hipSuccess ||
+        hw::fill_bytes_async(sel_item, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st) != hipSuccess ||
+        hw::fill_bytes_async(sel_score, 0, sizeof(double) * (size_t)n_batch * kmax, st) != hipSuccess)
+        return HW_ERR_LAUNCH;
     hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((cells + 255) / 256 > 4096 ? 4096 : (cells + 255) / 256)),
                        dim3(256), 0, st, results, cells, -INFINITY);
     hipLaunchKernelGGL(collect_slots_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, users, nb, first_idx_ws);

@@ -67,3 +67,11 @@ extern "C" int hw_scatter_add_rows(float* table, int64_t n_table_rows, int32_t d
                        n_table_rows, dim, idx, n, src);
     return HW_LAUNCH_RC();
 }
+
+// Graph-safe stream-ordered fill (hw_common.h: fill_bytes_async): what a caller that captures the engine's launches in a HIP
+// graph uses instead of hipMemsetAsync, whose memset NODES replay a stale pattern on this stack.
+extern "C" int hw_fill_bytes(void* dst, int32_t byte_value, int64_t n_bytes, void* stream) {
+    if (n_bytes < 0 || (n_bytes > 0 && !dst)) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    return hw::fill_bytes_async(dst, byte_value, (size_t)n_bytes, (hipStream_t)stream) == hipSuccess ? HW_OK : HW_ERR_LAUNCH;
+}

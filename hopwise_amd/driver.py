@@ -120,16 +120,48 @@ class GraphedTrainStep:
         self.keys = sorted(k for k in example if torch.is_tensor(example[k]))  # dict or Interaction: iterate field names
         self.static = {k: example[k].clone() for k in self.keys}
         self.shapes = {k: tuple(v.shape) for k, v in self.static.items()}
+        self._params = [p for grp in optimizer.param_groups for p in grp["params"]]
+        saved = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up: lazy state of the optimizer, workspace caches
             for _ in range(2):
                 self._step()
         torch.cuda.current_stream().wait_stream(side)
+        # the warm-up steps were real optimizer steps on the example batch: undo them in place (the capture below records
+        # pointers), so that the first replay IS the first step on this batch, as in Trainer._train_epoch
+        self._restore(saved)
         self.graph = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss = self._step()
+
+    def _snapshot(self):
+        """Copies of everything a warm-up step changes: parameters, module buffers, the optimizer's per-parameter state."""
+        state = {}
+        for p in self._params:
+            st = self.opt.state.get(p)
+            if st:
+                state[p] = {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
+        return ([p.detach().clone() for p in self._params], [b.detach().clone() for b in self.model.buffers()], state)
+
+    @torch.no_grad()
+    def _restore(self, saved):
+        """Put the snapshot back IN PLACE.  State tensors the warm-up created (the optimizer's lazy initialisation: step
+        counters and moments, all of which start at zero in torch's Adam and in FusedAdam) are zeroed."""
+        params, buffers, state = saved
+        for p, v in zip(self._params, params):
+            p.copy_(v)
+        for b, v in zip(self.model.buffers(), buffers):
+            b.copy_(v)
+        for p in self._params:
+            before = state.get(p, {})
+            for k, v in self.opt.state.get(p, {}).items():
+                if torch.is_tensor(v):
+                    if k in before:
+                        v.copy_(before[k])
+                    else:
+                        v.zero_()
 
     def _step(self):
         self.opt.zero_grad(set_to_none=True)
@@ -148,6 +180,9 @@ class GraphedTrainStep:
         # one multi-tensor launch instead of a copy per field (7 of ~25 launches of a RotatE step otherwise)
         torch._foreach_copy_([self.static[k] for k in self.keys], [interaction[k] for k in self.keys], non_blocking=True)
         self.graph.replay()
+        # the replay rewrites the parameters without running any Python of the optimizer: keep autograd's version counters
+        # honest (caches keyed on a weight's _version, saved-tensor checks), as an eager optimizer step does
+        torch.autograd.graph.increment_version(self._params)
         return self.loss
 
 

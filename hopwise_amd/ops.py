@@ -774,6 +774,17 @@ def scatter_add_rows_(table, idx, src):
     return table
 
 
+def fill_bytes_(t, byte_value):
+    """Every byte of the contiguous HIP tensor ``t`` = byte_value, by kernel launches on the current stream: the graph-safe
+    stand-in for hipMemsetAsync (include/hopwise_amd.h: hw_fill_bytes)."""
+    lib = _lib.load()
+    if not (torch.is_tensor(t) and t.is_cuda and t.is_contiguous()):
+        raise ValueError("fill_bytes_: a contiguous HIP tensor is required (no CPU path)")
+    check(lib.hw_fill_bytes(C.c_void_p(t.data_ptr()), int(byte_value) & 0xff, t.numel() * t.element_size(), _stream()),
+          "hw_fill_bytes")
+    return t
+
+
 # ------------------------------------------------------------------------------------------------
 # device-side routing of a row-sharded lookup (csrc/shard.hip)
 # ------------------------------------------------------------------------------------------------

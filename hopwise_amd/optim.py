@@ -148,15 +148,21 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] = st["step"].to(device=p.device, dtype=torch.int64)
         return st
 
+    def _stepped(self, group):
+        """The group's parameters this step updates: those with a gradient and, with sinks, those a backward reached since
+        the last step (as torch.optim.Adam skips ``grad is None``)."""
+        ps = [p for p in group["params"] if p.grad is not None]
+        if self._sinks is not None:
+            ps = [p for p in ps if p.data_ptr() in self._sinks.touched]
+        return ps
+
     def _launches(self, group):
         """[(AdamArgs, step tensor)] for the group's parameters that have a gradient, 16 per launch; cached per
         composition on the identity of every buffer involved.
 
         A launch reads ONE device step counter, so parameters share a counter only while they are always stepped
         together: a parameter that sits a step out (untouched, see _SinkState) is split off with its own counter."""
-        ps = [p for p in group["params"] if p.grad is not None]
-        if self._sinks is not None:  # as torch.optim.Adam: a parameter no backward reached since the last step is skipped
-            ps = [p for p in ps if p.data_ptr() in self._sinks.touched]
+        ps = self._stepped(group)
         states = [self._state_of(p) for p in ps]
         key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
                      s["step"].data_ptr()) for p, s in zip(ps, states))
@@ -246,6 +252,12 @@ class FusedAdam(torch.optim.Optimizer):
         lib = _lib.load()
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            # hw_adam_step writes the parameters through raw pointers, which autograd's version counters do not see:
+            # bump them by hand, as every in-place torch op would, so that anything derived from a weight and cached on
+            # (data_ptr, _version) -- CAFE's transposed module weights, PGPR's pre-split policy planes -- is rebuilt
+            stepped = self._stepped(group)
+            if stepped:
+                torch.autograd.graph.increment_version(stepped)
             for args, step in self._launches(group):
                 rc = lib.hw_adam_step(C.byref(args), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                       float(group["weight_decay"]), C.c_void_p(step.data_ptr()),

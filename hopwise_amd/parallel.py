@@ -17,10 +17,13 @@ One lookup (forward), with no host read anywhere on the way (SURVEY.md §8(e) ro
 lookup's `max_ids` -- a number fixed per kind of lookup and IDENTICAL ON EVERY RANK (RowShardedKGE freezes it at the first
 batch of a kind as the maximum over ranks, or takes it from its `max_ids` argument): equal-split all-to-alls need equal
 message sizes on all ranks, and a ragged last batch must not change them.  Message sizes therefore never depend on data and
-nothing is read back on the good path.  An owner asked for more than `cap` distinct rows raises a device flag; the step's
-loss then comes back NaN (decided on the device: the reference trainer's `_check_nan` stops before backward,
-trainer.py:337-339), `sync_grads` checks the flag before any optimizer step can apply the clamped rows, and the evaluation
-entry points check it before returning.
+nothing is read back on the good path.  An owner asked for more than `cap` distinct rows raises a device flag on the
+REQUESTING rank; RowShardedKGE max-reduces that flag over the ranks right after a step's lookups (one 4-byte all-reduce), so
+the decision is the same everywhere: the step's loss comes back NaN on EVERY rank (decided on the device: the reference
+trainer's `_check_nan` stops all of them before backward, trainer.py:337-339 -- a rank that raised alone would leave its
+peers waiting in the backward all-to-all), `sync_grads` checks the flag before any optimizer step can apply the clamped rows,
+and the evaluation entry points check it before returning.  A batch LARGER than `max_ids` takes the same road: it is routed
+like any other, and either fits the capacity or raises the flag for everybody.
 The fused scorers then run unchanged on the compact tables with remapped ids, so the kernels never see the
 sharding.  Backward is the mirror image: compact row-grads --all_to_all--> hw_shard_scatter_add into the owner's
 gradient shard.  xGMI is point-to-point (7 links per GPU): all-to-all uses all links at once; there is no ring
@@ -85,6 +88,16 @@ def all_reduce_sum(t, group=None):
     return t
 
 
+def all_reduce_max(t, group=None):
+    if _staged(group, t):
+        c = t.cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
 def all_gather(parts, t, group=None):
     if _staged(group, t):
         cp = [torch.empty(p.shape, dtype=p.dtype) for p in parts]
@@ -126,10 +139,10 @@ class _Plan:
     def __init__(self, ids, n_rows, group, factor, overflow, n_tables, max_ids=None):
         rank, P = world(group)
         self.group, self.P, self.T = group, P, int(n_tables)
+        # the capacity comes from max_ids alone, never from this rank's batch: a rank must not decide by itself to refuse (its
+        # peers would wait in the collectives below).  More ids than max_ids are routed like any others; if an owner's share
+        # does not fit, the overflow flag says so -- to every rank, once the caller has reduced it (RowShardedKGE does)
         n_cap = ids.numel() if max_ids is None else int(max_ids)
-        if ids.numel() > n_cap:
-            raise ValueError(f"row-sharded lookup of {ids.numel()} ids exceeds max_ids = {n_cap}: the exchange capacity is "
-                             "sized from max_ids on every rank (pad or split the batch, or build with a larger max_ids)")
         self.cap = capacity(n_cap, n_rows, P, factor)
         plan = _shard_ops["plan"] or ops.shard_plan
         self.inv, self.send_meta = plan(ids, n_rows, P, self.cap, overflow, self.T)
@@ -214,7 +227,9 @@ def sharded_lookup(shards, ids, n_rows, group=None, capacity_factor=1.25, overfl
     """Rows of the row-sharded tables ``shards`` (same sharding, e.g. re/im; ``n_rows`` = rows of the full table) for
     ``ids``.  Returns (compact tables tuple (views of one [P * T * cap, d] buffer), inverse map shaped like ids, overflow
     flag tensor).  ``max_ids``: the id count the exchange capacity is sized from -- it MUST be the same on every rank
-    (default: this call's ids.numel(), i.e. callers guarantee equal batch sizes); fewer ids than that are fine."""
+    (default: this call's ids.numel(), i.e. callers guarantee equal batch sizes); fewer ids than that are fine, more are
+    routed too and raise the flag if an owner's share exceeds the capacity.  The flag is LOCAL to the requesting rank: a
+    caller that acts on it must max-reduce it over the group first (``all_reduce_max``), or the ranks will disagree."""
     if overflow is None:
         overflow = torch.zeros(1, dtype=torch.int32, device=ids.device)
     plan = _Plan(ids, n_rows, group, capacity_factor, overflow, len(shards), max_ids)
@@ -306,12 +321,19 @@ class RowShardedKGE(nn.Module):
         else:
             seen = int(self._overflow.item())
         if seen:
+            self._overflow.zero_()  # reported once: the caller may raise capacity_factor / max_ids and go on
+            if self._ovf_host is not None:
+                self._ovf_host.zero_()
             raise RuntimeError(
-                f"row-sharded lookup: an owner was asked for {seen} distinct rows, more than the exchange capacity "
-                f"(capacity_factor={self.capacity_factor}); the affected step is invalid -- raise capacity_factor "
-                f"(P = {self.P} is the worst case)")
+                f"row-sharded lookup: an owner was asked for {seen} distinct rows by one rank, more than the exchange "
+                f"capacity (capacity_factor={self.capacity_factor}, max_ids={self._max_ids}); the affected step is invalid on "
+                f"every rank -- raise capacity_factor (P = {self.P} is the worst case) or max_ids")
 
     def _post_overflow_copy(self):
+        """After the LAST lookup of a call: make the flag the maximum over ranks (a 4-byte all-reduce; every rank calls this at
+        the same point of the same call, so it lines up like the all-to-alls around it), then post the pinned copy."""
+        if self._overflow is not None and _exchange(self.P):
+            all_reduce_max(self._overflow, self.group)
         if self._overflow is not None and self._overflow.is_cuda:
             if self._ovf_host is None:
                 self._ovf_host = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -340,7 +362,10 @@ class RowShardedKGE(nn.Module):
 
     def calculate_loss(self, interaction):
         m = self.model
-        self.check_overflow(wait=False)  # the previous call's flag: its copy landed long ago, no stall
+        # the previous call's flag (already the maximum over ranks).  At P > 1 the check must come out the same on every rank,
+        # so it waits for that call's pinned copy (posted right after its routing kernels: landed long ago) instead of
+        # polling it -- a poll could be seen by one rank and missed by another, which would then wait in the all-to-all
+        self.check_overflow(wait="lookups" if _exchange(self.P) else False)
         keys = (m.ITEM_ID, m.NEG_ITEM_ID, m.HEAD_ENTITY_ID, m.TAIL_ENTITY_ID, m.NEG_TAIL_ENTITY_ID)
         ent_ids = torch.cat([interaction[k].reshape(-1) for k in keys])
         ent_rows, ent_inv = self._lookup(m.ENTITY_TABLES, ent_ids, self.n_entities, "train_entity")

@@ -527,6 +527,13 @@ int hw_gather_rows(const float* table, int64_t n_table_rows, int32_t dim, const 
 int hw_scatter_add_rows(float* table, int64_t n_table_rows, int32_t dim, const int64_t* idx, int64_t n,
                         const float* src, void* stream);
 
+/* dst[0 .. n_bytes) = (uint8_t)byte_value, as KERNEL launches on `stream` (any size and alignment).  The stream-ordered fill
+ * to use in code that may be captured in a HIP graph -- e.g. driver.GraphedTrainStep around Trainer._train_epoch
+ * (trainer/trainer.py:208-268) -- instead of hipMemsetAsync: a memset NODE of an instantiated graph writes its captured value
+ * on the first launch only and a stale 16-byte staging pattern afterwards on this stack (tools/memset_pattern_probe.py,
+ * DESIGN.md section 2); every fill inside this library goes through the same kernels. */
+int hw_fill_bytes(void* dst, int32_t byte_value, int64_t n_bytes, void* stream);
+
 /* Device-side routing of one sharded lookup ("bucket indices by owner -> all_to_all(ids) -> local
  * gather -> all_to_all(rows)"; owner = id % n_ranks, local row = id / n_ranks).  No host read anywhere:
  *   inv[i]                               = owner(ids[i]) * inv_stride + rank of ids[i] among the owner's distinct ids (ascending)

@@ -241,6 +241,29 @@ def _worker(rank, world_size, port, tmp):
         finally:
             par.capacity = _orig_cap
 
+        # ---- 2f. only ONE rank overflows: the decision is still collective -- NaN loss on both ranks, both stopped before the
+        #          gradient all-reduce, nobody left waiting in a collective; the flag is reported once and the wrapper goes on ----
+        lone = par.RowShardedKGE(_StubModel(tables, nU, nE, nI), capacity_factor=1.0)
+        par.capacity = lambda n, rows, P, f: 5
+        try:
+            b1 = batch(rank)
+            if rank == 0:  # a narrow batch: ids 1..4, at most two distinct rows per owner
+                b1 = {k: v % 4 + 1 for k, v in b1.items()}
+            mine = torch.zeros(1, dtype=torch.int32)
+            _cpu_plan(torch.cat([b1[k] for k in ("item_id", "neg_item_id", "head_id", "tail_id", "neg_tail_id")]), nE,
+                      world_size, 5, mine)
+            assert (int(mine.item()) > 0) == (rank == 1)  # this rank's own routing: only rank 1 does not fit
+            loss = lone.calculate_loss(b1)
+            assert torch.isnan(loss).item()  # ... yet BOTH ranks see the NaN the trainer's check stops at
+            with pytest.raises(RuntimeError, match="capacity"):
+                lone.sync_grads()  # and both are stopped here, ahead of the all-reduce
+        finally:
+            par.capacity = _orig_cap
+        loss = lone.calculate_loss(batch(rank))  # reported once: at the real capacity the same wrapper goes on
+        assert torch.isfinite(loss).item()
+        loss.backward()
+        lone.sync_grads()
+
         # ---- 2e. ranks with different batch sizes (a ragged last batch): the message sizes come from max_ids, not from the
         #          local batch, so the equal-split all-to-alls still line up -----------------------------------------------
         ragged = par.RowShardedKGE(_StubModel(tables, nU, nE, nI), max_ids={"train_entity": 5 * 12, "train_user": 9})
@@ -256,8 +279,10 @@ def _worker(rank, world_size, port, tmp):
         for n in _StubModel.USER_TABLES + _StubModel.ENTITY_TABLES:
             assert torch.allclose(getattr(ragged, "shard_" + n).grad, getattr(ref2, n).weight.grad[rank::world_size], atol=1e-6), n
         assert torch.allclose(ragged.model.relation_embedding.weight.grad, ref2.relation_embedding.weight.grad, atol=1e-6)
-        with pytest.raises(ValueError, match="max_ids"):  # a LARGER batch than max_ids is refused before any collective
-            par.sharded_lookup((sa.detach(), sb.detach()), ids, N, max_ids=ids.numel() - 1)
+        # a batch LARGER than max_ids is not refused by one rank on its own (its peers would wait in the all-to-all): it is
+        # routed like any other, and fits here (the capacity is the whole shard)
+        (ca2, cb2), inv2, ovf2 = par.sharded_lookup((sa.detach(), sb.detach()), ids, N, max_ids=ids.numel() - 1)
+        assert int(ovf2.item()) == 0 and torch.equal(ca2[inv2], full_a[ids]) and torch.equal(cb2[inv2], full_b[ids])
         # without max_ids the first batch freezes the maximum over ranks (rank 0 has the larger batch here)
         auto = par.RowShardedKGE(_StubModel(tables, nU, nE, nI))
         auto.calculate_loss(cut(batch(rank), *sizes[rank]))

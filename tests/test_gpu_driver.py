@@ -103,12 +103,13 @@ def test_graphed_train_step_equals_eager(model_name):
     batches = [batch() for _ in range(6)]
     opt_e = torch.optim.Adam(eager.parameters(), lr=1e-3, capturable=True)
     opt_g = torch.optim.Adam(graphed.parameters(), lr=1e-3, capturable=True)
+    before = {k: v.clone() for k, v in graphed.state_dict().items()}
     step = GraphedTrainStep(graphed, opt_g, batches[0])
-    # the constructor ran warm-up + capture steps on batches[0] (the capture itself does not execute): mirror them
-    for _ in range(2):
-        opt_e.zero_grad()
-        eager.calculate_loss(batches[0]).backward()
-        opt_e.step()
+    # the constructor's warm-up steps are undone before the capture: parameters and Adam state are what they were
+    for k, v in graphed.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    for st in opt_g.state.values():
+        assert float(st["step"]) == 0 and not st["exp_avg"].any() and not st["exp_avg_sq"].any()
     for b in batches:
         opt_e.zero_grad()
         le = eager.calculate_loss(b)
@@ -174,9 +175,7 @@ def test_graphed_trainer_mixin_equals_the_plain_loop():
     cfg = {"learning_rate": 1e-3, "learner": "adam", "single_spec": True}
     plain, graphed = Base(cfg, plain_m), graphed_trainer(Base)(cfg, graph_m)
     assert type(graphed).__name__ == "GraphedBase" and isinstance(graphed.optimizer, FusedAdam)
-    # GraphedTrainStep's constructor runs two warm-up steps on its example batch: give the plain loop the same start
-    plain._train_epoch([epoch[0], epoch[0]], 0)
-    for ep in range(2):
+    for ep in range(2):  # the same trajectory from the first batch on: GraphedTrainStep undoes its warm-up steps
         lp = plain._train_epoch(epoch, ep)
         lg = graphed._train_epoch(epoch, ep)
         np.testing.assert_allclose(lg, lp, rtol=2e-4)
