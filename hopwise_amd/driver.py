@@ -97,6 +97,32 @@ def train_epoch(model, batches, optimizer, clip_grad_norm=None, device=None):
     return float(total.item()) if total is not None else 0.0
 
 
+def count_memset_nodes(graph):
+    """Memset nodes in the hipGraph_t a ``torch.cuda.CUDAGraph(keep_graph=True)`` captured, read through the HIP graph API
+    of the runtime torch loaded (hipGraphGetNodes / hipGraphNodeGetType).  None when the runtime cannot be asked."""
+    import ctypes as C
+    import os
+
+    try:
+        raw = graph.raw_cuda_graph()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        hip = C.CDLL(path if os.path.exists(path) else "libamdhip64.so")
+        n = C.c_size_t(0)
+        if hip.hipGraphGetNodes(C.c_void_p(raw), None, C.byref(n)) != 0:
+            return None
+        nodes = (C.c_void_p * max(n.value, 1))()
+        if n.value and hip.hipGraphGetNodes(C.c_void_p(raw), nodes, C.byref(n)) != 0:
+            return None
+        count = 0
+        for i in range(n.value):
+            t = C.c_int(-1)
+            if hip.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(t)) == 0 and t.value == 2:  # hipGraphNodeTypeMemset
+                count += 1
+        return count
+    except (OSError, AttributeError, RuntimeError):
+        return None
+
+
 class GraphedTrainStep:
     """zero_grad -> calculate_loss -> backward -> optimizer.step captured once in a HIP graph and replayed per batch.
 
@@ -106,7 +132,8 @@ class GraphedTrainStep:
     like any other stream work; index tensors are copied into static buffers before each replay.
     Valid for models whose step has no host-side state: the pairwise gather scorers.  Models that pass a Python-side
     Philox offset to a kernel (TuckER / ConvE dropout, PGPR) would replay the same mask and are refused; batches of any
-    other shape than the captured one run eagerly."""
+    other shape than the captured one run eagerly.  A capture that holds a memset node is refused too: on this HIP runtime
+    such a node replays a stale pattern; the engine itself only launches kernels."""
 
     REFUSED = ("TuckER", "ConvE", "ConvKB", "PGPR", "TPRec", "CAFE")
 
@@ -131,10 +158,23 @@ class GraphedTrainStep:
         # the warm-up steps were real optimizer steps on the example batch: undo them in place (the capture below records
         # pointers), so that the first replay IS the first step on this batch, as in Trainer._train_epoch
         self._restore(saved)
-        self.graph = torch.cuda.CUDAGraph()
+        try:  # keep the captured hipGraph_t so that it can be inspected before it is instantiated
+            self.graph, kept = torch.cuda.CUDAGraph(keep_graph=True), True
+        except TypeError:  # a torch without keep_graph
+            self.graph, kept = torch.cuda.CUDAGraph(), False
         self.opt.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss = self._step()
+        if kept:
+            n_memset = count_memset_nodes(self.graph)
+            if n_memset:
+                raise ValueError(
+                    f"the captured training step holds {n_memset} memset node(s) (a hipMemsetAsync / cudaMemsetAsync issued by "
+                    "the model, the optimizer or a torch op inside the step).  On this HIP runtime a memset node writes its "
+                    "value on the first launch of the graph only and a stale staging pattern afterwards (DESIGN.md section "
+                    "2, tools/memset_pattern_probe.py): replaying this step would be silently wrong.  Fill with a kernel "
+                    "(tensor.zero_(), hopwise_amd.ops.fill_bytes_) or run the step eagerly")
+            self.graph.instantiate()
 
     def _snapshot(self):
         """Copies of everything a warm-up step changes: parameters, module buffers, the optimizer's per-parameter state."""

@@ -129,3 +129,41 @@ def test_fill_kernel_on_unaligned_and_odd_sized_buffers():
         assert int(n_rows.item()) == n
         assert bool((backing[off : off + 3 * n] == 0).all()), (n, off)
         assert bool((backing[:off] == 7).all()) and bool((backing[off + 3 * n :] == 7).all()), (n, off)
+
+
+@pytest.mark.gpu
+def test_a_capture_with_a_memset_node_is_refused():
+    """GraphedTrainStep inspects the captured graph: a hipMemsetAsync inside the step (here smuggled into calculate_loss)
+    would replay a stale pattern from the second launch on, so the capture is refused instead of instantiated."""
+    import ctypes as C
+
+    import hopwise_amd.model as M
+    from hopwise_amd.driver import GraphedTrainStep, count_memset_nodes
+    from hopwise_amd.optim import FusedAdam
+    from tests.helpers import FakeDataset, make_config
+
+    dev = torch.device("cuda", 0)
+    nU, nI, nE, nR, nb = 60, 40, 120, 6, 64
+    torch.manual_seed(0)
+    m = M.TransE(make_config(dev, 16, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
+    rng = np.random.default_rng(0)
+    it = {k: torch.from_numpy(rng.integers(1, hi, nb)).to(dev) for k, hi in (
+        ("user_id", nU), ("item_id", nI), ("neg_item_id", nI), ("head_id", nE), ("relation_id", nR - 1), ("tail_id", nE),
+        ("neg_tail_id", nE))}
+    good = GraphedTrainStep(m, FusedAdam(m.parameters(), lr=1e-3), it)
+    assert count_memset_nodes(good.graph) == 0
+    assert bool(torch.isfinite(good(it)))
+
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    scratch = torch.empty(1024, device=dev)
+    m2 = M.TransE(make_config(dev, 16, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
+    plain = m2.calculate_loss
+
+    def with_memset(interaction):
+        assert hip.hipMemsetAsync(scratch.data_ptr(), 0, 4096, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        return plain(interaction)
+
+    m2.calculate_loss = with_memset
+    with pytest.raises(ValueError, match="memset node"):
+        GraphedTrainStep(m2, FusedAdam(m2.parameters(), lr=1e-3), it)
