@@ -76,7 +76,9 @@ def algorithmic_bytes(m, res, hops):
                                                           deg * d * 4 gathered rows: the float64 trim tables u.U[n],
                                                           (u + r_ui).E[n], R[r].E[n] are precomputed per batch)
         first policy layer              n_parts * H1 * 4 (one 2 KB slot-table row per state slot; 4 at state_history 1)
-        children                        min(k, n_acts) * 60   (48-byte path record + 3 float32 hop values)
+        children                        min(k, n_acts) * 60   (48-byte path record + 3 float32 hop values); * 16 on the last
+                                                          hop when it writes compact leaves {parent row, relation, node,
+                                                          value} (BeamResult.leaves)
     `res` must come from beam_search_device(..., keep_buffers=True).  Returns (total, per-hop list)."""
     g, buf = m.graph, res.buffers
     nr = res.n_rows_per_hop.cpu().numpy()
@@ -93,7 +95,9 @@ def algorithmic_bytes(m, res, hops):
         deg = g.ptr[gid + 1] - g.ptr[gid]
         # n_acts of this hop is overwritten by later hops in the shared buffer: children are bounded by k and by deg + 1
         kids = torch.minimum(torch.full_like(deg, k), torch.minimum(deg + 1, torch.full_like(deg, m.act_dim)))
-        per_row = deg * 8 + torch.where(deg > m.max_acts, deg * 16, torch.zeros_like(deg)) + n_parts * h1 * 4 + kids * 60
+        child_bytes = 16 if (hop == len(hops) - 1 and getattr(res, "leaves", None) is not None) else 60
+        per_row = (deg * 8 + torch.where(deg > m.max_acts, deg * 16, torch.zeros_like(deg)) + n_parts * h1 * 4
+                   + kids * child_bytes)
         b = int(per_row.sum().item())
         per_hop.append({"rows": n, "bytes": b})
         total += b
@@ -131,6 +135,22 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
     # byte accounting and per-stage times on more (untimed) searches of the same size
     res = m.beam_search_device(batch(steps), keep_buffers=True)
     abytes, per_hop = algorithmic_bytes(m, res, HOPS)
+    # what the compact last level costs downstream, outside the timed region: the collector on it (reads the leaves in
+    # place) and a rebuild of every leaf as a full 60-byte record (what nothing on the evaluation path asks for)
+    leaf_layout = {"bytes_per_leaf": 16 if res.leaves is not None else 60}
+    users_probe = batch(steps)
+    res = m.beam_search_device(users_probe)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    e[0].record()
+    m.collect_scores_device(users_probe, res)
+    e[1].record()
+    if res.leaves is not None:
+        _ = res.paths  # materialises all leaves
+    e[2].record()
+    torch.cuda.synchronize()
+    leaf_layout["collect_scores_ms"] = round(e[0].elapsed_time(e[1]), 4)
+    if res.leaves is not None:
+        leaf_layout["materialize_all_records_ms"] = round(e[1].elapsed_time(e[2]), 4)
     del res
     stage_ms = {}
     n_probe = 5
@@ -159,6 +179,9 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         "graph": {"n_users": kg.n_users, "n_items": kg.n_items, "n_entities": kg.n_entities, "nnz": m.graph.nnz,
                   "max_degree": m.graph.max_degree},
         "policy": ("one launch per hop (hw_pgpr_policy_fused)" if m.fused_policy else "three launches per hop (lookup, l2, actor)"),
+        "tail": ("softmax + top-k + expand in one launch per hop (hw_pgpr_topk_expand)" if m.fused_tail
+                 else "top-k and expand as two launches per hop"),
+        "leaf_layout": leaf_layout,
         "roofline": {
             "bound": "hbm", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
             "frac": abytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_search": abytes, "traffic": traffic,
@@ -166,11 +189,15 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
             "stage_ms": {k: round(v, 4) for k, v in sorted(by_stage.items())},
             "stage_ms_by_hop": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
             "note": "bytes this algorithm must move (CSR slice deg * 8 + 2 float64 trim-score lookups per candidate of an "
-                    "over-full row + one 2 KB slot-table row per state slot + 60 B per child; bench_pgpr.algorithmic_bytes) / "
+                    "over-full row + one 2 KB slot-table row per state slot + 60 B per child, 16 B per child of the last hop when it "
+                    "leaves as a compact leaf {parent row, relation, node, value}; bench_pgpr.algorithmic_bytes) / "
                     "wall time of the whole search.  The search is not one bandwidth-bound kernel: the policy network is "
                     "MFMA / issue bound and the action kernels are L2-gather bound (DESIGN.md §4), so this fraction is a "
                     "reported figure, not a target.  stage_ms: HIP events between the stages of a search (5 untimed "
-                    "searches); per-kernel durations: profiles/r3/pgpr_kernel_stats_*.csv; traffic: fabric-side bytes of all "
+                    "searches; with the one-launch tail the top-k has no launch of its own and is inside 'expand'); "
+                    "leaf_layout: the collector on the compact leaves and a full rebuild of all 60-byte records, timed once "
+                    "outside the timed region; per-kernel durations: profiles/r4/pgpr_kernel_stats_*.csv; traffic: fabric-side "
+                    "bytes of all "
                     "kernels of one search from the FETCH_SIZE / WRITE_SIZE passes",
         },
     }

@@ -295,6 +295,15 @@ SIGNATURES = {
         [C.POINTER(PgprGraph), c_i32p, c_f32p, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int64, c_i32p, c_f32p, C.c_int32,
          c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, C.c_int64, C.c_void_p],
     ),
+    "hw_pgpr_topk_expand": (
+        C.c_int,
+        [C.POINTER(PgprGraph), c_i32p, c_f32p, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,
+         c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_void_p],
+    ),
+    "hw_pgpr_materialize_leaves": (
+        C.c_int,
+        [C.POINTER(PgprGraph), c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, c_i32p, C.c_int64, c_i32p, c_f32p, C.c_void_p],
+    ),
     "hw_pgpr_action_dropout": (
         C.c_int,
         [c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_double, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p],
@@ -327,6 +336,12 @@ SIGNATURES = {
         C.c_int,
         [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p, C.c_int64,
          c_i32p, c_f32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_i32p, c_f32p, c_i32p,
+         C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_void_p],
+    ),
+    "hw_pgpr_collect_leaves": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p, C.c_int64,
+         c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_i32p, c_f32p, c_i32p,
          C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_void_p],
     ),
     "hw_gather_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_f32p, c_i32p, C.c_void_p]),

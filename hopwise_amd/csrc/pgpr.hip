@@ -995,9 +995,107 @@ __device__ __forceinline__ void sort64(uint32_t& key, int lane) {
     if constexpr (SIZE < 64) sort64<SIZE * 2>(key, lane);
 }
 
-// SELECT (k <= 64): the k-th largest key is found by a bit-by-bit search with wave ballots (4 compares per bit, the counting
-// on the scalar unit; the search stops as soon as exactly k keys lie above the candidate), the k survivors are compacted to
-// one per lane and only those 64 are sorted: ~1/3 of the vector instructions of sorting all 256.  Same output.
+// Masked softmax of one row held by one wave (blocked layout: lane owns elements 4 * lane .. 4 * lane + 3) and its ranking keys:
+// (mantissa of p + 1) << 8 | (255 - index), top bit set for valid actions, 0 otherwise -- a plain unsigned compare gives
+// (value desc, index asc).  p + 1 rounds to exactly 2.0 when p >= 1 - 2^-25; such a row cannot also hold 1.99999988 (the
+// probabilities sum to 1), so 2.0 shares the top mantissa code and `row_has_two` tells them apart.
+__device__ __forceinline__ void row_softmax_keys(const float* __restrict__ lr, int act_dim, int na, int lane,
+                                                 float* __restrict__ probs_row, uint32_t (&key)[4], bool& row_has_two) {
+    // p is rounded to float32 before the + 1 (probs + mask.float() on a float32 tensor, pgpr.py:453): no fused multiply-add,
+    // or the same row would rank differently depending on which kernel the function was inlined into
+#pragma clang fp contract(off)
+    float x[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // clamped index, select afterwards: the four loads are issued together
+        const int j = lane * 4 + i;  // blocked layout: element j of the row
+        x[i] = lr[j < act_dim ? j : act_dim - 1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane * 4 + i;
+        x[i] = (j < na && j < act_dim) ? x[i] : -INFINITY;
+        mx = fmaxf(mx, x[i]);
+    }
+    mx = wave_max_f32(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = x[i] == -INFINITY ? 0.f : __expf(x[i] - mx);  // v_exp_f32: the ranking key keeps 23 bits of p + 1 anyway
+        sum += x[i];
+    }
+    sum = group_sum<64>(sum);
+    const float inv_sum = 1.f / sum;  // one division per row
+    bool two = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane * 4 + i;
+        const float pr = x[i] * inv_sum;
+        if (probs_row && j < act_dim) probs_row[j] = j < na ? pr : 0.f;
+        const uint32_t bits = __float_as_uint(pr + 1.0f);  // [1, 2]: 0x3F800000 .. 0x40000000
+        const bool valid = j < na && j < act_dim;
+        two |= valid && bits >= 0x40000000u;
+        const uint32_t mant = bits >= 0x40000000u ? 0x7FFFFFu : (bits & 0x7FFFFFu);
+        key[i] = valid ? ((mant << 8) | (uint32_t)(255 - j)) + 0x80000000u : 0u;
+    }
+    row_has_two = __any(two);
+}
+
+__device__ __forceinline__ void decode_topk_key(uint32_t kk, bool row_has_two, int& idx, float& v) {
+    idx = 255 - (int)(kk & 0xFFu);
+    const uint32_t mant = (kk & 0x7FFFFFFFu) >> 8;
+    v = (row_has_two && mant == 0x7FFFFFu) ? 2.0f : __uint_as_float(0x3F800000u | mant);
+}
+
+// The k (<= 64) largest keys of a row, one per lane in rank order (lane j = rank j; 0 where the row has fewer valid actions):
+// the k-th largest key is found by a bit-by-bit search with wave ballots (4 compares per bit, the counting on the scalar
+// unit; the search stops as soon as exactly k keys lie above the candidate), the k survivors are compacted to one per lane
+// through `surv` (64 words of LDS owned by the wave) and only those 64 are sorted: ~1/3 of the vector instructions of sorting
+// all 256.
+__device__ __forceinline__ uint32_t select_sort_topk(const uint32_t (&key)[4], int k, int lane, uint32_t* surv) {
+    auto count_ge = [&](uint32_t c) {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n += __builtin_popcountll(__ballot(key[i] >= c));
+        return n;  // wave-uniform
+    };
+    // valid keys have the top bit set and are distinct; T = the k-th largest of them (all of them if fewer than k)
+    uint32_t T = 0x80000000u;
+    if (count_ge(T) > k) {
+        // no key has a bit set above the largest key's highest one: the search starts there (probabilities of a
+        // 250-way softmax leave the top ~8 mantissa bits of p + 1 clear, i.e. ~8 of the ~25 rounds)
+        uint32_t mk = max(max(key[0], key[1]), max(key[2], key[3]));
+        mk = wave_max_u32(mk);
+        const int top = 31 - __builtin_clz((__builtin_amdgcn_readfirstlane(mk) & 0x7FFFFFFFu) | 1u);
+        for (int bit = top; bit >= 0; --bit) {
+            const uint32_t cand = T | (1u << bit);
+            const int c = count_ge(cand);
+            if (c >= k) T = cand;
+            if (c == k) break;
+        }
+    }
+    surv[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool sel = key[i] >= T;  // T >= 0x80000000: invalid slots (key 0) never qualify
+        const uint64_t m = __ballot(sel);
+        const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        if (sel) surv[pos] = key[i];
+        base += __builtin_popcountll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t one = surv[lane];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the next row of this wave overwrites surv
+    sort64<2>(one, lane);
+    return one;
+}
+
+// SELECT (k <= 64): select_sort_topk; otherwise all 256 keys go through one bitonic sort.  Same output.
 template <bool SELECT>
 __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __restrict__ logits, int ld, int act_dim,
                                                                const int32_t* __restrict__ n_acts,
@@ -1008,95 +1106,21 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     for (int row = blockIdx.x * 4 + wave_in_block(); row < n_rows; row += gridDim.x * 4) {
         const int na = n_acts[row];
-        const float* __restrict__ lr = logits + (size_t)row * ld;
-        float x[4];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {  // clamped index, select afterwards: the four loads are issued together
-            const int j = lane * 4 + i;  // blocked layout: element j of the row
-            x[i] = lr[j < act_dim ? j : act_dim - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = lane * 4 + i;
-            x[i] = (j < na && j < act_dim) ? x[i] : -INFINITY;
-            mx = fmaxf(mx, x[i]);
-        }
-        mx = wave_max_f32(mx);
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[i] = x[i] == -INFINITY ? 0.f : __expf(x[i] - mx);  // v_exp_f32: the ranking key keeps 23 bits of p + 1 anyway
-            sum += x[i];
-        }
-        sum = group_sum<64>(sum);
-        const float inv_sum = 1.f / sum;  // one division per row
         uint32_t key[4];
-        bool two = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int j = lane * 4 + i;
-            const float pr = x[i] * inv_sum;
-            if (probs_out && j < act_dim) probs_out[(size_t)row * act_dim + j] = j < na ? pr : 0.f;
-            const uint32_t bits = __float_as_uint(pr + 1.0f);  // [1, 2]: 0x3F800000 .. 0x40000000
-            const bool valid = j < na && j < act_dim;
-            // p + 1 rounds to exactly 2.0 when p >= 1 - 2^-25; such a row cannot also hold 1.99999988 (the
-            // probabilities sum to 1), so 2.0 shares the top mantissa code and a row flag tells them apart
-            two |= valid && bits >= 0x40000000u;
-            const uint32_t mant = bits >= 0x40000000u ? 0x7FFFFFu : (bits & 0x7FFFFFu);
-            key[i] = valid ? ((mant << 8) | (uint32_t)(255 - j)) + 0x80000000u : 0u;
-        }
-        const bool row_has_two = __any(two);
+        bool row_has_two;
+        row_softmax_keys(logits + (size_t)row * ld, act_dim, na, lane, probs_out ? probs_out + (size_t)row * act_dim : nullptr,
+                         key, row_has_two);
         auto emit = [&](uint32_t kk, int rnk) {
             const bool ok = kk != 0u;
-            const int idx = 255 - (int)(kk & 0xFFu);
-            const uint32_t mant = (kk & 0x7FFFFFFFu) >> 8;
-            const float v = (row_has_two && mant == 0x7FFFFFu) ? 2.0f : __uint_as_float(0x3F800000u | mant);
+            int idx;
+            float v;
+            decode_topk_key(kk, row_has_two, idx, v);
             out_idx[(size_t)row * k + rnk] = ok ? idx : -1;
             out_val[(size_t)row * k + rnk] = ok ? v : 0.f;
         };
         if constexpr (SELECT) {
             __shared__ uint32_t surv_all[4][64];
-            uint32_t* surv = surv_all[threadIdx.x >> 6];
-            auto count_ge = [&](uint32_t c) {
-                int n = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) n += __builtin_popcountll(__ballot(key[i] >= c));
-                return n;  // wave-uniform
-            };
-            // valid keys have the top bit set and are distinct; T = the k-th largest of them (all of them if fewer than k)
-            uint32_t T = 0x80000000u;
-            if (count_ge(T) > k) {
-                // no key has a bit set above the largest key's highest one: the search starts there (probabilities of a
-                // 250-way softmax leave the top ~8 mantissa bits of p + 1 clear, i.e. ~8 of the ~25 rounds)
-                uint32_t mk = max(max(key[0], key[1]), max(key[2], key[3]));
-                mk = wave_max_u32(mk);
-                const int top = 31 - __builtin_clz((__builtin_amdgcn_readfirstlane(mk) & 0x7FFFFFFFu) | 1u);
-                for (int bit = top; bit >= 0; --bit) {
-                    const uint32_t cand = T | (1u << bit);
-                    const int c = count_ge(cand);
-                    if (c >= k) T = cand;
-                    if (c == k) break;
-                }
-            }
-            surv[lane] = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            int base = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool sel = key[i] >= T;  // T >= 0x80000000: invalid slots (key 0) never qualify
-                const uint64_t m = __ballot(sel);
-                const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                if (sel) surv[pos] = key[i];
-                base += __builtin_popcountll(m);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            uint32_t one = surv[lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // the next row of this wave overwrites surv
-            sort64<2>(one, lane);
+            const uint32_t one = select_sort_topk(key, k, lane, surv_all[threadIdx.x >> 6]);
             if (lane < k) emit(one, lane);
         } else {
             bitonic_sort256<2>(key, lane);  // descending overall: element index e = lane * 4 + i
@@ -1240,6 +1264,126 @@ __global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const
         for (int c = lane; c < n_live * 3; c += 64) po[c] = prob_lds[w][c];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// ---- A13, fused: masked softmax + top-k + expand of a hop in ONE launch (act_dim <= 256, k <= 64) ------------------------
+// One wave per beam row: the row's logits are ranked as in policy_topk_sort_kernel<true> (same keys, same select, same
+// order), after which lane j holds the row's j-th child -- its action is gathered and the child record written straight to
+// its slot offsets[row] + j.  Against topk + expand as two launches: the [rows, k] index / value arrays are never written
+// or read back (0.5 GB each way on the last hop of a 64/64/64 beam), the parent record is read once per row through the
+// scalar unit instead of once per child, and a launch goes.  Child order and every value are those of the two-launch form.
+// LEAF = the last hop's compact output: a child is {parent row, relation, node, bits of its hop value} = 16 bytes instead of
+// the 60-byte record that repeats the parent's prefix 64 times; hw_pgpr_materialize_leaves rebuilds records on demand and
+// the collector reads the compact form directly.
+template <bool LEAF>
+__global__ __launch_bounds__(256) void pgpr_topk_expand_kernel(
+    hw_pgpr_graph g, const int32_t* __restrict__ paths, const float* __restrict__ probs, const int32_t* __restrict__ acts,
+    int act_dim, const int32_t* __restrict__ n_acts, const int32_t* __restrict__ n_rows_ptr,
+    const float* __restrict__ logits, int ld, int k, const int32_t* __restrict__ offsets, int32_t* __restrict__ paths_out,
+    float* __restrict__ probs_out, int4* __restrict__ leaf_out, int64_t cap) {
+    __shared__ uint32_t surv_all[4][64];
+    __shared__ __attribute__((aligned(16))) int rec_lds[LEAF ? 1 : 4][LEAF ? 4 : 64 * PATH_INTS];
+    __shared__ float prob_lds[LEAF ? 1 : 4][LEAF ? 4 : 64 * 3];
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int n_rows = n_rows_ptr[0];
+    const int lane = threadIdx.x & 63, w = wave_in_block();
+    for (int row_v = blockIdx.x * 4 + w; row_v < n_rows; row_v += gridDim.x * 4) {
+        const int row = __builtin_amdgcn_readfirstlane(row_v);
+        const int na = n_acts[row];
+        uint32_t key[4];
+        bool row_has_two;
+        row_softmax_keys(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key, row_has_two);
+        const uint32_t one = select_sort_topk(key, k, lane, surv_all[w]);
+        const int64_t o0 = offsets[row];
+        const int64_t room = cap - o0;  // children past the output capacity are dropped, as in pgpr_expand_kernel
+        const int n_child = min(k, na);
+        const int n_live = (int)(room < (int64_t)n_child ? (room < 0 ? 0 : room) : (int64_t)n_child);  // wave-uniform
+        if (n_live <= 0) continue;
+        const bool live = lane < n_live;
+        int idx;
+        float v;
+        decode_topk_key(one, row_has_two, idx, v);
+        // the parent record, once per row, through the scalar unit (the row index is wave-uniform)
+        static_assert(PATH_INTS == 12, "three 16-byte pieces");
+        const i32x4* pr = reinterpret_cast<const i32x4*>(paths + (size_t)row * PATH_INTS);
+        const i32x4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+        const int len = q0.y;
+        const int cur_t = len == 1 ? T_USER : (len == 2 ? q0.w : (len == 3 ? q1.z : q2.y));
+        const int2 act = *reinterpret_cast<const int2*>(&acts[((size_t)row * act_dim + (live ? idx : 0)) * 2]);
+        const int rel = act.x, node = act.y;
+        if constexpr (LEAF) {
+            if (live) leaf_out[o0 + lane] = make_int4(row, rel, node, (int)__float_as_uint(v));
+        } else {
+            const int nt = rel == SELF_LOOP ? cur_t : next_type(g, cur_t, rel);
+            const float* pp = probs + (size_t)row * 3;
+            const float p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            if (live) {
+                int* slot = &rec_lds[w][lane * PATH_INTS];
+                i32x4* q = reinterpret_cast<i32x4*>(slot);
+                q[0] = q0, q[1] = q1, q[2] = q2;
+                slot[1] = len + 1;
+                const int at = 2 + 3 * (len - 1);  // wave-uniform position of the new hop inside the record
+                slot[at] = rel, slot[at + 1] = nt, slot[at + 2] = node;
+                prob_lds[w][lane * 3 + 0] = len == 1 ? v : p0;
+                prob_lds[w][lane * 3 + 1] = len == 2 ? v : p1;
+                prob_lds[w][lane * 3 + 2] = len == 3 ? v : p2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // the row's children are the consecutive slots o0 .. o0 + n_live - 1: one contiguous run of 16-byte pieces
+            i32x4* __restrict__ qo = reinterpret_cast<i32x4*>(paths_out + (size_t)o0 * PATH_INTS);
+            const i32x4* ql = reinterpret_cast<const i32x4*>(&rec_lds[w][0]);
+            for (int c = lane; c < n_live * 3; c += 64) qo[c] = ql[c];
+            float* __restrict__ po = probs_out + (size_t)o0 * 3;
+            for (int c = lane; c < n_live * 3; c += 64) po[c] = prob_lds[w][c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// Compact leaves -> 12-int records + probability triples (the layout every other kernel and the host decoders read).
+// `sel` (optional): output row t = leaf sel[t] (negative entries give an all-zero record); otherwise every leaf in order.
+__global__ __launch_bounds__(256) void pgpr_materialize_leaves_kernel(hw_pgpr_graph g, const int32_t* __restrict__ parents,
+                                                                      const float* __restrict__ parent_probs,
+                                                                      const int4* __restrict__ leaf,
+                                                                      const int32_t* __restrict__ n_leaf_ptr,
+                                                                      const int32_t* __restrict__ sel, int64_t n_sel,
+                                                                      int64_t max_out, int32_t* __restrict__ paths_out,
+                                                                      float* __restrict__ probs_out) {
+    const int64_t n_leaf = n_leaf_ptr[0];
+    const int64_t n = sel ? n_sel : (n_leaf < max_out ? n_leaf : max_out);  // never past the output buffer
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = sel ? (int64_t)sel[t] : t;
+        int32_t* o = paths_out + (size_t)t * PATH_INTS;
+        float* q = probs_out + (size_t)t * 3;
+        if (i < 0 || i >= n_leaf) {
+#pragma unroll
+            for (int c = 0; c < PATH_INTS; ++c) o[c] = 0;
+            q[0] = q[1] = q[2] = 0.f;
+            continue;
+        }
+        const int4 lf = leaf[i];
+        PathRec rec;
+        rec.load(parents, lf.x);
+        const int len = rec.len;
+        const int cur_t = len == 1 ? T_USER : rec.type(len - 1);
+        const int rel = lf.y, node = lf.z;
+        const int nt = rel == SELF_LOOP ? cur_t : next_type(g, cur_t, rel);
+        int f[PATH_INTS] = {rec.uid, len + 1, rec.hr[0], rec.ht[0], rec.hn[0], rec.hr[1], rec.ht[1], rec.hn[1],
+                            rec.hr[2], rec.ht[2], rec.hn[2], rec.batch};
+#pragma unroll
+        for (int j = 1; j <= 3; ++j)
+            if (j == len) f[2 + 3 * (j - 1)] = rel, f[3 + 3 * (j - 1)] = nt, f[4 + 3 * (j - 1)] = node;
+#pragma unroll
+        for (int c = 0; c < PATH_INTS; ++c) o[c] = f[c];
+        const float* pp = parent_probs + (size_t)lf.x * 3;
+        const float v = __uint_as_float((uint32_t)lf.w);
+        q[0] = len == 1 ? v : pp[0];
+        q[1] = len == 2 ? v : pp[1];
+        q[2] = len == 3 ? v : pp[2];
     }
 }
 
@@ -1480,5 +1624,69 @@ extern "C" int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, 
         hipLaunchKernelGGL(pgpr_expand_kernel, dim3((unsigned)grid), dim3(256), 0, st, *graph, paths, probs, acts,
                            act_dim, n_acts, n_rows, topk_idx, topk_val, k, offsets, paths_out, probs_out, out_capacity);
     }
+    return HW_LAUNCH_RC();
+}
+
+
+static int launch_child_offsets(const int32_t* n_acts, const int32_t* n_rows, int64_t max_rows, int32_t k, int32_t* offsets,
+                                int32_t* block_sums_ws, int32_t* n_rows_out, int64_t out_capacity, hipStream_t st) {
+    const int nb = (int)((max_rows + OFF_ROWS_PER_BLOCK - 1) / OFF_ROWS_PER_BLOCK);
+    if (nb > 65536 || !block_sums_ws) return HW_ERR_WORKSPACE;
+    const int nb1 = nb < 1 ? 1 : nb;
+    hipLaunchKernelGGL(pgpr_offsets_partial_kernel, dim3(nb1), dim3(256), 0, st, n_acts, n_rows, k, block_sums_ws);
+    hipLaunchKernelGGL(pgpr_offsets_scan_kernel, dim3(1), dim3(1024), 0, st, block_sums_ws, nb1, n_rows_out, out_capacity);
+    hipLaunchKernelGGL(pgpr_offsets_final_kernel, dim3(nb1), dim3(256), 0, st, n_acts, n_rows, k, block_sums_ws, offsets);
+    return HW_OK;
+}
+
+extern "C" int hw_pgpr_topk_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float* probs, const int32_t* acts,
+                                   int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows, int64_t max_rows,
+                                   const float* logits, int64_t ld, int32_t k, int32_t* offsets, int32_t* block_sums_ws,
+                                   int32_t* paths_out, float* probs_out, int32_t* leaf_out, int32_t* n_rows_out,
+                                   int64_t out_capacity, void* stream) {
+    int rc = check_graph(graph);
+    if (rc) return rc;
+    if (!paths || !probs || !acts || !n_acts || !n_rows || !logits || !offsets || !n_rows_out) return HW_ERR_INVALID_ARG;
+    if (!leaf_out && (!paths_out || !probs_out)) return HW_ERR_INVALID_ARG;
+    if (act_dim < 1 || act_dim > 256 || ld < act_dim || k < 1 || k > 64 || k > act_dim || max_rows < 0 || out_capacity < 0 ||
+        out_capacity > INT32_MAX)
+        return HW_ERR_INVALID_ARG;
+    if (max_rows * (int64_t)k > INT32_MAX) return HW_ERR_INVALID_ARG;  // child offsets are 32-bit
+    if ((((uintptr_t)paths | (uintptr_t)paths_out | (uintptr_t)leaf_out) & 15) != 0) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_child_offsets(n_acts, n_rows, max_rows, k, offsets, block_sums_ws, n_rows_out, out_capacity, st);
+    if (rc) return rc;
+    if (max_rows > 0) {
+        int64_t grid = (max_rows + 3) / 4;
+        if (grid > 16384) grid = 16384;
+        if (leaf_out)
+            hipLaunchKernelGGL(pgpr_topk_expand_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, *graph, paths, probs,
+                               acts, act_dim, n_acts, n_rows, logits, (int)ld, k, offsets, paths_out, probs_out,
+                               reinterpret_cast<int4*>(leaf_out), out_capacity);
+        else
+            hipLaunchKernelGGL(pgpr_topk_expand_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, *graph, paths, probs,
+                               acts, act_dim, n_acts, n_rows, logits, (int)ld, k, offsets, paths_out, probs_out,
+                               reinterpret_cast<int4*>(leaf_out), out_capacity);
+    }
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_materialize_leaves(const hw_pgpr_graph* graph, const int32_t* parents, const float* parent_probs,
+                                          const int32_t* leaf, const int32_t* n_leaf, int64_t max_leaf, const int32_t* sel,
+                                          int64_t n_sel, int32_t* paths_out, float* probs_out, void* stream) {
+    int rc = check_graph(graph);
+    if (rc) return rc;
+    if (!parents || !parent_probs || !leaf || !n_leaf || !paths_out || !probs_out || max_leaf < 0 || n_sel < 0 ||
+        (((uintptr_t)parents | (uintptr_t)leaf) & 15) != 0)
+        return HW_ERR_INVALID_ARG;
+    const int64_t n = sel ? n_sel : max_leaf;
+    if (n == 0) return HW_OK;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(pgpr_materialize_leaves_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, *graph,
+                       parents, parent_probs, reinterpret_cast<const int4*>(leaf), n_leaf, sel, n_sel, max_leaf, paths_out,
+                       probs_out);
     return HW_LAUNCH_RC();
 }

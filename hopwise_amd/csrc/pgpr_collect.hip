@@ -30,27 +30,52 @@ __device__ __forceinline__ bool bit_test(const uint32_t* __restrict__ bits, int6
     return (bits[(size_t)uid * words + (item >> 5)] >> (item & 31)) & 1u;
 }
 
+// COMPACT: the last hop's children as {parent row, relation, node, value bits} (pgpr.hip: pgpr_topk_expand_kernel<true>) next
+// to the parent rows they extend, instead of one 12-int record + probability triple per leaf.  Same tests, same key.
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void collect_mark_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf,
                                                            const float* __restrict__ probs,
+                                                           const int4* __restrict__ cleaf,
                                                            const int32_t* __restrict__ n_leaf_ptr, int n_nodes,
                                                            const int32_t* __restrict__ first_idx,
                                                            const uint32_t* __restrict__ pos_bits, int64_t pos_words,
                                                            unsigned long long* __restrict__ best) {
     const int n_leaf = n_leaf_ptr[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_leaf; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t* p = leaf + (size_t)i * CPATH_INTS;
-        if (p[1] != n_nodes) continue;
-        bool ok = true;
-        for (int j = 1; j < n_nodes; ++j) ok &= p[2 + 3 * (j - 1)] != -1;            // no self loop after the root
-        const int lt = p[2 + 3 * (n_nodes - 2) + 1], pid = p[2 + 3 * (n_nodes - 2) + 2];
-        ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
-        if (!ok) continue;
-        const int uid = p[0];
-        if (bit_test(pos_bits, pos_words, uid, pid)) continue;                         // already a train positive
-        const float* q = probs + (size_t)i * 3;
-        float pp = q[0];
-        for (int j = 1; j < n_nodes - 1; ++j) pp = pp * q[j];                          // reduce(mul) in float32
-        const int slot = first_idx[p[11]];
+        int uid, pid, batch;
+        float pp;
+        if constexpr (COMPACT) {
+            const int4 lf = cleaf[i];
+            const int32_t* p = leaf + (size_t)lf.x * CPATH_INTS;  // the parent: n_nodes - 1 nodes
+            if (p[1] != n_nodes - 1) continue;
+            bool ok = lf.y != -1;                                                         // no self loop after the root
+            for (int j = 1; j < n_nodes - 1; ++j) ok &= p[2 + 3 * (j - 1)] != -1;
+            const int cur_t = n_nodes == 2 ? 0 : p[2 + 3 * (n_nodes - 3) + 1];
+            const int lt = (cur_t == 1 && lf.y == g.ui_relation) ? 0 : 1;                 // pgpr.py:209-213
+            pid = lf.z;
+            ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
+            if (!ok) continue;
+            uid = p[0], batch = p[11];
+            const float* q = probs + (size_t)lf.x * 3;
+            const float v = __uint_as_float((uint32_t)lf.w);
+            pp = n_nodes == 2 ? v : q[0];
+            for (int j = 1; j < n_nodes - 1; ++j) pp = pp * (j == n_nodes - 2 ? v : q[j]);  // reduce(mul) in float32
+        } else {
+            const int32_t* p = leaf + (size_t)i * CPATH_INTS;
+            if (p[1] != n_nodes) continue;
+            bool ok = true;
+            for (int j = 1; j < n_nodes; ++j) ok &= p[2 + 3 * (j - 1)] != -1;            // no self loop after the root
+            const int lt = p[2 + 3 * (n_nodes - 2) + 1];
+            pid = p[2 + 3 * (n_nodes - 2) + 2];
+            ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
+            if (!ok) continue;
+            uid = p[0], batch = p[11];
+            const float* q = probs + (size_t)i * 3;
+            pp = q[0];
+            for (int j = 1; j < n_nodes - 1; ++j) pp = pp * q[j];                          // reduce(mul) in float32
+        }
+        if (bit_test(pos_bits, pos_words, uid, pid)) continue;                             // already a train positive
+        const int slot = first_idx[batch];
         const unsigned long long key = ((unsigned long long)__float_as_uint(pp) << 32) | (uint32_t)(~(uint32_t)i);
         atomicMax(best + (size_t)slot * g.n_items + pid, key);
     }
@@ -178,7 +203,8 @@ __global__ void collect_rows_kernel(const int32_t* __restrict__ sel_count, int n
     }
 }
 
-__global__ void collect_fill_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf, const double* __restrict__ score_ws,
+__global__ void collect_fill_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf, const int4* __restrict__ cleaf,
+                                    const double* __restrict__ score_ws,
                                     int kmax, int n_nodes, int32_t* __restrict__ sel_item, double* __restrict__ sel_score,
                                     const int32_t* __restrict__ sel_count, const int32_t* __restrict__ sel_row,
                                     float* __restrict__ results, int n_slots) {
@@ -189,7 +215,7 @@ __global__ void collect_fill_kernel(hw_pgpr_graph g, const int32_t* __restrict__
         int item = sel_item[(size_t)slot * kmax + j];
         if (item <= -2) {
             const int lf = -2 - item;
-            item = leaf[(size_t)lf * CPATH_INTS + 2 + 3 * (n_nodes - 2) + 2];
+            item = cleaf ? cleaf[lf].z : leaf[(size_t)lf * CPATH_INTS + 2 + 3 * (n_nodes - 2) + 2];
             sel_item[(size_t)slot * kmax + j] = item;
         }
         if (item < 0) continue;
@@ -207,24 +233,25 @@ __global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v) {
 
 using namespace hw;
 
-extern "C" int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
-                               const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
-                               const uint32_t* positives_bits, int64_t positives_words, const int32_t* leaf_paths,
-                               const float* leaf_probs, const int32_t* n_leaf, int64_t max_leaf, int32_t n_nodes,
-                               int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws, float* results,
-                               int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
-                               int32_t* sel_row, void* stream) {
+static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                        const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                        const uint32_t* positives_bits, int64_t positives_words, const int32_t* leaf_paths,
+                        const float* leaf_probs, const int32_t* compact_leaves, const int32_t* n_leaf, int64_t max_leaf,
+                        int32_t n_nodes, int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws,
+                        float* results, int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
+                        int32_t* sel_row, void* stream) {
     if (!graph || !user_emb64 || !entity_emb64 || !relation_emb64 || !users || !positives_bits || !leaf_paths ||
         !leaf_probs || !n_leaf || !best_ws || !score_ws || !first_idx_ws || !results || !sel_item || !sel_score ||
         !sel_leaf || !sel_count || !sel_row)
         return HW_ERR_INVALID_ARG;
     if (dim < 1 || dim > HW_PGPR_MAX_DIM || n_batch < 1 || n_batch > 65535 || kmax < 1 || kmax > 1024 || n_nodes < 2 ||
-        n_nodes > 4 || max_leaf < 0 || positives_words * 32 < graph->n_items)
+        n_nodes > 4 || max_leaf < 0 || positives_words * 32 < graph->n_items || (((uintptr_t)compact_leaves) & 15) != 0)
         return HW_ERR_INVALID_ARG;
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)n_batch;
     const int64_t cells = n_batch * (int64_t)graph->n_items;
+    const int4* cleaf = reinterpret_cast<const int4*>(compact_leaves);
     if (hw::fill_bytes_async(best_ws, 0, sizeof(uint64_t) * (size_t)cells, st) != hipSuccess ||
         hw::fill_bytes_async(sel_leaf, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st) != hipSuccess ||
         hw::fill_bytes_async(sel_item, 0xff, sizeof(int32_t) * (size_t)n_batch * kmax, st) != hipSuccess ||
@@ -236,15 +263,47 @@ extern "C" int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_em
     if (max_leaf > 0) {
         int64_t grid = (max_leaf + 255) / 256;
         if (grid > 16384) grid = 16384;
-        hipLaunchKernelGGL(collect_mark_kernel, dim3((unsigned)grid), dim3(256), 0, st, *graph, leaf_paths, leaf_probs,
-                           n_leaf, n_nodes, first_idx_ws, positives_bits, positives_words,
-                           (unsigned long long*)best_ws);
+        if (cleaf)
+            hipLaunchKernelGGL(collect_mark_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, *graph, leaf_paths,
+                               leaf_probs, cleaf, n_leaf, n_nodes, first_idx_ws, positives_bits, positives_words,
+                               (unsigned long long*)best_ws);
+        else
+            hipLaunchKernelGGL(collect_mark_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, *graph, leaf_paths,
+                               leaf_probs, cleaf, n_leaf, n_nodes, first_idx_ws, positives_bits, positives_words,
+                               (unsigned long long*)best_ws);
     }
     hipLaunchKernelGGL(collect_select_kernel, dim3(nb), dim3(256), 0, st, *graph, user_emb64, entity_emb64,
                        relation_emb64, dim, users, first_idx_ws, positives_bits, positives_words,
                        (const unsigned long long*)best_ws, score_ws, kmax, sel_item, sel_score, sel_leaf, sel_count);
     hipLaunchKernelGGL(collect_rows_kernel, dim3(1), dim3(1), 0, st, sel_count, nb, sel_row);
-    hipLaunchKernelGGL(collect_fill_kernel, dim3(nb), dim3(64), 0, st, *graph, leaf_paths, score_ws, kmax, n_nodes,
+    hipLaunchKernelGGL(collect_fill_kernel, dim3(nb), dim3(64), 0, st, *graph, leaf_paths, cleaf, score_ws, kmax, n_nodes,
                        sel_item, sel_score, sel_count, sel_row, results, nb);
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                               const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                               const uint32_t* positives_bits, int64_t positives_words, const int32_t* leaf_paths,
+                               const float* leaf_probs, const int32_t* n_leaf, int64_t max_leaf, int32_t n_nodes,
+                               int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws, float* results,
+                               int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
+                               int32_t* sel_row, void* stream) {
+    return collect_impl(graph, user_emb64, entity_emb64, relation_emb64, dim, users, n_batch, positives_bits,
+                        positives_words, leaf_paths, leaf_probs, nullptr, n_leaf, max_leaf, n_nodes, kmax, best_ws, score_ws,
+                        first_idx_ws, results, sel_item, sel_score, sel_leaf, sel_count, sel_row, stream);
+}
+
+// The same on the compact output of the last hop (hw_pgpr_topk_expand with leaf_out): parent_paths / parent_probs are the
+// rows the last hop expanded, leaves[i] = {parent row, relation, node, bits of the hop value}; sel_leaf indexes leaves.
+extern "C" int hw_pgpr_collect_leaves(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                                      const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                                      const uint32_t* positives_bits, int64_t positives_words, const int32_t* parent_paths,
+                                      const float* parent_probs, const int32_t* leaves, const int32_t* n_leaf,
+                                      int64_t max_leaf, int32_t n_nodes, int32_t kmax, uint64_t* best_ws, double* score_ws,
+                                      int32_t* first_idx_ws, float* results, int32_t* sel_item, double* sel_score,
+                                      int32_t* sel_leaf, int32_t* sel_count, int32_t* sel_row, void* stream) {
+    if (!leaves) return HW_ERR_INVALID_ARG;
+    return collect_impl(graph, user_emb64, entity_emb64, relation_emb64, dim, users, n_batch, positives_bits,
+                        positives_words, parent_paths, parent_probs, leaves, n_leaf, max_leaf, n_nodes, kmax, best_ws,
+                        score_ws, first_idx_ws, results, sel_item, sel_score, sel_leaf, sel_count, sel_row, stream);
 }

@@ -34,18 +34,59 @@ from .knowledge_graph_embedding_recommender import _cfg
 
 
 class BeamResult:
-    """Leaf (or intermediate) beam rows on the device."""
+    """Leaf (or intermediate) beam rows on the device.
 
-    def __init__(self, paths, probs, n_rows):
-        self.paths, self.probs, self._n = paths, probs, n_rows
+    Two layouts.  Full: ``paths`` int32 [rows, 12] records + ``probs`` float32 [rows, 3].  Compact (the default output of the
+    last hop, ``leaves`` is not None): ``leaves`` int32 [rows, 4] = {parent row, relation, node, bits of the hop's value} next
+    to the parent rows in ``parent_paths`` / ``parent_probs`` -- the 60 bytes of a full record repeat the parent's prefix once
+    per child, 64 times over on a 64-wide beam.  ``paths`` / ``probs`` then materialise on first use
+    (hw_pgpr_materialize_leaves); ``rows(idx)`` rebuilds only the asked records; the collector reads the compact form."""
+
+    def __init__(self, paths, probs, n_rows, graph=None, leaves=None):
+        self._paths, self._probs, self._n = paths, probs, n_rows
+        self.graph, self.leaves = graph, leaves
+        self.parent_paths, self.parent_probs = (paths, probs) if leaves is not None else (None, None)
+        if leaves is not None:
+            self._paths = self._probs = None
 
     @property
     def n(self):
         return int(self._n.item())  # the only synchronisation of a search
 
+    @property
+    def capacity(self):
+        return (self.leaves if self.leaves is not None else self._paths).shape[0]
+
+    def _materialize(self):
+        if self._paths is None:
+            self._paths, self._probs = P.materialize_leaves(self.graph, self.parent_paths, self.parent_probs, self.leaves,
+                                                            self._n)
+
+    @property
+    def paths(self):
+        self._materialize()
+        return self._paths
+
+    @property
+    def probs(self):
+        self._materialize()
+        return self._probs
+
+    def rows(self, idx):
+        """(paths, probs) of the leaf rows ``idx`` (int tensor / array) as device tensors."""
+        idx = torch.as_tensor(idx)
+        if self.leaves is not None and self._paths is None:
+            return P.materialize_leaves(self.graph, self.parent_paths, self.parent_probs, self.leaves, self._n,
+                                        sel=idx.to(self.leaves.device))
+        idx = idx.to(self._paths.device).long()
+        return self._paths[idx], self._probs[idx]
+
     def numpy(self):
         n = self.n
-        return self.paths[:n].cpu().numpy(), self.probs[:n].cpu().numpy()
+        if self.leaves is not None and self._paths is None:
+            p, q = P.materialize_leaves(self.graph, self.parent_paths, self.parent_probs, self.leaves, self._n, n_out=n)
+            return p.cpu().numpy(), q.cpu().numpy()
+        return self._paths[:n].cpu().numpy(), self._probs[:n].cpu().numpy()
 
 
 class _EpisodeLoss(torch.autograd.Function):
@@ -84,6 +125,10 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.l1_lookup = bool(_cfg(config, "l1_lookup", True))  # beam search: first policy layer from slot tables
         # beam search: the whole policy network of a hop in one launch when the shapes allow (HW_PGPR_FUSED=0: three launches)
         self.fused_policy = bool(_cfg(config, "fused_policy", os.environ.get("HW_PGPR_FUSED", "1") != "0"))
+        # beam search: softmax + top-k + expand of a hop in one launch, the last hop's children as 16-byte leaves
+        # (HW_PGPR_TAIL=0: top-k and expand as two launches, full 60-byte records everywhere)
+        self.fused_tail = bool(_cfg(config, "fused_topk_expand", os.environ.get("HW_PGPR_TAIL", "1") != "0"))
+        self.compact_leaves = bool(_cfg(config, "compact_leaves", self.fused_tail))
         self.user_chunk = int(_cfg(config, "beam_user_chunk", 64))
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         dev = torch.device(self.device)
@@ -133,7 +178,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.last_loss_parts = None
 
     # ------------------------------------------------------------------------------------------------
-    def _alloc(self, B, hops):
+    def _alloc(self, B, hops, compact_leaves=False):
         dev = self._t64[0].device
         rows = [B]
         for k in hops:
@@ -141,10 +186,12 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         rmax = max(rows[:-1])
         i32 = lambda *s: torch.empty(s, dtype=torch.int32, device=dev)
         f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        full = rows[:-1] if compact_leaves else rows  # the last level is held as 16-byte leaves instead of 60-byte records
         buf = dict(
             rows=rows,
-            paths=[i32(r, P.ROW_INTS) for r in rows],
-            probs=[f32(r, 3) for r in rows],
+            paths=[i32(r, P.ROW_INTS) for r in full] + ([None] if compact_leaves else []),
+            probs=[f32(r, 3) for r in full] + ([None] if compact_leaves else []),
+            leaves=i32(rows[-1], 4) if compact_leaves else None,
             n_rows=torch.zeros(len(rows), dtype=torch.int32, device=dev),
             acts=i32(rmax, self.act_dim, 2),
             n_acts=i32(rmax),
@@ -214,9 +261,13 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         P.mlp_layer(buf["x2"], self.actor.weight, self.actor.bias, buf["logits"], n_rows, rmax, False)
 
     @torch.no_grad()
-    def beam_search_device(self, users, hops=None, drops=None, keep_trace=False, keep_buffers=False, stage_events=None):
+    def beam_search_device(self, users, hops=None, drops=None, keep_trace=False, keep_buffers=False, stage_events=None,
+                           fused_tail=None, compact_leaves=None):
         """Expand ``users`` (int64 tensor on the device) hop by hop; returns a :class:`BeamResult` of leaf rows.
         ``drops``: optional per hop (mask1 [rows, h0], mask2 [rows, h1]) multiplicative masks.
+        ``fused_tail`` (default: config ``fused_topk_expand`` / HW_PGPR_TAIL, on): softmax + top-k + expand of a hop as one
+        launch where the shapes allow (act_dim <= 256, k <= 64); ``compact_leaves`` (default: with the fused tail, unless a
+        trace is kept): the last hop writes 16-byte leaves instead of full records (see :class:`BeamResult`).
         ``stage_events``: a list that receives (stage, hop, HIP event) marks on the launch stream after every stage of
         every hop (bench_pgpr's per-stage times; nothing is recorded when None)."""
         hops = list(self.beam_search_hop if hops is None else hops)
@@ -226,7 +277,13 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             raise RuntimeError("selected index k out of range")  # what torch.topk raises in the reference
         users = users.to(self._t64[0].device, torch.int64).contiguous()
         B = users.numel()
-        buf = self._alloc(B, hops)
+        if fused_tail is None:
+            fused_tail = self.fused_tail
+        fused_tail = bool(fused_tail) and not keep_trace
+        if compact_leaves is None:
+            compact_leaves = self.compact_leaves
+        compact_leaves = bool(compact_leaves) and fused_tail and P.topk_expand_supported(self.act_dim, hops[-1])
+        buf = self._alloc(B, hops, compact_leaves)
         g = self.graph
         U64, E64, R64 = self._t64
         U32, E32, R32 = self._t32
@@ -255,18 +312,30 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             mark("actions", hop)
             self._policy_logits(buf, n_rows, rmax, drops, hop, paths if lookup else None)
             mark("policy", hop)
-            P.policy_topk(buf["logits"], self.act_dim, buf["n_acts"], n_rows, rmax, k, buf["tk_idx"], buf["tk_val"])
-            mark("topk", hop)
-            P.expand(g, paths, probs, buf["acts"], self.act_dim, buf["n_acts"], n_rows, rmax, buf["tk_idx"],
-                     buf["tk_val"], k, buf["offsets"], buf["paths"][hop + 1], buf["probs"][hop + 1],
-                     nr[hop + 1 : hop + 2], buf["rows"][hop + 1])
+            if fused_tail and P.topk_expand_supported(self.act_dim, k):
+                last = hop == len(hops) - 1
+                mark("topk", hop)  # no launch of its own: the stage is part of "expand"
+                P.topk_expand(g, paths, probs, buf["acts"], self.act_dim, buf["n_acts"], n_rows, rmax, buf["logits"], k,
+                              buf["offsets"], buf["paths"][hop + 1], buf["probs"][hop + 1],
+                              buf["leaves"] if (last and compact_leaves) else None, nr[hop + 1 : hop + 2],
+                              buf["rows"][hop + 1])
+            else:
+                P.policy_topk(buf["logits"], self.act_dim, buf["n_acts"], n_rows, rmax, k, buf["tk_idx"], buf["tk_val"])
+                mark("topk", hop)
+                P.expand(g, paths, probs, buf["acts"], self.act_dim, buf["n_acts"], n_rows, rmax, buf["tk_idx"],
+                         buf["tk_val"], k, buf["offsets"], buf["paths"][hop + 1], buf["probs"][hop + 1],
+                         nr[hop + 1 : hop + 2], buf["rows"][hop + 1])
             mark("expand", hop)
             if keep_trace:
                 n = int(n_rows.item())
                 trace.append(dict(acts=buf["acts"][:n].clone(), n_acts=buf["n_acts"][:n].clone(),
                                   state=buf["state"][:n].clone(), logits=buf["logits"][:n].clone(),
                                   tk_idx=buf["tk_idx"][:n, :k].clone(), tk_val=buf["tk_val"][:n, :k].clone()))
-        res = BeamResult(buf["paths"][-1], buf["probs"][-1], nr[len(hops) : len(hops) + 1])
+        if compact_leaves:  # parents = the rows the last hop expanded
+            res = BeamResult(buf["paths"][-2], buf["probs"][-2], nr[len(hops) : len(hops) + 1], graph=g,
+                             leaves=buf["leaves"])
+        else:
+            res = BeamResult(buf["paths"][-1], buf["probs"][-1], nr[len(hops) : len(hops) + 1], graph=g)
         res.n_rows_per_hop = nr
         res.trace = trace
         res.buffers = buf if keep_buffers else None  # per-hop path rows / action counts (bench_pgpr's byte accounting)
@@ -433,6 +502,9 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         """scores [len(users), n_items] on the device + the selection arrays (pgpr.py:486-552)."""
         users = users.to(self._t64[0].device, torch.int64).contiguous()
         n_nodes = len(self.beam_search_hop) + 1 if n_nodes is None else n_nodes
+        if getattr(res, "leaves", None) is not None:  # compact leaves: read in place, nothing is materialised
+            return P.collect(self.graph, *self._collect_tables(), users, self._pos_bits, res.parent_paths, res.parent_probs,
+                             res._n, res.leaves.shape[0], n_nodes, max(self.topk), leaves=res.leaves)
         return P.collect(self.graph, *self._collect_tables(), users, self._pos_bits, res.paths, res.probs, res._n,
                          res.paths.shape[0], n_nodes, max(self.topk))
 
@@ -441,7 +513,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         cnt, item, score, leaf = (sel[k].cpu().numpy() for k in ("count", "item", "score", "leaf"))
         ulist = users.cpu().numpy()
         need = np.unique(leaf[leaf >= 0])
-        rows = res.paths[torch.from_numpy(need).to(res.paths.device).long()].cpu().numpy() if len(need) else np.zeros((0, 12))
+        rows = res.rows(torch.from_numpy(need))[0].cpu().numpy() if len(need) else np.zeros((0, 12))
         prs = np.zeros((len(need), 3), np.float32)
         dec, _ = self.decode_paths(rows, prs)
         by_leaf = dict(zip(need.tolist(), dec))

@@ -251,6 +251,48 @@ def expand(graph, paths, probs, acts, act_dim, n_acts, n_rows, max_rows, topk_id
     )
 
 
+def topk_expand_supported(act_dim, k):
+    """Shapes hw_pgpr_topk_expand takes: one wave ranks a row's <= 256 logits in registers and owns its <= 64 children."""
+    return int(act_dim) <= 256 and 1 <= int(k) <= 64
+
+
+def topk_expand(graph, paths, probs, acts, act_dim, n_acts, n_rows, max_rows, logits, k, offsets, paths_out, probs_out,
+                leaf_out, n_rows_out, capacity):
+    """Masked softmax + top-k + expand of one hop in a single launch (csrc/pgpr.hip: pgpr_topk_expand_kernel); the same
+    children, in the same order, as policy_topk followed by expand.  ``leaf_out`` (int32 [capacity, 4]) selects the compact
+    output of the last hop: {parent row, relation, node, value bits} instead of a 12-int record + probability triple."""
+    lib = _lib.load()
+    block_sums = torch.empty((int(max_rows) + 1023) // 1024 + 1, dtype=torch.int32, device=paths.device)
+    check(
+        lib.hw_pgpr_topk_expand(C.byref(graph.c), _ptr(paths), _ptr(probs), _ptr(acts), int(act_dim), _ptr(n_acts),
+                                _ptr(n_rows), int(max_rows), _ptr(logits), logits.stride(0), int(k), _ptr(offsets),
+                                _ptr(block_sums), _ptr(paths_out), _ptr(probs_out), _ptr(leaf_out), _ptr(n_rows_out),
+                                int(capacity), _stream()),
+        "hw_pgpr_topk_expand",
+    )
+
+
+def materialize_leaves(graph, parent_paths, parent_probs, leaves, n_leaf, sel=None, n_out=None):
+    """Compact leaves -> (paths int32 [n, 12], probs float32 [n, 3]).  ``sel`` (int32 tensor): only those leaves, in that
+    order; otherwise ``n_out`` rows (default: all of the buffer; rows past n_leaf[0] are left unwritten)."""
+    lib = _lib.load()
+    dev = leaves.device
+    if sel is not None:
+        sel = sel.to(device=dev, dtype=torch.int32).contiguous()
+        n = sel.numel()
+    else:
+        n = leaves.shape[0] if n_out is None else int(n_out)
+    paths = torch.empty((n, ROW_INTS), dtype=torch.int32, device=dev)
+    probs = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    check(
+        lib.hw_pgpr_materialize_leaves(C.byref(graph.c), _ptr(parent_paths), _ptr(parent_probs), _ptr(leaves), _ptr(n_leaf),
+                                       n if sel is None else leaves.shape[0], _ptr(sel), n if sel is not None else 0,
+                                       _ptr(paths), _ptr(probs), _stream()),
+        "hw_pgpr_materialize_leaves",
+    )
+    return paths, probs
+
+
 def positives_bitset(positives, n_users, n_items, device):
     """Bitset [n_users, ceil(n_items / 32)] of the rows of dataset.history_item_matrix()[0] (zeros included as they
     appear: `pid in self.positives[uid]` in the reference is a plain membership test on the padded row)."""
@@ -264,7 +306,9 @@ def positives_bitset(positives, n_users, n_items, device):
     return torch.from_numpy(bits.view(np.int32)).to(device)
 
 
-def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_leaf, max_leaf, n_nodes, kmax):
+def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_leaf, max_leaf, n_nodes, kmax, leaves=None):
+    """``leaves`` (int32 [max_leaf, 4]): the compact output of the last hop; leaf_paths / leaf_probs are then the PARENT rows
+    (hw_pgpr_collect_leaves)."""
     lib = _lib.load()
     dev = users.device
     B, nI = users.numel(), graph.n_items
@@ -277,6 +321,16 @@ def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_lea
     sel_leaf = torch.empty((B, kmax), dtype=torch.int32, device=dev)
     sel_count = torch.empty(B, dtype=torch.int32, device=dev)
     sel_row = torch.empty(B, dtype=torch.int32, device=dev)
+    if leaves is not None:
+        check(
+            lib.hw_pgpr_collect_leaves(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), U64.shape[1], _ptr(users), B,
+                                       _ptr(pos_bits), pos_bits.shape[1], _ptr(leaf_paths), _ptr(leaf_probs), _ptr(leaves),
+                                       _ptr(n_leaf), int(max_leaf), int(n_nodes), int(kmax), _ptr(best), _ptr(score_ws),
+                                       _ptr(first), _ptr(results), _ptr(sel_item), _ptr(sel_score), _ptr(sel_leaf),
+                                       _ptr(sel_count), _ptr(sel_row), _stream()),
+            "hw_pgpr_collect_leaves",
+        )
+        return results, dict(item=sel_item, score=sel_score, leaf=sel_leaf, count=sel_count, row=sel_row)
     check(
         lib.hw_pgpr_collect(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), U64.shape[1], _ptr(users), B, _ptr(pos_bits),
                             pos_bits.shape[1], _ptr(leaf_paths), _ptr(leaf_probs), _ptr(n_leaf), int(max_leaf),

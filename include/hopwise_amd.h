@@ -458,6 +458,28 @@ int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float
                    int32_t* offsets, int32_t* block_sums_ws, int32_t* paths_out, float* probs_out,
                    int32_t* n_rows_out, int64_t out_capacity, void* stream);
 
+/* The tail of a beam-search hop in ONE launch: masked softmax -> (+1 on valid actions, pgpr.py:453) -> top-k (value desc,
+ * index asc, pgpr.py:454) -> children emitted in row order, top-k order inside a row (pgpr.py:460-479); what
+ * hw_pgpr_policy_topk + hw_pgpr_expand do in two, with identical outputs, without the [max_rows, k] index / value arrays.
+ * act_dim <= 256, k <= 64 (one wave ranks a row in registers); other shapes use the two calls above.
+ * leaf_out == NULL: children as 12-int records + probability triples in paths_out / probs_out [out_capacity].
+ * leaf_out != NULL (int32 [out_capacity, 4], 16-byte aligned; the LAST hop of a search): children as compact leaves
+ * {parent row, relation, node id, bits of the hop's value} -- the 48 + 12 bytes of a full record repeat the parent's prefix
+ * once per child; hw_pgpr_materialize_leaves rebuilds records, hw_pgpr_collect_leaves consumes the compact form.
+ * Workspaces as hw_pgpr_expand. */
+int hw_pgpr_topk_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float* probs, const int32_t* acts,
+                        int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows, int64_t max_rows,
+                        const float* logits, int64_t ld, int32_t k, int32_t* offsets, int32_t* block_sums_ws,
+                        int32_t* paths_out, float* probs_out, int32_t* leaf_out, int32_t* n_rows_out,
+                        int64_t out_capacity, void* stream);
+
+/* Compact leaves -> full records (the path_pool / probs_pool entries of pgpr.py:464-478): row t of paths_out / probs_out =
+ * leaf sel[t] (sel int32 [n_sel]; negative or out-of-range entries give zero rows), or every leaf in order when sel is NULL
+ * (then n_leaf[0] rows are written, at most max_leaf). */
+int hw_pgpr_materialize_leaves(const hw_pgpr_graph* graph, const int32_t* parent_paths, const float* parent_probs,
+                               const int32_t* leaves, const int32_t* n_leaf, int64_t max_leaf, const int32_t* sel,
+                               int64_t n_sel, int32_t* paths_out, float* probs_out, void* stream);
+
 /* collect_scores (pgpr.py:486-552) on the leaf rows of a search over `users[n_batch]`:
  * results [n_batch, n_items] float32 (-inf where nothing is written), plus per user slot the written
  * (item, float64 score, leaf row of the attached path) triples in writing order: sel_* [n_batch, kmax],
@@ -471,6 +493,16 @@ int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_emb64, const 
                     int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws, float* results,
                     int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
                     int32_t* sel_row, void* stream);
+/* The same on compact leaves: parent_paths / parent_probs are the rows the last hop expanded, leaves int32 [max_leaf, 4]
+ * as hw_pgpr_topk_expand wrote them; sel_leaf indexes `leaves`.  Bit-identical results to hw_pgpr_collect on the
+ * materialised records. */
+int hw_pgpr_collect_leaves(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                           const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                           const uint32_t* positives_bits, int64_t positives_words, const int32_t* parent_paths,
+                           const float* parent_probs, const int32_t* leaves, const int32_t* n_leaf, int64_t max_leaf,
+                           int32_t n_nodes, int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws,
+                           float* results, int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
+                           int32_t* sel_row, void* stream);
 
 /* ---- PGPR policy-gradient training (pgpr.py:120-203, 335-396) --------------------------------------------------
  * One episode = max_path_len steps of: actions -> action dropout -> state -> policy MLP -> Categorical draw ->

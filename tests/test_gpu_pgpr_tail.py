@@ -1,0 +1,131 @@
+"""The tail of a beam-search hop as one launch (hw_pgpr_topk_expand: masked softmax + top-k + expand) and the compact
+16-byte leaves of the last hop, against the two-launch form with full records (policy_topk + expand, each pinned by the
+reference goldens in tests/test_gpu_pgpr.py): every array bit for bit."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_pgpr import TAGS, beam_names, build_model, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(m, users, hops, **kw):
+    m._drop_calls = 0
+    res = m.beam_search_device(users, hops, **kw)
+    return res, res.numpy()
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_fused_tail_and_compact_leaves_equal_the_two_launch_form(tag):
+    g, z, orc, m = build_model(tag)
+    users = torch.from_numpy(z["users"]).to(dev())
+    hop_sets = [[int(x) for x in z[f"beam.{hn}.hops"]] for hn in beam_names(z)] + [[min(64, m.act_dim), 3, 2], [9, 1], [7]]
+    for hops in hop_sets:
+        _, (p0, q0) = _search(m, users, hops, fused_tail=False)
+        _, (p1, q1) = _search(m, users, hops, fused_tail=True, compact_leaves=False)
+        res2, (p2, q2) = _search(m, users, hops, fused_tail=True, compact_leaves=True)
+        assert res2.leaves is not None and len(p0) > 0
+        for p, q in ((p1, q1), (p2, q2)):
+            np.testing.assert_array_equal(p, p0, err_msg=f"{tag} {hops}")
+            if min(hops) > 8:  # the two-launch form ranks with the same kernel body (policy_topk_sort_kernel<true>)
+                np.testing.assert_array_equal(q, q0, err_msg=f"{tag} {hops}")
+            else:  # k <= 8 goes through policy_topk_kernel there (expf and a division per element): an ulp apart
+                np.testing.assert_allclose(q, q0, rtol=3e-7, atol=0, err_msg=f"{tag} {hops}")
+        np.testing.assert_array_equal(q2, q1)  # compact leaves against full records of the same launch: always bit for bit
+        # single rows through the selective rebuild, out-of-range entries as zero rows
+        n = len(p0)
+        idx = np.array([0, n - 1, n // 2, -1, n], np.int64)
+        rp, rq = res2.rows(torch.from_numpy(idx))
+        rp, rq = rp.cpu().numpy(), rq.cpu().numpy()
+        np.testing.assert_array_equal(rp[:3], p0[idx[:3]])
+        np.testing.assert_array_equal(rq[:3], q0[idx[:3]])
+        assert not rp[3:].any() and not rq[3:].any()
+
+
+@pytest.mark.parametrize("tag", ["default", "trim20", "hist2"])
+def test_reference_dropout_stream_is_the_same_through_the_fused_tail(tag):
+    """Philox policy dropout: the tail does not touch the stream (same _drop_calls, same children)."""
+    g, z, orc, m = build_model(tag, dropout="reference")
+    users = torch.from_numpy(z["users"]).to(dev())
+    _, (p0, q0) = _search(m, users, [12, 10, 9], fused_tail=False)
+    _, (p1, q1) = _search(m, users, [12, 10, 9], fused_tail=True, compact_leaves=True)
+    np.testing.assert_array_equal(p1, p0)
+    np.testing.assert_array_equal(q1, q0)
+
+
+@pytest.mark.parametrize("tag", ["default", "trim70"])
+def test_collect_on_compact_leaves_equals_collect_on_records(tag):
+    g, z, orc, m = build_model(tag)
+    users = torch.from_numpy(z["users"]).to(dev())
+    for hops in ([25, 5, 1], [6, 4, 3], [10, 4], [12]):
+        full, _ = _search(m, users, hops, fused_tail=True, compact_leaves=False)
+        comp, _ = _search(m, users, hops, fused_tail=True, compact_leaves=True)
+        n_nodes = len(hops) + 1
+        s0, sel0 = m.collect_scores_device(users, full, n_nodes=n_nodes)
+        s1, sel1 = m.collect_scores_device(users, comp, n_nodes=n_nodes)
+        assert comp._paths is None, "the collector must read the compact leaves in place"
+        np.testing.assert_array_equal(s1.cpu().numpy(), s0.cpu().numpy())
+        for k in ("item", "score", "leaf", "count", "row"):
+            assert torch.equal(sel1[k], sel0[k]), (tag, hops, k)
+        if len(hops) == 3:  # shorter walks rarely end on an unseen item of this small fixture
+            assert int(sel0["count"].sum()) > 0
+        assert m.explanations(users, comp, sel1) == m.explanations(users, full, sel0)
+
+
+def test_output_capacity_is_respected():
+    """Children past out_capacity are dropped, the row count is capped, nothing is written past the buffers -- as expand."""
+    from hopwise_amd import pgpr_ops as P
+
+    g, z, orc, m = build_model("default")
+    users = torch.from_numpy(z["users"]).to(dev())
+    res = m.beam_search_device(users, [6, 9], fused_tail=False, keep_buffers=True)
+    buf = res.buffers
+    n1 = int(buf["n_rows"][1].item())
+    # redo the second hop's tail by hand at a capacity that cuts a row's children in the middle
+    paths, probs, n_rows = buf["paths"][1], buf["probs"][1], buf["n_rows"][1:2]
+    P.actions(m.graph, *P.user_scores(m.graph, *m._t64, users), m._score_rel_entity, paths, n_rows, paths.shape[0], m.max_acts,
+              m.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"])
+    m._drop_calls = 0
+    m._policy_logits(buf, n_rows, paths.shape[0], None, 1, paths)
+    full_n = int(torch.minimum(buf["n_acts"][:n1], torch.tensor(9, device=dev())).sum().item())
+    cap = full_n - 3
+    sentinel = -123
+    outs = []
+    for leaf_mode in (False, True):
+        po = torch.full((cap + 8, 12), sentinel, dtype=torch.int32, device=dev())
+        qo = torch.full((cap + 8, 3), -5.0, device=dev())
+        lo = torch.full((cap + 8, 4), sentinel, dtype=torch.int32, device=dev())
+        n_out = torch.zeros(1, dtype=torch.int32, device=dev())
+        P.topk_expand(m.graph, paths, probs, buf["acts"], m.act_dim, buf["n_acts"], n_rows, paths.shape[0], buf["logits"], 9,
+                      buf["offsets"], po, qo, lo if leaf_mode else None, n_out, cap)
+        assert int(n_out.item()) == cap
+        if leaf_mode:
+            assert bool((lo[cap:] == sentinel).all()) and bool((po == sentinel).all())
+            lp, lq = P.materialize_leaves(m.graph, paths, probs, lo, n_out, n_out=cap)
+            outs.append((lp.cpu().numpy(), lq.cpu().numpy()))
+        else:
+            assert bool((po[cap:] == sentinel).all()) and bool((qo[cap:] == -5.0).all())
+            outs.append((po[:cap].cpu().numpy(), qo[:cap].cpu().numpy()))
+    # the two-launch form at the same capacity
+    tk_i = torch.empty((paths.shape[0], 9), dtype=torch.int32, device=dev())
+    tk_v = torch.empty((paths.shape[0], 9), device=dev())
+    P.policy_topk(buf["logits"], m.act_dim, buf["n_acts"], n_rows, paths.shape[0], 9, tk_i, tk_v)
+    po = torch.full((cap + 8, 12), sentinel, dtype=torch.int32, device=dev())
+    qo = torch.full((cap + 8, 3), -5.0, device=dev())
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev())
+    P.expand(m.graph, paths, probs, buf["acts"], m.act_dim, buf["n_acts"], n_rows, paths.shape[0], tk_i, tk_v, 9, buf["offsets"],
+             po, qo, n_out, cap)
+    assert int(n_out.item()) == cap
+    for p, q in outs:
+        np.testing.assert_array_equal(p, po[:cap].cpu().numpy())
+        np.testing.assert_array_equal(q, qo[:cap].cpu().numpy())
+
+
+def test_unsupported_shapes_fall_back():
+    """k > 64 keeps the two launches (and full records); the search still runs and the result is a full BeamResult."""
+    g, z, orc, m = build_model("default")
+    users = torch.from_numpy(z["users"]).to(dev())[:2]
+    res = m.beam_search_device(users, [3, 100])
+    assert res.leaves is None and res.n > 0
