@@ -298,7 +298,7 @@ SIGNATURES = {
     "hw_pgpr_topk_expand": (
         C.c_int,
         [C.POINTER(PgprGraph), c_i32p, c_f32p, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int64, c_f32p, C.c_int64, C.c_int32,
-         c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_void_p],
+         c_i32p, c_i32p, c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_void_p],
     ),
     "hw_pgpr_materialize_leaves": (
         C.c_int,

@@ -93,10 +93,36 @@ struct PathRec {
     __device__ __forceinline__ int node(int j) const { return pick(hn, j); }
 };
 
+// Where a row's action list goes.  A16 = false: [act_dim] (relation, dst) int32 pairs, action 0 = (SELF_LOOP, current node) -- the
+// layout the training kernels, the traces and hw_pgpr_expand read.  A16 = true (beam search with the one-launch tail, rows of
+// at most TRIM_BLOCK_MAX_DEG neighbours): [act16_ld(act_dim)] uint16 EDGE OFFSETS into the current node's CSR slice, 0xFFFF for
+// the self loop -- an action is a neighbour, and the CSR (12 MB here, L2 / Infinity-Cache resident) already holds its relation
+// and id; 2 bytes instead of 8 per action written by the action kernels and gathered by the tail of the hop.
+__host__ __device__ __forceinline__ int act16_ld(int act_dim) { return (act_dim + 7) & ~7; }  // 16-byte aligned rows
+constexpr unsigned ACT16_SELF = 0xFFFFu;
+template <bool A16>
+struct ActOut {
+    int32_t* p32;
+    uint16_t* p16;
+    __device__ __forceinline__ ActOut(int32_t* acts, int row, int act_dim) {
+        p32 = A16 ? nullptr : acts + (size_t)row * act_dim * 2;
+        p16 = A16 ? reinterpret_cast<uint16_t*>(acts) + (size_t)row * act16_ld(act_dim) : nullptr;
+    }
+    __device__ __forceinline__ void put(int pos, int rel, int dst, int edge) const {
+        if constexpr (A16) p16[pos] = (uint16_t)edge;
+        else *reinterpret_cast<int2*>(&p32[2 * pos]) = make_int2(rel, dst);  // (relation, dst): one 8-byte store
+    }
+    __device__ __forceinline__ void self_loop(int cur_n) const {
+        if constexpr (A16) p16[0] = (uint16_t)ACT16_SELF;
+        else p32[0] = SELF_LOOP, p32[1] = cur_n;
+    }
+};
+
 // First pass, one WAVE per row and no block barrier: rows whose unvisited neighbours fit max_acts -- 98 % of the rows of
 // a 64/64/64 beam on the ml-1m-shaped graph, median degree 99 -- are finished here in ONE sweep over their edges with
 // ballot / popcount compaction in CSR (= relation, dst) order; rows that overflow max_acts get n_acts = -1 and are queued
 // for the trim kernels below.
+template <bool A16>
 __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g, const int32_t* __restrict__ paths,
                                                                  const int32_t* __restrict__ n_rows_ptr, int max_acts,
                                                                  int flags, int32_t* __restrict__ acts,
@@ -131,7 +157,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
         // One sweep: entries are written as they are found (CSR = (relation, dst) order) and the row is handed to the trim
         // kernels as soon as more than max_acts have been seen -- what was written so far is overwritten there.  Four
         // 64-edge chunks per trip with their loads issued together (clamped index, selects afterwards).
-        int32_t* arow = acts + (size_t)row * act_dim * 2;
+        const ActOut<A16> arow(acts, row, act_dim);
         int running = 0;
         for (int base = 0; base < deg && running <= max_acts; base += 256) {
             int rr[4], nn[4];
@@ -151,9 +177,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
                 const bool f = e < deg && !seen;
                 const unsigned long long m = __ballot(f);
                 const int pos = 1 + running + __popcll(m & lt_mask);
-                if (f && pos <= max_acts) {
-                    *reinterpret_cast<int2*>(&arow[2 * pos]) = make_int2(rr[u], nn[u]);  // (relation, dst): one 8-byte store
-                }
+                if (f && pos <= max_acts) arow.put(pos, rr[u], nn[u], e);
                 running += __popcll(m);
             }
         }
@@ -170,7 +194,7 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
             }
             continue;
         }
-        if (lane == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + running;
+        if (lane == 0) arow.self_loop(cur_n), n_acts[row] = 1 + running;
     }
 }
 
@@ -211,14 +235,14 @@ __device__ __forceinline__ void load_select_keys(const hw_pgpr_graph& g, const d
 // barriers and LDS atomics (8 digit passes x 5 syncs); a hop over item nodes (every row trimmed, degree ~10^3) spent
 // 160-180 us there, this pass needs under 10.  Same keys, same threshold, same tie rule (ties kept from the END of the
 // row) and the same CSR output order as the block kernel; the descending order of fix_scores_sorting_bug stays there.
-template <int KPL>
+template <int KPL, bool A16>
 __device__ __forceinline__ void trim_row_in_registers(const hw_pgpr_graph& g, const double* __restrict__ su,
                                                       const double* __restrict__ se,
                                                       const double* __restrict__ score_rel_entity, int cur_t,
                                                       const int (&vt)[4], const int (&vn)[4],
                                                       const int32_t* __restrict__ erel,
                                                       const int32_t* __restrict__ edst, int deg, int max_acts,
-                                                      int32_t* __restrict__ arow, int lane,
+                                                      const ActOut<A16>& arow, int lane,
                                                       unsigned long long lt_mask) {
     uint64_t key[KPL];
     load_select_keys<KPL, 64>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, lane, key);
@@ -253,13 +277,14 @@ __device__ __forceinline__ void trim_row_in_registers(const hw_pgpr_graph& g, co
         const unsigned long long kb = __ballot(keep);
         if (keep) {
             const int pos = 1 + run_keep + __popcll(kb & lt_mask);
-            *reinterpret_cast<int2*>(&arow[2 * pos]) = make_int2(r, n);
+            arow.put(pos, r, n, e);
         }
         run_keep += __popcll(kb);
         run_tie += __popcll(tb);
     }
 }
 
+template <bool A16>
 __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
     hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
     const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
@@ -297,24 +322,24 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
         const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
         const int32_t* __restrict__ erel = g.rel + lo;
         const int32_t* __restrict__ edst = g.dst + lo;
-        int32_t* arow = acts + (size_t)row * act_dim * 2;
-        if (deg <= 512) trim_row_in_registers<8>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
-        else if (deg <= 1024) trim_row_in_registers<16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
-        else trim_row_in_registers<32>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
-        if (lane == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + max_acts;
+        const ActOut<A16> arow(acts, row, act_dim);
+        if (deg <= 512) trim_row_in_registers<8, A16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
+        else if (deg <= 1024) trim_row_in_registers<16, A16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
+        else trim_row_in_registers<32, A16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lane, lt_mask);
+        if (lane == 0) arow.self_loop(cur_n), n_acts[row] = 1 + max_acts;
     }
 }
 
 // Third pass, one BLOCK per row for 2048 < neighbours <= 8192: the same register-resident search with the counts of the
 // four waves summed through LDS -- one barrier per search step and three for the output, against the ~150 barriers and the
 // same-bin LDS atomics of the radix select below (a 6 000-neighbour item row took ~120 us there).
-template <int KPL>
+template <int KPL, bool A16>
 __device__ __forceinline__ void trim_row_in_block(const hw_pgpr_graph& g, const double* __restrict__ su,
                                                   const double* __restrict__ se,
                                                   const double* __restrict__ score_rel_entity, int cur_t,
                                                   const int (&vt)[4], const int (&vn)[4],
                                                   const int32_t* __restrict__ erel, const int32_t* __restrict__ edst,
-                                                  int deg, int max_acts, int32_t* __restrict__ arow,
+                                                  int deg, int max_acts, const ActOut<A16>& arow,
                                                   unsigned long long lt_mask, int (*sh_cnt)[2][4], int (*sh_slot)[32][4]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     uint64_t key[KPL];
@@ -396,11 +421,12 @@ __device__ __forceinline__ void trim_row_in_block(const hw_pgpr_graph& g, const 
         const int before = step_prefix(sh_slot[1], i, run_k);
         if (keep) {
             const int pos = 1 + before + __popcll(kb & lt_mask);
-            *reinterpret_cast<int2*>(&arow[2 * pos]) = make_int2(r, n);
+            arow.put(pos, r, n, e);
         }
     }
 }
 
+template <bool A16>
 __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
     hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
     const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
@@ -440,12 +466,12 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
         const double* __restrict__ se = score_entity + (size_t)b * g.n_entities;
         const int32_t* __restrict__ erel = g.rel + lo;
         const int32_t* __restrict__ edst = g.dst + lo;
-        int32_t* arow = acts + (size_t)row * act_dim * 2;
+        const ActOut<A16> arow(acts, row, act_dim);
         __syncthreads();  // LDS of the previous row is free
-        if (deg <= 4096) trim_row_in_block<16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lt_mask, sh_cnt, sh_slot);
-        else trim_row_in_block<32>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lt_mask, sh_cnt, sh_slot);
+        if (deg <= 4096) trim_row_in_block<16, A16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lt_mask, sh_cnt, sh_slot);
+        else trim_row_in_block<32, A16>(g, su, se, score_rel_entity, cur_t, vt, vn, erel, edst, deg, max_acts, arow, lt_mask, sh_cnt, sh_slot);
         __syncthreads();  // every wave has finished the row before it is marked done
-        if (threadIdx.x == 0) arow[0] = SELF_LOOP, arow[1] = cur_n, n_acts[row] = 1 + max_acts;
+        if (threadIdx.x == 0) arow.self_loop(cur_n), n_acts[row] = 1 + max_acts;
     }
 }
 
@@ -1277,7 +1303,7 @@ __global__ __launch_bounds__(256) void pgpr_expand_kernel(hw_pgpr_graph g, const
 // LEAF = the last hop's compact output: a child is {parent row, relation, node, bits of its hop value} = 16 bytes instead of
 // the 60-byte record that repeats the parent's prefix 64 times; hw_pgpr_materialize_leaves rebuilds records on demand and
 // the collector reads the compact form directly.
-template <bool LEAF>
+template <bool LEAF, bool A16>
 __global__ __launch_bounds__(256) void pgpr_topk_expand_kernel(
     hw_pgpr_graph g, const int32_t* __restrict__ paths, const float* __restrict__ probs, const int32_t* __restrict__ acts,
     int act_dim, const int32_t* __restrict__ n_acts, const int32_t* __restrict__ n_rows_ptr,
@@ -1292,6 +1318,24 @@ __global__ __launch_bounds__(256) void pgpr_topk_expand_kernel(
     for (int row_v = blockIdx.x * 4 + w; row_v < n_rows; row_v += gridDim.x * 4) {
         const int row = __builtin_amdgcn_readfirstlane(row_v);
         const int na = n_acts[row];
+        // A16: everything the tail of the row needs that does not depend on the ranking is requested BEFORE it -- the row's whole
+        // offset list (<= 256 x 2 bytes: four entries per lane; the chosen entry is picked out of the lanes' registers
+        // afterwards) and the current node's CSR base -- and pinned there: left to itself the scheduler sinks these loads to
+        // their first use, behind the ranking, where each adds a dependent memory round trip to a chain that is all latency
+        // (last hop of the 64/64/64 bench, one card: 0.91 ms with the entry gathered after the ranking, 0.85 ms this way)
+        uint2 a16 = make_uint2(0u, 0u);
+        int64_t lo_pref = 0;
+        if constexpr (A16) {
+            const int ld16 = act16_ld(act_dim);
+            const uint2* arow = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(acts) + (size_t)row * ld16);
+            a16 = arow[lane * 4 < ld16 ? lane : 0];  // clamped: lanes past the row re-read its first piece
+            const int32_t* prec = paths + (size_t)row * PATH_INTS;
+            const int plen = prec[1];
+            const int pt = plen == 1 ? T_USER : prec[2 + 3 * (plen - 2) + 1];
+            const int pn = plen == 1 ? prec[0] : prec[2 + 3 * (plen - 2) + 2];
+            lo_pref = g.ptr[pt == T_USER ? pn : (int64_t)g.n_users + pn];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         uint32_t key[4];
         bool row_has_two;
         row_softmax_keys(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key, row_has_two);
@@ -1311,8 +1355,24 @@ __global__ __launch_bounds__(256) void pgpr_topk_expand_kernel(
         const i32x4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
         const int len = q0.y;
         const int cur_t = len == 1 ? T_USER : (len == 2 ? q0.w : (len == 3 ? q1.z : q2.y));
-        const int2 act = *reinterpret_cast<const int2*>(&acts[((size_t)row * act_dim + (live ? idx : 0)) * 2]);
-        const int rel = act.x, node = act.y;
+        int rel, node;
+        if constexpr (A16) {  // the action is an edge of the current node: (relation, id) from the CSR
+            const int cur_n = len == 1 ? q0.x : (len == 2 ? q1.x : (len == 3 ? q1.w : q2.z));
+            const int64_t lo = lo_pref;
+            const int ia = live ? idx : 0;  // entry ia sits in lane ia / 4, 16-bit piece ia % 4
+            const unsigned w0 = (unsigned)__shfl((int)a16.x, ia >> 2, 64), w1 = (unsigned)__shfl((int)a16.y, ia >> 2, 64);
+            const unsigned word = (ia & 2) ? w1 : w0;
+            const unsigned off = (ia & 1) ? (word >> 16) : (word & 0xFFFFu);
+            const bool self = off == ACT16_SELF;
+            const int64_t e = self ? 0 : lo + (int64_t)off;  // edge 0 always exists; a node without edges has no slice to read
+            // (the CSR's relation / dst arrays interleaved so that this is one 8-byte gather instead of two 4-byte ones:
+            // measured on one card, 0.91 = 0.91 ms -- not kept)
+            const int er = g.rel[e], ed = g.dst[e];
+            rel = self ? SELF_LOOP : er, node = self ? cur_n : ed;
+        } else {
+            const int2 act = *reinterpret_cast<const int2*>(&acts[((size_t)row * act_dim + (live ? idx : 0)) * 2]);
+            rel = act.x, node = act.y;
+        }
         if constexpr (LEAF) {
             if (live) leaf_out[o0 + lane] = make_int4(row, rel, node, (int)__float_as_uint(v));
         } else {
@@ -1478,6 +1538,9 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_u
     if (max_acts < 1 || max_acts > 1023 || max_rows < 0 || max_rows > INT32_MAX) return HW_ERR_INVALID_ARG;
     if (max_rows == 0) return HW_OK;
     if (work && work_ints < 4 + 3 * max_rows) return HW_ERR_WORKSPACE;
+    // bit 2: action lists as uint16 edge offsets (ActOut<true>); only the wave / block kernels write that layout
+    const bool a16 = (fix_scores_sorting_bug & 4) != 0;
+    if (a16 && ((fix_scores_sorting_bug & 1) || graph->max_degree > TRIM_BLOCK_MAX_DEG)) return HW_ERR_INVALID_ARG;
     // every block that may meet a row with more than ACT_LDS_KEYS neighbours needs a private scratch slice
     int64_t grid = max_rows < 2048 ? max_rows : 2048;
     if (graph->max_degree > ACT_LDS_KEYS) {
@@ -1500,20 +1563,34 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_u
     {
         int64_t g1 = (max_rows + 3) / 4;
         if (g1 > 8192) g1 = 8192;
-        hipLaunchKernelGGL(pgpr_actions_small_kernel, dim3((unsigned)g1), dim3(256), 0, st, *graph, paths, n_rows, max_acts,
-                           fix_scores_sorting_bug, acts, n_acts, work, max_rows);
+        if (a16)
+            hipLaunchKernelGGL(pgpr_actions_small_kernel<true>, dim3((unsigned)g1), dim3(256), 0, st, *graph, paths, n_rows,
+                               max_acts, fix_scores_sorting_bug, acts, n_acts, work, max_rows);
+        else
+            hipLaunchKernelGGL(pgpr_actions_small_kernel<false>, dim3((unsigned)g1), dim3(256), 0, st, *graph, paths, n_rows,
+                               max_acts, fix_scores_sorting_bug, acts, n_acts, work, max_rows);
     }
     if (!(fix_scores_sorting_bug & 1)) {
         int64_t g2 = (max_rows + 3) / 4;
         if (g2 > 4096) g2 = 4096;
-        hipLaunchKernelGGL(pgpr_actions_trim_wave_kernel, dim3((unsigned)g2), dim3(256), 0, st, *graph, score_user,
-                           score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
-                           lists[0], lens[0]);
+        if (a16)
+            hipLaunchKernelGGL(pgpr_actions_trim_wave_kernel<true>, dim3((unsigned)g2), dim3(256), 0, st, *graph, score_user,
+                               score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
+                               lists[0], lens[0]);
+        else
+            hipLaunchKernelGGL(pgpr_actions_trim_wave_kernel<false>, dim3((unsigned)g2), dim3(256), 0, st, *graph, score_user,
+                               score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
+                               lists[0], lens[0]);
         if (graph->max_degree > TRIM_WAVE_MAX_DEG) {
             const int64_t g3 = max_rows < 2048 ? max_rows : 2048;
-            hipLaunchKernelGGL(pgpr_actions_trim_block_kernel, dim3((unsigned)g3), dim3(256), 0, st, *graph, score_user,
-                               score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts,
-                               n_acts, lists[1], lens[1]);
+            if (a16)
+                hipLaunchKernelGGL(pgpr_actions_trim_block_kernel<true>, dim3((unsigned)g3), dim3(256), 0, st, *graph,
+                                   score_user, score_entity, score_rel_entity, paths, n_rows, max_acts,
+                                   fix_scores_sorting_bug, acts, n_acts, lists[1], lens[1]);
+            else
+                hipLaunchKernelGGL(pgpr_actions_trim_block_kernel<false>, dim3((unsigned)g3), dim3(256), 0, st, *graph,
+                                   score_user, score_entity, score_rel_entity, paths, n_rows, max_acts,
+                                   fix_scores_sorting_bug, acts, n_acts, lists[1], lens[1]);
         }
     }
     if ((fix_scores_sorting_bug & 1) || graph->max_degree > TRIM_BLOCK_MAX_DEG)
@@ -1643,7 +1720,7 @@ extern "C" int hw_pgpr_topk_expand(const hw_pgpr_graph* graph, const int32_t* pa
                                    int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows, int64_t max_rows,
                                    const float* logits, int64_t ld, int32_t k, int32_t* offsets, int32_t* block_sums_ws,
                                    int32_t* paths_out, float* probs_out, int32_t* leaf_out, int32_t* n_rows_out,
-                                   int64_t out_capacity, void* stream) {
+                                   int64_t out_capacity, int32_t acts_u16, void* stream) {
     int rc = check_graph(graph);
     if (rc) return rc;
     if (!paths || !probs || !acts || !n_acts || !n_rows || !logits || !offsets || !n_rows_out) return HW_ERR_INVALID_ARG;
@@ -1660,14 +1737,15 @@ extern "C" int hw_pgpr_topk_expand(const hw_pgpr_graph* graph, const int32_t* pa
     if (max_rows > 0) {
         int64_t grid = (max_rows + 3) / 4;
         if (grid > 16384) grid = 16384;
-        if (leaf_out)
-            hipLaunchKernelGGL(pgpr_topk_expand_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, *graph, paths, probs,
-                               acts, act_dim, n_acts, n_rows, logits, (int)ld, k, offsets, paths_out, probs_out,
-                               reinterpret_cast<int4*>(leaf_out), out_capacity);
-        else
-            hipLaunchKernelGGL(pgpr_topk_expand_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, *graph, paths, probs,
-                               acts, act_dim, n_acts, n_rows, logits, (int)ld, k, offsets, paths_out, probs_out,
-                               reinterpret_cast<int4*>(leaf_out), out_capacity);
+#define TAIL(LEAF_, A16_)                                                                                                 \
+    hipLaunchKernelGGL((pgpr_topk_expand_kernel<LEAF_, A16_>), dim3((unsigned)grid), dim3(256), 0, st, *graph, paths, probs, \
+                       acts, act_dim, n_acts, n_rows, logits, (int)ld, k, offsets, paths_out, probs_out,                    \
+                       reinterpret_cast<int4*>(leaf_out), out_capacity)
+        if (leaf_out && acts_u16) TAIL(true, true);
+        else if (leaf_out) TAIL(true, false);
+        else if (acts_u16) TAIL(false, true);
+        else TAIL(false, false);
+#undef TAIL
     }
     return HW_LAUNCH_RC();
 }

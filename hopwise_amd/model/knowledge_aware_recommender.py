@@ -129,6 +129,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         # (HW_PGPR_TAIL=0: top-k and expand as two launches, full 60-byte records everywhere)
         self.fused_tail = bool(_cfg(config, "fused_topk_expand", os.environ.get("HW_PGPR_TAIL", "1") != "0"))
         self.compact_leaves = bool(_cfg(config, "compact_leaves", self.fused_tail))
+        self.acts_u16 = bool(_cfg(config, "acts_u16", os.environ.get("HW_PGPR_ACTS16", "1") != "0"))
         self.user_chunk = int(_cfg(config, "beam_user_chunk", 64))
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         dev = torch.device(self.device)
@@ -178,7 +179,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.last_loss_parts = None
 
     # ------------------------------------------------------------------------------------------------
-    def _alloc(self, B, hops, compact_leaves=False):
+    def _alloc(self, B, hops, compact_leaves=False, acts_u16=False):
         dev = self._t64[0].device
         rows = [B]
         for k in hops:
@@ -193,7 +194,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             probs=[f32(r, 3) for r in full] + ([None] if compact_leaves else []),
             leaves=i32(rows[-1], 4) if compact_leaves else None,
             n_rows=torch.zeros(len(rows), dtype=torch.int32, device=dev),
-            acts=i32(rmax, self.act_dim, 2),
+            acts=(torch.empty((rmax, P.act16_ld(self.act_dim)), dtype=torch.int16, device=dev) if acts_u16
+                  else i32(rmax, self.act_dim, 2)),
             n_acts=i32(rmax),
             state=f32(rmax, self.state_dim),
             x1=f32(rmax, self.hidden_sizes[0]),
@@ -283,7 +285,10 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         if compact_leaves is None:
             compact_leaves = self.compact_leaves
         compact_leaves = bool(compact_leaves) and fused_tail and P.topk_expand_supported(self.act_dim, hops[-1])
-        buf = self._alloc(B, hops, compact_leaves)
+        # action lists as 2-byte edge offsets when every hop's tail is the one-launch form (the only reader of that layout)
+        acts_u16 = (fused_tail and self.acts_u16 and all(P.topk_expand_supported(self.act_dim, k) for k in hops)
+                    and P.acts_u16_supported(self.graph, self.fix_scores_sorting_bug))
+        buf = self._alloc(B, hops, compact_leaves, acts_u16)
         g = self.graph
         U64, E64, R64 = self._t64
         U32, E32, R32 = self._t32
@@ -308,7 +313,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 # three hops every hop sees a fresh state, which is the same thing.
                 P.state(g, U32, E32, R32, self.state_history, paths, n_rows, rmax, buf["state"])
             P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, rmax, self.max_acts,
-                      self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"])
+                      self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"], u16=acts_u16)
             mark("actions", hop)
             self._policy_logits(buf, n_rows, rmax, drops, hop, paths if lookup else None)
             mark("policy", hop)
@@ -318,7 +323,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 P.topk_expand(g, paths, probs, buf["acts"], self.act_dim, buf["n_acts"], n_rows, rmax, buf["logits"], k,
                               buf["offsets"], buf["paths"][hop + 1], buf["probs"][hop + 1],
                               buf["leaves"] if (last and compact_leaves) else None, nr[hop + 1 : hop + 2],
-                              buf["rows"][hop + 1])
+                              buf["rows"][hop + 1], acts_u16=acts_u16)
             else:
                 P.policy_topk(buf["logits"], self.act_dim, buf["n_acts"], n_rows, rmax, k, buf["tk_idx"], buf["tk_val"])
                 mark("topk", hop)

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -103,9 +104,25 @@ _ACTION_WORK = {}
 QUEUE_TRIM_ROWS = True  # False: hw_pgpr_actions without its work buffer (the trim kernels scan every row)
 
 
+TRIM_BLOCK_MAX_DEG = 8192  # csrc/pgpr.hip: rows beyond it go to the radix-select kernel, which writes (relation, dst) pairs only
+
+
+def act16_ld(act_dim):
+    return (int(act_dim) + 7) & ~7  # HW_PGPR_ACT16_LD
+
+
+def acts_u16_supported(graph, fix_bug):
+    """Whether the action lists of a search can be uint16 edge offsets (hw_pgpr_actions flag bit 2)."""
+    return not fix_bug and graph.max_degree <= TRIM_BLOCK_MAX_DEG
+
+
 def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, max_rows, max_acts, fix_bug, acts, n_acts,
-            scratch=None, start_user_revisitable=False):
+            scratch=None, start_user_revisitable=False, u16=False):
+    """``u16``: ``acts`` is an int16 [max_rows, act16_ld(max_acts + 1)] tensor that receives edge offsets into the current
+    node's CSR slice (0xFFFF = self loop) instead of int32 (relation, dst) pairs -- read only by topk_expand(acts_u16=True)."""
     lib = _lib.load()
+    if u16 and (acts.dtype != torch.int16 or acts.shape[-1] != act16_ld(max_acts + 1) or not acts.is_contiguous()):
+        raise ValueError("u16 action lists: int16 [rows, act16_ld(act_dim)] contiguous")
     sb = ss = 0
     if scratch is not None:
         sb, ss = scratch.shape
@@ -119,7 +136,8 @@ def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, ma
             _ACTION_WORK[key] = work
     check(
         lib.hw_pgpr_actions(C.byref(graph.c), _ptr(score_user), _ptr(score_entity), _ptr(score_rel_entity), _ptr(paths),
-                            _ptr(n_rows), int(max_rows), int(max_acts), int(bool(fix_bug)) | (2 if start_user_revisitable else 0), _ptr(acts), _ptr(n_acts),
+                            _ptr(n_rows), int(max_rows), int(max_acts), int(bool(fix_bug)) | (2 if start_user_revisitable else 0) | (4 if u16 else 0), _ptr(acts),
+                            _ptr(n_acts),
                             _ptr(scratch), sb, ss, _ptr(work), 0 if work is None else work.numel(), _stream()),
         "hw_pgpr_actions",
     )
@@ -257,7 +275,7 @@ def topk_expand_supported(act_dim, k):
 
 
 def topk_expand(graph, paths, probs, acts, act_dim, n_acts, n_rows, max_rows, logits, k, offsets, paths_out, probs_out,
-                leaf_out, n_rows_out, capacity):
+                leaf_out, n_rows_out, capacity, acts_u16=False):
     """Masked softmax + top-k + expand of one hop in a single launch (csrc/pgpr.hip: pgpr_topk_expand_kernel); the same
     children, in the same order, as policy_topk followed by expand.  ``leaf_out`` (int32 [capacity, 4]) selects the compact
     output of the last hop: {parent row, relation, node, value bits} instead of a 12-int record + probability triple."""
@@ -267,7 +285,7 @@ def topk_expand(graph, paths, probs, acts, act_dim, n_acts, n_rows, max_rows, lo
         lib.hw_pgpr_topk_expand(C.byref(graph.c), _ptr(paths), _ptr(probs), _ptr(acts), int(act_dim), _ptr(n_acts),
                                 _ptr(n_rows), int(max_rows), _ptr(logits), logits.stride(0), int(k), _ptr(offsets),
                                 _ptr(block_sums), _ptr(paths_out), _ptr(probs_out), _ptr(leaf_out), _ptr(n_rows_out),
-                                int(capacity), _stream()),
+                                int(capacity), 1 if acts_u16 else 0, _stream()),
         "hw_pgpr_topk_expand",
     )
 

@@ -299,9 +299,14 @@ int hw_pgpr_user_scores_tp(const hw_pgpr_graph* graph, const double* user_emb64,
  * fix_scores_sorting_bug is a bit set: bit 0 = config fix_scores_sorting_bug; bit 1 = the start user is NOT in the
  * visited set -- the reference's training episodes keep the user id as a 0-dim tensor in path[0] (reset(), pgpr.py:215-216),
  * whose hash never matches an int (the tensor also rides along leading self-loop steps), so only calculate_loss lets
- * a path return to its own user. */
+ * a path return to its own user; bit 2 = `acts` is written as uint16 EDGE OFFSETS into the current node's CSR slice
+ * ([max_rows, HW_PGPR_ACT16_LD(max_acts + 1)] uint16, 0xFFFF = the self loop) instead of (relation, dst) pairs: an action
+ * is a neighbour and the CSR already holds its relation and id, so the beam search moves 2 bytes per action instead of 8;
+ * only hw_pgpr_topk_expand (acts_u16) reads this layout.  Not with bit 0, nor when graph->max_degree > 8192. */
 #define HW_PGPR_FIX_SORTING 1
 #define HW_PGPR_START_USER_REVISITABLE 2
+#define HW_PGPR_ACTS_U16 4
+#define HW_PGPR_ACT16_LD(act_dim) (((act_dim) + 7) & ~7)
 /* work (nullable): hw_pgpr_actions_workspace_ints(max_rows) int32 of scratch in which the first pass queues the rows
  * that need the trim, by degree class, for the trim kernels; without it they scan every row. */
 int64_t hw_pgpr_actions_workspace_ints(int64_t max_rows);
@@ -466,12 +471,13 @@ int hw_pgpr_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float
  * leaf_out != NULL (int32 [out_capacity, 4], 16-byte aligned; the LAST hop of a search): children as compact leaves
  * {parent row, relation, node id, bits of the hop's value} -- the 48 + 12 bytes of a full record repeat the parent's prefix
  * once per child; hw_pgpr_materialize_leaves rebuilds records, hw_pgpr_collect_leaves consumes the compact form.
+ * acts_u16 != 0: `acts` holds uint16 edge offsets as hw_pgpr_actions writes them with flag bit 2 (see there).
  * Workspaces as hw_pgpr_expand. */
 int hw_pgpr_topk_expand(const hw_pgpr_graph* graph, const int32_t* paths, const float* probs, const int32_t* acts,
                         int32_t act_dim, const int32_t* n_acts, const int32_t* n_rows, int64_t max_rows,
                         const float* logits, int64_t ld, int32_t k, int32_t* offsets, int32_t* block_sums_ws,
                         int32_t* paths_out, float* probs_out, int32_t* leaf_out, int32_t* n_rows_out,
-                        int64_t out_capacity, void* stream);
+                        int64_t out_capacity, int32_t acts_u16, void* stream);
 
 /* Compact leaves -> full records (the path_pool / probs_pool entries of pgpr.py:464-478): row t of paths_out / probs_out =
  * leaf sel[t] (sel int32 [n_sel]; negative or out-of-range entries give zero rows), or every leaf in order when sel is NULL

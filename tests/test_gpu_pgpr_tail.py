@@ -34,6 +34,12 @@ def test_fused_tail_and_compact_leaves_equal_the_two_launch_form(tag):
             else:  # k <= 8 goes through policy_topk_kernel there (expf and a division per element): an ulp apart
                 np.testing.assert_allclose(q, q0, rtol=3e-7, atol=0, err_msg=f"{tag} {hops}")
         np.testing.assert_array_equal(q2, q1)  # compact leaves against full records of the same launch: always bit for bit
+        # action lists as (relation, dst) pairs instead of 2-byte edge offsets: the same children
+        m.acts_u16 = False
+        _, (p3, q3) = _search(m, users, hops, fused_tail=True, compact_leaves=True)
+        m.acts_u16 = True
+        np.testing.assert_array_equal(p3, p2)
+        np.testing.assert_array_equal(q3, q2)
         # single rows through the selective rebuild, out-of-range entries as zero rows
         n = len(p0)
         idx = np.array([0, n - 1, n // 2, -1, n], np.int64)
@@ -129,3 +135,41 @@ def test_unsupported_shapes_fall_back():
     users = torch.from_numpy(z["users"]).to(dev())[:2]
     res = m.beam_search_device(users, [3, 100])
     assert res.leaves is None and res.n > 0
+
+
+@pytest.mark.parametrize("tag", [t for t in TAGS if "fix" not in t])
+def test_u16_action_lists_decode_to_the_pair_lists(tag):
+    """hw_pgpr_actions with flag bit 2: entry a of a row is the offset of action a's edge in the current node's CSR slice
+    (0xFFFF = the self loop); decoded through the CSR it is the (relation, dst) pair of the int32 layout, for every row class
+    (short rows, wave-trimmed, block-trimmed where the fixture has them)."""
+    from hopwise_amd import pgpr_ops as P
+    from tests.test_gpu_pgpr import paths_to_records, prim_paths
+
+    g, z, orc, m = build_model(tag)
+    paths = prim_paths(z)
+    n = len(paths)
+    recs = paths_to_records(paths)
+    roots = sorted({p[0][2] for p in paths})
+    recs[:, 11] = [roots.index(p[0][2]) for p in paths]
+    rec = torch.from_numpy(recs).to(dev())
+    n_rows = torch.tensor([n], dtype=torch.int32, device=dev())
+    su, se = P.user_scores(m.graph, *m._t64, torch.tensor(roots, device=dev()))
+    a32 = torch.full((n, m.act_dim, 2), -7, dtype=torch.int32, device=dev())
+    n32 = torch.zeros(n, dtype=torch.int32, device=dev())
+    P.actions(m.graph, su, se, m._score_rel_entity, rec, n_rows, n, m.max_acts, False, a32, n32, None)
+    a16 = torch.full((n, P.act16_ld(m.act_dim)), -7, dtype=torch.int16, device=dev())
+    n16 = torch.zeros(n, dtype=torch.int32, device=dev())
+    P.actions(m.graph, su, se, m._score_rel_entity, rec, n_rows, n, m.max_acts, False, a16, n16, None, u16=True)
+    assert torch.equal(n16, n32)
+    ptr, rel, dst = (x.cpu().numpy() for x in (m.graph.ptr, m.graph.rel, m.graph.dst))
+    a32, a16, cnt = a32.cpu().numpy(), a16.cpu().numpy().view(np.uint16), n32.cpu().numpy()
+    n_trimmed = 0
+    for i, p in enumerate(paths):
+        t, nid = (0, p[0][2]) if len(p) == 1 else (p[-1][1], p[-1][2])
+        lo = ptr[nid if t == 0 else int(g["n_users"]) + nid]
+        assert a16[i, 0] == 0xFFFF and tuple(a32[i, 0]) == (-1, nid)
+        offs = a16[i, 1 : cnt[i]].astype(np.int64)
+        np.testing.assert_array_equal(np.stack([rel[lo + offs], dst[lo + offs]], 1), a32[i, 1 : cnt[i]], err_msg=f"row {i}")
+        assert (a16[i, cnt[i] :] == np.uint16(-7 & 0xFFFF)).all()  # nothing written past the list
+        n_trimmed += cnt[i] == m.act_dim
+    assert n_trimmed > 0 or tag in ("default", "hist0", "hist2")
