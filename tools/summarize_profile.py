@@ -130,11 +130,14 @@ if fetch and write:
 pf, pw = one("pgpr_fetch/*/*counter_collection.csv"), one("pgpr_write/*/*counter_collection.csv")
 if pf and pw:
     f, w = per_kernel(pf, "FETCH_SIZE"), per_kernel(pw, "WRITE_SIZE")
-    searches_f = max(1, max((len(v) for k, v in f.items() if "pgpr_expand_kernel" in k), default=3) // 3)
-    searches_w = max(1, max((len(v) for k, v in w.items() if "pgpr_expand_kernel" in k), default=3) // 3)
+    # one launch of the first action pass per hop, three hops per search (whatever the layout of the hop's tail)
+    searches_f = max(1, sum(len(v) for k, v in f.items() if "pgpr_actions_small_kernel" in k) // 3)
+    searches_w = max(1, sum(len(v) for k, v in w.items() if "pgpr_actions_small_kernel" in k) // 3)
+    # bench_pgpr.py also runs the collector and a full rebuild of the leaves once (pgpr.leaf_layout): not part of a search
+    not_search = ("collect_", "pgpr_materialize_leaves")
     per = []
     for k in sorted(set(f) | set(w)):
-        if not k.startswith(("hw::", "void hw::")):
+        if not k.startswith(("hw::", "void hw::")) or any(x in k for x in not_search):
             continue
         b = 2.0 * 1024.0 * sum(f.get(k, [])) / searches_f + 1024.0 * sum(w.get(k, [])) / searches_w
         per.append(dict(kernel=k.split("(")[0], bytes_per_search=b, launches_per_search=len(f.get(k, [])) / searches_f))
