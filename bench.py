@@ -707,7 +707,9 @@ def leg_sharded(D, args):
             "xgmi_GBps_per_gpu_over_step": xbytes / (dt / n_steps) / 1e9,
             "collectives_per_step": "6 all-to-alls (per lookup -- entity ids, user ids -- one int32 [count, rows] message, one "
                                     "float message with both tables' rows forward, one with their gradients backward) + "
-                                    "ONE all-reduce of the flattened replicated (relation) gradients" if P > 1 else "none (P = 1: the exchange is the identity)",
+                                    "ONE all-reduce of the flattened replicated (relation) gradients + one 4-byte max-reduce of "
+                                    "the overflow flag (the decision to reject a step is the same on every rank)"
+                                    if P > 1 else "none (P = 1: the exchange is the identity)",
         },
         "table_bytes_per_rank": 2 * (nU + nE) * Dm * 4 / P, "scaling": "weak", "parallelism": f"row-sharded x{P}",
         "backend": ("rccl" if D.backend == "nccl" else f"{D.backend} (rehearsal: collectives staged through host memory)")
