@@ -173,3 +173,53 @@ def test_u16_action_lists_decode_to_the_pair_lists(tag):
         assert (a16[i, cnt[i] :] == np.uint16(-7 & 0xFFFF)).all()  # nothing written past the list
         n_trimmed += cnt[i] == m.act_dim
     assert n_trimmed > 0 or tag in ("default", "hist0", "hist2")
+
+
+def test_u16_action_lists_on_hub_rows_of_the_bench_graph():
+    """The ml-1m-shaped synthetic CKG of bench_pgpr.py (max degree ~6 300): rows that end on the most connected items and
+    users go through the wave trim (<= 2 048 neighbours) and the block trim (<= 8 192), rows that end on quiet nodes through
+    the first pass -- in both layouts, which must describe the same actions."""
+    import bench_pgpr
+    from hopwise_amd import pgpr_ops as P
+
+    kg, ds, m = bench_pgpr.make_model(dev(), dropout="identity")
+    g = m.graph
+    deg = (g.ptr[1:] - g.ptr[:-1]).cpu().numpy()
+    item_deg = deg[g.n_users : g.n_users + g.n_items]
+    hubs = np.argsort(-item_deg)[:40]  # items, by degree
+    quiet = np.argsort(item_deg)[-400:-360]
+    busy_users = np.argsort(-deg[: g.n_users])[:20]
+    assert item_deg[hubs[0]] > 2048 and (item_deg[hubs] <= 8192).all()
+    rng = np.random.default_rng(0)
+    users = rng.integers(1, g.n_users, 8)
+    rows = []
+    for b, u in enumerate(users):
+        for it in np.concatenate([hubs, quiet]):  # user -> item
+            rows.append([u, 2, g.ui_relation, 1, it, 0, 0, 0, 0, 0, 0, b])
+        for v in busy_users:  # user -> hub item -> busy user
+            if v != u:
+                rows.append([u, 3, g.ui_relation, 1, hubs[0], g.ui_relation, 0, v, 0, 0, 0, b])
+    rec = torch.tensor(rows, dtype=torch.int32, device=dev())
+    n = rec.shape[0]
+    n_rows = torch.tensor([n], dtype=torch.int32, device=dev())
+    su, se = P.user_scores(g, *m._t64, torch.from_numpy(users).to(dev()))
+    scratch = torch.empty((min(2048, n), g.max_degree), dtype=torch.int64, device=dev())  # the launcher asks for it past 4 096
+    a32 = torch.full((n, m.act_dim, 2), -7, dtype=torch.int32, device=dev())
+    n32 = torch.zeros(n, dtype=torch.int32, device=dev())
+    P.actions(g, su, se, m._score_rel_entity, rec, n_rows, n, m.max_acts, False, a32, n32, scratch)
+    a16 = torch.full((n, P.act16_ld(m.act_dim)), -7, dtype=torch.int16, device=dev())
+    n16 = torch.zeros(n, dtype=torch.int32, device=dev())
+    P.actions(g, su, se, m._score_rel_entity, rec, n_rows, n, m.max_acts, False, a16, n16, scratch, u16=True)
+    assert torch.equal(n16, n32)
+    ptr, rel, dst = (x.cpu().numpy() for x in (g.ptr, g.rel, g.dst))
+    a32, a16, cnt = a32.cpu().numpy(), a16.cpu().numpy().view(np.uint16), n32.cpu().numpy()
+    classes = {"first pass": 0, "wave trim": 0, "block trim": 0}
+    for i, r in enumerate(rows):
+        t, nid = (r[3], r[4]) if r[1] == 2 else (r[6], r[7])
+        gid = nid if t == 0 else g.n_users + nid
+        lo, d = ptr[gid], deg[gid]
+        offs = a16[i, 1 : cnt[i]].astype(np.int64)
+        assert a16[i, 0] == 0xFFFF and (offs < d).all()
+        np.testing.assert_array_equal(np.stack([rel[lo + offs], dst[lo + offs]], 1), a32[i, 1 : cnt[i]], err_msg=f"row {i}")
+        classes["first pass" if cnt[i] < m.act_dim else ("wave trim" if d <= 2048 else "block trim")] += 1
+    assert all(v > 0 for v in classes.values()), classes
