@@ -317,6 +317,9 @@ __device__ __forceinline__ float bce_elem_unclamped(float x, float omt, float t_
 // VEC = true : dim % 4 == 0; lane gl owns float4 chunks gl, gl+G, ...  (NE/4 chunks)  -> 16-B loads
 // VEC = false: any dim;      lane gl owns elements   gl, gl+G, ...     (NE elements)  -> 4-B loads
 // Slots past the end of the row hold 0.
+#ifndef HW_ROW_BUFFER_LOAD
+#define HW_ROW_BUFFER_LOAD 1
+#endif
 template <int G, int NE, bool VEC>
 struct Row {
     float v[NE];
@@ -333,7 +336,19 @@ struct Row {
     // Same loads without the zeroing: padding slots hold copies of valid data; the caller masks their
     // contribution (Scorer::partial with MASK = true).
     __device__ __forceinline__ void load_raw(const float* __restrict__ base, int dim, int gl) {
-        if constexpr (VEC) {
+        if constexpr (VEC && G == 64 && HW_ROW_BUFFER_LOAD) {
+            // a whole wave on one row: the row as a raw buffer of dim * 4 bytes -- lanes past its end are out of range and
+            // read zeros without an address clamp
+            __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, dim * 4, 0x00020000);
+#pragma unroll
+            for (int c = 0; c < NE / 4; ++c) {
+                const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (gl + c * G) * 16, 0, 0));
+                v[4 * c + 0] = x.x;
+                v[4 * c + 1] = x.y;
+                v[4 * c + 2] = x.z;
+                v[4 * c + 3] = x.w;
+            }
+        } else if constexpr (VEC) {
             const int d4 = dim >> 2;
             const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(base);
 #pragma unroll
