@@ -8,6 +8,7 @@
 //             (2) select: one block per user slot -> score row in float64, top-kmax of candidates, pads
 //             (3) rows + fill: row numbering scan, scatter into results.
 #include "hw_common.h"
+#include <cstdlib>
 
 namespace hw {
 
@@ -30,8 +31,55 @@ __device__ __forceinline__ bool bit_test(const uint32_t* __restrict__ bits, int6
     return (bits[(size_t)uid * words + (item >> 5)] >> (item & 31)) & 1u;
 }
 
+// One leaf -> (user slot, item, key) of collect_scores' "best path per (user, item)" (pgpr.py:494-524), or false when the
+// path is dropped (a self loop, not ending on an unseen item).  key = (bits of the float32 product of the hop values, ~leaf
+// index): the maximum over a cell's leaves is the most probable path, the earlier leaf among equals.
 // COMPACT: the last hop's children as {parent row, relation, node, value bits} (pgpr.hip: pgpr_topk_expand_kernel<true>) next
 // to the parent rows they extend, instead of one 12-int record + probability triple per leaf.  Same tests, same key.
+template <bool COMPACT>
+__device__ __forceinline__ bool leaf_key(const hw_pgpr_graph& g, const int32_t* __restrict__ leaf,
+                                         const float* __restrict__ probs, const int4* __restrict__ cleaf, int64_t i,
+                                         int n_nodes, const int32_t* __restrict__ first_idx,
+                                         const uint32_t* __restrict__ pos_bits, int64_t pos_words, int& slot, int& pid,
+                                         unsigned long long& key) {
+    int uid, batch;
+    float pp;
+    if constexpr (COMPACT) {
+        const int4 lf = cleaf[i];
+        const int32_t* p = leaf + (size_t)lf.x * CPATH_INTS;  // the parent: n_nodes - 1 nodes
+        if (p[1] != n_nodes - 1) return false;
+        bool ok = lf.y != -1;                                                         // no self loop after the root
+        for (int j = 1; j < n_nodes - 1; ++j) ok &= p[2 + 3 * (j - 1)] != -1;
+        const int cur_t = n_nodes == 2 ? 0 : p[2 + 3 * (n_nodes - 3) + 1];
+        const int lt = (cur_t == 1 && lf.y == g.ui_relation) ? 0 : 1;                 // pgpr.py:209-213
+        pid = lf.z;
+        ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
+        if (!ok) return false;
+        uid = p[0], batch = p[11];
+        const float* q = probs + (size_t)lf.x * 3;
+        const float v = __uint_as_float((uint32_t)lf.w);
+        pp = n_nodes == 2 ? v : q[0];
+        for (int j = 1; j < n_nodes - 1; ++j) pp = pp * (j == n_nodes - 2 ? v : q[j]);  // reduce(mul) in float32
+    } else {
+        const int32_t* p = leaf + (size_t)i * CPATH_INTS;
+        if (p[1] != n_nodes) return false;
+        bool ok = true;
+        for (int j = 1; j < n_nodes; ++j) ok &= p[2 + 3 * (j - 1)] != -1;            // no self loop after the root
+        const int lt = p[2 + 3 * (n_nodes - 2) + 1];
+        pid = p[2 + 3 * (n_nodes - 2) + 2];
+        ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
+        if (!ok) return false;
+        uid = p[0], batch = p[11];
+        const float* q = probs + (size_t)i * 3;
+        pp = q[0];
+        for (int j = 1; j < n_nodes - 1; ++j) pp = pp * q[j];                          // reduce(mul) in float32
+    }
+    if (bit_test(pos_bits, pos_words, uid, pid)) return false;                         // already a train positive
+    slot = first_idx[batch];
+    key = ((unsigned long long)__float_as_uint(pp) << 32) | (uint32_t)(~(uint32_t)i);
+    return true;
+}
+
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void collect_mark_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf,
                                                            const float* __restrict__ probs,
@@ -42,42 +90,54 @@ __global__ __launch_bounds__(256) void collect_mark_kernel(hw_pgpr_graph g, cons
                                                            unsigned long long* __restrict__ best) {
     const int n_leaf = n_leaf_ptr[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_leaf; i += (int64_t)gridDim.x * blockDim.x) {
-        int uid, pid, batch;
-        float pp;
-        if constexpr (COMPACT) {
-            const int4 lf = cleaf[i];
-            const int32_t* p = leaf + (size_t)lf.x * CPATH_INTS;  // the parent: n_nodes - 1 nodes
-            if (p[1] != n_nodes - 1) continue;
-            bool ok = lf.y != -1;                                                         // no self loop after the root
-            for (int j = 1; j < n_nodes - 1; ++j) ok &= p[2 + 3 * (j - 1)] != -1;
-            const int cur_t = n_nodes == 2 ? 0 : p[2 + 3 * (n_nodes - 3) + 1];
-            const int lt = (cur_t == 1 && lf.y == g.ui_relation) ? 0 : 1;                 // pgpr.py:209-213
-            pid = lf.z;
-            ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
-            if (!ok) continue;
-            uid = p[0], batch = p[11];
-            const float* q = probs + (size_t)lf.x * 3;
-            const float v = __uint_as_float((uint32_t)lf.w);
-            pp = n_nodes == 2 ? v : q[0];
-            for (int j = 1; j < n_nodes - 1; ++j) pp = pp * (j == n_nodes - 2 ? v : q[j]);  // reduce(mul) in float32
-        } else {
-            const int32_t* p = leaf + (size_t)i * CPATH_INTS;
-            if (p[1] != n_nodes) continue;
-            bool ok = true;
-            for (int j = 1; j < n_nodes; ++j) ok &= p[2 + 3 * (j - 1)] != -1;            // no self loop after the root
-            const int lt = p[2 + 3 * (n_nodes - 2) + 1];
-            pid = p[2 + 3 * (n_nodes - 2) + 2];
-            ok &= (lt == 1) && (pid < g.n_items);                                         // ends on an item
-            if (!ok) continue;
-            uid = p[0], batch = p[11];
-            const float* q = probs + (size_t)i * 3;
-            pp = q[0];
-            for (int j = 1; j < n_nodes - 1; ++j) pp = pp * q[j];                          // reduce(mul) in float32
-        }
-        if (bit_test(pos_bits, pos_words, uid, pid)) continue;                             // already a train positive
-        const int slot = first_idx[batch];
-        const unsigned long long key = ((unsigned long long)__float_as_uint(pp) << 32) | (uint32_t)(~(uint32_t)i);
-        atomicMax(best + (size_t)slot * g.n_items + pid, key);
+        int slot, pid;
+        unsigned long long key;
+        if (leaf_key<COMPACT>(g, leaf, probs, cleaf, i, n_nodes, first_idx, pos_bits, pos_words, slot, pid, key))
+            atomicMax(best + (size_t)slot * g.n_items + pid, key);
+    }
+}
+
+// The same with the maxima of a block's leaves taken in LDS first.  A device-scope atomic on this part is carried out at the
+// memory side (nothing stays in an XCD's L2), ~25 G of them per second: the 66 M leaves of a 256-user 64/64/64 search cost
+// 2.65 ms that way.  Leaves are emitted user by user, so a block that takes MARK_LEAVES consecutive leaves sees one user (two
+// at a boundary): it keeps that user's [n_items] maxima in LDS (ds_max_u64) and only flushes the cells it touched -- a few
+// thousand memory-side atomics per block instead of 32 768.  Leaves of another user go straight to memory.  max() is
+// associative and commutative: the table ends up bit-identical.
+constexpr int MARK_LEAVES = 32768;
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void collect_mark_lds_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf,
+                                                               const float* __restrict__ probs,
+                                                               const int4* __restrict__ cleaf,
+                                                               const int32_t* __restrict__ n_leaf_ptr, int n_nodes,
+                                                               const int32_t* __restrict__ first_idx,
+                                                               const uint32_t* __restrict__ pos_bits, int64_t pos_words,
+                                                               unsigned long long* __restrict__ best) {
+    extern __shared__ unsigned long long lds_best[];  // [n_items]
+    __shared__ int slot0_sh;
+    const int n_leaf = n_leaf_ptr[0];
+    const int64_t lo = (int64_t)blockIdx.x * MARK_LEAVES;
+    if (lo >= n_leaf) return;
+    const int64_t hi = lo + MARK_LEAVES < n_leaf ? lo + MARK_LEAVES : n_leaf;
+    for (int c = threadIdx.x; c < g.n_items; c += 256) lds_best[c] = 0ull;
+    if (threadIdx.x == 0) {  // the user slot of the block's first leaf: the one its LDS table stands for
+        int batch;
+        if constexpr (COMPACT) batch = leaf[(size_t)cleaf[lo].x * CPATH_INTS + 11];
+        else batch = leaf[(size_t)lo * CPATH_INTS + 11];
+        slot0_sh = first_idx[batch];
+    }
+    __syncthreads();
+    const int slot0 = slot0_sh;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        int slot, pid;
+        unsigned long long key;
+        if (!leaf_key<COMPACT>(g, leaf, probs, cleaf, i, n_nodes, first_idx, pos_bits, pos_words, slot, pid, key)) continue;
+        if (slot == slot0) atomicMax(&lds_best[pid], key);
+        else atomicMax(best + (size_t)slot * g.n_items + pid, key);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < g.n_items; c += 256) {
+        const unsigned long long k = lds_best[c];
+        if (k) atomicMax(best + (size_t)slot0 * g.n_items + c, k);
     }
 }
 
@@ -263,14 +323,20 @@ static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, co
     if (max_leaf > 0) {
         int64_t grid = (max_leaf + 255) / 256;
         if (grid > 16384) grid = 16384;
-        if (cleaf)
-            hipLaunchKernelGGL(collect_mark_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, *graph, leaf_paths,
-                               leaf_probs, cleaf, n_leaf, n_nodes, first_idx_ws, positives_bits, positives_words,
-                               (unsigned long long*)best_ws);
-        else
-            hipLaunchKernelGGL(collect_mark_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, *graph, leaf_paths,
-                               leaf_probs, cleaf, n_leaf, n_nodes, first_idx_ws, positives_bits, positives_words,
-                               (unsigned long long*)best_ws);
+        const size_t lds_bytes = (size_t)graph->n_items * sizeof(unsigned long long);
+        // an item table per block fits in LDS, and there are enough leaves for blocks of MARK_LEAVES to fill the chip;
+        // HW_PGPR_MARK_LDS=0 keeps the direct form (what the tests compare the LDS form with)
+        static const bool lds_off = [] { const char* e = getenv("HW_PGPR_MARK_LDS"); return e && e[0] == '0'; }();
+        const bool in_lds = !lds_off && lds_bytes <= 48 * 1024 && max_leaf >= 2 * MARK_LEAVES;
+        const int64_t grid_lds = (max_leaf + MARK_LEAVES - 1) / MARK_LEAVES;
+#define MARK(KERNEL, GRID, LDS)                                                                                          \
+    hipLaunchKernelGGL(KERNEL, dim3((unsigned)(GRID)), dim3(256), LDS, st, *graph, leaf_paths, leaf_probs, cleaf, n_leaf, \
+                       n_nodes, first_idx_ws, positives_bits, positives_words, (unsigned long long*)best_ws)
+        if (in_lds && cleaf) MARK(collect_mark_lds_kernel<true>, grid_lds, lds_bytes);
+        else if (in_lds) MARK(collect_mark_lds_kernel<false>, grid_lds, lds_bytes);
+        else if (cleaf) MARK(collect_mark_kernel<true>, grid, 0);
+        else MARK(collect_mark_kernel<false>, grid, 0);
+#undef MARK
     }
     hipLaunchKernelGGL(collect_select_kernel, dim3(nb), dim3(256), 0, st, *graph, user_emb64, entity_emb64,
                        relation_emb64, dim, users, first_idx_ws, positives_bits, positives_words,

@@ -65,7 +65,7 @@ def test_reference_dropout_stream_is_the_same_through_the_fused_tail(tag):
 def test_collect_on_compact_leaves_equals_collect_on_records(tag):
     g, z, orc, m = build_model(tag)
     users = torch.from_numpy(z["users"]).to(dev())
-    for hops in ([25, 5, 1], [6, 4, 3], [10, 4], [12]):
+    for hops in ([25, 5, 1], [6, 4, 3], [10, 4], [12], [64, 64, 64]):  # the last one: enough leaves for the LDS mark pass
         full, _ = _search(m, users, hops, fused_tail=True, compact_leaves=False)
         comp, _ = _search(m, users, hops, fused_tail=True, compact_leaves=True)
         n_nodes = len(hops) + 1
@@ -223,3 +223,40 @@ def test_u16_action_lists_on_hub_rows_of_the_bench_graph():
         np.testing.assert_array_equal(np.stack([rel[lo + offs], dst[lo + offs]], 1), a32[i, 1 : cnt[i]], err_msg=f"row {i}")
         classes["first pass" if cnt[i] < m.act_dim else ("wave trim" if d <= 2048 else "block trim")] += 1
     assert all(v > 0 for v in classes.values()), classes
+
+
+def test_lds_mark_pass_equals_the_direct_one():
+    """collect_mark_lds_kernel (a block's leaves maximised in LDS, touched cells flushed) against collect_mark_kernel (one
+    memory-side atomic per leaf): same table, hence the same scores and selections bit for bit.  The switch is read once per
+    process, so the direct form runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, ROOTDIR)\n"
+        "from tests.test_gpu_pgpr import build_model, dev\n"
+        "g, z, orc, m = build_model('default')\n"
+        "users = torch.from_numpy(z['users']).to(dev())\n"
+        "out = {}\n"
+        "for compact in (False, True):\n"
+        "    m._drop_calls = 0\n"
+        "    res = m.beam_search_device(users, [64, 64, 64], fused_tail=True, compact_leaves=compact)\n"
+        "    s, sel = m.collect_scores_device(users, res, n_nodes=4)\n"
+        "    out['s%d' % compact] = s.cpu().numpy()\n"
+        "    for k, v in sel.items(): out['%s%d' % (k, compact)] = v.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ).replace("ROOTDIR", repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    got = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("1", "0"):
+            path = os.path.join(td, f"m{mode}.npz")
+            env = dict(os.environ, HW_PGPR_MARK_LDS=mode)
+            p = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+            assert p.returncode == 0, p.stderr[-2000:]
+            got[mode] = dict(np.load(path))
+    assert set(got["1"]) == set(got["0"]) and np.isfinite(got["1"]["s0"]).any()
+    for k in got["1"]:
+        np.testing.assert_array_equal(got["1"][k], got["0"][k], err_msg=k)
