@@ -82,6 +82,8 @@ def parse_args(argv=None):
                     help="users per beam search: 64 -> 5.8 G paths/s, 256 -> 6.7 G (the first hops' fixed cost amortised), ~8 GB of work buffers")
     ap.add_argument("--sharded-steps", type=int, default=10)
     ap.add_argument("--sharded-batch", type=int, default=8192, help="rec positives and kg triples per rank per step")
+    ap.add_argument("--sharded-deadline", type=float, default=300.0,
+                    help="N > 1: seconds the row-sharded leg may take before the line is printed without it")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args(argv)
 
@@ -965,7 +967,7 @@ def main():
             out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
             torch.cuda.empty_cache()
 
-    if not args.no_sharded:
+    if not args.no_sharded and D.world == 1:
         guarded("sharded", lambda: leg_sharded(D, args))
     if D.world == 1 and not args.no_tucker:
         guarded("tucker", lambda: leg_tucker(D, args))
@@ -987,6 +989,28 @@ def main():
 
         torch.cuda.empty_cache()
         guarded("cafe", lambda: bench_cafe.run(D.dev, n_users=256, cpu_users=(2 if not args.no_cpu_baseline else 0)))
+    if not args.no_sharded and D.world > 1:
+        # The one leg whose ranks talk to each other (all-to-alls, all-reduces) runs LAST at N > 1, under a deadline: every
+        # number above is a replica measurement that needs no peer, and a collective that never completes (a rank that died,
+        # a fabric problem) must not take them along.  Each rank arms the same timer; when it fires rank 0 prints the line
+        # with the leg marked as timed out and every rank leaves at once.
+        import threading
+
+        finished = threading.Event()
+
+        def on_deadline():
+            if finished.wait(args.sharded_deadline):
+                return
+            if D.rank == 0:
+                out["sharded"] = {"error": f"timed out after {args.sharded_deadline:.0f} s inside the row-sharded leg (a "
+                                           "collective did not complete); the replica legs above are unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)  # every rank: the launcher treats a non-zero worker as a failed run and would drop the line
+
+        threading.Thread(target=on_deadline, daemon=True).start()
+        torch.cuda.empty_cache()
+        guarded("sharded", lambda: leg_sharded(D, args))
+        finished.set()
     if args.workload == "sharded" and "value" in out.get("sharded", {}):
         sh = out["sharded"]
         out["replica_configs1"] = {k: out[k] for k in ("metric", "value", "unit", "ms_per_step", "config")}
