@@ -12,6 +12,7 @@
 //   paths   12 x int32 per beam row: [uid, n_nodes, (rel, type, id) x 3, batch index]; node 0 is (SELF, USER, uid).
 //   acts    [rows, act_dim] (rel, dst) pairs, action 0 = self loop; n_acts[rows].
 #include "hw_common.h"
+#include <type_traits>
 
 namespace hw {
 
@@ -159,28 +160,37 @@ __global__ __launch_bounds__(256) void pgpr_actions_small_kernel(hw_pgpr_graph g
         // 64-edge chunks per trip with their loads issued together (clamped index, selects afterwards).
         const ActOut<A16> arow(acts, row, act_dim);
         int running = 0;
-        for (int base = 0; base < deg && running <= max_acts; base += 256) {
-            int rr[4], nn[4];
+        // NCH 64-edge chunks per trip, their loads issued together.  The kernel is bound by instruction issue on the scalar
+        // unit (~170 scalar instructions per row: ballots, popcounts, the wave-uniform record fields; counters in
+        // profiles/r4/pmc_pgpr_r4.txt), and the median row of a beam has ~100 neighbours: rows of at most 128 take two
+        // chunks per trip instead of four clamped ones.
+        auto sweep = [&](auto nch_c) {
+            constexpr int NCH = decltype(nch_c)::value;
+            for (int base = 0; base < deg && running <= max_acts; base += 64 * NCH) {
+                int rr[NCH], nn[NCH];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = base + 64 * u + lane;
-                const int ec = e < deg ? e : deg - 1;
-                rr[u] = erel[ec], nn[u] = edst[ec];
+                for (int u = 0; u < NCH; ++u) {
+                    const int e = base + 64 * u + lane;
+                    const int ec = e < deg ? e : deg - 1;
+                    rr[u] = erel[ec], nn[u] = edst[ec];
+                }
+#pragma unroll
+                for (int u = 0; u < NCH; ++u) {
+                    const int e = base + 64 * u + lane;
+                    const int nt = next_type(g, cur_t, rr[u]);
+                    bool seen = false;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) seen |= (vt[k] == nt && vn[k] == nn[u]);
+                    const bool f = e < deg && !seen;
+                    const unsigned long long m = __ballot(f);
+                    const int pos = 1 + running + __popcll(m & lt_mask);
+                    if (f && pos <= max_acts) arow.put(pos, rr[u], nn[u], e);
+                    running += __popcll(m);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = base + 64 * u + lane;
-                const int nt = next_type(g, cur_t, rr[u]);
-                bool seen = false;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) seen |= (vt[k] == nt && vn[k] == nn[u]);
-                const bool f = e < deg && !seen;
-                const unsigned long long m = __ballot(f);
-                const int pos = 1 + running + __popcll(m & lt_mask);
-                if (f && pos <= max_acts) arow.put(pos, rr[u], nn[u], e);
-                running += __popcll(m);
-            }
-        }
+        };
+        if (deg <= 128) sweep(std::integral_constant<int, 2>{});
+        else sweep(std::integral_constant<int, 4>{});
         if (running > max_acts) {
             // the trim kernels score and cut this row; with a work buffer it is queued by degree class so that they
             // walk short lists instead of scanning every row for n_acts < 0
