@@ -1035,28 +1035,34 @@ __device__ __forceinline__ void sort64(uint32_t& key, int lane) {
 // (mantissa of p + 1) << 8 | (255 - index), top bit set for valid actions, 0 otherwise -- a plain unsigned compare gives
 // (value desc, index asc).  p + 1 rounds to exactly 2.0 when p >= 1 - 2^-25; such a row cannot also hold 1.99999988 (the
 // probabilities sum to 1), so 2.0 shares the top mantissa code and `row_has_two` tells them apart.
+// NPL = slots per lane: 4 covers 256 actions; rows with at most 128 actions (97 % of the last hop of a 64/64/64 beam) are
+// ranked with NPL = 2 -- the ranking is bound by vector-instruction issue, and half the slots are half the exps, key builds
+// and counting compares.  The sum of a row's exps is taken in a different order in the two forms (an ulp of p): every
+// kernel that ranks a row picks the form by the same rule (rank_slots), so they still agree bit for bit.
+__device__ __forceinline__ int rank_slots(int na) { return na <= 128 ? 2 : 4; }
+template <int NPL>
 __device__ __forceinline__ void row_softmax_keys(const float* __restrict__ lr, int act_dim, int na, int lane,
-                                                 float* __restrict__ probs_row, uint32_t (&key)[4], bool& row_has_two) {
+                                                 float* __restrict__ probs_row, uint32_t (&key)[NPL], bool& row_has_two) {
     // p is rounded to float32 before the + 1 (probs + mask.float() on a float32 tensor, pgpr.py:453): no fused multiply-add,
     // or the same row would rank differently depending on which kernel the function was inlined into
 #pragma clang fp contract(off)
-    float x[4];
+    float x[NPL];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // clamped index, select afterwards: the four loads are issued together
-        const int j = lane * 4 + i;  // blocked layout: element j of the row
+    for (int i = 0; i < NPL; ++i) {  // clamped index, select afterwards: the four loads are issued together
+        const int j = lane * NPL + i;  // blocked layout: element j of the row
         x[i] = lr[j < act_dim ? j : act_dim - 1];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = lane * 4 + i;
+    for (int i = 0; i < NPL; ++i) {
+        const int j = lane * NPL + i;
         x[i] = (j < na && j < act_dim) ? x[i] : -INFINITY;
         mx = fmaxf(mx, x[i]);
     }
     mx = wave_max_f32(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         x[i] = x[i] == -INFINITY ? 0.f : __expf(x[i] - mx);  // v_exp_f32: the ranking key keeps 23 bits of p + 1 anyway
         sum += x[i];
     }
@@ -1064,8 +1070,8 @@ __device__ __forceinline__ void row_softmax_keys(const float* __restrict__ lr, i
     const float inv_sum = 1.f / sum;  // one division per row
     bool two = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = lane * 4 + i;
+    for (int i = 0; i < NPL; ++i) {
+        const int j = lane * NPL + i;
         const float pr = x[i] * inv_sum;
         if (probs_row && j < act_dim) probs_row[j] = j < na ? pr : 0.f;
         const uint32_t bits = __float_as_uint(pr + 1.0f);  // [1, 2]: 0x3F800000 .. 0x40000000
@@ -1088,11 +1094,12 @@ __device__ __forceinline__ void decode_topk_key(uint32_t kk, bool row_has_two, i
 // unit; the search stops as soon as exactly k keys lie above the candidate), the k survivors are compacted to one per lane
 // through `surv` (64 words of LDS owned by the wave) and only those 64 are sorted: ~1/3 of the vector instructions of sorting
 // all 256.
-__device__ __forceinline__ uint32_t select_sort_topk(const uint32_t (&key)[4], int k, int lane, uint32_t* surv) {
+template <int NPL>
+__device__ __forceinline__ uint32_t select_sort_topk(const uint32_t (&key)[NPL], int k, int lane, uint32_t* surv) {
     auto count_ge = [&](uint32_t c) {
         int n = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) n += __builtin_popcountll(__ballot(key[i] >= c));
+        for (int i = 0; i < NPL; ++i) n += __builtin_popcountll(__ballot(key[i] >= c));
         return n;  // wave-uniform
     };
     // valid keys have the top bit set and are distinct; T = the k-th largest of them (all of them if fewer than k)
@@ -1100,7 +1107,9 @@ __device__ __forceinline__ uint32_t select_sort_topk(const uint32_t (&key)[4], i
     if (count_ge(T) > k) {
         // no key has a bit set above the largest key's highest one: the search starts there (probabilities of a
         // 250-way softmax leave the top ~8 mantissa bits of p + 1 clear, i.e. ~8 of the ~25 rounds)
-        uint32_t mk = max(max(key[0], key[1]), max(key[2], key[3]));
+        uint32_t mk = key[0];
+#pragma unroll
+        for (int i = 1; i < NPL; ++i) mk = max(mk, key[i]);
         mk = wave_max_u32(mk);
         const int top = 31 - __builtin_clz((__builtin_amdgcn_readfirstlane(mk) & 0x7FFFFFFFu) | 1u);
         for (int bit = top; bit >= 0; --bit) {
@@ -1115,7 +1124,7 @@ __device__ __forceinline__ uint32_t select_sort_topk(const uint32_t (&key)[4], i
     __builtin_amdgcn_wave_barrier();
     int base = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         const bool sel = key[i] >= T;  // T >= 0x80000000: invalid slots (key 0) never qualify
         const uint64_t m = __ballot(sel);
         const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -1144,8 +1153,11 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
         const int na = n_acts[row];
         uint32_t key[4];
         bool row_has_two;
-        row_softmax_keys(logits + (size_t)row * ld, act_dim, na, lane, probs_out ? probs_out + (size_t)row * act_dim : nullptr,
-                         key, row_has_two);
+        // the two-slot form leaves probs_out past 2 * 64 unwritten: only without probs_out (the beam search never asks for it)
+        const bool two_slots = SELECT && !probs_out && rank_slots(na) == 2;  // wave-uniform
+        if (!two_slots)
+            row_softmax_keys<4>(logits + (size_t)row * ld, act_dim, na, lane,
+                                probs_out ? probs_out + (size_t)row * act_dim : nullptr, key, row_has_two);
         auto emit = [&](uint32_t kk, int rnk) {
             const bool ok = kk != 0u;
             int idx;
@@ -1156,7 +1168,14 @@ __global__ __launch_bounds__(256) void policy_topk_sort_kernel(const float* __re
         };
         if constexpr (SELECT) {
             __shared__ uint32_t surv_all[4][64];
-            const uint32_t one = select_sort_topk(key, k, lane, surv_all[threadIdx.x >> 6]);
+            uint32_t one;
+            if (two_slots) {
+                uint32_t key2[2];
+                row_softmax_keys<2>(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key2, row_has_two);
+                one = select_sort_topk<2>(key2, k, lane, surv_all[threadIdx.x >> 6]);
+            } else {
+                one = select_sort_topk<4>(key, k, lane, surv_all[threadIdx.x >> 6]);
+            }
             if (lane < k) emit(one, lane);
         } else {
             bitonic_sort256<2>(key, lane);  // descending overall: element index e = lane * 4 + i
@@ -1346,10 +1365,17 @@ __global__ __launch_bounds__(256) void pgpr_topk_expand_kernel(
             lo_pref = g.ptr[pt == T_USER ? pn : (int64_t)g.n_users + pn];
             __builtin_amdgcn_sched_barrier(0);
         }
-        uint32_t key[4];
         bool row_has_two;
-        row_softmax_keys(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key, row_has_two);
-        const uint32_t one = select_sort_topk(key, k, lane, surv_all[w]);
+        uint32_t one;
+        if (rank_slots(na) == 2) {  // wave-uniform
+            uint32_t key[2];
+            row_softmax_keys<2>(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key, row_has_two);
+            one = select_sort_topk<2>(key, k, lane, surv_all[w]);
+        } else {
+            uint32_t key[4];
+            row_softmax_keys<4>(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key, row_has_two);
+            one = select_sort_topk<4>(key, k, lane, surv_all[w]);
+        }
         const int64_t o0 = offsets[row];
         const int64_t room = cap - o0;  // children past the output capacity are dropped, as in pgpr_expand_kernel
         const int n_child = min(k, na);
