@@ -10,7 +10,9 @@
 //   tables  float64 copies for the top-max_acts trim (the reference scores in float64, pgpr.py:276) and
 //           float32 copies for the state gather (torch.FloatTensor(state), pgpr.py:447).
 //   paths   12 x int32 per beam row: [uid, n_nodes, (rel, type, id) x 3, batch index]; node 0 is (SELF, USER, uid).
-//   acts    [rows, act_dim] (rel, dst) pairs, action 0 = self loop; n_acts[rows].
+//   acts    [rows, act_dim] (rel, dst) pairs, action 0 = self loop; n_acts[rows].  On the beam-search path the lists are
+//           uint16 offsets into the current node's CSR slice instead (ActOut<true>), and the last hop's children leave as
+//           16-byte leaves {parent row, rel, node, value bits} (pgpr_topk_expand_kernel<true, .>).
 #include "hw_common.h"
 #include <type_traits>
 

@@ -136,9 +136,10 @@ def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, ma
             _ACTION_WORK[key] = work
     check(
         lib.hw_pgpr_actions(C.byref(graph.c), _ptr(score_user), _ptr(score_entity), _ptr(score_rel_entity), _ptr(paths),
-                            _ptr(n_rows), int(max_rows), int(max_acts), int(bool(fix_bug)) | (2 if start_user_revisitable else 0) | (4 if u16 else 0), _ptr(acts),
-                            _ptr(n_acts),
-                            _ptr(scratch), sb, ss, _ptr(work), 0 if work is None else work.numel(), _stream()),
+                            _ptr(n_rows), int(max_rows), int(max_acts),
+                            int(bool(fix_bug)) | (2 if start_user_revisitable else 0) | (4 if u16 else 0),  # HW_PGPR_* flag bits
+                            _ptr(acts), _ptr(n_acts), _ptr(scratch), sb, ss, _ptr(work), 0 if work is None else work.numel(),
+                            _stream()),
         "hw_pgpr_actions",
     )
 
