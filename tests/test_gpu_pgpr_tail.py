@@ -260,3 +260,23 @@ def test_lds_mark_pass_equals_the_direct_one():
     assert set(got["1"]) == set(got["0"]) and np.isfinite(got["1"]["s0"]).any()
     for k in got["1"]:
         np.testing.assert_array_equal(got["1"][k], got["0"][k], err_msg=k)
+
+
+def test_duplicate_users_in_a_batch_compact_equals_full():
+    """A user listed twice in a search: both copies expand (their leaves carry different batch indices) and the collector
+    folds them into the first copy's slot -- the same through compact leaves and through full records."""
+    g, z, orc, m = build_model("default")
+    u = torch.from_numpy(z["users"]).to(dev())
+    users = torch.cat([u[:5], u[2:4], u[:1]])
+    for hops in ([25, 5, 1], [64, 64, 64]):
+        full, (p0, q0) = _search(m, users, hops, fused_tail=True, compact_leaves=False)
+        comp, (p1, q1) = _search(m, users, hops, fused_tail=True, compact_leaves=True)
+        np.testing.assert_array_equal(p1, p0)
+        np.testing.assert_array_equal(q1, q0)
+        s0, sel0 = m.collect_scores_device(users, full, n_nodes=4)
+        s1, sel1 = m.collect_scores_device(users, comp, n_nodes=4)
+        np.testing.assert_array_equal(s1.cpu().numpy(), s0.cpu().numpy())
+        for k in sel0:
+            assert torch.equal(sel1[k], sel0[k]), (hops, k)
+        cnt = sel0["count"].cpu().numpy()
+        assert (cnt[5:] == 0).all() and cnt[:5].sum() > 0  # the later copies own no result row
