@@ -80,6 +80,7 @@ def parse_args(argv=None):
     ap.add_argument("--pgpr-steps", type=int, default=0, help="0: enough searches for 0.5 s of timed work (>= 5)")
     ap.add_argument("--pgpr-users", type=int, default=256,
                     help="users per beam search: 64 -> 5.8 G paths/s, 256 -> 6.7 G (the first hops' fixed cost amortised), ~8 GB of work buffers")
+    ap.add_argument("--cafe-users", type=int, default=1024, help="users per CAFE run_program call")
     ap.add_argument("--sharded-steps", type=int, default=10)
     ap.add_argument("--sharded-batch", type=int, default=8192, help="rec positives and kg triples per rank per step")
     ap.add_argument("--sharded-deadline", type=float, default=300.0,
@@ -988,7 +989,9 @@ def main():
         import bench_cafe
 
         torch.cuda.empty_cache()
-        guarded("cafe", lambda: bench_cafe.run(D.dev, n_users=256, cpu_users=(2 if not args.no_cpu_baseline else 0)))
+        # 1 024 users per call: one workgroup per user, four per CU (256 per call leave three quarters of the chip idle)
+        guarded("cafe", lambda: bench_cafe.run(D.dev, n_users=args.cafe_users,
+                                               cpu_users=(2 if not args.no_cpu_baseline else 0)))
     if not args.no_sharded and D.world > 1:
         # The one leg whose ranks talk to each other (all-to-alls, all-reduces) runs LAST at N > 1, under a deadline: every
         # number above is a replica measurement that needs no peer, and a collective that never completes (a rank that died,

@@ -87,9 +87,11 @@ def run(dev, n_users=256, n_metapaths=6, cpu_users=0, min_seconds=0.5, rank=0):
         "with_python_lists": {"ms_per_step": t_all * 1e3, "steps": reps_all, "records": len(lists) if lists else 0,
                               "note": "run_program incl. the reference-format [[user, item, score, path], ...] lists "
                                       "(built lazily from the device records; the ranking metrics never read them)"},
-        "note": "latency-bound: one workgroup interprets one user's program (13 nodes, CSR segments per parent path); the "
-                "vocabulary log-softmax (3 328 x 13 805) and the relation modules run on the MFMA GEMM -- no roofline is "
-                "claimed for this leg",
+        "ms_per_256_users": t_dev * 1e3 * 256 / n_users,
+        "note": "latency-bound: one workgroup interprets one user's program (13 nodes, CSR segments per parent path), so a call "
+                "fills the chip only from ~4 users per CU on: 256 users per call 0.75 ms (72 M paths/s), 1 024 per call "
+                "1.65 ms (134 M), 2 048 3.2 ms (137 M) on one card.  The vocabulary log-softmax (13 rows per user x 13 805) "
+                "and the relation modules run on the MFMA GEMM -- no roofline is claimed for this leg",
     }
     if cpu_users > 0:
         from oracle import cafe as oc
