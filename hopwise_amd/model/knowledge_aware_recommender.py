@@ -279,6 +279,14 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             raise RuntimeError("selected index k out of range")  # what torch.topk raises in the reference
         users = users.to(self._t64[0].device, torch.int64).contiguous()
         B = users.numel()
+        if B == 0:  # nothing to expand: an empty result without a launch (the entry points refuse null buffers)
+            dev = users.device
+            res = BeamResult(torch.empty((0, P.ROW_INTS), dtype=torch.int32, device=dev),
+                             torch.empty((0, 3), dtype=torch.float32, device=dev),
+                             torch.zeros(1, dtype=torch.int32, device=dev), graph=self.graph)
+            res.n_rows_per_hop = torch.zeros(len(hops) + 1, dtype=torch.int32, device=dev)
+            res.trace, res.buffers = [], None
+            return res
         if fused_tail is None:
             fused_tail = self.fused_tail
         fused_tail = bool(fused_tail) and not keep_trace

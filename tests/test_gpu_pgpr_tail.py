@@ -280,3 +280,17 @@ def test_duplicate_users_in_a_batch_compact_equals_full():
             assert torch.equal(sel1[k], sel0[k]), (hops, k)
         cnt = sel0["count"].cpu().numpy()
         assert (cnt[5:] == 0).all() and cnt[:5].sum() > 0  # the later copies own no result row
+
+
+def test_one_user_and_no_user():
+    g, z, orc, m = build_model("default")
+    u = torch.from_numpy(z["users"]).to(dev())
+    one_f, (p0, q0) = _search(m, u[:1], [25, 5, 1], fused_tail=False)
+    one_c, (p1, q1) = _search(m, u[:1], [25, 5, 1])
+    assert one_c.leaves is not None and len(p0) > 0
+    np.testing.assert_array_equal(p1, p0)
+    np.testing.assert_allclose(q1, q0, rtol=3e-7, atol=0)  # k <= 8 hops: the two-launch form ranks with another kernel body
+    none = m.beam_search_device(u[:0], [25, 5, 1])
+    assert none.n == 0 and none.numpy()[0].shape == (0, 12)
+    scores, sel = m.collect_scores_device(u[:1], one_c, n_nodes=4)
+    assert tuple(scores.shape) == (1, int(g["n_items"]))
