@@ -127,6 +127,15 @@ class _GatherKGE(KnowledgeRecommender):
         """The reference's calculate_loss as one autograd node (ops.FusedPairLoss): rec side (user, [UI-Relation], item /
         neg item) + kg side (head, relation, tail / neg tail).  ``group_rec``: the rec batch tiles each positive
         sample_num times (abstract_dataloader.py:192-198); score it as [P, 1 + K] groups, positives weighted K."""
+        n_rec, n_kg = interaction[self.USER_ID].numel(), interaction[self.HEAD_ENTITY_ID].numel()
+        if n_rec == 0 or n_kg == 0:
+            # The reference on an empty side: its gathers give [0, d] rows and a mean over no element is NaN -- for the BCE
+            # models, which take one mean per side (rotate.py:123-131), as soon as ONE side is empty; for the margin models,
+            # which take one mean over the concatenated rows (transe.py:91-96), only when both are.  Trainer._check_nan
+            # (trainer.py:337-339) turns the NaN into its ValueError; the kernels are not asked to score nothing.
+            if kind == "bce" or (n_rec == 0 and n_kg == 0):
+                return torch.full((), float("nan"), device=interaction[self.USER_ID].device)
+            # a margin loss with one empty side: the mean over the other side's rows alone (an empty side is left out below)
         # table positions in the parameter list are static per model: built once (unless the tables are supplied per call,
         # as parallel.RowShardedKGE does with its compact tables)
         static = "_tables" not in self.__dict__
@@ -153,15 +162,17 @@ class _GatherKGE(KnowledgeRecommender):
             tail_rows = self.n_items if (name == "rec" and self._narrow_rec_tails) else None
             return ops.PairSide(*layout[name], h_idx, r_idx, r_fixed, t_idx, tail_rows, pos_weight)
 
-        if group_rec:
+        sides = []
+        if n_rec and group_rec:
             users, tails = self._rec_grouped_from_tiled(interaction)
-            rec = side("rec", users, None, self._rec_rel_loss(), tails, float(self.sample_num))
-        else:
-            rec = side("rec", interaction[self.USER_ID], None, self._rec_rel_loss(),
-                       self._pair(interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID]))
-        kg = side("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
-                  self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID]))
-        return ops.fused_pair_loss(self.LOSS_MODEL or self.MODEL, kind, self.margin, eps, scale, [rec, kg], params)
+            sides.append(side("rec", users, None, self._rec_rel_loss(), tails, float(self.sample_num)))
+        elif n_rec:
+            sides.append(side("rec", interaction[self.USER_ID], None, self._rec_rel_loss(),
+                              self._pair(interaction[self.ITEM_ID], interaction[self.NEG_ITEM_ID])))
+        if n_kg:
+            sides.append(side("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
+                              self._pair(interaction[self.TAIL_ENTITY_ID], interaction[self.NEG_TAIL_ENTITY_ID])))
+        return ops.fused_pair_loss(self.LOSS_MODEL or self.MODEL, kind, self.margin, eps, scale, sides, params)
 
     # -- reference API ------------------------------------------------------------------------------
     def forward(self, *rows):

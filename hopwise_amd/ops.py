@@ -234,6 +234,8 @@ def kge_full_sort_raw(desc, h_idx, r_idx, r_fixed, lo, hi):
         r_idx = _idx(r_idx, "r_idx").contiguous()
     B = h_idx.shape[0]
     out = torch.empty((B, hi - lo), dtype=torch.float32, device=h_idx.device)
+    if B == 0:  # no query: the [0, N] matrix the reference would return (the entry point refuses null buffers)
+        return out
     rc = lib.hw_kge_full_sort(
         C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, int(lo), int(hi), _ptr(out), hi - lo,
         _ptr(_OobCounter.get(h_idx.device)), _stream(),
@@ -507,6 +509,9 @@ def fused_pair_loss(model, kind, margin, eps, scale, sides, params):
 
 def kge_score_grouped(model, head, rel, tail, h_idx, r_idx, r_fixed, t_idx, margin=0.0, eps=0.0, j_major_out=False,
                       tail_rows=None):
+    if h_idx.numel() == 0:  # an empty batch scores to an empty matrix, as the reference's gathers would
+        nt = t_idx.shape[1] if t_idx.dim() == 2 else 1
+        return head[0].new_zeros((nt, 0) if j_major_out else (0, nt))
     return KgeScoreGrouped.apply(model, float(margin), float(eps), h_idx, r_idx, int(r_fixed), t_idx, j_major_out,
                                  tail_rows, *head, *rel, *tail)
 
@@ -525,6 +530,9 @@ def kge_full_sort_topk(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, k,
     if r_idx is not None:
         r_idx = _idx(r_idx, "r_idx").contiguous()
     B = h_idx.shape[0]
+    if B == 0:
+        return (torch.empty((0, k), dtype=torch.float32, device=h_idx.device),
+                torch.empty((0, k), dtype=torch.int64, device=h_idx.device))
     hr = hc = None
     nh = 0
     if history_index is not None:
@@ -691,6 +699,8 @@ def mask_scores_(scores, history_index=None):
         hr = _idx(history_index[0], "history rows").contiguous()
         hc = _idx(history_index[1], "history cols").contiguous()
         n = hr.numel()
+    if s.shape[0] == 0:
+        return scores
     check(lib.hw_mask_scores(_ptr(s), s.shape[0], s.shape[1], _ptr(hr), _ptr(hc), n, _stream()), "hw_mask_scores")
     return scores
 
@@ -704,6 +714,8 @@ def topk_rows(scores, k):
     R, N = s.shape
     val = torch.empty((R, k), dtype=torch.float32, device=s.device)
     idx = torch.empty((R, k), dtype=torch.int64, device=s.device)
+    if R == 0:
+        return val, idx
     check(lib.hw_topk_rows(_ptr(s), R, N, s.stride(0), int(k), _ptr(val), _ptr(idx), _stream()), "hw_topk_rows")
     return val, idx
 
