@@ -97,6 +97,8 @@ class AbstractSampler:
         if not isinstance(key_ids, torch.Tensor):
             key_ids = torch.as_tensor(np.asarray(key_ids), dtype=torch.int64)
         keys = key_ids.to(self.device, torch.int64)
+        if keys.numel() == 0 and out is None:  # sampler.py:140-183 on no key: np.tile of nothing -> an empty draw
+            return torch.empty(0, dtype=torch.int64, device=self.device)
         self._calls += 1
         before = ops.oob_count(self.device) if self.check_keys else 0
         res = ops.neg_sample(self._used_ptr, self._used_idx, keys, num, self.value_num, self.seed, self._calls,
