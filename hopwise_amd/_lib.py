@@ -216,6 +216,11 @@ SIGNATURES = {
     ),
     "hw_mask_scores": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_void_p]),
     "hw_topk_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_f32p, c_i64p, C.c_void_p]),
+    "hw_topk_rows_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
+    "hw_topk_rows_ws": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_f32p, c_i64p, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
     "hw_neg_sample": (
         C.c_int,
         [c_i64p, c_i64p, C.c_int64, c_i64p, C.c_int64, C.c_int32, C.c_int64, c_f32p, c_i64p, c_i64p, C.c_int64,

@@ -183,6 +183,106 @@ __global__ __launch_bounds__(THREADS) void topk_rows_kernel(const float* __restr
     }
 }
 
+
+// ---- long rows: two stages ----
+// The one-block-per-row form above walks the whole row k times with two barriers per walk: fine for a few thousand columns,
+// 0.5 ms for 256 rows of 45 539 (too few blocks, every block ten passes deep).  For long rows the row is cut into chunks of
+// TOPK_CHUNK columns; stage 1 (one block per (row, chunk)) holds its chunk in registers, reads it ONCE, and emits the chunk's
+// k best keys; stage 2 (one block per row) takes the k best of the n_chunks * k keys.  max over the unique keys is
+// associative, so the result is the one-stage kernel's bit for bit, ties included.
+constexpr int TOPK_CHUNK_THREADS = 256;
+constexpr int TOPK_CHUNK_PER = 16;
+constexpr int TOPK_CHUNK = TOPK_CHUNK_THREADS * TOPK_CHUNK_PER;  // 4096 columns
+constexpr int TOPK_TWO_STAGE_MIN_COLS = 2 * TOPK_CHUNK;
+constexpr int TOPK_TWO_STAGE_MAX_K = 64;
+
+__global__ __launch_bounds__(TOPK_CHUNK_THREADS) void topk_chunk_kernel(const float* __restrict__ s, int64_t n_cols,
+                                                                        int64_t ld, int k, int n_chunks,
+                                                                        uint64_t* __restrict__ cand) {
+    constexpr int NW = TOPK_CHUNK_THREADS / HW_WAVE;
+    __shared__ uint64_t red[2][NW];
+    const int chunk = blockIdx.x % n_chunks;
+    const int64_t r = blockIdx.x / n_chunks;
+    const float* __restrict__ row = s + r * ld;
+    const int64_t base = (int64_t)chunk * TOPK_CHUNK + threadIdx.x;
+    uint32_t ord[TOPK_CHUNK_PER];  // the key's high word (order-preserving image of the value); the low word is ~column
+#pragma unroll
+    for (int i = 0; i < TOPK_CHUNK_PER; ++i) {
+        const int64_t c = base + (int64_t)i * TOPK_CHUNK_THREADS;
+        ord[i] = 0;
+        if (c < n_cols) ord[i] = (uint32_t)(topk_key(row[c], 0u) >> 32);
+    }
+    auto local_best = [&](uint64_t bound) {
+        uint64_t best = 0;
+#pragma unroll
+        for (int i = 0; i < TOPK_CHUNK_PER; ++i) {
+            const int64_t c = base + (int64_t)i * TOPK_CHUNK_THREADS;
+            const uint64_t key = ((uint64_t)ord[i] << 32) | (uint32_t)(~(uint32_t)c);
+            if (c < n_cols && key < bound && key > best) best = key;
+        }
+        return best;
+    };
+    uint64_t* __restrict__ out = cand + ((int64_t)blockIdx.x) * k;
+    uint64_t mine = local_best(~0ull);
+    for (int round = 0; round < k; ++round) {
+        const uint64_t w = wave_max_u64(mine);
+        if ((threadIdx.x & 63) == 0) red[round & 1][threadIdx.x / HW_WAVE] = w;
+        __syncthreads();  // one barrier per round: the two halves of red[] alternate
+        uint64_t win = red[round & 1][0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) win = red[round & 1][i] > win ? red[round & 1][i] : win;
+        if (threadIdx.x == 0) out[round] = win;  // 0 = chunk exhausted
+        if (win == 0) {
+            for (int q = round + 1 + (int)threadIdx.x; q < k; q += TOPK_CHUNK_THREADS) out[q] = 0;
+            break;
+        }
+        if (mine == win) mine = local_best(win);  // only the owner of the winner looks again
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void topk_merge_kernel(const float* __restrict__ s, int64_t ld,
+                                                             const uint64_t* __restrict__ cand, int n_cand, int k,
+                                                             float* __restrict__ out_val, int64_t* __restrict__ out_idx) {
+    __shared__ uint64_t red[THREADS / HW_WAVE];
+    __shared__ uint64_t winner;
+    const float* __restrict__ row = s + (int64_t)blockIdx.x * ld;
+    const uint64_t* __restrict__ keys = cand + (int64_t)blockIdx.x * n_cand;
+    uint64_t bound = ~0ull;
+    for (int round = 0; round < k; ++round) {
+        uint64_t best = 0;
+        for (int c = threadIdx.x; c < n_cand; c += THREADS) {
+            const uint64_t key = keys[c];
+            if (key < bound && key > best) best = key;
+        }
+        best = wave_max_u64(best);
+        if (THREADS > HW_WAVE) {
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x / HW_WAVE] = best;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint64_t w = red[0];
+#pragma unroll
+                for (int i = 1; i < THREADS / HW_WAVE; ++i) w = red[i] > w ? red[i] : w;
+                winner = w;
+            }
+            __syncthreads();
+            best = winner;
+        }
+        if (threadIdx.x == 0) {
+            const int64_t o = (int64_t)blockIdx.x * k + round;
+            if (best == 0) {  // fewer than k columns
+                out_val[o] = -INFINITY;
+                out_idx[o] = -1;
+            } else {
+                const uint32_t idx = ~(uint32_t)(best & 0xffffffffu);
+                out_val[o] = row[idx];
+                out_idx[o] = idx;
+            }
+        }
+        bound = best;
+    }
+}
+
 }  // namespace hw
 
 using namespace hw;
@@ -289,5 +389,41 @@ extern "C" int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols,
     else
         hipLaunchKernelGGL((topk_rows_kernel<256>), dim3((unsigned)n_rows), dim3(256), 0, st, scores, n_cols, ld, k,
                            out_val, out_idx);
+    return HW_LAUNCH_RC();
+}
+
+static bool topk_two_stage(int64_t n_cols, int32_t k) {
+    return n_cols >= TOPK_TWO_STAGE_MIN_COLS && k <= TOPK_TWO_STAGE_MAX_K;
+}
+
+extern "C" int64_t hw_topk_rows_workspace_bytes(int64_t n_rows, int64_t n_cols, int32_t k) {
+    if (n_rows <= 0 || n_cols < 1 || k < 1 || !topk_two_stage(n_cols, k)) return 0;
+    const int64_t n_chunks = (n_cols + TOPK_CHUNK - 1) / TOPK_CHUNK;
+    return n_rows * n_chunks * k * (int64_t)sizeof(uint64_t);
+}
+
+extern "C" int hw_topk_rows_ws(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k, float* out_val,
+                               int64_t* out_idx, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_rows >= 0 && n_cols >= 1 && k >= 1 && !topk_two_stage(n_cols, k))
+        return hw_topk_rows(scores, n_rows, n_cols, ld, k, out_val, out_idx, stream);
+    if (!scores || !out_val || !out_idx || n_rows < 0 || n_cols < 1 || ld < n_cols || k < 1) return HW_ERR_INVALID_ARG;
+    if (n_cols > 0xffffffffll || n_rows > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (n_rows == 0) return HW_OK;
+    const int64_t n_chunks = (n_cols + TOPK_CHUNK - 1) / TOPK_CHUNK;
+    if (n_rows * n_chunks > INT32_MAX || n_chunks * k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (!workspace || ((uintptr_t)workspace & 7) || workspace_bytes < hw_topk_rows_workspace_bytes(n_rows, n_cols, k))
+        return HW_ERR_WORKSPACE;
+    HW_CLEAR_ERR();
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t* cand = (uint64_t*)workspace;
+    hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)(n_rows * n_chunks)), dim3(TOPK_CHUNK_THREADS), 0, st, scores,
+                       n_cols, ld, (int)k, (int)n_chunks, cand);
+    const int n_cand = (int)(n_chunks * k);
+    if (n_cand <= 512)
+        hipLaunchKernelGGL((topk_merge_kernel<64>), dim3((unsigned)n_rows), dim3(64), 0, st, scores, ld, cand, n_cand,
+                           (int)k, out_val, out_idx);
+    else
+        hipLaunchKernelGGL((topk_merge_kernel<256>), dim3((unsigned)n_rows), dim3(256), 0, st, scores, ld, cand, n_cand,
+                           (int)k, out_val, out_idx);
     return HW_LAUNCH_RC();
 }

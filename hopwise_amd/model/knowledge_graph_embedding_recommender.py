@@ -22,6 +22,7 @@ weighting over the ``train_neg_sample_args.sample_num`` negatives of each positi
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch import nn
@@ -79,6 +80,8 @@ class _GatherKGE(KnowledgeRecommender):
         self.rec_tiled_layout = bool(_cfg(config, "rec_tiled_layout", True))
         # calculate_loss as one autograd node (ops.FusedPairLoss); False keeps the per-op graph (scorer nodes + loss nodes)
         self.fused_loss = bool(_cfg(config, "fused_loss", True))
+        # bilinear scorers (BILINEAR below): full sorts as one product on the MFMA GEMM (HW_FULLSORT_GEMM=0: the gather kernel)
+        self.gemm_full_sort = bool(_cfg(config, "gemm_full_sort", os.environ.get("HW_FULLSORT_GEMM", "1") != "0"))
         self.apply(xavier_normal_initialization)
 
     def REL_ROW_FACTOR(self):
@@ -190,19 +193,67 @@ class _GatherKGE(KnowledgeRecommender):
         return self._score("kg", head, interaction[self.RELATION_ID], 0,
                            interaction[self.TAIL_ENTITY_ID].view(-1, 1)).view(-1)
 
+    # -- bilinear scorers: the full sort is a dense product ---------------------------------------------------------
+    # DistMult / ComplEx / Analogy score <query(h, r), t> with the tail's tables side by side (distmult.py:50-51,
+    # complex.py:53-62, analogy.py:66-70): against EVERY candidate that is query [B, K] x table^T [K, N] -- the genuinely dense
+    # contraction the MFMA GEMM is for.  The gather kernel streams every tail row past four queries held in registers and is
+    # bound by vector-instruction issue (~20 wave instructions per score); the product on the split-bf16 GEMM (fp32-level
+    # error) measures 4x faster at Yelp2018's 45 539 items (ComplEx d = 256, 2 048 users: 2.24 -> 0.54 ms; DistMult d = 200:
+    # 1.53 -> 0.35 ms; scores equal to 8e-7 of the largest one; tools/bench_fullsort_gemm.py).
+    BILINEAR = False
+
+    def _bilinear_query(self, h, r):
+        """query rows [B, K] from the gathered head rows ``h`` and relation rows ``r`` (tuples in table-slot order): the
+        folds of csrc/kge_model.h (Scorer::fold), K = number of tail tables x embedding size."""
+        raise NotImplementedError
+
+    def _bilinear_table(self, tail, n):
+        """The first ``n`` rows of the tail tables side by side, [n, K]: the table itself for one table, else a cached copy
+        (rebuilt when a table's storage or version changes; optimizers bump the version, FusedAdam included)."""
+        if len(tail) == 1:
+            return tail[0][:n]
+        key = (n,) + tuple((t.data_ptr(), t._version) for t in tail)
+        hit = self.__dict__.get("_bilinear_cat")
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([t.detach()[:n] for t in tail], dim=1).contiguous())
+            self.__dict__["_bilinear_cat"] = hit
+        return hit[1]
+
+    def _full_sort_gemm(self, side, h_idx, r_idx, r_fixed, n):
+        head, rel, tail = self._tables(side)
+        h = tuple(t.detach()[h_idx] for t in head)
+        r = tuple((t.detach()[r_idx] if r_idx is not None else t.detach()[r_fixed].unsqueeze(0)) for t in rel)
+        q = self._bilinear_query(h, r).contiguous()
+        return ops.gemm(q, self._bilinear_table(tail, n))
+
+    def _use_gemm_full_sort(self, n_queries):
+        return self.BILINEAR and self.gemm_full_sort and n_queries > 0 and "_tables" not in self.__dict__
+
     def full_sort_predict(self, interaction):
         user = interaction[self.USER_ID]
+        if self._use_gemm_full_sort(user.numel()):
+            return self._full_sort_gemm("rec", user, None, self._rec_rel_full_sort(), self.n_items)
         head, rel, tail = self._tables("rec")
         return ops.kge_full_sort(self.MODEL, head, rel, tail, user, None, self._rec_rel_full_sort(), 0, self.n_items,
                                  self.margin)
 
     def full_sort_predict_kg(self, interaction):
+        if self._use_gemm_full_sort(interaction[self.HEAD_ENTITY_ID].numel()):
+            return self._full_sort_gemm("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
+                                        self.n_entities)
         head, rel, tail = self._tables("kg")
         return ops.kge_full_sort(self.MODEL, head, rel, tail, interaction[self.HEAD_ENTITY_ID],
                                  interaction[self.RELATION_ID], 0, 0, self.n_entities, self.margin)
 
     def full_sort_topk(self, interaction, k, history_index=None, kg=False):
         """Top-k of the masked full sort (trainer.py:731-734 + collector.py:173-183) without the [B, N] matrix."""
+        n_q = interaction[self.HEAD_ENTITY_ID if kg else self.USER_ID].numel()
+        if self._use_gemm_full_sort(n_q):
+            # the product + mask + top-k on the written matrix beats the fused gather kernel for these scorers (the matrix is
+            # written and re-read, but at a quarter of the scoring time)
+            scores = self.full_sort_predict_kg(interaction) if kg else self.full_sort_predict(interaction)
+            ops.mask_scores_(scores, history_index)
+            return ops.topk_rows(scores, k)
         if kg:
             head, rel, tail = self._tables("kg")
             return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, interaction[self.HEAD_ENTITY_ID],
@@ -261,6 +312,10 @@ class DistMult(_GatherKGE):
         return self.n_relations - 1
 
     _rec_rel_full_sort = _rec_rel_loss
+    BILINEAR = True
+
+    def _bilinear_query(self, h, r):
+        return h[0] * r[0]
 
     def calculate_loss(self, interaction):  # distmult.py:69-95
         if self.fused_loss:
@@ -276,6 +331,7 @@ class RESCAL(DistMult):
     cat(rec, kg) (rescal.py:73-99); the rec side uses relation_embedding.weight[-1] (rescal.py:60,108,133)."""
 
     MODEL = "RESCAL"
+    BILINEAR = False  # the query h^T M_r is a d x d product per (h, r): built inside the gather kernel
 
     def REL_ROW_FACTOR(self):
         return self.embedding_size
@@ -336,6 +392,11 @@ class ComplEx(_BceKGE):
 
     def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (complex.py:167-168)
         return self.n_relations - 1
+
+    BILINEAR = True
+
+    def _bilinear_query(self, h, r):  # complex.py:54-59, the reference's t_im in the last term included
+        return torch.cat([h[0] * r[0], h[1] * r[0] + h[0] * r[1] - h[1] * r[1]], dim=1)
 
 
 class TorusE(TransE):
@@ -411,6 +472,11 @@ class Analogy(_GatherKGE):
 
     def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (analogy.py:222-224)
         return self.n_relations - 1
+
+    BILINEAR = True
+
+    def _bilinear_query(self, h, r):  # analogy.py:66-70: DistMult on (e) + the complex product on (re, im)
+        return torch.cat([h[0] * r[0], h[1] * r[1] - h[2] * r[2], h[1] * r[2] + h[2] * r[1]], dim=1)
 
     def calculate_loss(self, interaction):
         # LogisticLoss(-pos, -neg) = mean softplus(-pos) + mean softplus(neg) (loss.py:172-190): twice the BCE-with-logits

@@ -705,8 +705,10 @@ def mask_scores_(scores, history_index=None):
     return scores
 
 
-def topk_rows(scores, k):
-    """Row-wise top-k ordered (value desc, index asc): (values [R, k] fp32, indices [R, k] int64)."""
+def topk_rows(scores, k, two_stage=True):
+    """Row-wise top-k ordered (value desc, index asc): (values [R, k] fp32, indices [R, k] int64).  Long rows (>= 8192 columns,
+    k <= 64) go through the two-stage form (hw_topk_rows_ws: each row read once); ``two_stage=False`` keeps the one-block-per-row
+    kernel, for the tests that hold the two against each other."""
     lib = _lib.load()
     s = _dev(scores, torch.float32, "scores")
     if s.dim() != 2 or s.stride(1) != 1:
@@ -716,7 +718,13 @@ def topk_rows(scores, k):
     idx = torch.empty((R, k), dtype=torch.int64, device=s.device)
     if R == 0:
         return val, idx
-    check(lib.hw_topk_rows(_ptr(s), R, N, s.stride(0), int(k), _ptr(val), _ptr(idx), _stream()), "hw_topk_rows")
+    ws_bytes = int(lib.hw_topk_rows_workspace_bytes(R, N, int(k))) if two_stage else 0
+    if ws_bytes:
+        ws = torch.empty(ws_bytes // 8, dtype=torch.int64, device=s.device)
+        check(lib.hw_topk_rows_ws(_ptr(s), R, N, s.stride(0), int(k), _ptr(val), _ptr(idx), _ptr(ws), ws_bytes, _stream()),
+              "hw_topk_rows_ws")
+    else:
+        check(lib.hw_topk_rows(_ptr(s), R, N, s.stride(0), int(k), _ptr(val), _ptr(idx), _stream()), "hw_topk_rows")
     return val, idx
 
 

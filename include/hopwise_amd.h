@@ -234,6 +234,14 @@ int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols,
 int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
                  float* out_val, int64_t* out_idx, void* stream);
 
+/* The same result (bit for bit, ties included) for long rows in two stages: the row is cut into chunks of 4096 columns,
+ * each read once and reduced to its k best, then the k best of those.  Taken when n_cols >= 8192 and k <= 64; otherwise the
+ * call is hw_topk_rows and needs no workspace (hw_topk_rows_workspace_bytes returns 0).  workspace: 8-byte aligned,
+ * n_rows * ceil(n_cols / 4096) * k * 8 bytes; HW_ERR_WORKSPACE when smaller. */
+int64_t hw_topk_rows_workspace_bytes(int64_t n_rows, int64_t n_cols, int32_t k);
+int hw_topk_rows_ws(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k,
+                    float* out_val, int64_t* out_idx, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- negative sampling ----------------------------------------------------------------------------
  * Device restatement of AbstractSampler.sample_by_key_ids (sampler/sampler.py:140-183) for
  * KGSampler (:294-357) and Sampler (:186-291): for key i and draw j, the value written to

@@ -142,6 +142,8 @@ def test_fused_full_sort_topk_equals_unfused(model):
         nU, nR = 50, 6
         tables = random_tables(model, nU, nE, nR, dim, seed=dim + B)
         m = build(model, tables, dim, nU, nI, nE, nR)
+        if hasattr(m, "gemm_full_sort"):
+            m.gemm_full_sort = False  # this test is about hw_kge_full_sort_topk (the GEMM form: test_gpu_fullsort_gemm.py)
         rng = np.random.default_rng(B)
         users = torch.from_numpy(rng.integers(0, nU, B)).to(dev())
         heads = torch.from_numpy(rng.integers(0, nE, B)).to(dev())
