@@ -215,6 +215,7 @@ SIGNATURES = {
         [c_f32p, C.c_int64, C.c_int64, C.c_float, c_f32p, c_f32p, c_f32p, C.c_void_p],
     ),
     "hw_mask_scores": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_void_p]),
+    "hw_mask_scores_ex": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_int32, C.c_void_p]),
     "hw_topk_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_f32p, c_i64p, C.c_void_p]),
     "hw_topk_rows_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
     "hw_topk_rows_ws": (

@@ -123,9 +123,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void sum_partial_kernel(const float* 
 
 // ---- evaluation mask (trainer.py:731-734) ----
 __global__ void mask_scores_kernel(float* __restrict__ s, int64_t n_rows, int64_t n_cols,
-                                   const int64_t* __restrict__ hr, const int64_t* __restrict__ hc, int64_t n_hist) {
+                                   const int64_t* __restrict__ hr, const int64_t* __restrict__ hc, int64_t n_hist,
+                                   int mask_column0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_rows) s[i * n_cols] = -INFINITY;
+    if (mask_column0 && i < n_rows) s[i * n_cols] = -INFINITY;
     if (i < n_hist) {
         const int64_t r = hr[i], c = hc[i];
         if (r >= 0 && r < n_rows && c >= 0 && c < n_cols) s[r * n_cols + c] = -INFINITY;
@@ -363,16 +364,21 @@ extern "C" int hw_loss_self_adversarial(const float* scores, int64_t n_groups, i
     return HW_LAUNCH_RC();
 }
 
-extern "C" int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols, const int64_t* hist_rows,
-                              const int64_t* hist_cols, int64_t n_hist, void* stream) {
+extern "C" int hw_mask_scores_ex(float* scores, int64_t n_rows, int64_t n_cols, const int64_t* hist_rows,
+                                 const int64_t* hist_cols, int64_t n_hist, int32_t mask_column0, void* stream) {
     if (!scores || n_rows < 0 || n_cols < 1 || n_hist < 0 || (n_hist > 0 && (!hist_rows || !hist_cols)))
         return HW_ERR_INVALID_ARG;
-    const int64_t n = n_rows > n_hist ? n_rows : n_hist;
-    if (n == 0) return HW_OK;
+    const int64_t n = (mask_column0 && n_rows > n_hist) ? n_rows : n_hist;
+    if (n == 0 || n_rows == 0) return HW_OK;
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(mask_scores_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores,
-                       n_rows, n_cols, hist_rows, hist_cols, n_hist);
+                       n_rows, n_cols, hist_rows, hist_cols, n_hist, (int)(mask_column0 != 0));
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols, const int64_t* hist_rows,
+                              const int64_t* hist_cols, int64_t n_hist, void* stream) {
+    return hw_mask_scores_ex(scores, n_rows, n_cols, hist_rows, hist_cols, n_hist, 1, stream);
 }
 
 extern "C" int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, int32_t k, float* out_val,

@@ -687,8 +687,9 @@ def self_adversarial_mean(scores, alpha):
 # ------------------------------------------------------------------------------------------------
 # evaluation
 # ------------------------------------------------------------------------------------------------
-def mask_scores_(scores, history_index=None):
-    """In place: scores[:, 0] = -inf; scores[history_index] = -inf (trainer.py:731-734)."""
+def mask_scores_(scores, history_index=None, column0=True):
+    """In place: scores[:, 0] = -inf; scores[history_index] = -inf (trainer.py:731-734).  ``column0=False``: history entries
+    only (a shard whose column 0 is not entity 0); entries outside the matrix are ignored."""
     lib = _lib.load()
     s = _dev(scores, torch.float32, "scores")
     if s.dim() != 2 or not s.is_contiguous():
@@ -701,7 +702,8 @@ def mask_scores_(scores, history_index=None):
         n = hr.numel()
     if s.shape[0] == 0:
         return scores
-    check(lib.hw_mask_scores(_ptr(s), s.shape[0], s.shape[1], _ptr(hr), _ptr(hc), n, _stream()), "hw_mask_scores")
+    check(lib.hw_mask_scores_ex(_ptr(s), s.shape[0], s.shape[1], _ptr(hr), _ptr(hc), n, int(bool(column0)), _stream()),
+          "hw_mask_scores_ex")
     return scores
 
 

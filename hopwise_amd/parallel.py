@@ -425,6 +425,24 @@ class RowShardedKGE(nn.Module):
         n = self.n_entities if kg else self.n_items
         return n, local_rows(n, self.rank, self.P)
 
+    def _gemm_eval(self, n_queries):
+        """DistMult / ComplEx / Analogy: this rank's [B, n_loc] block of the full sort is one product of the query rows with its
+        own tail shard on the MFMA GEMM (the model's ``gemm_full_sort`` switch); the device primitives replaced for the CPU
+        tests keep the gather form."""
+        m = self.model
+        return (getattr(m, "BILINEAR", False) and m.gemm_full_sort and n_queries > 0
+                and _shard_ops["full_sort"] is None and _shard_ops["full_sort_topk"] is None)
+
+    def _local_scores_gemm(self, head, inv, r_idx, r_fixed, n_loc):
+        m = self.model
+        h = tuple(t[inv] for t in head)
+        r = tuple((t.detach()[r_idx] if r_idx is not None else t.detach()[r_fixed].unsqueeze(0))
+                  for t in m._w(m.RELATION_TABLES))
+        q = m._bilinear_query(h, r).contiguous()
+        if n_loc == 0:
+            return torch.empty((q.shape[0], 0), dtype=torch.float32, device=q.device)
+        return ops.gemm(q, m._bilinear_table(self._shards(m.ENTITY_TABLES), n_loc))
+
     @torch.no_grad()
     def full_sort_topk(self, interaction, k, history_index=None, kg=False):
         """Global masked top-k (trainer.py:731-734 + collector.py:173-183): (values [B, k], global ids [B, k]), ordered
@@ -439,8 +457,14 @@ class RowShardedKGE(nn.Module):
             hist = (hr, torch.where(hc % self.P == self.rank, torch.div(hc, self.P, rounding_mode="floor"),
                                     torch.full_like(hc, -1)))
         kk = min(int(k), n_loc)
-        val, idx = (_shard_ops["full_sort_topk"] or ops.kge_full_sort_topk)(m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx,
-                                          r_fixed, 0, n_loc, kk, hist, self.rank == 0, m.margin)
+        if self._gemm_eval(inv.numel()):
+            local = self._local_scores_gemm(head, inv, r_idx, r_fixed, n_loc)
+            ops.mask_scores_(local, hist, column0=self.rank == 0)
+            val, idx = ops.topk_rows(local, kk)
+        else:
+            val, idx = (_shard_ops["full_sort_topk"] or ops.kge_full_sort_topk)(
+                m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx, r_fixed, 0, n_loc, kk, hist,
+                self.rank == 0, m.margin)
         gid = idx * self.P + self.rank  # column 0 = [PAD] lives on rank 0 only
         if kk < k:  # fewer local candidates than k: pad with -inf / ids past the table so they lose every comparison
             pad = int(k) - kk
@@ -455,8 +479,12 @@ class RowShardedKGE(nn.Module):
         m = self.model
         head, inv, r_idx, r_fixed = self._queries(interaction, kg)
         n, n_loc = self._local_cols(kg)
-        local = (_shard_ops["full_sort"] or ops.kge_full_sort)(m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx, r_fixed,
-                                  0, n_loc, m.margin).view(-1, n_loc)
+        if self._gemm_eval(inv.numel()):
+            local = self._local_scores_gemm(head, inv, r_idx, r_fixed, n_loc)
+        else:
+            local = (_shard_ops["full_sort"] or ops.kge_full_sort)(
+                m.MODEL, head, m._w(m.RELATION_TABLES), self._shards(m.ENTITY_TABLES), inv, r_idx, r_fixed, 0, n_loc,
+                m.margin).view(-1, n_loc)
         self.check_overflow(wait="lookups")
         if not _exchange(self.P):
             return local

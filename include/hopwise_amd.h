@@ -228,6 +228,11 @@ int hw_loss_self_adversarial(const float* scores, int64_t n_groups, int64_t n_co
  * (trainer/trainer.py:731-734): column 0 and every (hist_rows[i], hist_cols[i]) := -inf. */
 int hw_mask_scores(float* scores, int64_t n_rows, int64_t n_cols,
                    const int64_t* hist_rows, const int64_t* hist_cols, int64_t n_hist, void* stream);
+/* The same with the column-0 rule optional: a rank of the row-sharded layout that does not own entity 0 ([PAD]) masks its
+ * history entries only (mask_column0 = 0).  History entries outside [0, n_rows) x [0, n_cols) are ignored in both. */
+int hw_mask_scores_ex(float* scores, int64_t n_rows, int64_t n_cols,
+                      const int64_t* hist_rows, const int64_t* hist_cols, int64_t n_hist,
+                      int32_t mask_column0, void* stream);
 
 /* Row-wise top-k ordered (value desc, index asc) -- replaces torch.topk in
  * evaluator/collector.py:173-183 and pgpr.py:454.  k <= 1024. */

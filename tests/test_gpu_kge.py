@@ -266,6 +266,29 @@ def test_topk_ties_and_short_rows():
     np.testing.assert_array_equal(v.cpu().numpy(), rv)
 
 
+def test_mask_scores_with_and_without_the_column0_rule():
+    """hw_mask_scores_ex: a shard that does not own entity 0 masks its history entries only; entries outside the matrix (the
+    sharded wrapper writes column -1 for ids owned elsewhere) are ignored."""
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((6, 50)).astype(np.float32)
+    hr = np.array([0, 0, 5, 2, 7, 3, 1], np.int64)
+    hc = np.array([0, 7, 49, -1, 3, 50, 0], np.int64)
+    hist = (torch.from_numpy(hr).to(dev()), torch.from_numpy(hc).to(dev()))
+    for column0 in (True, False):
+        want = a.copy()
+        if column0:
+            want[:, 0] = -np.inf
+        for r, c in zip(hr, hc):
+            if 0 <= r < 6 and 0 <= c < 50:
+                want[r, c] = -np.inf
+        got = ops.mask_scores_(torch.from_numpy(a).to(dev()), hist, column0=column0)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got = ops.mask_scores_(torch.from_numpy(a).to(dev()), None, column0=False)  # nothing to do: no launch
+    np.testing.assert_array_equal(got.cpu().numpy(), a)
+
+
 def test_cpu_tensors_are_rejected():
     from hopwise_amd import _lib, ops
 
