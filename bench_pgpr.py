@@ -104,8 +104,10 @@ def algorithmic_bytes(m, res, hops):
     return total, per_hop
 
 
-def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5):
-    """steps = 0: as many searches as fill `min_seconds` of timed work (at least 5)."""
+def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5, streams=1):
+    """steps = 0: as many searches as fill `min_seconds` of timed work (at least 5).  ``streams`` > 1: the timed searches are
+    dealt round-robin over that many HIP streams (independent user batches: a search's policy launch is matrix-bound, its
+    action / ranking launches are not, and kernels of two searches can share the chip)."""
     kg, ds, m = make_model(dev)
     rng = np.random.default_rng(100 + rank)
     expanded = 0
@@ -124,10 +126,19 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         steps = max(5, int(np.ceil(1.1 * min_seconds / max((time.perf_counter() - t0) / 3, 1e-4))))
     user_batches = [batch(i) for i in range(steps)]  # ids resident on the device before the clock starts
     counts = []
+    side = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
+    if side is not None:  # one untimed search per stream: its allocator pool is filled before the clock starts
+        for st in side:
+            with torch.cuda.stream(st):
+                m.beam_search_device(user_batches[0])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        res = m.beam_search_device(user_batches[i])
+        if side is None:
+            res = m.beam_search_device(user_batches[i])
+        else:
+            with torch.cuda.stream(side[i % streams]):
+                res = m.beam_search_device(user_batches[i])
         counts.append(res.n_rows_per_hop)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -249,5 +260,6 @@ if __name__ == "__main__":
     ap.add_argument("--users", type=int, default=64)
     ap.add_argument("--steps", type=int, default=0, help="0: enough searches for 0.5 s of timed work")
     ap.add_argument("--cpu-users", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=1)
     a = ap.parse_args()
-    print(json.dumps(run(torch.device("cuda", 0), a.users, a.steps, 1, a.cpu_users)))
+    print(json.dumps(run(torch.device("cuda", 0), a.users, a.steps, 1, a.cpu_users, streams=a.streams)))

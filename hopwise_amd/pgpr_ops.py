@@ -100,7 +100,6 @@ def user_scores(graph, U64, E64, R64, users, user_vec=None):
     return su, se
 
 
-_ACTION_WORK = {}
 QUEUE_TRIM_ROWS = True  # False: hw_pgpr_actions without its work buffer (the trim kernels scan every row)
 
 
@@ -127,13 +126,12 @@ def actions(graph, score_user, score_entity, score_rel_entity, paths, n_rows, ma
     if scratch is not None:
         sb, ss = scratch.shape
     work = None
-    if QUEUE_TRIM_ROWS:  # queues of the rows that need the trim; one buffer per (device, row capacity)
-        key = (paths.device, int(max_rows))
-        work = _ACTION_WORK.get(key)
-        if work is None:
-            work = torch.empty(int(lib.hw_pgpr_actions_workspace_ints(int(max_rows))), dtype=torch.int32,
-                               device=paths.device)
-            _ACTION_WORK[key] = work
+    if QUEUE_TRIM_ROWS:
+        # queues of the rows that need the trim.  Allocated per call (torch's allocator hands the block back in stream
+        # order): until round 4 ONE buffer per (device, row capacity) was cached here, which two searches running on two
+        # streams then shared -- queues of one search overwritten by the other's, row numbers beyond its own row count, a
+        # memory access fault with three streams (tests/test_gpu_pgpr_streams.py)
+        work = torch.empty(int(lib.hw_pgpr_actions_workspace_ints(int(max_rows))), dtype=torch.int32, device=paths.device)
     check(
         lib.hw_pgpr_actions(C.byref(graph.c), _ptr(score_user), _ptr(score_entity), _ptr(score_rel_entity), _ptr(paths),
                             _ptr(n_rows), int(max_rows), int(max_acts),
@@ -153,9 +151,6 @@ def state(graph, U32, E32, R32, state_history, paths, n_rows, max_rows, out):
     )
 
 
-_GEMM_WS = {}
-
-
 def mlp_layer(a, w, bias, out, m_rows, m_max, elu, drop_mask=None, drop_mode=0, seed=0, offset=0):
     """out[:m, :n] = f(a[:m, :k] @ w.T + bias); a / out may be wider than k / n (leading dimension = stride(0))."""
     lib = _lib.load()
@@ -165,10 +160,7 @@ def mlp_layer(a, w, bias, out, m_rows, m_max, elu, drop_mask=None, drop_mode=0, 
         # few rows (the first hops of a beam search): give the GEMM split-K room, or a lone tile walks K at one load
         # latency per 16-deep step
         splits = min(max(768 // tiles, 2), k // 64)
-        key = (a.device, splits * int(m_max) * n)
-        ws = _GEMM_WS.get(key)
-        if ws is None:
-            ws = _GEMM_WS[key] = torch.empty(key[1], dtype=torch.float32, device=a.device)
+        ws = torch.empty(splits * int(m_max) * n, dtype=torch.float32, device=a.device)  # per call: see actions()
         check(
             lib.hw_gemm_f32(_ptr(a), a.stride(0), 1, _ptr(w), k, 1, _ptr(out), out.stride(0), _ptr(m_rows), int(m_max), n, k,
                             _ptr(bias), int(bool(elu)), _ptr(drop_mask), int(drop_mode), C.c_uint64(seed),

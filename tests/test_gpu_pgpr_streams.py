@@ -1,0 +1,62 @@
+"""Beam searches of one PGPR model running concurrently on several HIP streams (what a caller overlapping two evaluation
+batches does, and bench_pgpr.py --streams 2): same children, values and item scores as the same searches one after another.
+
+Until round 4 hw_pgpr_actions' trim queues and the split-K workspace of the small policy products were ONE cached buffer per
+(device, size) in pgpr_ops, shared by whatever ran at the time; three concurrent 256-user searches ended in a memory access
+fault.  Scratch is allocated per call now (stream-ordered by torch's allocator)."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import FakeKGDataset, pgpr_config
+from tests.test_gpu_pgpr_random import _graph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fused_policy", [True, False])
+def test_concurrent_searches_equal_sequential_ones(fused_policy):
+    from hopwise_amd.model.knowledge_aware_recommender import PGPR
+
+    dev = torch.device("cuda", 0)
+    sizes = (600, 80, 200, 6, 12000, 1500)  # hub items far over max_acts: every hop queues rows for the trim kernels
+    n_users, n_items, n_entities, n_rel, n_inter, n_kg = sizes
+    dim, hops = 16, (24, 12, 6)
+    rng, ui, iu, ii, heads, rels, tails = _graph(5, *sizes)
+    U = rng.standard_normal((n_users, dim)) / np.sqrt(dim)
+    E = rng.standard_normal((n_entities, dim)) / np.sqrt(dim)
+    R = rng.standard_normal((n_rel, dim)) / np.sqrt(dim)
+    positives = np.zeros((n_users, 2), np.int64)
+    ds = FakeKGDataset(n_users, n_items, n_entities, n_rel, ui, iu, ii, heads, rels, tails, positives, U, E, R)
+    torch.manual_seed(0)
+    cfg = pgpr_config(dev, 60, 1, hops, False, (10,), "identity")
+    cfg["fused_policy"] = fused_policy
+    m = PGPR(cfg, ds).to(dev)
+    batches = [torch.from_numpy(rng.integers(1, n_users, 96)).to(dev) for _ in range(6)]
+
+    def search(users):  # no host synchronisation in here: the launches of consecutive searches must be free to overlap
+        res = m.beam_search_device(users, list(hops))
+        scores, _ = m.collect_scores_device(users, res, n_nodes=4)
+        return res, scores
+
+    def settle(res, scores):  # after a device synchronisation
+        n = res.n
+        return res.paths[:n].clone(), res.probs[:n].clone(), scores.clone()
+
+    want = []
+    for b in batches:
+        out = search(b)
+        torch.cuda.synchronize()
+        want.append(settle(*out))
+    assert all(w[0].shape[0] > 1000 for w in want)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for _ in range(3):
+        got = [None] * len(batches)
+        for i, b in enumerate(batches):
+            with torch.cuda.stream(streams[i % 3]):
+                got[i] = search(b)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            for a, c in zip(settle(*g), w):
+                assert torch.equal(a, c)
