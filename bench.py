@@ -80,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--pgpr-steps", type=int, default=0, help="0: enough searches for 0.5 s of timed work (>= 5)")
     ap.add_argument("--pgpr-users", type=int, default=256,
                     help="users per beam search: 64 -> 5.8 G paths/s, 256 -> 6.7 G (the first hops' fixed cost amortised), ~8 GB of work buffers")
+    ap.add_argument("--pgpr-streams", type=int, default=3,
+                    help="HIP streams the timed PGPR searches (independent user batches) are dealt over")
     ap.add_argument("--cafe-users", type=int, default=1024, help="users per CAFE run_program call")
     ap.add_argument("--sharded-steps", type=int, default=10)
     ap.add_argument("--sharded-batch", type=int, default=8192, help="rec positives and kg triples per rank per step")
@@ -979,7 +981,8 @@ def main():
 
         torch.cuda.empty_cache()
         pg = bench_pgpr.run(D.dev, n_users=args.pgpr_users, steps=args.pgpr_steps, warmup=1,
-                            cpu_users=(1 if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline else 0), rank=D.rank)
+                            cpu_users=(1 if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline else 0), rank=D.rank,
+                            streams=args.pgpr_streams)
         if D.world > 1:  # whole-job rate on the slowest rank's clock
             tm, tp = D.reduce(pg["ms_per_step"], "max"), D.reduce(pg["paths_per_step"], "sum")
             pg.update(value=tp / (tm * 1e-3), ms_per_step=tm, paths_per_step=tp, n_gpus=D.world)

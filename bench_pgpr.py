@@ -187,6 +187,7 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         "metric": "PGPR paths expanded per second (3-hop beam 64/64/64, d=100, max_acts=250)",
         "value": expanded / dt, "unit": "paths/s", "users_per_step": n_users, "steps": steps, "timed_seconds": dt,
         "ms_per_step": ms, "paths_per_step": expanded / steps,
+        "streams": streams,  # the timed searches (independent user batches) are dealt round-robin over this many HIP streams
         "graph": {"n_users": kg.n_users, "n_items": kg.n_items, "n_entities": kg.n_entities, "nnz": m.graph.nnz,
                   "max_degree": m.graph.max_degree},
         "policy": ("one launch per hop (hw_pgpr_policy_fused)" if m.fused_policy else "three launches per hop (lookup, l2, actor)"),

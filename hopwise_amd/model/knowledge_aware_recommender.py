@@ -179,7 +179,9 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.last_loss_parts = None
 
     # ------------------------------------------------------------------------------------------------
-    def _alloc(self, B, hops, compact_leaves=False, acts_u16=False):
+    def _alloc(self, B, hops, compact_leaves=False, acts_u16=False, mlp_buffers=True, topk_buffers=True):
+        """Work buffers of one search.  ``mlp_buffers`` / ``topk_buffers`` = False leave out what only the three-launch policy
+        network (state, x1, x2: 4.8 GB at 1 M beam rows) and the two-launch tail (top-k indices / values) write."""
         dev = self._t64[0].device
         rows = [B]
         for k in hops:
@@ -197,13 +199,13 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             acts=(torch.empty((rmax, P.act16_ld(self.act_dim)), dtype=torch.int16, device=dev) if acts_u16
                   else i32(rmax, self.act_dim, 2)),
             n_acts=i32(rmax),
-            state=f32(rmax, self.state_dim),
-            x1=f32(rmax, self.hidden_sizes[0]),
-            x2=f32(rmax, self.hidden_sizes[1]),
+            state=f32(rmax, self.state_dim) if mlp_buffers else None,
+            x1=f32(rmax, self.hidden_sizes[0]) if mlp_buffers else None,
+            x2=f32(rmax, self.hidden_sizes[1]) if mlp_buffers else None,
             # rows padded to 256 floats: the fused policy kernel stores whole 16-byte pieces; the top-k reads [:, :act_dim]
             logits=f32(rmax, max(256, self.act_dim))[:, : self.act_dim],
-            tk_idx=i32(rmax, max(hops)),
-            tk_val=f32(rmax, max(hops)),
+            tk_idx=i32(rmax, max(hops)) if topk_buffers else None,
+            tk_val=f32(rmax, max(hops)) if topk_buffers else None,
             offsets=i32(rmax),
             scratch=None,
         )
@@ -296,7 +298,12 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         # action lists as 2-byte edge offsets when every hop's tail is the one-launch form (the only reader of that layout)
         acts_u16 = (fused_tail and self.acts_u16 and all(P.topk_expand_supported(self.act_dim, k) for k in hops)
                     and P.acts_u16_supported(self.graph, self.fix_scores_sorting_bug))
-        buf = self._alloc(B, hops, compact_leaves, acts_u16)
+        lookup = self.l1_lookup and self.hidden_sizes[0] % 4 == 0
+        one_launch_policy = (lookup and self.fused_policy and not keep_trace
+                             and P.policy_fused_supported(self.hidden_sizes, self.act_dim))
+        all_fused_tails = fused_tail and all(P.topk_expand_supported(self.act_dim, k) for k in hops)
+        buf = self._alloc(B, hops, compact_leaves, acts_u16, mlp_buffers=not one_launch_policy,
+                          topk_buffers=not all_fused_tails)
         g = self.graph
         U64, E64, R64 = self._t64
         U32, E32, R32 = self._t32
@@ -315,7 +322,6 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         for hop, k in enumerate(hops):
             rmax = buf["rows"][hop]
             paths, probs, n_rows = buf["paths"][hop], buf["probs"][hop], nr[hop : hop + 1]
-            lookup = self.l1_lookup and self.hidden_sizes[0] % 4 == 0
             if hop <= 2 and (keep_trace or not lookup):
                 # the reference refreshes state_pool at the end of hops 0 and 1 only (pgpr.py:481); with at most
                 # three hops every hop sees a fresh state, which is the same thing.
