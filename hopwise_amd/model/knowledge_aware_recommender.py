@@ -53,6 +53,13 @@ class BeamResult:
     def n(self):
         return int(self._n.item())  # the only synchronisation of a search
 
+    def record_stream(self, stream):
+        """The result was produced on another stream than the one that will read it: tell torch's allocator."""
+        for t in (self._paths, self._probs, self._n, self.leaves, self.parent_paths, self.parent_probs,
+                  getattr(self, "n_rows_per_hop", None)):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
+
     @property
     def capacity(self):
         return (self.leaves if self.leaves is not None else self._paths).shape[0]
@@ -130,7 +137,12 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.fused_tail = bool(_cfg(config, "fused_topk_expand", os.environ.get("HW_PGPR_TAIL", "1") != "0"))
         self.compact_leaves = bool(_cfg(config, "compact_leaves", self.fused_tail))
         self.acts_u16 = bool(_cfg(config, "acts_u16", os.environ.get("HW_PGPR_ACTS16", "1") != "0"))
-        self.user_chunk = int(_cfg(config, "beam_user_chunk", 64))
+        # users per search: the first two hops are launch-bound, so a search of 256 users expands 2x the paths per second of
+        # one of 64 (bench_pgpr.py); ~3 GB of work buffers at the default beam
+        self.user_chunk = int(_cfg(config, "beam_user_chunk", 256))
+        # evaluation batches larger than user_chunk: consecutive searches are dealt over this many HIP streams (a search's
+        # policy launch is matrix-bound, its action / ranking launches are not: +15 % on the bench); 1 = one after another
+        self.search_streams = max(1, int(_cfg(config, "search_streams", os.environ.get("HW_PGPR_STREAMS", "3"))))
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         dev = torch.device(self.device)
 
@@ -543,13 +555,41 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         return out
 
     def _search_and_collect(self, users):
+        """[(user chunk, BeamResult, scores, selection)] for chunks of ``user_chunk`` users.  More than one chunk: the
+        searches are dealt round-robin over ``search_streams`` side streams -- they are independent and hold no state
+        between calls (tests/test_gpu_pgpr_streams.py) -- fenced against the caller's stream on both sides, so that the caller
+        sees what it would see after the same searches one after another."""
         users = torch.as_tensor(users)
-        outs, expl = [], []
-        for s in range(0, users.numel(), self.user_chunk):
-            chunk = users[s : s + self.user_chunk]
-            res = self.beam_search_device(chunk)
-            scores, sel = self.collect_scores_device(chunk, res)
+        chunks = [users[s : s + self.user_chunk] for s in range(0, users.numel(), self.user_chunk)]
+        dev = self._t64[0].device
+        n_streams = min(self.search_streams, len(chunks))
+        if n_streams <= 1 or dev.type != "cuda":
+            outs = []
+            for chunk in chunks:
+                res = self.beam_search_device(chunk)
+                scores, sel = self.collect_scores_device(chunk, res)
+                outs.append((chunk, res, scores, sel))
+            return outs
+        main = torch.cuda.current_stream(dev)
+        side = self.__dict__.setdefault("_search_stream_pool", [])
+        while len(side) < n_streams:
+            side.append(torch.cuda.Stream(device=dev))
+        for st in side[:n_streams]:
+            st.wait_stream(main)  # the ids, the weights and whatever else the caller queued are in place
+        outs = []
+        for i, chunk in enumerate(chunks):
+            with torch.cuda.stream(side[i % n_streams]):
+                res = self.beam_search_device(chunk)
+                scores, sel = self.collect_scores_device(chunk, res)
             outs.append((chunk, res, scores, sel))
+        for st in side[:n_streams]:
+            main.wait_stream(st)
+        for _, res, scores, sel in outs:  # allocated on a side stream, used by the caller on its own from here on
+            res.record_stream(main)
+            scores.record_stream(main)
+            for t in sel.values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)
         return outs
 
     def full_sort_predict(self, interaction):  # pgpr.py:408-415

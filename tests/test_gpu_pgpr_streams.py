@@ -60,3 +60,40 @@ def test_concurrent_searches_equal_sequential_ones(fused_policy):
         for g, w in zip(got, want):
             for a, c in zip(settle(*g), w):
                 assert torch.equal(a, c)
+
+
+def test_full_sort_predict_and_explain_over_streams_equal_the_sequential_ones():
+    """An evaluation batch larger than ``beam_user_chunk``: the chunks' searches dealt over three side streams
+    (``search_streams``, the default) give the score matrix and the explanation lists of the same chunks one after another."""
+    from hopwise_amd.model.knowledge_aware_recommender import PGPR
+
+    dev = torch.device("cuda", 0)
+    sizes = (500, 70, 160, 5, 9000, 1200)
+    n_users, n_items, n_entities, n_rel, n_inter, n_kg = sizes
+    dim, hops = 16, (16, 8, 4)
+    rng, ui, iu, ii, heads, rels, tails = _graph(9, *sizes)
+    U = rng.standard_normal((n_users, dim)) / np.sqrt(dim)
+    E = rng.standard_normal((n_entities, dim)) / np.sqrt(dim)
+    R = rng.standard_normal((n_rel, dim)) / np.sqrt(dim)
+    positives = np.zeros((n_users, 3), np.int64)
+    for u in range(1, n_users):
+        positives[u, :2] = rng.integers(1, n_items, 2)
+    ds = FakeKGDataset(n_users, n_items, n_entities, n_rel, ui, iu, ii, heads, rels, tails, positives, U, E, R)
+    torch.manual_seed(1)
+    cfg = pgpr_config(dev, 40, 1, hops, False, (10,), "identity")
+    cfg["beam_user_chunk"] = 48
+    m = PGPR(cfg, ds).to(dev)
+    assert m.search_streams == 3 and m.user_chunk == 48
+    users = torch.from_numpy(rng.integers(1, n_users, 300)).to(dev)  # seven chunks, the last one ragged
+    inter = {m.USER_ID: users}
+    m.search_streams = 1
+    want = m.full_sort_predict(inter).clone()
+    want_scores, want_expl = m.explain(inter)
+    m.search_streams = 3
+    for _ in range(3):
+        got = m.full_sort_predict(inter)
+        # the caller's stream goes straight on with the result: no synchronisation in between
+        assert torch.equal(got, want)
+    got_scores, got_expl = m.explain(inter)
+    assert torch.equal(got_scores, want_scores)
+    assert got_expl == want_expl and len(want_expl) > 100
