@@ -83,6 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--pgpr-streams", type=int, default=3,
                     help="HIP streams the timed PGPR searches (independent user batches) are dealt over")
     ap.add_argument("--cafe-users", type=int, default=1024, help="users per CAFE run_program call")
+    ap.add_argument("--cafe-streams", type=int, default=2, help="HIP streams the timed CAFE calls are dealt over")
     ap.add_argument("--sharded-steps", type=int, default=10)
     ap.add_argument("--sharded-batch", type=int, default=8192, help="rec positives and kg triples per rank per step")
     ap.add_argument("--sharded-deadline", type=float, default=300.0,
@@ -994,7 +995,7 @@ def main():
         torch.cuda.empty_cache()
         # 1 024 users per call: one workgroup per user, four per CU (256 per call leave three quarters of the chip idle)
         guarded("cafe", lambda: bench_cafe.run(D.dev, n_users=args.cafe_users,
-                                               cpu_users=(2 if not args.no_cpu_baseline else 0)))
+                                               cpu_users=(2 if not args.no_cpu_baseline else 0), streams=args.cafe_streams))
     if not args.no_sharded and D.world > 1:
         # The one leg whose ranks talk to each other (all-to-alls, all-reduces) runs LAST at N > 1, under a deadline: every
         # number above is a replica measurement that needs no peer, and a collective that never completes (a rank that died,
