@@ -97,3 +97,29 @@ def test_full_sort_predict_and_explain_over_streams_equal_the_sequential_ones():
     got_scores, got_expl = m.explain(inter)
     assert torch.equal(got_scores, want_scores)
     assert got_expl == want_expl and len(want_expl) > 100
+
+
+def test_cafe_calls_over_streams_equal_sequential_ones():
+    """CAFE.run_program_device holds no state between calls either (bench.py --cafe-streams 2)."""
+    from tests.test_gpu_cafe import build
+
+    z, orc, m = build()
+    rng = np.random.default_rng(3)
+    n_users = int(z["n_users"])
+    batches = [torch.from_numpy(rng.integers(1, n_users, 40)) for _ in range(6)]  # host ids: a call then never waits
+    want = []
+    for b in batches:
+        scores, rec, _, _ = m.run_program_device(b)
+        torch.cuda.synchronize()
+        want.append((scores.clone(), {k: v.clone() for k, v in rec.items() if torch.is_tensor(v)}))
+    streams = [torch.cuda.Stream(device=torch.device("cuda", 0)) for _ in range(3)]
+    for _ in range(3):
+        got = [None] * len(batches)
+        for i, b in enumerate(batches):
+            with torch.cuda.stream(streams[i % 3]):
+                got[i] = m.run_program_device(b)
+        torch.cuda.synchronize()
+        for (scores, rec, _, _), (ws, wr) in zip(got, want):
+            assert torch.equal(torch.nan_to_num(scores, nan=-1.0), torch.nan_to_num(ws, nan=-1.0))
+            for k, v in wr.items():
+                assert torch.equal(rec[k], v), k
