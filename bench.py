@@ -432,7 +432,8 @@ def leg_kge(D, args, out):
                     "launch_ms_under_overlap while it shares the chip)"}
     out["roofline"] = {"configs1_launch": l2}
     ctx = dict(kg=kg, head=head, rel=rel, tail=tail, users=users, t_idx=t_idx, desc=desc, abytes=abytes,
-               uptr_np=uptr.cpu().numpy(),
+               uptr_np=uptr.cpu().numpy(), uidx_np=uidx.cpu().numpy(),
+               launch_scores=(scores if fused else None), launch_loss=(loss if fused_loss else None),
                triples_per_batch=triples_per_batch, traffic=traffic, tabs=(user_re, user_im, theta, ent_re, ent_im))
     return ctx
 
@@ -630,8 +631,36 @@ def leg_cpu_baseline(D, args, out, ctx):
         "sample": f"{reps} passes of the same 2048 x 257 grouped RotatE scoring batch (scorer only) through "
                   f"oracle/kge_ref.c (OpenMP) in {cdt:.1f} s; host has {os.cpu_count()} logical CPUs",
     }
+    # full-size parity of the headline path, outside the timed region: the LAST launch of the single-stream pass left its
+    # sampled ids, its scores and its loss behind (sampler + scorer + loss in one launch); the C restatement scored the same
+    # 2048 x 257 ids above.  Reported in the line, and a failed check fails the bench.
     gpu_scores = ops.kge_score_grouped_raw(ctx["desc"], ctx["users"], None, kg.ui_relation, ctx["t_idx"]).cpu().numpy()
     np.testing.assert_allclose(gpu_scores, outb, rtol=1e-4, atol=1e-5)  # same inputs, same answers
+    rel = np.abs(gpu_scores - outb) / np.maximum(np.abs(outb), 1e-3)
+    parity = {"triples": int(outb.size), "max_rel_score_err": float(rel.max()), "max_abs_score_err": float(np.abs(gpu_scores - outb).max()),
+              "rule": "scores of the full 2048 x 257 batch against oracle/kge_ref.c at 1e-4 relative (+1e-5 absolute)"}
+    if ctx.get("launch_scores") is not None:  # what the one-launch form itself wrote
+        ls = ctx["launch_scores"].cpu().numpy()
+        parity["one_launch_scores_equal_plain_scorer"] = bool(np.array_equal(ls, gpu_scores))
+        assert parity["one_launch_scores_equal_plain_scorer"], "sampler + scorer launch: scores differ from the plain scorer on its own ids"
+    if ctx.get("launch_loss") is not None:
+        from oracle import kge as okge
+
+        want = float(okge.self_adversarial_loss(outb, 1.0))
+        got = float(ctx["launch_loss"].item())
+        parity["loss"] = {"device": got, "oracle_float64": want, "rel_err": abs(got - want) / abs(want)}
+        assert parity["loss"]["rel_err"] < 1e-4, parity["loss"]
+    # the sampled negatives: item ids, none of them in the key's used set (sampler.py:140-183's contract)
+    uptr, uidx = ctx["uptr_np"], ctx["uidx_np"]
+    neg = t_np[:, 1:]
+    in_range = bool(((neg >= 1) & (neg < kg.n_items)).all())
+    hits = 0
+    for gi, u in enumerate(h_np):
+        hits += int(np.isin(neg[gi], uidx[uptr[u]:uptr[u + 1]]).sum())
+    parity["negatives"] = {"drawn": int(neg.size), "in_item_range": in_range, "in_used_set": hits,
+                           "distinct_ids": int(np.unique(neg).size)}
+    assert in_range and hits == 0, parity["negatives"]
+    out["parity"] = parity
 
 
 # ---------------------------------------------------------------------------------------------------------------------
