@@ -137,9 +137,11 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.fused_tail = bool(_cfg(config, "fused_topk_expand", os.environ.get("HW_PGPR_TAIL", "1") != "0"))
         self.compact_leaves = bool(_cfg(config, "compact_leaves", self.fused_tail))
         self.acts_u16 = bool(_cfg(config, "acts_u16", os.environ.get("HW_PGPR_ACTS16", "1") != "0"))
-        # users per search: the first two hops are launch-bound, so a search of 256 users expands 2x the paths per second of
-        # one of 64 (bench_pgpr.py); ~3 GB of work buffers at the default beam
-        self.user_chunk = int(_cfg(config, "beam_user_chunk", 256))
+        # users per search (config beam_user_chunk; 0 = sized from the beam).  The first hops of a search are launch-bound, so
+        # few users per search waste the chip (64/64/64: 256 users per search expand 2x the paths per second of 64;
+        # hopwise's default 25/5/1 with its 4 096-user evaluation batches: 0.51 ms per 256 users as ONE search against 1.18 in
+        # chunks of 256, tools/bench_pgpr_eval.py); many users cost memory: the rows of the widest expanded hop, ~3 KB each
+        self.user_chunk = int(_cfg(config, "beam_user_chunk", 0))
         # evaluation batches larger than user_chunk: consecutive searches are dealt over this many HIP streams (a search's
         # policy launch is matrix-bound, its action / ranking launches are not: +15 % on the bench); 1 = one after another
         self.search_streams = max(1, int(_cfg(config, "search_streams", os.environ.get("HW_PGPR_STREAMS", "3"))))
@@ -520,8 +522,9 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         """Reference signature (pgpr.py:440): users tensor -> (path_pool, probs_pool) Python lists."""
         out_p, out_q = [], []
         users = torch.as_tensor(users)
-        for s in range(0, users.numel(), self.user_chunk):
-            res = self.beam_search_device(users[s : s + self.user_chunk])
+        step = self._users_per_search()
+        for s in range(0, users.numel(), step):
+            res = self.beam_search_device(users[s : s + step])
             p, q = self.decode_paths(*res.numpy())
             out_p += p
             out_q += q
@@ -554,13 +557,30 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 out.append([int(ulist[slot]), int(item[slot, j]), float(score[slot, j]), by_leaf[int(leaf[slot, j])]])
         return out
 
+    TARGET_BEAM_ROWS = 1 << 20  # rows of the widest expanded hop of one search when beam_user_chunk is left to the model
+
+    def _users_per_search(self, hops=None):
+        if self.user_chunk > 0:
+            return self.user_chunk
+        hops = list(self.beam_search_hop if hops is None else hops)
+        widest = 1
+        for k in hops[:-1]:
+            widest *= int(k)
+        n = self.TARGET_BEAM_ROWS // max(widest, 1)
+        # the float64 trim tables of a search are [users, n_users + n_entities]: at most 4 GB of them
+        g = getattr(self, "graph", None)
+        if g is not None:
+            n = min(n, (4 << 30) // (8 * max(1, g.n_users + g.n_entities)))
+        return max(64, n // 64 * 64)
+
     def _search_and_collect(self, users):
         """[(user chunk, BeamResult, scores, selection)] for chunks of ``user_chunk`` users.  More than one chunk: the
         searches are dealt round-robin over ``search_streams`` side streams -- they are independent and hold no state
         between calls (tests/test_gpu_pgpr_streams.py) -- fenced against the caller's stream on both sides, so that the caller
         sees what it would see after the same searches one after another."""
         users = torch.as_tensor(users)
-        chunks = [users[s : s + self.user_chunk] for s in range(0, users.numel(), self.user_chunk)]
+        step = self._users_per_search()
+        chunks = [users[s : s + step] for s in range(0, users.numel(), step)]
         dev = self._t64[0].device
         n_streams = min(self.search_streams, len(chunks))
         if n_streams <= 1 or dev.type != "cuda":

@@ -54,3 +54,19 @@ def test_rskg_batch_layout():
         n_kg += len(h)
     assert sorted(seen_pairs) == sorted(zip(users, items))  # every interaction exactly once per epoch
     assert n_kg >= len(b) * 1  # kg iterator restarted as often as needed (90 triples < 25 steps * 32)
+
+
+def test_pgpr_users_per_search_follows_the_beam():
+    """beam_user_chunk left at 0: a search takes as many users as keep the widest expanded hop near 1 M rows."""
+    from hopwise_amd.model.knowledge_aware_recommender import PGPR
+
+    class Stub:
+        user_chunk, beam_search_hop = 0, [64, 64, 64]
+        TARGET_BEAM_ROWS = PGPR.TARGET_BEAM_ROWS
+
+    s = Stub()
+    assert PGPR._users_per_search(s) == 256                      # the bench's beam
+    assert PGPR._users_per_search(s, [25, 5, 1]) == 8384         # hopwise's PGPR.yaml default: one search per 4 096-user batch
+    assert PGPR._users_per_search(s, [250, 250, 1]) == 64        # never fewer than 64
+    s.user_chunk = 48
+    assert PGPR._users_per_search(s) == 48                       # an explicit beam_user_chunk wins

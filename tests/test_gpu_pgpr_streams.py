@@ -83,7 +83,7 @@ def test_full_sort_predict_and_explain_over_streams_equal_the_sequential_ones():
     cfg = pgpr_config(dev, 40, 1, hops, False, (10,), "identity")
     cfg["beam_user_chunk"] = 48
     m = PGPR(cfg, ds).to(dev)
-    assert m.search_streams == 3 and m.user_chunk == 48
+    assert m.search_streams == 3 and m._users_per_search() == 48
     users = torch.from_numpy(rng.integers(1, n_users, 300)).to(dev)  # seven chunks, the last one ragged
     inter = {m.USER_ID: users}
     m.search_streams = 1

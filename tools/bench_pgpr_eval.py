@@ -17,9 +17,13 @@ dev = torch.device("cuda", 0)
 kg, ds, m = bench_pgpr.make_model(dev)
 rng = np.random.default_rng(0)
 n_users = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+if len(sys.argv) > 2:  # beam, e.g. 25,5,1 (hopwise's PGPR.yaml default; the bench line runs 64,64,64)
+    m.beam_search_hop = [int(x) for x in sys.argv[2].split(",")]
+if len(sys.argv) > 3:
+    m.user_chunk = int(sys.argv[3])
 users = torch.from_numpy(rng.integers(1, kg.n_users, n_users)).to(dev)
 inter = {m.USER_ID: users}
-out = {"users": n_users, "beam_user_chunk": m.user_chunk, "n_items": kg.n_items}
+out = {"users": n_users, "beam": list(m.beam_search_hop), "beam_user_chunk": m.user_chunk, "n_items": kg.n_items}
 for streams in (1, 3, 1, 3):
     m.search_streams = streams
     m.full_sort_predict(inter)
