@@ -328,6 +328,8 @@ SIGNATURES = {
         [c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_uint64, C.c_uint64, c_f32p, C.c_void_p],
     ),
     "hw_colsum_f32": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_void_p]),
+    "hw_colsum_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64]),
+    "hw_colsum_f32_ws": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     "hw_pgpr_reward": (
         C.c_int,
         [c_i32p, C.c_int64, c_i32p, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32,

@@ -733,6 +733,71 @@ __global__ __launch_bounds__(256) void batched_dot64_kernel(const double* __rest
     for (int q = 0; q < ns; ++q) out[(size_t)(s0 + q) * n_rows + n] = acc[q];
 }
 
+// The same sums for many sources (a PGPR training batch: 2 048 users) as a register-tiled product: the kernel above gives
+// every lane its own table row to walk (64 cache lines per load instruction) and re-reads the table once per 8 sources --
+// 0.65 ms of a 1.8 ms training step for the two [users, n_users | n_entities] tables.  Here a block owns 128 sources x 64
+// table rows, both tiles staged k-major in LDS with coalesced loads, a thread 8 sources x 4 rows in registers.  Every output
+// still runs ONE fma chain over ascending k with the same operands, so the tables are bit-identical (the trims compare them).
+constexpr int DRT_S = 128, DRT_N = 64, DRT_KC = 16;
+__global__ __launch_bounds__(256) void batched_dot64_rt_kernel(const double* __restrict__ src, int n_src,
+                                                               const double* __restrict__ T, int n_rows, int d,
+                                                               double* __restrict__ out) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) double sS[DRT_KC][DRT_S + 2];
+    __shared__ __attribute__((aligned(16))) double sT[DRT_KC][DRT_N + 2];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int s0 = blockIdx.y * DRT_S, row0 = blockIdx.x * DRT_N;
+    double acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = 0; k0 < d; k0 += DRT_KC) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // 128 sources x 16 k: a 128-byte piece of a source row per 16 threads
+            const int idx = j * 256 + tid, sl = idx >> 4, kk = idx & 15;
+            const int sg = s0 + sl, k = k0 + kk;
+            sS[kk][sl] = (sg < n_src && k < d) ? src[(size_t)sg * d + k] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = j * 256 + tid, rl = idx >> 4, kk = idx & 15;
+            const int rg = row0 + rl, k = k0 + kk;
+            sT[kk][rl] = (rg < n_rows && k < d) ? T[(size_t)rg * d + k] : 0.0;
+        }
+        __syncthreads();
+        const int kn = d - k0 < DRT_KC ? d - k0 : DRT_KC;
+        for (int kk = 0; kk < kn; ++kk) {
+            double a[8], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f64x2 v = *reinterpret_cast<const f64x2*>(&sS[kk][8 * ty + 2 * i]);
+                a[2 * i] = v.x, a[2 * i + 1] = v.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f64x2 v = *reinterpret_cast<const f64x2*>(&sT[kk][4 * tx + 2 * j]);
+                b[2 * j] = v.x, b[2 * j + 1] = v.y;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int sg = s0 + 8 * ty + i;
+        if (sg >= n_src) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rg = row0 + 4 * tx + j;
+            if (rg < n_rows) out[(size_t)sg * n_rows + rg] = acc[i][j];
+        }
+    }
+}
+
 // ---- A11: state ---------------------------------------------------------------------------------------
 // state[row] = [u, cur, last_node, last_rel (, older_node, older_rel)] gathered from the float32 tables
 // (zeros for missing history and for the self-loop relation), pgpr.py:296-333 + KGState :568-580.
@@ -1509,6 +1574,11 @@ extern "C" int hw_pgpr_init_paths(const int64_t* users, int64_t n_users_in_batch
 
 static int launch_dot64(const double* src, int64_t n_src, const double* T, int64_t n_rows, int dim, double* out,
                         hipStream_t st) {
+    if (n_src >= 64) {  // many sources: the register-tiled product (same sums bit for bit)
+        dim3 grid((unsigned)((n_rows + DRT_N - 1) / DRT_N), (unsigned)((n_src + DRT_S - 1) / DRT_S));
+        hipLaunchKernelGGL(batched_dot64_rt_kernel, grid, dim3(256), 0, st, src, (int)n_src, T, (int)n_rows, dim, out);
+        return HW_OK;
+    }
     dim3 grid((unsigned)((n_rows + 255) / 256), (unsigned)((n_src + DOT_SB - 1) / DOT_SB));
     hipLaunchKernelGGL(batched_dot64_kernel, grid, dim3(256), 0, st, src, (int)n_src, T, (int)n_rows, dim, out);
     return HW_OK;

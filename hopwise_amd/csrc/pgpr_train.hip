@@ -219,6 +219,40 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     if (r0 == 0 && c < n) out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// The same in two stages for tall matrices: the one-stage kernel has n / 64 blocks (8 for a 512-wide layer) each walking all
+// m rows -- 360 us for the [6 144, 512] gradient of a 2 048-user PGPR episode, a third of the training step.  Stage 1: block
+// (column block, row chunk) sums its chunk's rows; stage 2: the chunks' partial sums in fixed order.  Deterministic.
+constexpr int COLSUM_MAX_CHUNKS = 256;
+__host__ __device__ __forceinline__ int64_t colsum_chunks(int64_t m) {
+    const int64_t c = (m + 31) / 32;  // at least 32 rows per chunk
+    return c < 1 ? 1 : (c > COLSUM_MAX_CHUNKS ? COLSUM_MAX_CHUNKS : c);
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t m, int64_t n,
+                                                             int64_t rows_per_chunk, float* __restrict__ part_out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r0 = threadIdx.x >> 6;
+    const int64_t lo = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t hi = lo + rows_per_chunk < m ? lo + rows_per_chunk : m;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four loads in flight per thread; combined in a fixed order
+    if (c < n) {
+        int64_t r = lo + r0;
+        for (; r + 12 < hi; r += 16) {
+            s0 += x[r * ld + c];
+            s1 += x[(r + 4) * ld + c];
+            s2 += x[(r + 8) * ld + c];
+            s3 += x[(r + 12) * ld + c];
+        }
+        for (; r < hi; r += 4) s0 += x[r * ld + c];
+    }
+    part[r0][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (r0 == 0 && c < n)
+        part_out[(int64_t)blockIdx.y * n + c] =
+            (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
 // ---- _get_reward ----------------------------------------------------------------------------------------------------
 // patterns: int32 [n_patterns, 4] = (length incl. the leading self loop, rel, rel, rel); a path matches when its
 // relation sequence equals one pattern of the same length.  score_entity [n_batch, n_entities] is the float64 table
@@ -360,6 +394,26 @@ int hw_colsum_f32(const float* x, int64_t ld, int64_t m_rows, int64_t n, float* 
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(hw::colsum_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, ld,
                        m_rows, n, out);
+    return HW_LAUNCH_RC();
+}
+
+int64_t hw_colsum_workspace_floats(int64_t m_rows, int64_t n) {
+    return (m_rows <= 0 || n <= 0) ? 0 : hw::colsum_chunks(m_rows) * n;
+}
+
+int hw_colsum_f32_ws(const float* x, int64_t ld, int64_t m_rows, int64_t n, float* out, float* workspace,
+                     int64_t workspace_floats, void* stream) {
+    if (!x || !out || ld < n || m_rows < 0) return HW_ERR_INVALID_ARG;
+    if (n == 0) return HW_OK;
+    const int64_t chunks = hw::colsum_chunks(m_rows);
+    if (chunks <= 1) return hw_colsum_f32(x, ld, m_rows, n, out, stream);
+    if (!workspace || workspace_floats < chunks * n) return HW_ERR_WORKSPACE;
+    HW_CLEAR_ERR();
+    const int64_t rows_per_chunk = (m_rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(hw::colsum_partial_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)chunks), dim3(256), 0,
+                       (hipStream_t)stream, x, ld, m_rows, n, rows_per_chunk, workspace);
+    hipLaunchKernelGGL(hw::colsum_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, workspace, n,
+                       chunks, n, out);
     return HW_LAUNCH_RC();
 }
 

@@ -532,7 +532,10 @@ def act_dropout_backward(dy, y, act, drop_mask=None, drop_mode=0, seed=0, offset
 def colsum(x, out=None):
     lib = _lib.load()
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device) if out is None else out
-    check(lib.hw_colsum_f32(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), _stream()), "hw_colsum_f32")
+    n_ws = int(lib.hw_colsum_workspace_floats(x.shape[0], x.shape[1]))
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
+    check(lib.hw_colsum_f32_ws(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), _ptr(ws), n_ws, _stream()),
+          "hw_colsum_f32_ws")
     return out
 
 

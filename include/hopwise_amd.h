@@ -554,6 +554,11 @@ int hw_act_dropout_backward(const float* dy, const float* y, int64_t m_rows, int
 
 /* out[n] = column sums of x[m_rows, n] (bias gradients), deterministic order. */
 int hw_colsum_f32(const float* x, int64_t ld, int64_t m_rows, int64_t n, float* out, void* stream);
+/* The same for tall matrices in two stages (row chunks of >= 32 rows, at most 256, then their partial sums in fixed order):
+ * workspace of hw_colsum_workspace_floats(m_rows, n) floats; m_rows <= 32 takes the one-stage kernel. */
+int64_t hw_colsum_workspace_floats(int64_t m_rows, int64_t n);
+int hw_colsum_f32_ws(const float* x, int64_t ld, int64_t m_rows, int64_t n, float* out, float* workspace,
+                     int64_t workspace_floats, void* stream);
 
 /* _get_reward (pgpr.py:339-357) for paths [n_rows, HW_PGPR_ROW_INTS]: 0 unless the path has more than 2 nodes, its
  * relation sequence equals a pattern (patterns int32 [n_patterns, 4] = (n_nodes, rel, rel, rel), self loop = -1)

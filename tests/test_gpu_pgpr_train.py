@@ -156,3 +156,36 @@ def test_calculate_loss_trains_through_autograd():
         np.testing.assert_allclose(m.last_loss_parts.cpu().numpy()[0], losses[-1])
     assert np.isfinite(losses).all()
     assert all(not torch.equal(before[k], v) for k, v in m.named_parameters())
+
+
+@pytest.mark.parametrize("m_rows,n,ld", [(6144, 512, 512), (6144, 252, 256), (33, 70, 70), (32, 64, 64), (1, 5, 8),
+                                         (100000, 130, 136)])
+def test_colsum_two_stage_is_deterministic_and_right(m_rows, n, ld):
+    """hw_colsum_f32_ws (bias gradients): row chunks summed in parallel, then the chunks in fixed order."""
+    from hopwise_amd import pgpr_ops as P
+
+    g = torch.Generator().manual_seed(m_rows + n)
+    buf = torch.randn((m_rows, ld), generator=g).to(dev())
+    x = buf[:, :n]
+    a = P.colsum(x)
+    b = P.colsum(x)
+    assert torch.equal(a, b)
+    want = x.double().sum(0)
+    np.testing.assert_allclose(a.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=1e-5 * float(np.sqrt(m_rows)))
+
+
+def test_trim_tables_of_a_large_batch_equal_those_of_small_batches():
+    """hw_pgpr_user_scores takes the register-tiled float64 kernel from 64 users on: one fma chain over ascending k per output
+    in both kernels, so the [users, n_users | n_entities] tables are bit-identical (the action trims compare their entries)."""
+    from hopwise_amd import pgpr_ops as P
+
+    g, z, orc, m = build("b", dropout="identity", action_dropout=0.0)
+    U64, E64, R64 = m._t64
+    rng = np.random.default_rng(7)
+    users = torch.from_numpy(rng.integers(1, m.graph.n_users, 333)).to(dev())
+    su, se = P.user_scores(m.graph, U64, E64, R64, users)
+    for lo in range(0, 333, 50):  # chunks below 64 users: the one-row-per-lane kernel
+        a, b = P.user_scores(m.graph, U64, E64, R64, users[lo : lo + 50])
+        assert torch.equal(su[lo : lo + 50], a) and torch.equal(se[lo : lo + 50], b)
+    want = (U64[users] + R64[m.graph.ui_relation]) @ E64.T  # loose check against a float64 product
+    np.testing.assert_allclose(se.cpu().numpy(), want.cpu().numpy(), rtol=1e-12, atol=1e-13)
