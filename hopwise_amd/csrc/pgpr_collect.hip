@@ -14,17 +14,23 @@ namespace hw {
 
 constexpr int CPATH_INTS = HW_PGPR_ROW_INTS;
 
-__global__ void collect_slots_kernel(const int64_t* __restrict__ users, int n, int32_t* __restrict__ first_idx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// first_idx[i] = the first slot that holds users[i].  One wave per slot, the earlier slots compared 64 at a time: a thread per
+// slot walking all earlier ones (the first form) took 0.39 ms for the 4 096 users of one evaluation batch.
+__global__ __launch_bounds__(256) void collect_slots_kernel(const int64_t* __restrict__ users, int n,
+                                                            int32_t* __restrict__ first_idx) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n) return;
     const int64_t u = users[i];
     int f = i;
-    for (int j = 0; j < i; ++j)
-        if (users[j] == u) {
-            f = j;
+    for (int j0 = 0; j0 < i; j0 += 64) {
+        const int j = j0 + lane;
+        const unsigned long long hit = __ballot(j < i && users[j] == u);
+        if (hit) {
+            f = j0 + __builtin_ctzll(hit);
             break;
         }
-    first_idx[i] = f;
+    }
+    if (lane == 0) first_idx[i] = f;
 }
 
 __device__ __forceinline__ bool bit_test(const uint32_t* __restrict__ bits, int64_t words, int uid, int item) {
@@ -256,11 +262,27 @@ __global__ __launch_bounds__(256) void collect_select_kernel(
     }
 }
 
-__global__ void collect_rows_kernel(const int32_t* __restrict__ sel_count, int n, int32_t* __restrict__ sel_row) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int r = 0;
-        for (int i = 0; i < n; ++i) sel_row[i] = sel_count[i] > 0 ? r++ : -1;
+// sel_row[i] = number of earlier slots with a result row, or -1.  One block: a contiguous piece per thread, the pieces'
+// counts scanned in LDS (one thread walking all n took 0.27 ms for 4 096 users).
+__global__ __launch_bounds__(256) void collect_rows_kernel(const int32_t* __restrict__ sel_count, int n,
+                                                           int32_t* __restrict__ sel_row) {
+    __shared__ int cnt[256];
+    const int per = (n + 255) / 256, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    int c = 0;
+    for (int i = lo; i < hi; ++i) c += sel_count[i] > 0;
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) {
+            const int v = cnt[t];
+            cnt[t] = run;
+            run += v;
+        }
     }
+    __syncthreads();
+    int r = cnt[threadIdx.x];
+    for (int i = lo; i < hi; ++i) sel_row[i] = sel_count[i] > 0 ? r++ : -1;
 }
 
 __global__ void collect_fill_kernel(hw_pgpr_graph g, const int32_t* __restrict__ leaf, const int4* __restrict__ cleaf,
@@ -319,7 +341,7 @@ static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, co
         return HW_ERR_LAUNCH;
     hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((cells + 255) / 256 > 4096 ? 4096 : (cells + 255) / 256)),
                        dim3(256), 0, st, results, cells, -INFINITY);
-    hipLaunchKernelGGL(collect_slots_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, users, nb, first_idx_ws);
+    hipLaunchKernelGGL(collect_slots_kernel, dim3((nb + 3) / 4), dim3(256), 0, st, users, nb, first_idx_ws);
     if (max_leaf > 0) {
         int64_t grid = (max_leaf + 255) / 256;
         if (grid > 16384) grid = 16384;
@@ -341,7 +363,7 @@ static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, co
     hipLaunchKernelGGL(collect_select_kernel, dim3(nb), dim3(256), 0, st, *graph, user_emb64, entity_emb64,
                        relation_emb64, dim, users, first_idx_ws, positives_bits, positives_words,
                        (const unsigned long long*)best_ws, score_ws, kmax, sel_item, sel_score, sel_leaf, sel_count);
-    hipLaunchKernelGGL(collect_rows_kernel, dim3(1), dim3(1), 0, st, sel_count, nb, sel_row);
+    hipLaunchKernelGGL(collect_rows_kernel, dim3(1), dim3(256), 0, st, sel_count, nb, sel_row);
     hipLaunchKernelGGL(collect_fill_kernel, dim3(nb), dim3(64), 0, st, *graph, leaf_paths, cleaf, score_ws, kmax, n_nodes,
                        sel_item, sel_score, sel_count, sel_row, results, nb);
     return HW_LAUNCH_RC();

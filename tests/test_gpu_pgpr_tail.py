@@ -294,3 +294,43 @@ def test_one_user_and_no_user():
     assert none.n == 0 and none.numpy()[0].shape == (0, 12)
     scores, sel = m.collect_scores_device(u[:1], one_c, n_nodes=4)
     assert tuple(scores.shape) == (1, int(g["n_items"]))
+
+
+def test_collector_slot_and_row_numbering_on_a_large_batch_with_duplicates():
+    """700 slots, users repeating across the 64- and 256-slot pieces the slot / row kernels work in: later copies own no result
+    row, result rows number the slots that have one in order, and a first copy's row is the row of the same user searched in
+    a batch without duplicates."""
+    g, z, orc, m = build_model("default")
+    rng = np.random.default_rng(11)
+    pool = np.unique(z["users"])
+    singles, repeated = pool[: len(pool) // 2], pool[len(pool) // 2 :]
+    users_np = rng.choice(repeated, size=700, replace=True)
+    users_np[rng.choice(700, size=len(singles), replace=False)] = singles  # these occur once, at scattered slots
+    users = torch.from_numpy(users_np).to(dev())
+    res = m.beam_search_device(users, [9, 3, 1])
+    scores, sel = m.collect_scores_device(users, res, n_nodes=4)
+    cnt, row = sel["count"].cpu().numpy(), sel["row"].cpu().numpy()
+    first = {}
+    for i, u in enumerate(users_np):
+        first.setdefault(int(u), i)
+    later = np.array([first[int(u)] != i for i, u in enumerate(users_np)])
+    assert later.sum() > 300 and (cnt[later] == 0).all()
+    want_row, r = [], 0
+    for c in cnt:
+        want_row.append(r if c > 0 else -1)
+        r += c > 0
+    np.testing.assert_array_equal(row, np.array(want_row))
+    uniq = torch.from_numpy(np.array(sorted(first, key=first.get), np.int64)).to(dev())  # first occurrences, in slot order
+    res_u = m.beam_search_device(uniq, [9, 3, 1])
+    scores_u, sel_u = m.collect_scores_device(uniq, res_u, n_nodes=4)
+    # dropout is off in this model: a user's beam does not depend on its position in the batch; only the FIRST copy's leaves
+    # differ from the folded ones when copies exist, so compare users that occur once
+    once = [i for i, u in enumerate(users_np) if (users_np == u).sum() == 1]
+    assert len(once) == len(singles) > 3
+    pos_u = {int(u): j for j, u in enumerate(uniq.cpu().numpy())}
+    row_u = sel_u["row"].cpu().numpy()
+    have = [i for i in once if row[i] >= 0]  # result rows are numbered over the slots that have one (sel["row"])
+    assert len(have) > 2 and all(row_u[pos_u[int(users_np[i])]] >= 0 for i in have)
+    a = scores.cpu().numpy()[row[have]]
+    b = scores_u.cpu().numpy()[[row_u[pos_u[int(users_np[i])]] for i in have]]
+    np.testing.assert_array_equal(a, b)
