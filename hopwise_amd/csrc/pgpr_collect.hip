@@ -169,6 +169,71 @@ __device__ __forceinline__ void block_max128(uint64_t& hi, uint64_t& lo, uint64_
     __syncthreads();
 }
 
+// path_scores[uid, :] of many slots as a register-tiled product.  The select kernel below scores its own slot, one block per
+// slot, and every block re-reads the whole item table from L2 -- 2.4 MB x 4 096 slots = 1.1 ms for one evaluation batch of
+// hopwise's default size; its sixteen-lanes-per-item sum spends more on the shuffle tree than on the products.  Here a
+// block owns 32 slots x 32 items (both tiles k-major in LDS, coalesced loads), a thread 2 x 2 outputs, and per output the
+// SAME sixteen partial sums (k = l, l + 16, ... ascending, one fma chain each) combined in the shuffle tree's order
+// (8, 4, 2, 1): bit-identical scores.
+constexpr int CIS_T = 32, CIS_KC = 16;
+__global__ __launch_bounds__(256) void collect_item_scores_kernel(hw_pgpr_graph g, const double* __restrict__ U64,
+                                                                  const double* __restrict__ E64,
+                                                                  const double* __restrict__ R64, int d,
+                                                                  const int64_t* __restrict__ users, int nb,
+                                                                  double* __restrict__ score_ws) {
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) double sS[CIS_KC][CIS_T + 2];
+    __shared__ __attribute__((aligned(16))) double sT[CIS_KC][CIS_T + 2];
+    __shared__ int64_t uid_sh[CIS_T];
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int s0 = blockIdx.y * CIS_T, it0 = blockIdx.x * CIS_T;
+    if (tid < CIS_T) uid_sh[tid] = users[s0 + tid < nb ? s0 + tid : nb - 1];
+    __syncthreads();
+    double p[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int l = 0; l < 16; ++l) p[i][j][l] = 0.0;
+    for (int k0 = 0; k0 < d; k0 += CIS_KC) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // 32 x 16 values per tile: two per thread
+            const int idx = j * 256 + tid, r = idx >> 4, kk = idx & 15, k = k0 + kk;
+            sS[kk][r] = k < d ? U64[(size_t)uid_sh[r] * d + k] + R64[(size_t)g.ui_relation * d + k] : 0.0;
+            const int it = it0 + r;
+            sT[kk][r] = (k < d && it < g.n_items) ? E64[(size_t)it * d + k] : 0.0;
+        }
+        __syncthreads();
+        const int kn = d - k0 < CIS_KC ? d - k0 : CIS_KC;
+#pragma unroll
+        for (int kk = 0; kk < CIS_KC; ++kk) {
+            if (kk < kn) {  // block-uniform
+                const f64x2 a = *reinterpret_cast<const f64x2*>(&sS[kk][2 * ty]);
+                const f64x2 b = *reinterpret_cast<const f64x2*>(&sT[kk][2 * tx]);
+                p[0][0][kk] += a.x * b.x;
+                p[0][1][kk] += a.x * b.y;
+                p[1][0][kk] += a.y * b.x;
+                p[1][1][kk] += a.y * b.y;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double* q = p[i][j];
+            // the xor-shuffle tree of the sixteen lanes, as lane 0 sees it: l ^ 8, then ^ 4, ^ 2, ^ 1
+            const double v0 = (q[0] + q[8]) + (q[4] + q[12]), v2 = (q[2] + q[10]) + (q[6] + q[14]);
+            const double v1 = (q[1] + q[9]) + (q[5] + q[13]), v3 = (q[3] + q[11]) + (q[7] + q[15]);
+            const double r = (v0 + v2) + (v1 + v3);
+            const int slot = s0 + 2 * ty + i, it = it0 + 2 * tx + j;
+            if (slot < nb && it < g.n_items) score_ws[(size_t)slot * g.n_items + it] = r;
+        }
+}
+
+template <bool SCORES_READY>
 __global__ __launch_bounds__(256) void collect_select_kernel(
     hw_pgpr_graph g, const double* __restrict__ U64, const double* __restrict__ E64, const double* __restrict__ R64, int d,
     const int64_t* __restrict__ users, const int32_t* __restrict__ first_idx, const uint32_t* __restrict__ pos_bits,
@@ -186,11 +251,13 @@ __global__ __launch_bounds__(256) void collect_select_kernel(
         return;
     }
     const int uid = (int)users[slot];
-    for (int k = tid; k < d; k += 256) src[k] = U64[(size_t)uid * d + k] + R64[(size_t)g.ui_relation * d + k];
-    __syncthreads();
+    if constexpr (!SCORES_READY) {
+        for (int k = tid; k < d; k += 256) src[k] = U64[(size_t)uid * d + k] + R64[(size_t)g.ui_relation * d + k];
+        __syncthreads();
+    }
     double* __restrict__ sc = score_ws + (size_t)slot * g.n_items;
     const unsigned long long* __restrict__ bst = best + (size_t)slot * g.n_items;
-    {  // path_scores[uid, :] in float64 (pgpr.py:490-492), 16 lanes per item
+    if constexpr (!SCORES_READY) {  // path_scores[uid, :] in float64 (pgpr.py:490-492), 16 lanes per item
         const int grp = tid >> 4, gl = tid & 15;
         for (int base = 0; base < g.n_items; base += 16) {
             const int it = base + grp;
@@ -360,9 +427,18 @@ static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, co
         else MARK(collect_mark_kernel<false>, grid, 0);
 #undef MARK
     }
-    hipLaunchKernelGGL(collect_select_kernel, dim3(nb), dim3(256), 0, st, *graph, user_emb64, entity_emb64,
-                       relation_emb64, dim, users, first_idx_ws, positives_bits, positives_words,
-                       (const unsigned long long*)best_ws, score_ws, kmax, sel_item, sel_score, sel_leaf, sel_count);
+    if (nb >= 1024) {  // many slots: their item scores as a tiled product first (same sums), then the ranking alone
+        hipLaunchKernelGGL(collect_item_scores_kernel, dim3((unsigned)((graph->n_items + CIS_T - 1) / CIS_T),
+                                                            (unsigned)((nb + CIS_T - 1) / CIS_T)),
+                           dim3(256), 0, st, *graph, user_emb64, entity_emb64, relation_emb64, dim, users, nb, score_ws);
+        hipLaunchKernelGGL((collect_select_kernel<true>), dim3(nb), dim3(256), 0, st, *graph, user_emb64, entity_emb64,
+                           relation_emb64, dim, users, first_idx_ws, positives_bits, positives_words,
+                           (const unsigned long long*)best_ws, score_ws, kmax, sel_item, sel_score, sel_leaf, sel_count);
+    } else {
+        hipLaunchKernelGGL((collect_select_kernel<false>), dim3(nb), dim3(256), 0, st, *graph, user_emb64, entity_emb64,
+                           relation_emb64, dim, users, first_idx_ws, positives_bits, positives_words,
+                           (const unsigned long long*)best_ws, score_ws, kmax, sel_item, sel_score, sel_leaf, sel_count);
+    }
     hipLaunchKernelGGL(collect_rows_kernel, dim3(1), dim3(256), 0, st, sel_count, nb, sel_row);
     hipLaunchKernelGGL(collect_fill_kernel, dim3(nb), dim3(64), 0, st, *graph, leaf_paths, cleaf, score_ws, kmax, n_nodes,
                        sel_item, sel_score, sel_count, sel_row, results, nb);
