@@ -427,7 +427,7 @@ static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, co
         else MARK(collect_mark_kernel<false>, grid, 0);
 #undef MARK
     }
-    if (nb >= 1024) {  // many slots: their item scores as a tiled product first (same sums), then the ranking alone
+    if (nb >= 64) {  // many slots: their item scores as a tiled product first (same sums), then the ranking alone
         hipLaunchKernelGGL(collect_item_scores_kernel, dim3((unsigned)((graph->n_items + CIS_T - 1) / CIS_T),
                                                             (unsigned)((nb + CIS_T - 1) / CIS_T)),
                            dim3(256), 0, st, *graph, user_emb64, entity_emb64, relation_emb64, dim, users, nb, score_ws);

@@ -125,10 +125,10 @@ def test_cafe_calls_over_streams_equal_sequential_ones():
                 assert torch.equal(rec[k], v), k
 
 
-def test_collector_on_1024_and_more_slots_equals_smaller_batches():
-    """From 1 024 slots on the collector scores the items of eight slots per block in a launch of its own (every block of the
-    one-slot form re-reads the item table); the sums are taken in the same order, so scores, selections and explanation
-    leaves are those of the same users collected in batches below 1 024."""
+def test_collector_on_64_and_more_slots_equals_smaller_batches():
+    """From 64 slots on the collector scores the items as a tiled product in a launch of its own (every block of the one-slot
+    form re-reads the item table); the sums are taken in the same order, so scores and selections are those of the same
+    users collected in batches below 64."""
     from hopwise_amd.model.knowledge_aware_recommender import PGPR
 
     dev = torch.device("cuda", 0)
@@ -151,8 +151,8 @@ def test_collector_on_1024_and_more_slots_equals_smaller_batches():
     got_sel = {int(u): (sel["item"][i].clone(), sel["score"][i].clone(), int(sel["count"][i]))
                for i, u in enumerate(users.cpu().numpy())}
     assert len(got_rows) > 800
-    for lo in (0, 550):
-        part = users[lo : lo + 550]
+    for lo in range(0, 1100, 50):
+        part = users[lo : lo + 50]
         res_p = m.beam_search_device(part, list(hops))
         sc_p, sel_p = m.collect_scores_device(part, res_p, n_nodes=4)
         row_p = sel_p["row"].cpu().numpy()
