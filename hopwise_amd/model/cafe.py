@@ -30,6 +30,7 @@ from torch import nn
 
 from .. import ops
 from .. import pgpr_ops as P
+from ..lazy import LazyList
 from ..utils import InputType
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
 
@@ -753,12 +754,16 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
 
     def full_sort_predict(self, interaction):
         scores, paths = self.run_program(interaction[self.USER_ID])
-        # convert_path_relations (cafe.py:341-348): relation names -> ids
-        paths = [[u, i, sc, [p[0]] + [(self.relation2rid[r], t, e) for r, t, e in p[1:]]] for u, i, sc, p in paths]
+        # convert_path_relations (cafe.py:341-348): relation names -> ids -- applied when somebody reads the records
+        rid = self.relation2rid
+        conv = lambda rec: [rec[0], rec[1], rec[2], [rec[3][0]] + [(rid[r], t, e) for r, t, e in rec[3][1:]]]
+        paths = paths.mapped(conv) if isinstance(paths, LazyList) else [conv(r) for r in paths]
         return scores, paths
 
     def explain(self, interaction):
         scores, explanations = self.run_program(interaction[self.USER_ID])
+        if isinstance(explanations, LazyList):  # decoded when read: ExplainableCollector only keeps them for rec.paths metrics
+            return scores, explanations.mapped(lambda e: e[:-1] + [self.decode_path(e[-1])])
         for e in explanations:
             e[-1] = self.decode_path(e[-1])
         return scores, explanations
@@ -869,44 +874,12 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         return reg_loss, rank_loss * self.rank_weight
 
 
-class _LazyRecords(list):
-    """The [[user, item, score, path], ...] list of run_program, materialised from the device records on first use.  A
-    real list afterwards; every way of reading or combining it (len, iteration, indexing, ==, +, the collector's
-    ``previous + value``) fills it first."""
+class _LazyRecords(LazyList):
+    """The [[user, item, score, path], ...] list of run_program, materialised from the device records on first use (a real
+    list afterwards: hopwise_amd/lazy.py)."""
 
     def __init__(self, model, rec, leaves, users_np):
-        super().__init__()
-        self._pending = (model, rec, leaves, users_np)
-
-    def _fill(self):
-        if self._pending is not None:
-            model, rec, leaves, users_np = self._pending
-            self._pending = None
-            list.extend(self, model._records_to_lists(rec, leaves, users_np))
-        return self
-
-    def __add__(self, other):
-        return list(self._fill()) + list(other)
-
-    def __radd__(self, other):
-        return list(other) + list(self._fill())
-
-    __hash__ = None
-
-
-def _filled(name):
-    def method(self, *a, **k):
-        self._fill()
-        return getattr(list, name)(self, *a, **k)
-
-    method.__name__ = name
-    return method
-
-
-for _n in ("__len__", "__iter__", "__getitem__", "__eq__", "__ne__", "__repr__", "__contains__", "__reversed__", "__iadd__",
-           "__mul__", "__setitem__", "__delitem__", "copy", "count", "index", "sort", "append", "extend", "insert", "pop",
-           "remove", "reverse"):
-    setattr(_LazyRecords, _n, _filled(_n))
+        super().__init__(lambda: model._records_to_lists(rec, leaves, users_np))
 
 
 def _chain_of(order, i):

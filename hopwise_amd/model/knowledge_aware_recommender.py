@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from .. import pgpr_ops as P
+from ..lazy import LazyList
 from ..utils import InputType, seed_for_rank
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
 from .knowledge_graph_embedding_recommender import _cfg
@@ -616,14 +617,21 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         return torch.cat([o[2] for o in self._search_and_collect(interaction[self.USER_ID])], dim=0)
 
     def explain(self, interaction):  # pgpr.py:417-435
+        """(scores, [[user, item, score, path], ...]).  The record list is built when it is read (hopwise.lazy.LazyList):
+        ExplainableCollector keeps it only for ``rec.paths`` metrics, and building it -- device-to-host copies of the
+        selections, a Python loop over every (user, item) -- costs more than the searches."""
         outs = self._search_and_collect(interaction[self.USER_ID])
         scores = torch.cat([o[2] for o in outs], dim=0)
-        expl = []
-        for chunk, res, _, sel in outs:
-            expl += self.explanations(chunk, res, sel)
-        for e in expl:
-            e[-1] = self.decode_path(e[-1])
-        return scores, expl
+
+        def build():
+            expl = []
+            for chunk, res, _, sel in outs:
+                expl += self.explanations(chunk, res, sel)
+            for e in expl:
+                e[-1] = self.decode_path(e[-1])
+            return expl
+
+        return scores, LazyList(build)
 
     def predict(self, interaction):
         return

@@ -70,3 +70,24 @@ def test_pgpr_users_per_search_follows_the_beam():
     assert PGPR._users_per_search(s, [250, 250, 1]) == 64        # never fewer than 64
     s.user_chunk = 48
     assert PGPR._users_per_search(s) == 48                       # an explicit beam_user_chunk wins
+
+
+def test_lazy_list_builds_once_and_behaves_like_a_list():
+    from hopwise_amd.lazy import LazyList
+
+    calls = []
+
+    def make():
+        calls.append(1)
+        return [[1, "a"], [2, "b"]]
+
+    a, b = LazyList(make), LazyList(make)
+    assert a.pending and not calls
+    assert a == b and len(calls) == 2            # comparing two unbuilt lists builds both
+    assert not a.pending and len(a) == 2 and a[1] == [2, "b"] and len(calls) == 2
+    assert [0] + LazyList(make) + [9] == [0, [1, "a"], [2, "b"], 9]
+    m = LazyList(make).mapped(lambda r: r[0] * 10)
+    assert m.pending and list(m) == [10, 20]
+    prev = []
+    prev = prev + LazyList(make)                 # the collector's `previous + value`
+    assert prev == [[1, "a"], [2, "b"]] and type(prev) is list

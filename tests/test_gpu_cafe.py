@@ -382,3 +382,22 @@ def test_shallow_relation_modules_fused_equals_the_python_loop(monkeypatch):
         assert torch.equal(out["2"][1][k], out["0"][1][k]), k
     assert int(out["0"][1]["count"].sum()) > 0
     torch.testing.assert_close(out["2"][0].nan_to_num(-1e30), out["0"][0].nan_to_num(-1e30), rtol=2e-5, atol=2e-5)
+
+
+def test_full_sort_predict_and_explain_keep_the_records_lazy():
+    """The reference-format lists are built when read, not by full_sort_predict / explain themselves (38 000 Python records per
+    1 024 users otherwise: 134 ms against 1.6 ms of device work) -- and read, they are what the eager form gives."""
+    from hopwise_amd.lazy import LazyList
+
+    z, orc, m = build()
+    inter = {"user_id": torch.from_numpy(z["users"])}
+    scores, paths = m.full_sort_predict(inter)
+    assert isinstance(paths, LazyList) and paths.pending
+    s2, expl = m.explain(inter)
+    assert isinstance(expl, LazyList) and expl.pending
+    raw_scores, raw = m.run_program(inter["user_id"])
+    rid = m.relation2rid
+    want = [[u, i, sc, [p[0]] + [(rid[r], t, e) for r, t, e in p[1:]]] for u, i, sc, p in raw]
+    assert list(paths) == want and not paths.pending
+    assert list(expl) == [list(r) for r in raw]
+    assert torch.equal(scores, raw_scores) and torch.equal(s2, raw_scores)
