@@ -197,47 +197,76 @@ constexpr int TOPK_CHUNK = TOPK_CHUNK_THREADS * TOPK_CHUNK_PER;  // 4096 columns
 constexpr int TOPK_TWO_STAGE_MIN_COLS = 2 * TOPK_CHUNK;
 constexpr int TOPK_TWO_STAGE_MAX_K = 64;
 
+// Stage 1, one block per (row, chunk): the chunk's k largest keys, descending, zeros when it has fewer.
+// Not k rounds over the whole chunk (each round a block-wide arg-max and a rescan by the winner's lane: ~4 600 wave
+// instructions per block, which made the first form of this kernel issue-bound at 1.5 TB/s).  Instead:
+//   1. every lane's largest key (its "lane maximum"), 256 of them in LDS;
+//   2. tau = the k-th largest lane maximum (one wave, k rounds over 4 keys per lane).  The chunk's k-th largest key is >= tau,
+//      and the keys >= tau all sit in the k lanes whose maximum is >= tau: at most 16 k of them, typically k + a few;
+//   3. every lane appends its keys >= tau to a candidate list in LDS;
+//   4. one wave takes the k largest candidates in order.
+// Keys are unique (value image, ~column), so "largest below the previous winner" needs no marking, and the result does not
+// depend on the order the candidates were appended in.
 __global__ __launch_bounds__(TOPK_CHUNK_THREADS) void topk_chunk_kernel(const float* __restrict__ s, int64_t n_cols,
                                                                         int64_t ld, int k, int n_chunks,
                                                                         uint64_t* __restrict__ cand) {
-    constexpr int NW = TOPK_CHUNK_THREADS / HW_WAVE;
-    __shared__ uint64_t red[2][NW];
+    __shared__ uint64_t lane_max[TOPK_CHUNK_THREADS];
+    __shared__ uint64_t list[TOPK_CHUNK_PER * TOPK_TWO_STAGE_MAX_K];
+    __shared__ uint64_t tau_sh;
+    __shared__ int n_list;
     const int chunk = blockIdx.x % n_chunks;
     const int64_t r = blockIdx.x / n_chunks;
     const float* __restrict__ row = s + r * ld;
     const int64_t base = (int64_t)chunk * TOPK_CHUNK + threadIdx.x;
-    uint32_t ord[TOPK_CHUNK_PER];  // the key's high word (order-preserving image of the value); the low word is ~column
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t key[TOPK_CHUNK_PER];  // 0 = no column here (a real key has a non-zero low word unless its column is 2^32 - 1)
+    uint64_t mine = 0;
 #pragma unroll
     for (int i = 0; i < TOPK_CHUNK_PER; ++i) {
         const int64_t c = base + (int64_t)i * TOPK_CHUNK_THREADS;
-        ord[i] = 0;
-        if (c < n_cols) ord[i] = (uint32_t)(topk_key(row[c], 0u) >> 32);
+        key[i] = c < n_cols ? topk_key(row[c], (uint32_t)c) : 0ull;
+        mine = key[i] > mine ? key[i] : mine;
     }
-    auto local_best = [&](uint64_t bound) {
-        uint64_t best = 0;
+    lane_max[threadIdx.x] = mine;
+    if (threadIdx.x == 0) n_list = 0;
+    __syncthreads();
+    if (wave == 0) {  // tau: k rounds of "largest lane maximum below the previous one"
+        uint64_t v[TOPK_CHUNK_THREADS / 64];
 #pragma unroll
-        for (int i = 0; i < TOPK_CHUNK_PER; ++i) {
-            const int64_t c = base + (int64_t)i * TOPK_CHUNK_THREADS;
-            const uint64_t key = ((uint64_t)ord[i] << 32) | (uint32_t)(~(uint32_t)c);
-            if (c < n_cols && key < bound && key > best) best = key;
-        }
-        return best;
-    };
-    uint64_t* __restrict__ out = cand + ((int64_t)blockIdx.x) * k;
-    uint64_t mine = local_best(~0ull);
-    for (int round = 0; round < k; ++round) {
-        const uint64_t w = wave_max_u64(mine);
-        if ((threadIdx.x & 63) == 0) red[round & 1][threadIdx.x / HW_WAVE] = w;
-        __syncthreads();  // one barrier per round: the two halves of red[] alternate
-        uint64_t win = red[round & 1][0];
+        for (int j = 0; j < TOPK_CHUNK_THREADS / 64; ++j) v[j] = lane_max[lane + 64 * j];
+        uint64_t bound = ~0ull;
+        for (int round = 0; round < k && bound != 0; ++round) {
+            uint64_t best = 0;
 #pragma unroll
-        for (int i = 1; i < NW; ++i) win = red[round & 1][i] > win ? red[round & 1][i] : win;
-        if (threadIdx.x == 0) out[round] = win;  // 0 = chunk exhausted
-        if (win == 0) {
-            for (int q = round + 1 + (int)threadIdx.x; q < k; q += TOPK_CHUNK_THREADS) out[q] = 0;
-            break;
+            for (int j = 0; j < TOPK_CHUNK_THREADS / 64; ++j) best = (v[j] < bound && v[j] > best) ? v[j] : best;
+            bound = wave_max_u64(best);  // 0 once the lane maxima are used up: every key of the chunk is a candidate then
         }
-        if (mine == win) mine = local_best(win);  // only the owner of the winner looks again
+        if (lane == 0) tau_sh = bound;
+    }
+    __syncthreads();
+    const uint64_t tau = tau_sh;
+#pragma unroll
+    for (int i = 0; i < TOPK_CHUNK_PER; ++i)
+        if (key[i] != 0 && key[i] >= tau) list[atomicAdd(&n_list, 1)] = key[i];
+    __syncthreads();
+    if (wave == 0) {
+        const int n = n_list;  // <= 16 k when tau != 0, <= the chunk's columns (< k lanes had any) otherwise
+        uint64_t* __restrict__ out = cand + ((int64_t)blockIdx.x) * k;
+        uint64_t bound = ~0ull;
+        for (int round = 0; round < k; ++round) {
+            uint64_t best = 0;
+            for (int j = lane; j < n; j += 64) {
+                const uint64_t x = list[j];
+                best = (x < bound && x > best) ? x : best;
+            }
+            best = wave_max_u64(best);
+            if (lane == 0) out[round] = best;
+            bound = best;  // 0 = used up: the remaining rounds write zeros
+            if (best == 0) {
+                for (int q = round + 1 + lane; q < k; q += 64) out[q] = 0;
+                break;
+            }
+        }
     }
 }
 
