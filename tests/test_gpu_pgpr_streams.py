@@ -97,6 +97,8 @@ def test_full_sort_predict_and_explain_over_streams_equal_the_sequential_ones():
     got_scores, got_expl = m.explain(inter)
     assert torch.equal(got_scores, want_scores)
     assert got_expl == want_expl and len(want_expl) > 100
+    # ids handed over on the host (what a dataloader without pinned staging does): same result
+    assert torch.equal(m.full_sort_predict({m.USER_ID: users.cpu()}), want)
 
 
 def test_cafe_calls_over_streams_equal_sequential_ones():
