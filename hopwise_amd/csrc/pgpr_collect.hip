@@ -52,7 +52,15 @@ __device__ __forceinline__ bool leaf_key(const hw_pgpr_graph& g, const int32_t* 
     float pp;
     if constexpr (COMPACT) {
         const int4 lf = cleaf[i];
-        const int32_t* p = leaf + (size_t)lf.x * CPATH_INTS;  // the parent: n_nodes - 1 nodes
+        // the parent (n_nodes - 1 nodes): its 48-byte record as three 16-byte loads -- field by field this kernel issued ten
+        // vector-memory instructions per leaf, and with 66 M leaves that is what paced it
+        int p[CPATH_INTS];
+        {
+            const int4* pr = reinterpret_cast<const int4*>(leaf + (size_t)lf.x * CPATH_INTS);
+            const int4 a = pr[0], b = pr[1], c = pr[2];
+            p[0] = a.x, p[1] = a.y, p[2] = a.z, p[3] = a.w, p[4] = b.x, p[5] = b.y, p[6] = b.z, p[7] = b.w;
+            p[8] = c.x, p[9] = c.y, p[10] = c.z, p[11] = c.w;
+        }
         if (p[1] != n_nodes - 1) return false;
         bool ok = lf.y != -1;                                                         // no self loop after the root
         for (int j = 1; j < n_nodes - 1; ++j) ok &= p[2 + 3 * (j - 1)] != -1;
@@ -67,7 +75,13 @@ __device__ __forceinline__ bool leaf_key(const hw_pgpr_graph& g, const int32_t* 
         pp = n_nodes == 2 ? v : q[0];
         for (int j = 1; j < n_nodes - 1; ++j) pp = pp * (j == n_nodes - 2 ? v : q[j]);  // reduce(mul) in float32
     } else {
-        const int32_t* p = leaf + (size_t)i * CPATH_INTS;
+        int p[CPATH_INTS];
+        {
+            const int4* pr = reinterpret_cast<const int4*>(leaf + (size_t)i * CPATH_INTS);
+            const int4 a = pr[0], b = pr[1], c = pr[2];
+            p[0] = a.x, p[1] = a.y, p[2] = a.z, p[3] = a.w, p[4] = b.x, p[5] = b.y, p[6] = b.z, p[7] = b.w;
+            p[8] = c.x, p[9] = c.y, p[10] = c.z, p[11] = c.w;
+        }
         if (p[1] != n_nodes) return false;
         bool ok = true;
         for (int j = 1; j < n_nodes; ++j) ok &= p[2 + 3 * (j - 1)] != -1;            // no self loop after the root
