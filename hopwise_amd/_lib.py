@@ -352,6 +352,12 @@ SIGNATURES = {
          c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_i32p, c_f32p, c_i32p,
          C.c_void_p, c_i32p, c_i32p, c_i32p, C.c_void_p],
     ),
+    "hw_pgpr_collect_leaves_ex": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, c_i64p, C.c_int64, C.c_void_p, C.c_int64,
+         c_i32p, c_f32p, c_i32p, c_i32p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, c_i32p, c_f32p, c_i32p,
+         C.c_void_p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int64, C.c_void_p],
+    ),
     "hw_gather_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_f32p, c_i32p, C.c_void_p]),
     "hw_scatter_add_rows": (C.c_int, [c_f32p, C.c_int64, C.c_int32, c_i64p, C.c_int64, c_f32p, C.c_void_p]),
     "hw_fill_bytes": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),

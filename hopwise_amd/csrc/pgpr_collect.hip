@@ -161,6 +161,68 @@ __global__ __launch_bounds__(256) void collect_mark_lds_kernel(hw_pgpr_graph g, 
     }
 }
 
+// The compact last level, parent by parent: a wave takes a parent row -- its record, probability prefix, user slot and the
+// validity tests that do not depend on the child arrive through the scalar unit, once per 64 children -- and a lane takes
+// one child (16 bytes, a positives bit, one LDS max).  The leaf-per-thread form above re-reads the parent per leaf: ten, then
+// six vector-memory instructions per leaf, which is what paced it (0.65 ms for 66 M leaves).  child_offsets[p] = first
+// leaf of parent p (hw_pgpr_topk_expand's `offsets`), at most 64 children per parent.  Same keys, same cells: max() is
+// order-free, the table is bit-identical.
+constexpr int MARK_PARENTS = 512;
+__global__ __launch_bounds__(256) void collect_mark_parents_kernel(hw_pgpr_graph g, const int32_t* __restrict__ parents,
+                                                                   const float* __restrict__ parent_probs,
+                                                                   const int4* __restrict__ cleaf,
+                                                                   const int32_t* __restrict__ n_leaf_ptr,
+                                                                   const int32_t* __restrict__ child_offsets,
+                                                                   const int32_t* __restrict__ n_parents_ptr, int n_nodes,
+                                                                   const int32_t* __restrict__ first_idx,
+                                                                   const uint32_t* __restrict__ pos_bits, int64_t pos_words,
+                                                                   unsigned long long* __restrict__ best) {
+    extern __shared__ unsigned long long lds_best[];  // [n_items]
+    __shared__ int slot0_sh;
+    const int n_leaf = n_leaf_ptr[0], n_par = n_parents_ptr[0];
+    const int p0 = blockIdx.x * MARK_PARENTS;
+    if (p0 >= n_par) return;
+    const int p1 = p0 + MARK_PARENTS < n_par ? p0 + MARK_PARENTS : n_par;
+    for (int c = threadIdx.x; c < g.n_items; c += 256) lds_best[c] = 0ull;
+    if (threadIdx.x == 0) slot0_sh = first_idx[parents[(size_t)p0 * CPATH_INTS + 11]];
+    __syncthreads();
+    const int slot0 = slot0_sh;
+    const int wave = wave_in_block(), lane = threadIdx.x & 63;
+    for (int p = p0 + wave; p < p1; p += 4) {  // everything up to the child loads is wave-uniform
+        const int32_t* __restrict__ pr = parents + (size_t)p * CPATH_INTS;
+        if (pr[1] != n_nodes - 1) continue;
+        bool okp = true;
+        for (int j = 1; j < n_nodes - 1; ++j) okp &= pr[2 + 3 * (j - 1)] != -1;  // no self loop after the root
+        if (!okp) continue;
+        const int cur_t = n_nodes == 2 ? 0 : pr[2 + 3 * (n_nodes - 3) + 1];
+        const int uid = pr[0];
+        const int slot = first_idx[pr[11]];
+        const float* __restrict__ q = parent_probs + (size_t)p * 3;
+        float prefix = n_nodes == 2 ? 1.f : q[0];  // reduce(mul) in float32, the leaf's own value last (leaf_key's order)
+        for (int j = 1; j < n_nodes - 2; ++j) prefix = prefix * q[j];
+        const int c0 = child_offsets[p];
+        int c1 = p + 1 < n_par ? child_offsets[p + 1] : n_leaf;
+        c1 = c1 < n_leaf ? c1 : n_leaf;
+        const int i = c0 + lane;
+        if (i >= c1) continue;
+        const int4 lf = cleaf[i];
+        const int lt = (cur_t == 1 && lf.y == g.ui_relation) ? 0 : 1;  // pgpr.py:209-213
+        const int pid = lf.z;
+        if (lf.y == -1 || lt != 1 || pid >= g.n_items) continue;       // a self loop / not an item
+        if (bit_test(pos_bits, pos_words, uid, pid)) continue;         // already a train positive
+        const float v = __uint_as_float((uint32_t)lf.w);
+        const float pp = n_nodes == 2 ? v : prefix * v;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(pp) << 32) | (uint32_t)(~(uint32_t)i);
+        if (slot == slot0) atomicMax(&lds_best[pid], key);
+        else atomicMax(best + (size_t)slot * g.n_items + pid, key);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < g.n_items; c += 256) {
+        const unsigned long long k = lds_best[c];
+        if (k) atomicMax(best + (size_t)slot0 * g.n_items + c, k);
+    }
+}
+
 __device__ __forceinline__ uint64_t ord64(double x) {
     uint64_t u = (uint64_t)__double_as_longlong(x);
     return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
@@ -402,7 +464,8 @@ static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, co
                         const float* leaf_probs, const int32_t* compact_leaves, const int32_t* n_leaf, int64_t max_leaf,
                         int32_t n_nodes, int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws,
                         float* results, int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
-                        int32_t* sel_row, void* stream) {
+                        int32_t* sel_row, void* stream, const int32_t* child_offsets = nullptr,
+                        const int32_t* n_parents = nullptr, int64_t max_parents = 0) {
     if (!graph || !user_emb64 || !entity_emb64 || !relation_emb64 || !users || !positives_bits || !leaf_paths ||
         !leaf_probs || !n_leaf || !best_ws || !score_ws || !first_idx_ws || !results || !sel_item || !sel_score ||
         !sel_leaf || !sel_count || !sel_row)
@@ -435,7 +498,13 @@ static int collect_impl(const hw_pgpr_graph* graph, const double* user_emb64, co
 #define MARK(KERNEL, GRID, LDS)                                                                                          \
     hipLaunchKernelGGL(KERNEL, dim3((unsigned)(GRID)), dim3(256), LDS, st, *graph, leaf_paths, leaf_probs, cleaf, n_leaf, \
                        n_nodes, first_idx_ws, positives_bits, positives_words, (unsigned long long*)best_ws)
-        if (in_lds && cleaf) MARK(collect_mark_lds_kernel<true>, grid_lds, lds_bytes);
+        static const bool by_leaf = [] { const char* e = getenv("HW_PGPR_MARK_PARENTS"); return e && e[0] == '0'; }();
+        if (in_lds && cleaf && child_offsets && n_parents && max_parents > 0 && !by_leaf)
+            hipLaunchKernelGGL(collect_mark_parents_kernel, dim3((unsigned)((max_parents + MARK_PARENTS - 1) / MARK_PARENTS)),
+                               dim3(256), lds_bytes, st, *graph, leaf_paths, leaf_probs, cleaf, n_leaf, child_offsets,
+                               n_parents, n_nodes, first_idx_ws, positives_bits, positives_words,
+                               (unsigned long long*)best_ws);
+        else if (in_lds && cleaf) MARK(collect_mark_lds_kernel<true>, grid_lds, lds_bytes);
         else if (in_lds) MARK(collect_mark_lds_kernel<false>, grid_lds, lds_bytes);
         else if (cleaf) MARK(collect_mark_kernel<true>, grid, 0);
         else MARK(collect_mark_kernel<false>, grid, 0);
@@ -473,6 +542,22 @@ extern "C" int hw_pgpr_collect(const hw_pgpr_graph* graph, const double* user_em
 
 // The same on the compact output of the last hop (hw_pgpr_topk_expand with leaf_out): parent_paths / parent_probs are the
 // rows the last hop expanded, leaves[i] = {parent row, relation, node, bits of the hop value}; sel_leaf indexes leaves.
+extern "C" int hw_pgpr_collect_leaves_ex(const hw_pgpr_graph* graph, const double* user_emb64,
+                                         const double* entity_emb64, const double* relation_emb64, int32_t dim,
+                                         const int64_t* users, int64_t n_batch, const uint32_t* positives_bits,
+                                         int64_t positives_words, const int32_t* parent_paths, const float* parent_probs,
+                                         const int32_t* leaves, const int32_t* n_leaf, int64_t max_leaf, int32_t n_nodes,
+                                         int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws,
+                                         float* results, int32_t* sel_item, double* sel_score, int32_t* sel_leaf,
+                                         int32_t* sel_count, int32_t* sel_row, const int32_t* child_offsets,
+                                         const int32_t* n_parents, int64_t max_parents, void* stream) {
+    if (!leaves || max_parents < 0 || max_parents > INT32_MAX) return HW_ERR_INVALID_ARG;
+    return collect_impl(graph, user_emb64, entity_emb64, relation_emb64, dim, users, n_batch, positives_bits,
+                        positives_words, parent_paths, parent_probs, leaves, n_leaf, max_leaf, n_nodes, kmax, best_ws,
+                        score_ws, first_idx_ws, results, sel_item, sel_score, sel_leaf, sel_count, sel_row, stream,
+                        child_offsets, n_parents, max_parents);
+}
+
 extern "C" int hw_pgpr_collect_leaves(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
                                       const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
                                       const uint32_t* positives_bits, int64_t positives_words, const int32_t* parent_paths,

@@ -43,9 +43,11 @@ class BeamResult:
     per child, 64 times over on a 64-wide beam.  ``paths`` / ``probs`` then materialise on first use
     (hw_pgpr_materialize_leaves); ``rows(idx)`` rebuilds only the asked records; the collector reads the compact form."""
 
-    def __init__(self, paths, probs, n_rows, graph=None, leaves=None):
+    def __init__(self, paths, probs, n_rows, graph=None, leaves=None, child_offsets=None, n_parents=None):
         self._paths, self._probs, self._n = paths, probs, n_rows
         self.graph, self.leaves = graph, leaves
+        # compact leaves: first leaf of every parent row + the device count of parent rows (the collector walks parents)
+        self.child_offsets, self.n_parents = child_offsets, n_parents
         self.parent_paths, self.parent_probs = (paths, probs) if leaves is not None else (None, None)
         if leaves is not None:
             self._paths = self._probs = None
@@ -57,7 +59,7 @@ class BeamResult:
     def record_stream(self, stream):
         """The result was produced on another stream than the one that will read it: tell torch's allocator."""
         for t in (self._paths, self._probs, self._n, self.leaves, self.parent_paths, self.parent_probs,
-                  getattr(self, "n_rows_per_hop", None)):
+                  self.child_offsets, self.n_parents, getattr(self, "n_rows_per_hop", None)):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(stream)
 
@@ -367,7 +369,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                                   tk_idx=buf["tk_idx"][:n, :k].clone(), tk_val=buf["tk_val"][:n, :k].clone()))
         if compact_leaves:  # parents = the rows the last hop expanded
             res = BeamResult(buf["paths"][-2], buf["probs"][-2], nr[len(hops) : len(hops) + 1], graph=g,
-                             leaves=buf["leaves"])
+                             leaves=buf["leaves"], child_offsets=buf["offsets"],
+                             n_parents=nr[len(hops) - 1 : len(hops)])
         else:
             res = BeamResult(buf["paths"][-1], buf["probs"][-1], nr[len(hops) : len(hops) + 1], graph=g)
         res.n_rows_per_hop = nr
@@ -539,7 +542,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         n_nodes = len(self.beam_search_hop) + 1 if n_nodes is None else n_nodes
         if getattr(res, "leaves", None) is not None:  # compact leaves: read in place, nothing is materialised
             return P.collect(self.graph, *self._collect_tables(), users, self._pos_bits, res.parent_paths, res.parent_probs,
-                             res._n, res.leaves.shape[0], n_nodes, max(self.topk), leaves=res.leaves)
+                             res._n, res.leaves.shape[0], n_nodes, max(self.topk), leaves=res.leaves,
+                             child_offsets=getattr(res, "child_offsets", None), n_parents=getattr(res, "n_parents", None))
         return P.collect(self.graph, *self._collect_tables(), users, self._pos_bits, res.paths, res.probs, res._n,
                          res.paths.shape[0], n_nodes, max(self.topk))
 

@@ -317,9 +317,11 @@ def positives_bitset(positives, n_users, n_items, device):
     return torch.from_numpy(bits.view(np.int32)).to(device)
 
 
-def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_leaf, max_leaf, n_nodes, kmax, leaves=None):
+def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_leaf, max_leaf, n_nodes, kmax, leaves=None,
+            child_offsets=None, n_parents=None):
     """``leaves`` (int32 [max_leaf, 4]): the compact output of the last hop; leaf_paths / leaf_probs are then the PARENT rows
-    (hw_pgpr_collect_leaves)."""
+    (hw_pgpr_collect_leaves).  ``child_offsets`` (int32, first leaf of every parent row: topk_expand's offsets of the last
+    hop) + ``n_parents`` (device int32 [1]): the best-path pass goes parent by parent (hw_pgpr_collect_leaves_ex)."""
     lib = _lib.load()
     dev = users.device
     B, nI = users.numel(), graph.n_items
@@ -332,6 +334,17 @@ def collect(graph, U64, E64, R64, users, pos_bits, leaf_paths, leaf_probs, n_lea
     sel_leaf = torch.empty((B, kmax), dtype=torch.int32, device=dev)
     sel_count = torch.empty(B, dtype=torch.int32, device=dev)
     sel_row = torch.empty(B, dtype=torch.int32, device=dev)
+    if leaves is not None and child_offsets is not None and n_parents is not None:
+        check(
+            lib.hw_pgpr_collect_leaves_ex(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), U64.shape[1], _ptr(users), B,
+                                          _ptr(pos_bits), pos_bits.shape[1], _ptr(leaf_paths), _ptr(leaf_probs),
+                                          _ptr(leaves), _ptr(n_leaf), int(max_leaf), int(n_nodes), int(kmax), _ptr(best),
+                                          _ptr(score_ws), _ptr(first), _ptr(results), _ptr(sel_item), _ptr(sel_score),
+                                          _ptr(sel_leaf), _ptr(sel_count), _ptr(sel_row), _ptr(child_offsets),
+                                          _ptr(n_parents), int(leaf_paths.shape[0]), _stream()),
+            "hw_pgpr_collect_leaves_ex",
+        )
+        return results, dict(item=sel_item, score=sel_score, leaf=sel_leaf, count=sel_count, row=sel_row)
     if leaves is not None:
         check(
             lib.hw_pgpr_collect_leaves(C.byref(graph.c), _ptr(U64), _ptr(E64), _ptr(R64), U64.shape[1], _ptr(users), B,

@@ -522,6 +522,18 @@ int hw_pgpr_collect_leaves(const hw_pgpr_graph* graph, const double* user_emb64,
                            int32_t n_nodes, int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws,
                            float* results, int32_t* sel_item, double* sel_score, int32_t* sel_leaf, int32_t* sel_count,
                            int32_t* sel_row, void* stream);
+/* The same with the parents' child ranges at hand: child_offsets int32 [max_parents] = first leaf of every parent row (the
+ * `offsets` hw_pgpr_topk_expand filled for the last hop; at most 64 children per parent), n_parents = device count of
+ * parent rows.  The best-path pass then takes a wave per parent (the parent through the scalar unit, a lane per child)
+ * instead of a thread per leaf that re-reads its parent; same table bit for bit.  Either pointer NULL: the call above. */
+int hw_pgpr_collect_leaves_ex(const hw_pgpr_graph* graph, const double* user_emb64, const double* entity_emb64,
+                              const double* relation_emb64, int32_t dim, const int64_t* users, int64_t n_batch,
+                              const uint32_t* positives_bits, int64_t positives_words, const int32_t* parent_paths,
+                              const float* parent_probs, const int32_t* leaves, const int32_t* n_leaf, int64_t max_leaf,
+                              int32_t n_nodes, int32_t kmax, uint64_t* best_ws, double* score_ws, int32_t* first_idx_ws,
+                              float* results, int32_t* sel_item, double* sel_score, int32_t* sel_leaf,
+                              int32_t* sel_count, int32_t* sel_row, const int32_t* child_offsets,
+                              const int32_t* n_parents, int64_t max_parents, void* stream);
 
 /* ---- PGPR policy-gradient training (pgpr.py:120-203, 335-396) --------------------------------------------------
  * One episode = max_path_len steps of: actions -> action dropout -> state -> policy MLP -> Categorical draw ->

@@ -334,3 +334,30 @@ def test_collector_slot_and_row_numbering_on_a_large_batch_with_duplicates():
     a = scores.cpu().numpy()[row[have]]
     b = scores_u.cpu().numpy()[[row_u[pos_u[int(users_np[i])]] for i in have]]
     np.testing.assert_array_equal(a, b)
+
+
+def test_collector_parent_walk_equals_the_record_form_on_a_large_search():
+    """With 65 536 leaf slots or more (and an item table that fits LDS) the collector's best-path pass over compact leaves goes
+    parent by parent (collect_mark_parents_kernel: the parent through the scalar unit, a lane per child); over full records it
+    goes leaf by leaf.  Same scores, same selections, same explanation leaves."""
+    g, z, orc, m = build_model("default")
+    u = torch.from_numpy(z["users"]).to(dev())
+    users = u.repeat(8)[:64]  # copies fold into the first one's slot on both paths
+    assert m.act_dim >= 32
+    hops = [32, 16, 8]
+    full, (p0, q0) = _search(m, users, hops, fused_tail=True, compact_leaves=False)
+    comp, (p1, q1) = _search(m, users, hops, fused_tail=True, compact_leaves=True)
+    assert comp.leaves.shape[0] >= 65536 and comp.child_offsets is not None
+    np.testing.assert_array_equal(p1, p0)
+    s0, sel0 = m.collect_scores_device(users, full, n_nodes=4)
+    s1, sel1 = m.collect_scores_device(users, comp, n_nodes=4)
+    np.testing.assert_array_equal(s1.cpu().numpy(), s0.cpu().numpy())
+    for k in sel0:
+        assert torch.equal(sel1[k], sel0[k]), k
+    assert int(sel0["count"].sum()) > 0
+    # and without the child ranges the leaf-by-leaf form over the same compact leaves
+    comp.child_offsets = None
+    s2, sel2 = m.collect_scores_device(users, comp, n_nodes=4)
+    np.testing.assert_array_equal(s2.cpu().numpy(), s0.cpu().numpy())
+    for k in sel0:
+        assert torch.equal(sel2[k], sel0[k]), k
