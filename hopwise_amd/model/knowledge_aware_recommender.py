@@ -34,6 +34,9 @@ from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
 from .knowledge_graph_embedding_recommender import _cfg
 
 
+_SEARCH_STREAMS = {}  # (device type, index) -> side streams of PGPR._search_and_collect
+
+
 class BeamResult:
     """Leaf (or intermediate) beam rows on the device.
 
@@ -596,7 +599,9 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 outs.append((chunk, res, scores, sel))
             return outs
         main = torch.cuda.current_stream(dev)
-        side = self.__dict__.setdefault("_search_stream_pool", [])
+        # side streams live in a module-level pool per device, not on the model: stream objects do not survive the
+        # copy.deepcopy / pickle a caller may apply to a model
+        side = _SEARCH_STREAMS.setdefault((dev.type, dev.index), [])
         while len(side) < n_streams:
             side.append(torch.cuda.Stream(device=dev))
         for st in side[:n_streams]:

@@ -99,6 +99,10 @@ def test_full_sort_predict_and_explain_over_streams_equal_the_sequential_ones():
     assert got_expl == want_expl and len(want_expl) > 100
     # ids handed over on the host (what a dataloader without pinned staging does): same result
     assert torch.equal(m.full_sort_predict({m.USER_ID: users.cpu()}), want)
+    # the side streams are not model state (hopwise checkpoints state_dict() + other_parameter(): trainer.py:295-305)
+    assert not any(isinstance(v, (list, tuple)) and v and isinstance(v[0], torch.cuda.Stream) for v in vars(m).values())
+    sd = m.state_dict()
+    assert all(torch.is_tensor(v) for v in sd.values())
 
 
 def test_cafe_calls_over_streams_equal_sequential_ones():
