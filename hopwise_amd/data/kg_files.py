@@ -42,12 +42,13 @@ def read_atomic(path):
 
 
 def factorize(tokens):
-    """pandas.factorize: codes in order of first appearance, and the unique tokens in that order."""
-    uniq, first, inv = np.unique(np.asarray(tokens, dtype=object), return_index=True, return_inverse=True)
-    order = np.argsort(first, kind="stable")
-    rank = np.empty(len(order), np.int64)
-    rank[order] = np.arange(len(order))
-    return rank[inv], uniq[order]
+    """pandas.factorize: codes in order of first appearance, and the unique tokens in that order.  One dictionary pass (sorting
+    a million Python strings through np.unique took half of the 6.8 s an ml-1m-sized dataset needed to load)."""
+    table = {}
+    codes = np.fromiter((table.setdefault(t, len(table)) for t in tokens), np.int64, len(tokens))
+    uniq = np.empty(len(table), dtype=object)
+    uniq[:] = list(table)
+    return codes, uniq
 
 
 class KGFiles:
