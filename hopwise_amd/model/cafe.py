@@ -31,6 +31,7 @@ from torch import nn
 from .. import ops
 from .. import pgpr_ops as P
 from ..lazy import LazyList
+from ..stream_cache import FencedValue
 from ..utils import InputType
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
 
@@ -282,13 +283,10 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         """[in, out] copy of an nn.Linear weight for hw_cafe_modules_forward_fused, cached per (storage, version): made once
         per weight version (evaluation reads the same weights call after call; an optimizer step bumps the version)."""
         cache = self.__dict__.setdefault("_wt_cache", {})
-        key = id(w)
-        hit = cache.get(key)
-        if hit is not None and hit[0] == (w.data_ptr(), w._version):
-            return hit[1]
-        wt = w.detach().t().contiguous()
-        cache[key] = ((w.data_ptr(), w._version), wt)
-        return wt
+        fv = cache.get(id(w))
+        if fv is None:
+            fv = cache[id(w)] = FencedValue()  # calls on several streams read the copy (stream_cache.py)
+        return fv.get((w.data_ptr(), w._version), lambda: w.detach().t().contiguous())
 
     def _module_structs(self, mods, user_vec, transposed=False):
         """ctypes table of the relation modules' parameters for hw_cafe_modules_forward, or None when the C++ loop does not
@@ -321,23 +319,28 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             per_mod.append((deep, ps, m))
         sig = tuple((id(p), p.data_ptr(), p._version) if p is not None else None for _, ps, _ in per_mod for p in ps)
         cache = self.__dict__.setdefault("_struct_cache", {})
-        hit = cache.get(bool(transposed))
-        if hit is not None and hit[0] == sig:
-            return hit[1]
-        arr = (CafeModule * len(mods))()
-        for i, (deep, ps, m) in enumerate(per_mod):
-            if any(p is not None and (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous())
-                   for p in ps) or ps[4] is None:
-                return None
-            for name, p in zip(("w1", "b1", "bn1_weight", "bn1_bias", "bn1_mean", "bn1_var", "w2", "b2", "bn2_weight", "bn2_bias",
-                                "bn2_mean", "bn2_var", "w3", "b3"), ps):
-                if transposed and p is not None and name in ("w1", "w2", "w3"):
-                    p = self._transposed(p)
-                setattr(arr[i], name, p.data_ptr() if p is not None else None)
-            arr[i].bn1_eps, arr[i].bn2_eps = float(m.bn1.eps), float(m.bn2.eps) if deep else 0.0
-            arr[i].deep = int(deep)
-        cache[bool(transposed)] = (sig, arr)
-        return arr
+        fv = cache.get(bool(transposed))
+        if fv is None:
+            fv = cache[bool(transposed)] = FencedValue()
+
+        def build():
+            arr, keep = (CafeModule * len(mods))(), []
+            for i, (deep, ps, m) in enumerate(per_mod):
+                if any(p is not None and (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous())
+                       for p in ps) or ps[4] is None:
+                    return None
+                for name, p in zip(("w1", "b1", "bn1_weight", "bn1_bias", "bn1_mean", "bn1_var", "w2", "b2", "bn2_weight",
+                                    "bn2_bias", "bn2_mean", "bn2_var", "w3", "b3"), ps):
+                    if transposed and p is not None and name in ("w1", "w2", "w3"):
+                        p = self._transposed(p)
+                        keep.append(p)
+                    setattr(arr[i], name, p.data_ptr() if p is not None else None)
+                arr[i].bn1_eps, arr[i].bn2_eps = float(m.bn1.eps), float(m.bn2.eps) if deep else 0.0
+                arr[i].deep = int(deep)
+            return arr, keep  # the transposed copies ride along: a reader on another stream is fenced against their build
+
+        hit = fv.get(sig, build)
+        return None if hit is None else hit[0]
 
     @torch.no_grad()
     def _run_programs(self, users, programs, ks, grow_excluded, exclude, raw=False, flat=None):

@@ -27,8 +27,10 @@ import numpy as np
 import torch
 from torch import nn
 
+from .. import ops
 from .. import pgpr_ops as P
 from ..lazy import LazyList
+from ..stream_cache import FencedValue
 from ..utils import InputType, seed_for_rank
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
 from .knowledge_graph_embedding_recommender import _cfg
@@ -233,25 +235,39 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             buf["scratch"] = torch.empty((min(2048, rmax), self.graph.max_degree), dtype=torch.int64, device=dev)
         return buf
 
+    def _fenced(self, name):
+        fv = self.__dict__.get(name)
+        if fv is None:
+            fv = self.__dict__[name] = FencedValue()
+        return fv
+
     def _l1_slot_tables(self):
-        """Slot tables of the first layer for the current l1 weights (rebuilt when the parameter version changes)."""
+        """Slot tables of the first layer for the current l1 weights (rebuilt when the parameter version changes).  Fenced:
+        searches on several streams read them (stream_cache.py)."""
         key = (self.l1.weight._version, self.l1.weight.data_ptr())
-        if getattr(self, "_l1_cache_key", None) != key:
-            self._l1_cache = P.layer1_tables(self._t32, self.l1.weight.detach(), self.state_history)
-            self._l1_cache_key = key
-        return self._l1_cache
+        return self._fenced("_l1_cache").get(
+            key, lambda: P.layer1_tables(self._t32, self.l1.weight.detach(), self.state_history))
 
     def _fused_policy_state(self):
         """(weight planes, zero row, padded actor bias) of hw_pgpr_policy_fused for the current l2 / actor parameters."""
         key = tuple((t._version, t.data_ptr()) for t in (self.l2.weight, self.actor.weight, self.actor.bias))
-        if getattr(self, "_fused_key", None) != key:
+
+        def build():
             dev = self.l2.weight.device
             ba = torch.zeros(256, dtype=torch.float32, device=dev)
             ba[: self.act_dim] = self.actor.bias.detach()
-            self._fused_cache = (P.policy_prepare(self.l2.weight, self.actor.weight),
-                                 torch.zeros(self.hidden_sizes[0], dtype=torch.float32, device=dev), ba)
-            self._fused_key = key
-        return self._fused_cache
+            return (P.policy_prepare(self.l2.weight, self.actor.weight),
+                    torch.zeros(self.hidden_sizes[0], dtype=torch.float32, device=dev), ba)
+
+        return self._fenced("_fused_cache").get(key, build)
+
+    def _warm_search_caches(self):
+        """Build, on the CURRENT stream, everything a search builds lazily: called before searches are dealt over side
+        streams, so that no side stream is the first (and only ordered) writer of a tensor the others read."""
+        if self.fused_policy and P.policy_fused_supported(self.hidden_sizes, self.act_dim):
+            self._fused_policy_state()
+        self._l1_slot_tables()
+        ops._OobCounter.get(self._t64[0].device)
 
     def _policy_logits(self, buf, n_rows, rmax, drops, hop, paths=None):
         """l1 -> ELU -> dropout -> l2 -> ELU -> dropout -> actor (pgpr.py:175-187), logits into buf['logits'].
@@ -569,7 +585,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
 
     def _users_per_search(self, hops=None):
         if self.user_chunk > 0:
-            return self.user_chunk
+            return min(self.user_chunk, 65535)
         hops = list(self.beam_search_hop if hops is None else hops)
         widest = 1
         for k in hops[:-1]:
@@ -579,6 +595,10 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         g = getattr(self, "graph", None)
         if g is not None:
             n = min(n, (4 << 30) // (8 * max(1, g.n_users + g.n_entities)))
+            # the collector's [users, n_items] tables (best key u64 + score f64 + result f32 = 20 B per cell), held by up to
+            # ``search_streams`` searches at a time: at most 8 GB of them
+            n = min(n, (8 << 30) // (20 * max(1, self.n_items) * max(1, self.search_streams)))
+        n = min(n, 65535)  # hw_pgpr_collect numbers a search's users in 16 bits
         return max(64, n // 64 * 64)
 
     def _search_and_collect(self, users):
@@ -604,6 +624,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         side = _SEARCH_STREAMS.setdefault((dev.type, dev.index), [])
         while len(side) < n_streams:
             side.append(torch.cuda.Stream(device=dev))
+        self._warm_search_caches()  # on the caller's stream, ahead of the fences below
         for st in side[:n_streams]:
             st.wait_stream(main)  # the ids, the weights and whatever else the caller queued are in place
         outs = []

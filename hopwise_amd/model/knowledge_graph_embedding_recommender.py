@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..stream_cache import FencedValue
 from ..utils import InputType, seed_for_rank
 from .abstract_recommender import KnowledgeRecommender
 
@@ -212,12 +213,16 @@ class _GatherKGE(KnowledgeRecommender):
         (rebuilt when a table's storage or version changes; optimizers bump the version, FusedAdam included)."""
         if len(tail) == 1:
             return tail[0][:n]
-        key = (n,) + tuple((t.data_ptr(), t._version) for t in tail)
-        hit = self.__dict__.get("_bilinear_cat")
-        if hit is None or hit[0] != key:
-            hit = (key, torch.cat([t.detach()[:n] for t in tail], dim=1).contiguous())
-            self.__dict__["_bilinear_cat"] = hit
-        return hit[1]
+        # ONE copy of the whole tables per version, whatever n is asked for (items in rec, entities in kg, a shard's rows):
+        # a slice of its first n rows is what the product reads
+        slot = tuple(t.data_ptr() for t in tail)
+        cache = self.__dict__.setdefault("_bilinear_cat", {})
+        fv = cache.get(slot)
+        if fv is None:
+            cache.clear()  # a table moved (resize, .to()): the old copy is dead weight
+            fv = cache[slot] = FencedValue()
+        full = fv.get(tuple(t._version for t in tail), lambda: torch.cat([t.detach() for t in tail], dim=1).contiguous())
+        return full[:n]
 
     def _full_sort_gemm(self, side, h_idx, r_idx, r_fixed, n):
         head, rel, tail = self._tables(side)

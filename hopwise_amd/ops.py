@@ -91,6 +91,11 @@ class _OobCounter:
         key = (device.type, device.index)
         if key not in cls._cache:
             cls._cache[key] = torch.zeros(1, dtype=torch.int32, device=device)
+            # every stream of the process bumps this one word from now on: its zero fill must have landed before a kernel
+            # on ANOTHER stream can touch it (once per process and device; not possible, nor needed, inside a capture --
+            # the warm-up steps in front of a capture have created the counter already)
+            if device.type == "cuda" and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(device).synchronize()
         return cls._cache[key]
 
 

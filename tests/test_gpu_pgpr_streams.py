@@ -168,3 +168,97 @@ def test_collector_on_64_and_more_slots_equals_smaller_batches():
             assert torch.equal(item[:count], sel_p["item"][i][:count]) and torch.equal(score[:count], sel_p["score"][i][:count])
             if row_p[i] >= 0:
                 assert torch.equal(got_rows[int(u)], sc_p[row_p[i]])
+
+
+@pytest.mark.parametrize("fused_policy", [True, False])
+def test_first_multi_stream_evaluation_after_an_optimizer_step_reads_finished_caches(fused_policy):
+    """The COLD case (round-4 review): the first-layer slot tables and the pre-split policy planes are rebuilt lazily after
+    every optimizer step.  Dealt over three side streams, the first chunk used to rebuild them on ITS stream while the chunks
+    on the other two streams found the cache key already set and read tables that were still being written.  The caches are
+    built on the caller's stream ahead of the fan-out now, and carry their build event (stream_cache.FencedValue).
+
+    A model whose caches have never been built, then one whose weights an optimizer step has just moved: the multi-stream
+    ``full_sort_predict`` runs FIRST and must equal, bit for bit, a deep copy evaluated on one stream."""
+    import copy
+
+    from hopwise_amd.model.knowledge_aware_recommender import PGPR
+    from hopwise_amd.optim import FusedAdam
+
+    dev = torch.device("cuda", 0)
+    sizes = (500, 70, 160, 5, 9000, 1200)
+    n_users, n_items, n_entities, n_rel, n_inter, n_kg = sizes
+    dim, hops = 100, (16, 8, 4)  # d = 100: the slot tables are (users + entities) x 512 floats per slot -- a build of some length
+    rng, ui, iu, ii, heads, rels, tails = _graph(11, *sizes)
+    U = rng.standard_normal((n_users, dim)) / np.sqrt(dim)
+    E = rng.standard_normal((n_entities, dim)) / np.sqrt(dim)
+    R = rng.standard_normal((n_rel, dim)) / np.sqrt(dim)
+    positives = np.zeros((n_users, 3), np.int64)
+    for u in range(1, n_users):
+        positives[u, :2] = rng.integers(1, n_items, 2)
+    ds = FakeKGDataset(n_users, n_items, n_entities, n_rel, ui, iu, ii, heads, rels, tails, positives, U, E, R)
+    torch.manual_seed(2)
+    cfg = pgpr_config(dev, 40, 1, hops, False, (10,), "identity")
+    cfg["beam_user_chunk"] = 32
+    cfg["fused_policy"] = fused_policy
+    m = PGPR(cfg, ds).to(dev)
+    users = torch.from_numpy(rng.integers(1, n_users, 320)).to(dev)  # ten chunks over three streams
+    inter = {m.USER_ID: users}
+
+    ref_model = PGPR(cfg, ds).to(dev)
+    ref_model.search_streams = 1
+
+    def sequential_copy():  # same weights, own caches, one stream
+        ref_model.load_state_dict(copy.deepcopy(m.state_dict()))
+        torch.cuda.synchronize()
+        return ref_model
+
+    # 1. never evaluated before: nothing is cached
+    assert m.search_streams == 3 and "_l1_cache" not in vars(m) and "_fused_cache" not in vars(m)
+    ref = sequential_copy()
+    got = m.full_sort_predict(inter)
+    want = ref.full_sort_predict(inter)
+    assert torch.equal(got, want)
+    assert torch.isfinite(got).any()
+    first_expl = list(ref.explain(inter)[1])
+
+    # 2. after optimizer steps (FusedAdam writes through raw pointers and bumps the version counters: the caches are stale)
+    opt = FusedAdam(m.parameters(), lr=5e-2)
+    for step in range(3):
+        for p in m.parameters():
+            p.grad = torch.randn_like(p)
+        opt.step()
+        ref = sequential_copy()
+        got = m.full_sort_predict(inter)  # multi-stream FIRST, on cold caches
+        want_step = ref.full_sort_predict(inter)
+        assert torch.equal(got, want_step), f"step {step}"
+        got_scores, got_expl = m.explain(inter)
+        want_scores, want_expl = ref.explain(inter)
+        assert torch.equal(got_scores, want_scores) and list(got_expl) == list(want_expl)
+    assert list(want_expl) != first_expl  # the steps did move the policy: other paths are the best ones now
+
+
+def test_fenced_value_orders_a_reader_on_another_stream_behind_the_build():
+    """stream_cache.FencedValue by itself: a long build on one stream, a reader on another stream that finds the cached
+    object must see the finished tensor."""
+    from hopwise_amd.stream_cache import FencedValue
+
+    dev = torch.device("cuda", 0)
+    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    src = torch.ones(64 << 20, device=dev)  # 256 MB
+    torch.cuda.synchronize()
+    fv = FencedValue()
+
+    def build():
+        t = src.clone()
+        for _ in range(40):  # ~40 passes over 256 MB queued on stream a
+            t.add_(1.0)
+        return t
+
+    with torch.cuda.stream(a):
+        fv.get(1, build)
+    with torch.cuda.stream(b):
+        got = fv.get(1, build)[-1000:].clone()  # cache hit on the host at once; the device must wait for the adds
+    torch.cuda.synchronize()
+    assert torch.all(got == 41.0)
+    import copy
+    assert copy.deepcopy(fv).key is None
