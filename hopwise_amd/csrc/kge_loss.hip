@@ -194,7 +194,12 @@ __global__ __launch_bounds__(THREADS) void topk_rows_kernel(const float* __restr
 constexpr int TOPK_CHUNK_THREADS = 256;
 constexpr int TOPK_CHUNK_PER = 16;
 constexpr int TOPK_CHUNK = TOPK_CHUNK_THREADS * TOPK_CHUNK_PER;  // 4096 columns
-constexpr int TOPK_TWO_STAGE_MIN_COLS = 2 * TOPK_CHUNK;
+// from 1 024 columns on (round 5; 8 192 before): the one-block-per-row kernel walks its row k times from memory with two barriers
+// per walk, the chunk kernel reads it once into registers -- 2 048 rows x 2 985 columns: 0.047 -> 0.021 ms at k = 10, 0.143 -> 0.048 ms at k = 32
+static int topk_two_stage_min_cols() {
+    static const int v = [] { const char* e = getenv("HW_TOPK_TWO_STAGE_MIN"); return e ? atoi(e) : 1024; }();
+    return v;
+}
 constexpr int TOPK_TWO_STAGE_MAX_K = 64;
 
 // Stage 1, one block per (row, chunk): the chunk's k largest keys, descending, zeros when it has fewer.
@@ -207,6 +212,9 @@ constexpr int TOPK_TWO_STAGE_MAX_K = 64;
 //   4. one wave takes the k largest candidates in order.
 // Keys are unique (value image, ~column), so "largest below the previous winner" needs no marking, and the result does not
 // depend on the order the candidates were appended in.
+// VEC: rows that start 16-byte aligned (a padded score matrix) are read as float4 -- lane t holds columns 4 t .. 4 t + 3 of each
+// 1 024-column stretch instead of columns t, t + 256, ...: which lane holds which column changes nothing in the argument above.
+template <bool VEC>
 __global__ __launch_bounds__(TOPK_CHUNK_THREADS) void topk_chunk_kernel(const float* __restrict__ s, int64_t n_cols,
                                                                         int64_t ld, int k, int n_chunks,
                                                                         uint64_t* __restrict__ cand) {
@@ -221,11 +229,27 @@ __global__ __launch_bounds__(TOPK_CHUNK_THREADS) void topk_chunk_kernel(const fl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t key[TOPK_CHUNK_PER];  // 0 = no column here (a real key has a non-zero low word unless its column is 2^32 - 1)
     uint64_t mine = 0;
+    if constexpr (VEC) {
+        static_assert(TOPK_CHUNK_PER % 4 == 0, "quads");
 #pragma unroll
-    for (int i = 0; i < TOPK_CHUNK_PER; ++i) {
-        const int64_t c = base + (int64_t)i * TOPK_CHUNK_THREADS;
-        key[i] = c < n_cols ? topk_key(row[c], (uint32_t)c) : 0ull;
-        mine = key[i] > mine ? key[i] : mine;
+        for (int i = 0; i < TOPK_CHUNK_PER / 4; ++i) {
+            const int64_t c0 = (int64_t)chunk * TOPK_CHUNK + (int64_t)i * (4 * TOPK_CHUNK_THREADS) + 4 * threadIdx.x;
+            hw::f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (c0 < n_cols) x = *reinterpret_cast<const hw::f32x4*>(row + c0);  // ld >= n_cols rounded up to 4 (launcher)
+            const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                key[4 * i + e] = c0 + e < n_cols ? topk_key(xv[e], (uint32_t)(c0 + e)) : 0ull;
+                mine = key[4 * i + e] > mine ? key[4 * i + e] : mine;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TOPK_CHUNK_PER; ++i) {
+            const int64_t c = base + (int64_t)i * TOPK_CHUNK_THREADS;
+            key[i] = c < n_cols ? topk_key(row[c], (uint32_t)c) : 0ull;
+            mine = key[i] > mine ? key[i] : mine;
+        }
     }
     lane_max[threadIdx.x] = mine;
     if (threadIdx.x == 0) n_list = 0;
@@ -428,7 +452,7 @@ extern "C" int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols,
 }
 
 static bool topk_two_stage(int64_t n_cols, int32_t k) {
-    return n_cols >= TOPK_TWO_STAGE_MIN_COLS && k <= TOPK_TWO_STAGE_MAX_K;
+    return n_cols >= topk_two_stage_min_cols() && k <= TOPK_TWO_STAGE_MAX_K;
 }
 
 extern "C" int64_t hw_topk_rows_workspace_bytes(int64_t n_rows, int64_t n_cols, int32_t k) {
@@ -451,8 +475,12 @@ extern "C" int hw_topk_rows_ws(const float* scores, int64_t n_rows, int64_t n_co
     HW_CLEAR_ERR();
     hipStream_t st = (hipStream_t)stream;
     uint64_t* cand = (uint64_t*)workspace;
-    hipLaunchKernelGGL(topk_chunk_kernel, dim3((unsigned)(n_rows * n_chunks)), dim3(TOPK_CHUNK_THREADS), 0, st, scores,
-                       n_cols, ld, (int)k, (int)n_chunks, cand);
+    if (((uintptr_t)scores & 15) == 0 && (ld & 3) == 0 && ld >= ((n_cols + 3) & ~(int64_t)3))
+        hipLaunchKernelGGL((topk_chunk_kernel<true>), dim3((unsigned)(n_rows * n_chunks)), dim3(TOPK_CHUNK_THREADS), 0, st,
+                           scores, n_cols, ld, (int)k, (int)n_chunks, cand);
+    else
+        hipLaunchKernelGGL((topk_chunk_kernel<false>), dim3((unsigned)(n_rows * n_chunks)), dim3(TOPK_CHUNK_THREADS), 0, st,
+                           scores, n_cols, ld, (int)k, (int)n_chunks, cand);
     const int n_cand = (int)(n_chunks * k);
     if (n_cand <= 512)
         hipLaunchKernelGGL((topk_merge_kernel<64>), dim3((unsigned)n_rows), dim3(64), 0, st, scores, ld, cand, n_cand,

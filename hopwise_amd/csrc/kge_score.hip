@@ -116,3 +116,18 @@ extern "C" int hw_kge_full_sort_topk(const hw_kge_desc* desc, const int64_t* h_i
     return full_sort_topk_impl<0>(desc, h_idx, r_idx, r_fixed, n_heads, tail_lo, tail_hi, hist_rows, hist_cols, n_hist,
                                   mask_first_col, k, workspace, workspace_bytes, out_val, out_idx, stream);
 }
+
+// The same launches under a device-side predicate: every workgroup leaves at once unless *run_if != 0 (nullptr: always run).
+// What the GEMM full sort of the distance scorers queues behind its re-rank (kge_fullsort_gemm.hip): the exact kernel redoes
+// the batch when a row could not prove its candidate set, and costs two empty launches otherwise -- no host read either way.
+extern "C" int hw_kge_full_sort_topk_if(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                                        int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
+                                        const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k,
+                                        void* workspace, int64_t workspace_bytes, float* out_val, int64_t* out_idx,
+                                        const int32_t* run_if, void* stream) {
+    if (desc && HW_FAMILY_OF(desc->model) == 1)
+        return ext_full_sort_topk(desc, h_idx, r_idx, r_fixed, n_heads, tail_lo, tail_hi, hist_rows, hist_cols, n_hist,
+                                  mask_first_col, k, workspace, workspace_bytes, out_val, out_idx, stream, run_if);
+    return full_sort_topk_impl<0>(desc, h_idx, r_idx, r_fixed, n_heads, tail_lo, tail_hi, hist_rows, hist_cols, n_hist,
+                                  mask_first_col, k, workspace, workspace_bytes, out_val, out_idx, stream, run_if);
+}

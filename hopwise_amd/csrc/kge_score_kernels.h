@@ -530,13 +530,15 @@ template <int MODEL, int G, int NE, bool VEC, int HB>
 __global__ __launch_bounds__(256) void kge_full_sort_topk_kernel(
     hw_kge_desc d, const int64_t* __restrict__ h_idx, const int64_t* __restrict__ r_idx, int64_t r_fixed,
     int n_heads, int64_t lo, int64_t hi, const uint32_t* __restrict__ mask_bits, int64_t mask_words, int64_t mask_col,
-    int k, float* __restrict__ cand_val, int64_t* __restrict__ cand_idx, int64_t n_sub) {
+    int k, float* __restrict__ cand_val, int64_t* __restrict__ cand_idx, int64_t n_sub,
+    const int32_t* __restrict__ run_if) {
     using SC = Scorer<MODEL, G, NE, VEC>;
     using MT = ModelTraits<MODEL>;
     using R = Row<G, NE, VEC>;
     constexpr int NS = HW_WAVE / G;
     constexpr int U = 2;
     __shared__ float lds_sc[4][HB][FS_SUB];
+    if (run_if && *run_if == 0) return;  // predicated launch (hw_kge_full_sort_topk_if): decided on the device, no host read
 
     const int lane = threadIdx.x & (HW_WAVE - 1);
     const int wave = wave_in_block();
@@ -645,9 +647,11 @@ __global__ __launch_bounds__(256) void kge_full_sort_topk_kernel(
 static __global__ __launch_bounds__(256) void topk_candidates_kernel(const float* __restrict__ cand_val,
                                                               const int64_t* __restrict__ cand_idx, int64_t n_cand,
                                                               int k, float* __restrict__ out_val,
-                                                              int64_t* __restrict__ out_idx) {
+                                                              int64_t* __restrict__ out_idx,
+                                                              const int32_t* __restrict__ run_if) {
     __shared__ uint64_t red[4];
     __shared__ uint64_t winner;
+    if (run_if && *run_if == 0) return;
     const float* __restrict__ v = cand_val + (size_t)blockIdx.x * n_cand;
     const int64_t* __restrict__ ix = cand_idx + (size_t)blockIdx.x * n_cand;
     uint64_t bound = ~0ull;
@@ -937,7 +941,7 @@ static int full_sort_topk_impl(const hw_kge_desc* desc, const int64_t* h_idx, co
                                      int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
                                      const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k,
                                      void* workspace, int64_t workspace_bytes, float* out_val, int64_t* out_idx,
-                                     void* stream) {
+                                     void* stream, const int32_t* run_if = nullptr) {
     int rc = check_desc(desc);
     if (rc) return rc;
     if (!h_idx || !out_val || !out_idx || !workspace || n_heads < 1 || n_heads > INT32_MAX) return HW_ERR_INVALID_ARG;
@@ -968,16 +972,16 @@ static int full_sort_topk_impl(const hw_kge_desc* desc, const int64_t* h_idx, co
         if (hb4)                                                                                                      \
             hipLaunchKernelGGL((kge_full_sort_topk_kernel<MODEL, G_, NE_, VEC_, 4>), dim3((unsigned)n_blocks),         \
                                dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, bits, words,      \
-                               mask_col, k, cand_val, cand_idx, n_sub);                                                \
+                               mask_col, k, cand_val, cand_idx, n_sub, run_if);                                        \
         else                                                                                                          \
             hipLaunchKernelGGL((kge_full_sort_topk_kernel<MODEL, G_, NE_, VEC_, 1>), dim3((unsigned)n_blocks),         \
                                dim3(256), 0, st, *desc, h_idx, r_idx, r_fixed, nh, tail_lo, tail_hi, bits, words,      \
-                               mask_col, k, cand_val, cand_idx, n_sub);                                                \
+                               mask_col, k, cand_val, cand_idx, n_sub, run_if);                                        \
     } while (0)
     HW_DISPATCH_MODEL(desc->model, shape, CALL);
 #undef CALL
     hipLaunchKernelGGL(topk_candidates_kernel, dim3((unsigned)n_heads), dim3(256), 0, st, cand_val, cand_idx, n_sub * k, k,
-                       out_val, out_idx);
+                       out_val, out_idx, run_if);
     return HW_LAUNCH_RC();
 }
 
@@ -991,6 +995,7 @@ int ext_full_sort(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* 
 int ext_full_sort_topk(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
                        int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
                        const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k, void* workspace,
-                       int64_t workspace_bytes, float* out_val, int64_t* out_idx, void* stream);
+                       int64_t workspace_bytes, float* out_val, int64_t* out_idx, void* stream,
+                       const int32_t* run_if = nullptr);
 
 }  // namespace hw

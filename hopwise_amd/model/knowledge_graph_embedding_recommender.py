@@ -83,6 +83,11 @@ class _GatherKGE(KnowledgeRecommender):
         self.fused_loss = bool(_cfg(config, "fused_loss", True))
         # bilinear scorers (BILINEAR below): full sorts as one product on the MFMA GEMM (HW_FULLSORT_GEMM=0: the gather kernel)
         self.gemm_full_sort = bool(_cfg(config, "gemm_full_sort", os.environ.get("HW_FULLSORT_GEMM", "1") != "0"))
+        # full_sort_topk of the product form: exact re-rank of the top candidates (None: on for the distance scorers, whose
+        # product scores carry the expansion's rounding; the bilinear products are fp32-accurate as they are)
+        rr = _cfg(config, "gemm_rerank", os.environ.get("HW_FULLSORT_RERANK"))
+        self.gemm_rerank = (self.GEMM_FORM == "distance") if rr is None else str(rr).lower() not in ("0", "false")
+        self.gemm_min_scores = int(_cfg(config, "gemm_min_scores", os.environ.get("HW_FULLSORT_GEMM_MIN", self.GEMM_MIN_SCORES)))
         self.apply(xavier_normal_initialization)
 
     def REL_ROW_FACTOR(self):
@@ -194,56 +199,89 @@ class _GatherKGE(KnowledgeRecommender):
         return self._score("kg", head, interaction[self.RELATION_ID], 0,
                            interaction[self.TAIL_ENTITY_ID].view(-1, 1)).view(-1)
 
-    # -- bilinear scorers: the full sort is a dense product ---------------------------------------------------------
+    # -- full sorts as one dense product ------------------------------------------------------------------------------
     # DistMult / ComplEx / Analogy score <query(h, r), t> with the tail's tables side by side (distmult.py:50-51,
     # complex.py:53-62, analogy.py:66-70): against EVERY candidate that is query [B, K] x table^T [K, N] -- the genuinely dense
-    # contraction the MFMA GEMM is for.  The gather kernel streams every tail row past four queries held in registers and is
-    # bound by vector-instruction issue (~20 wave instructions per score); the product on the split-bf16 GEMM (fp32-level
-    # error) measures 4x faster at Yelp2018's 45 539 items (ComplEx d = 256, 2 048 users: 2.24 -> 0.54 ms; DistMult d = 200:
-    # 1.53 -> 0.35 ms; scores equal to 8e-7 of the largest one; tools/bench_fullsort_gemm.py).
-    BILINEAR = False
+    # contraction the MFMA GEMM is for.  TransE and hopwise's RotatE are L2 distances over the row (transe.py:55-57;
+    # rotate.py:61-69: the Frobenius norm of the (re, im) differences), so ||q - t||^2 = ||q||^2 + ||t||^2 - 2 <q, t> is the
+    # same product followed by one in-place pass (csrc/kge_fullsort_gemm.hip: hw_kge_dist_finish, which recomputes the few
+    # entries where the expansion cancels).  The gather kernel streams every tail row past four queries held in registers
+    # and is bound by vector-instruction issue (~20 wave instructions per score); the product on the split-bf16 GEMM
+    # (fp32-level error) is 3-4x faster at Yelp2018's 45 539 items (tools/bench_fullsort_gemm.py).
+    # The query rows come from the scorers' own fold in one launch (hw_kge_query_rows).
+    GEMM_FORM = None  # "bilinear" | "distance": the scorer's full sort is a dense product
+    RERANK_MARGIN = 6  # full_sort_topk of the product form re-scores the top-(k + margin, rounded up to 8, at least 16) exactly
+    GEMM_MIN_SCORES = 1 << 21  # distance form: below B x N = 2 M scores the gather kernels' one or two launches win
 
-    def _bilinear_query(self, h, r):
-        """query rows [B, K] from the gathered head rows ``h`` and relation rows ``r`` (tuples in table-slot order): the
-        folds of csrc/kge_model.h (Scorer::fold), K = number of tail tables x embedding size."""
-        raise NotImplementedError
+    @classmethod
+    def _rerank_candidates(cls, k, n):
+        return min(max(16, (k + cls.RERANK_MARGIN + 7) // 8 * 8), 64, n)
 
-    def _bilinear_table(self, tail, n):
-        """The first ``n`` rows of the tail tables side by side, [n, K]: the table itself for one table, else a cached copy
-        (rebuilt when a table's storage or version changes; optimizers bump the version, FusedAdam included)."""
+    @property
+    def BILINEAR(self):
+        return self.GEMM_FORM == "bilinear"
+
+    def _cat_tables(self, tail):
+        """The tail tables side by side, [rows, K]: the table itself for one table, else ONE cached copy of the whole tables
+        per version (optimizers bump the version, FusedAdam included), whatever slice is asked for -- items in rec, entities
+        in kg, a shard's rows.  Fenced: evaluation may run on another stream than the one that built it."""
         if len(tail) == 1:
-            return tail[0][:n]
-        # ONE copy of the whole tables per version, whatever n is asked for (items in rec, entities in kg, a shard's rows):
-        # a slice of its first n rows is what the product reads
-        slot = tuple(t.data_ptr() for t in tail)
-        cache = self.__dict__.setdefault("_bilinear_cat", {})
+            return tail[0].detach()
+        slot = ("cat",) + tuple(t.data_ptr() for t in tail)
+        return self._table_cache(slot).get(tuple(t._version for t in tail),
+                                           lambda: torch.cat([t.detach() for t in tail], dim=1).contiguous())
+
+    def _table_cache(self, slot):
+        cache = self.__dict__.setdefault("_gemm_tables", {})
         fv = cache.get(slot)
         if fv is None:
-            cache.clear()  # a table moved (resize, .to()): the old copy is dead weight
+            for stale in [s for s in cache if s[0] == slot[0]]:
+                del cache[stale]  # a table moved (resize, .to()): the old copy is dead weight
             fv = cache[slot] = FencedValue()
-        full = fv.get(tuple(t._version for t in tail), lambda: torch.cat([t.detach() for t in tail], dim=1).contiguous())
-        return full[:n]
+        return fv
 
-    def _full_sort_gemm(self, side, h_idx, r_idx, r_fixed, n):
+    def _bilinear_table(self, tail, n):
+        return self._cat_tables(tail)[:n]
+
+    def _tail_sqnorm(self, tail):
+        """||t||^2 of every candidate row, cached per table version (the distance form)."""
+        slot = ("sqnorm",) + tuple(t.data_ptr() for t in tail)
+        return self._table_cache(slot).get(tuple(t._version for t in tail), lambda: ops.rows_sqnorm(self._cat_tables(tail)))
+
+    def _full_sort_gemm(self, side, h_idx, r_idx, r_fixed, n, padded=False):
+        """[B, n] scores of every candidate.  ``padded``: rows start 256-byte aligned (a view of a wider buffer) so that the
+        product's epilogue, the finish pass and the top-k read and write 16 bytes per lane."""
         head, rel, tail = self._tables(side)
-        h = tuple(t.detach()[h_idx] for t in head)
-        r = tuple((t.detach()[r_idx] if r_idx is not None else t.detach()[r_fixed].unsqueeze(0)) for t in rel)
-        q = self._bilinear_query(h, r).contiguous()
-        return ops.gemm(q, self._bilinear_table(tail, n))
+        dist = self.GEMM_FORM == "distance"
+        q, qn = ops.kge_query_rows(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=dist, margin=self.margin)
+        table = self._cat_tables(tail)[:n]
+        out = None
+        if padded:
+            out = torch.empty((q.shape[0], (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)[:, :n]
+        scores = ops.gemm(q, table, out=out)
+        if dist:
+            base = self.margin if self.MODEL == "RotatE" else 0.0
+            ops.kge_dist_finish_(scores, q, table, qn, self._tail_sqnorm(tail)[:n], base)
+        return scores
 
-    def _use_gemm_full_sort(self, n_queries):
-        return self.BILINEAR and self.gemm_full_sort and n_queries > 0 and "_tables" not in self.__dict__
+    def _use_gemm_full_sort(self, n_queries, n=None):
+        if (self.GEMM_FORM is None or not self.gemm_full_sort or n_queries <= 0 or "_tables" in self.__dict__
+                or self.MODEL not in ops.GEMM_QUERY_MODELS):
+            return False
+        # the product form is ~10 launches (query rows, product, finish, mask, top-c, re-score, re-rank, the predicated
+        # fallback): measured against the gather kernels it wins from a few million scores on (tools/bench_fullsort_dist.py)
+        return self.GEMM_FORM == "bilinear" or n is None or n_queries * n >= self.gemm_min_scores
 
     def full_sort_predict(self, interaction):
         user = interaction[self.USER_ID]
-        if self._use_gemm_full_sort(user.numel()):
+        if self._use_gemm_full_sort(user.numel(), self.n_items):
             return self._full_sort_gemm("rec", user, None, self._rec_rel_full_sort(), self.n_items)
         head, rel, tail = self._tables("rec")
         return ops.kge_full_sort(self.MODEL, head, rel, tail, user, None, self._rec_rel_full_sort(), 0, self.n_items,
                                  self.margin)
 
     def full_sort_predict_kg(self, interaction):
-        if self._use_gemm_full_sort(interaction[self.HEAD_ENTITY_ID].numel()):
+        if self._use_gemm_full_sort(interaction[self.HEAD_ENTITY_ID].numel(), self.n_entities):
             return self._full_sort_gemm("kg", interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], 0,
                                         self.n_entities)
         head, rel, tail = self._tables("kg")
@@ -251,22 +289,36 @@ class _GatherKGE(KnowledgeRecommender):
                                  interaction[self.RELATION_ID], 0, 0, self.n_entities, self.margin)
 
     def full_sort_topk(self, interaction, k, history_index=None, kg=False):
-        """Top-k of the masked full sort (trainer.py:731-734 + collector.py:173-183) without the [B, N] matrix."""
-        n_q = interaction[self.HEAD_ENTITY_ID if kg else self.USER_ID].numel()
-        if self._use_gemm_full_sort(n_q):
-            # the product + mask + top-k on the written matrix beats the fused gather kernel for these scorers (the matrix is
-            # written and re-read, but at a quarter of the scoring time)
-            scores = self.full_sort_predict_kg(interaction) if kg else self.full_sort_predict(interaction)
+        """Top-k of the masked full sort (trainer.py:731-734 + collector.py:173-183): (values [B, k], columns [B, k]).
+
+        Product form (GEMM_FORM): scores -> mask -> top-c.  With ``gemm_rerank`` (default for the distance scorers) the c
+        candidates are re-scored by the gather scorer -- the kernel ``predict`` runs -- and ranked by (exact value desc,
+        column asc); the re-rank proves on the device that no column outside the candidates can belong to the top-k, and the
+        fused gather kernel, queued behind it under that flag as its predicate, redoes the batch in the rare case it cannot.
+        The result is the gather path's, score for score."""
+        side = "kg" if kg else "rec"
+        h_idx = interaction[self.HEAD_ENTITY_ID if kg else self.USER_ID]
+        r_idx = interaction[self.RELATION_ID] if kg else None
+        r_fixed = 0 if kg else self._rec_rel_full_sort()
+        n = self.n_entities if kg else self.n_items
+        head, rel, tail = self._tables(side)
+        if self._use_gemm_full_sort(h_idx.numel(), n):
+            c = self._rerank_candidates(k, n)
+            rerank = self.gemm_rerank and k <= c
+            # the product + mask + top-k on the written matrix beats the fused gather kernel (the matrix is written and
+            # re-read, but at a quarter of the scoring time)
+            scores = self._full_sort_gemm(side, h_idx, r_idx, r_fixed, n, padded=True)
             ops.mask_scores_(scores, history_index)
-            return ops.topk_rows(scores, k)
-        if kg:
-            head, rel, tail = self._tables("kg")
-            return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, interaction[self.HEAD_ENTITY_ID],
-                                          interaction[self.RELATION_ID], 0, 0, self.n_entities, k, history_index, True,
-                                          self.margin)
-        head, rel, tail = self._tables("rec")
-        return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, interaction[self.USER_ID], None,
-                                      self._rec_rel_full_sort(), 0, self.n_items, k, history_index, True, self.margin)
+            if not rerank:
+                return ops.topk_rows(scores, k)
+            approx, cand = ops.topk_rows(scores, c)
+            desc = ops.make_desc(self.MODEL, head, rel, tail, self.margin, 0.0, n)
+            exact = ops.kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, cand)  # c <= n: every candidate is a column
+            val, idx, flag = ops.topk_rerank(cand, approx, exact, k)
+            return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, 0, n, k, history_index, True,
+                                          self.margin, run_if=flag, out=(val, idx))
+        return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, 0, n, k, history_index, True,
+                                      self.margin)
 
     # -- extension: grouped negatives ---------------------------------------------------------------
     def score_grouped(self, side, h_idx, r_idx, t_idx):
@@ -295,6 +347,7 @@ class TransE(_GatherKGE):
         return self.n_relations - 1
 
     _rec_rel_full_sort = _rec_rel_loss
+    GEMM_FORM = "distance"
 
     def calculate_loss(self, interaction):
         # TripletMarginLoss(margin, p=2) on (h + r, t+, t-) over cat(rec, kg) (transe.py:86-96); its
@@ -317,10 +370,7 @@ class DistMult(_GatherKGE):
         return self.n_relations - 1
 
     _rec_rel_full_sort = _rec_rel_loss
-    BILINEAR = True
-
-    def _bilinear_query(self, h, r):
-        return h[0] * r[0]
+    GEMM_FORM = "bilinear"
 
     def calculate_loss(self, interaction):  # distmult.py:69-95
         if self.fused_loss:
@@ -336,7 +386,7 @@ class RESCAL(DistMult):
     cat(rec, kg) (rescal.py:73-99); the rec side uses relation_embedding.weight[-1] (rescal.py:60,108,133)."""
 
     MODEL = "RESCAL"
-    BILINEAR = False  # the query h^T M_r is a d x d product per (h, r): built inside the gather kernel
+    GEMM_FORM = None  # the query h^T M_r is a d x d product per (h, r): built inside the gather kernel
 
     def REL_ROW_FACTOR(self):
         return self.embedding_size
@@ -376,6 +426,7 @@ class _BceKGE(_GatherKGE):
 
 class RotatE(_BceKGE):
     MODEL = "RotatE"
+    GEMM_FORM = "distance"  # rotate.py:61-69: margin - the L2 norm over the 2 d (re, im) differences
     USER_TABLES = ("user_embedding", "user_embedding_im")
     ENTITY_TABLES = ("entity_embedding", "entity_embedding_im")
     RELATION_TABLES = ("relation_embedding",)
@@ -398,10 +449,7 @@ class ComplEx(_BceKGE):
     def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (complex.py:167-168)
         return self.n_relations - 1
 
-    BILINEAR = True
-
-    def _bilinear_query(self, h, r):  # complex.py:54-59, the reference's t_im in the last term included
-        return torch.cat([h[0] * r[0], h[1] * r[0] + h[0] * r[1] - h[1] * r[1]], dim=1)
+    GEMM_FORM = "bilinear"  # query (Scorer::fold): complex.py:54-59, the reference's t_im in the last term included
 
 
 class TorusE(TransE):
@@ -410,6 +458,7 @@ class TorusE(TransE):
     used in training -- so the loss path runs the TransE scorer."""
 
     MODEL = "TorusE"
+    GEMM_FORM = None  # not an L2 distance of (q, t) / not a fold of (h, r): the gather kernels
     LOSS_MODEL = "TransE"
 
 
@@ -418,6 +467,7 @@ class TransH(TransE):
     so the projected difference is (h - t) * (1 - sum(w) w); TripletMarginLoss over cat(rec, kg); no kg-side predictors."""
 
     MODEL = "TransH"
+    GEMM_FORM = None  # not an L2 distance of (q, t) / not a fold of (h, r): the gather kernels
     RELATION_TABLES = ("relation_embedding", "norm_vec")
 
     def __init__(self, config, dataset):
@@ -438,6 +488,7 @@ class TransD(TransE):
     """transd.py:20-217: p_r(e) = r_vec (e . e_vec) + e; TripletMarginLoss over cat(rec, kg)."""
 
     MODEL = "TransD"
+    GEMM_FORM = None  # not an L2 distance of (q, t) / not a fold of (h, r): the gather kernels
     USER_TABLES = ("user_embedding", "user_vec_embedding")
     ENTITY_TABLES = ("entity_embedding", "entity_vec_embedding")
     RELATION_TABLES = ("relation_embedding", "relation_vec_embedding")
@@ -478,10 +529,7 @@ class Analogy(_GatherKGE):
     def _rec_rel_full_sort(self):  # relation_*_embedding.weight[-1]  (analogy.py:222-224)
         return self.n_relations - 1
 
-    BILINEAR = True
-
-    def _bilinear_query(self, h, r):  # analogy.py:66-70: DistMult on (e) + the complex product on (re, im)
-        return torch.cat([h[0] * r[0], h[1] * r[1] - h[2] * r[2], h[1] * r[2] + h[2] * r[1]], dim=1)
+    GEMM_FORM = "bilinear"  # query (Scorer::fold): analogy.py:66-70, DistMult on (e) + the complex product on (re, im)
 
     def calculate_loss(self, interaction):
         # LogisticLoss(-pos, -neg) = mean softplus(-pos) + mean softplus(neg) (loss.py:172-190): twice the BCE-with-logits
@@ -497,6 +545,7 @@ class HolE(TransE):
     MarginRankingLoss(sigmoid(pos), sigmoid(neg), 1) over cat(rec, kg)."""
 
     MODEL = "HolE"
+    GEMM_FORM = None  # not an L2 distance of (q, t) / not a fold of (h, r): the gather kernels
 
     def calculate_loss(self, interaction):
         if self.fused_loss:

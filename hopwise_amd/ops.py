@@ -527,8 +527,10 @@ def kge_full_sort(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, margin=
 
 
 def kge_full_sort_topk(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, k, history_index=None, mask_first_col=True,
-                       margin=0.0):
-    """Masked top-k of the full sort without the [B, N] matrix: (values [B, k], column indices [B, k])."""
+                       margin=0.0, run_if=None, out=None):
+    """Masked top-k of the full sort without the [B, N] matrix: (values [B, k], column indices [B, k]).
+    ``run_if`` (int32 [1] on the device) + ``out`` = (values, indices): the launches are predicated on ``run_if[0] != 0`` and
+    leave ``out`` untouched otherwise (hw_kge_full_sort_topk_if: the exact fallback behind :func:`topk_rerank`)."""
     lib = _lib.load()
     desc = make_desc(model, head, rel, tail, margin, 0.0)
     h_idx = _idx(h_idx, "h_idx").contiguous()
@@ -545,12 +547,95 @@ def kge_full_sort_topk(model, head, rel, tail, h_idx, r_idx, r_fixed, lo, hi, k,
         nh = hr.numel()
     nbytes = int(lib.hw_kge_full_sort_topk_workspace_bytes(B, hi - lo, int(k)))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=h_idx.device)
-    val = torch.empty((B, k), dtype=torch.float32, device=h_idx.device)
-    idx = torch.empty((B, k), dtype=torch.int64, device=h_idx.device)
-    check(lib.hw_kge_full_sort_topk(C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, int(lo), int(hi), _ptr(hr),
-                                    _ptr(hc), nh, int(bool(mask_first_col)), int(k), _ptr(ws), nbytes, _ptr(val), _ptr(idx),
-                                    _stream()), "hw_kge_full_sort_topk")
+    if out is None:
+        val = torch.empty((B, k), dtype=torch.float32, device=h_idx.device)
+        idx = torch.empty((B, k), dtype=torch.int64, device=h_idx.device)
+    else:
+        val, idx = _dev(out[0], torch.float32, "out values"), _dev(out[1], torch.int64, "out indices")
+        if val.shape != (B, k) or idx.shape != (B, k) or not val.is_contiguous() or not idx.is_contiguous():
+            raise ValueError("out must be contiguous ([B, k] float32, [B, k] int64)")
+    if run_if is None:
+        check(lib.hw_kge_full_sort_topk(C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, int(lo), int(hi), _ptr(hr),
+                                        _ptr(hc), nh, int(bool(mask_first_col)), int(k), _ptr(ws), nbytes, _ptr(val),
+                                        _ptr(idx), _stream()), "hw_kge_full_sort_topk")
+    else:
+        run_if = _dev(run_if, torch.int32, "run_if")
+        check(lib.hw_kge_full_sort_topk_if(C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, int(lo), int(hi),
+                                           _ptr(hr), _ptr(hc), nh, int(bool(mask_first_col)), int(k), _ptr(ws), nbytes,
+                                           _ptr(val), _ptr(idx), _ptr(run_if), _stream()), "hw_kge_full_sort_topk_if")
     return val, idx
+
+
+# ---- full sorts as one dense product (csrc/kge_fullsort_gemm.hip) -----------------------------------------------------
+GEMM_QUERY_MODELS = ("TransE", "DistMult", "RotatE", "ComplEx", "Analogy")
+DIST_RESCORE_FRAC = 1.0 / 16.0  # d^2 below this fraction of ||q||^2 + ||t||^2: recomputed from the rows (cancellation)
+
+
+def kge_query_rows(model, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=False, margin=0.0):
+    """(query rows [B, NQ * dim], ||query||^2 [B] or None): the folded queries of a full sort as a dense matrix."""
+    lib = _lib.load()
+    desc = make_desc(model, head, rel, tail, margin, 0.0)
+    h_idx = _idx(h_idx, "h_idx").contiguous()
+    if r_idx is not None:
+        r_idx = _idx(r_idx, "r_idx").contiguous()
+    B = h_idx.shape[0]
+    K = len(tail) * desc.dim
+    out = torch.empty((B, K), dtype=torch.float32, device=h_idx.device)
+    qn = torch.empty(B, dtype=torch.float32, device=h_idx.device) if sqnorm else None
+    if B:
+        check(lib.hw_kge_query_rows(C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, _ptr(out), K, _ptr(qn),
+                                    _ptr(_OobCounter.get(h_idx.device)), _stream()), "hw_kge_query_rows")
+    return out, qn
+
+
+def rows_sqnorm(x):
+    """sum_k x[j, k]^2 per row of a [rows, k] fp32 matrix (unit inner stride)."""
+    lib = _lib.load()
+    x = _dev(x, torch.float32, "x")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be [rows, k] with unit inner stride")
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    if x.shape[0]:
+        check(lib.hw_rows_sqnorm(_ptr(x), x.stride(0), x.shape[0], x.shape[1], _ptr(out), _stream()), "hw_rows_sqnorm")
+    return out
+
+
+def kge_dist_finish_(dots, q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRAC, mask_column0=False, counter=None):
+    """In place: dots[i, j] = <q_i, t_j>  ->  base - ||q_i - t_j||  (hw_kge_dist_finish)."""
+    lib = _lib.load()
+    c = _dev(dots, torch.float32, "dots")
+    q, t = _dev(q, torch.float32, "q"), _dev(t, torch.float32, "t")
+    qn, tn = _dev(qn, torch.float32, "qn").contiguous(), _dev(tn, torch.float32, "tn").contiguous()
+    if c.dim() != 2 or c.stride(1) != 1 or q.stride(1) != 1 or t.stride(1) != 1:
+        raise ValueError("matrices need unit inner stride")
+    m, n = c.shape
+    if q.shape[0] != m or t.shape[0] != n or q.shape[1] != t.shape[1] or qn.numel() != m or tn.numel() != n:
+        raise ValueError("shape mismatch")
+    if m and n:
+        check(lib.hw_kge_dist_finish(_ptr(c), c.stride(0), m, n, _ptr(q), q.stride(0), _ptr(t), t.stride(0), q.shape[1],
+                                     _ptr(qn), _ptr(tn), float(base), float(rescore_frac), int(bool(mask_column0)),
+                                     _ptr(counter), _stream()), "hw_kge_dist_finish")
+    return dots
+
+
+def topk_rerank(cand_idx, cand_approx, cand_exact, k, rel_slack=5e-5, abs_slack=1e-6, unverified=None):
+    """(values [R, k], indices [R, k], unverified int32 [1]): the exact top-k out of c <= 64 re-scored candidates per row
+    (hw_topk_rerank), with the device-side proof that the candidate set sufficed."""
+    lib = _lib.load()
+    ci = _idx(cand_idx, "cand_idx").contiguous()
+    ca = _dev(cand_approx, torch.float32, "cand_approx").contiguous()
+    ce = _dev(cand_exact, torch.float32, "cand_exact").contiguous()
+    R, c = ci.shape
+    if ca.shape != (R, c) or ce.shape != (R, c):
+        raise ValueError("candidate arrays must share one [rows, c] shape")
+    val = torch.empty((R, k), dtype=torch.float32, device=ci.device)
+    idx = torch.empty((R, k), dtype=torch.int64, device=ci.device)
+    if unverified is None:
+        unverified = torch.zeros(1, dtype=torch.int32, device=ci.device)
+    if R:
+        check(lib.hw_topk_rerank(_ptr(ci), _ptr(ca), _ptr(ce), R, c, int(k), float(rel_slack), float(abs_slack), _ptr(val),
+                                 _ptr(idx), _ptr(unverified), _stream()), "hw_topk_rerank")
+    return val, idx, unverified
 
 
 class ProjectRows(torch.autograd.Function):
@@ -694,11 +779,12 @@ def self_adversarial_mean(scores, alpha):
 # ------------------------------------------------------------------------------------------------
 def mask_scores_(scores, history_index=None, column0=True):
     """In place: scores[:, 0] = -inf; scores[history_index] = -inf (trainer.py:731-734).  ``column0=False``: history entries
-    only (a shard whose column 0 is not entity 0); entries outside the matrix are ignored."""
+    only (a shard whose column 0 is not entity 0); entries outside the matrix are ignored.  Rows may be padded (any leading
+    dimension, unit column stride)."""
     lib = _lib.load()
     s = _dev(scores, torch.float32, "scores")
-    if s.dim() != 2 or not s.is_contiguous():
-        raise ValueError("scores must be contiguous [rows, cols]")
+    if s.dim() != 2 or (s.shape[1] > 1 and s.stride(1) != 1):
+        raise ValueError("scores must be [rows, cols] with unit column stride")
     hr = hc = None
     n = 0
     if history_index is not None:
@@ -707,13 +793,13 @@ def mask_scores_(scores, history_index=None, column0=True):
         n = hr.numel()
     if s.shape[0] == 0:
         return scores
-    check(lib.hw_mask_scores_ex(_ptr(s), s.shape[0], s.shape[1], _ptr(hr), _ptr(hc), n, int(bool(column0)), _stream()),
-          "hw_mask_scores_ex")
+    check(lib.hw_mask_scores_ld(_ptr(s), s.shape[0], s.shape[1], max(s.stride(0), s.shape[1]), _ptr(hr), _ptr(hc), n,
+                                int(bool(column0)), _stream()), "hw_mask_scores_ld")
     return scores
 
 
 def topk_rows(scores, k, two_stage=True):
-    """Row-wise top-k ordered (value desc, index asc): (values [R, k] fp32, indices [R, k] int64).  Long rows (>= 8192 columns,
+    """Row-wise top-k ordered (value desc, index asc): (values [R, k] fp32, indices [R, k] int64).  Long rows (>= 1024 columns,
     k <= 64) go through the two-stage form (hw_topk_rows_ws: each row read once); ``two_stage=False`` keeps the one-block-per-row
     kernel, for the tests that hold the two against each other."""
     lib = _lib.load()

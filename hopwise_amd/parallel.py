@@ -435,13 +435,11 @@ class RowShardedKGE(nn.Module):
 
     def _local_scores_gemm(self, head, inv, r_idx, r_fixed, n_loc):
         m = self.model
-        h = tuple(t[inv] for t in head)
-        r = tuple((t.detach()[r_idx] if r_idx is not None else t.detach()[r_fixed].unsqueeze(0))
-                  for t in m._w(m.RELATION_TABLES))
-        q = m._bilinear_query(h, r).contiguous()
+        shards = self._shards(m.ENTITY_TABLES)
+        q, _ = ops.kge_query_rows(m.MODEL, head, m._w(m.RELATION_TABLES), shards, inv, r_idx, r_fixed)
         if n_loc == 0:
             return torch.empty((q.shape[0], 0), dtype=torch.float32, device=q.device)
-        return ops.gemm(q, m._bilinear_table(self._shards(m.ENTITY_TABLES), n_loc))
+        return ops.gemm(q, m._bilinear_table(shards, n_loc))
 
     @torch.no_grad()
     def full_sort_topk(self, interaction, k, history_index=None, kg=False):

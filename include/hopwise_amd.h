@@ -155,6 +155,49 @@ int hw_kge_full_sort_topk(const hw_kge_desc* desc, const int64_t* h_idx, const i
                           const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k,
                           void* workspace, int64_t workspace_bytes, float* out_val, int64_t* out_idx, void* stream);
 
+/* hw_kge_full_sort_topk under a device-side predicate: every workgroup leaves at once unless *run_if != 0 (run_if == NULL:
+ * always run).  The exact fallback queued behind the re-rank of the GEMM full sort below; no host read decides it. */
+int hw_kge_full_sort_topk_if(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
+                             int64_t n_heads, int64_t tail_lo, int64_t tail_hi, const int64_t* hist_rows,
+                             const int64_t* hist_cols, int64_t n_hist, int32_t mask_first_col, int32_t k,
+                             void* workspace, int64_t workspace_bytes, float* out_val, int64_t* out_idx,
+                             const int32_t* run_if, void* stream);
+
+/* ---- full sorts as one dense product (csrc/kge_fullsort_gemm.hip) ------------------------------------------------------
+ * The full_sort_predict / full_sort_predict_kg of the reference expand the query against every candidate row
+ * (transe.py:112-154, rotate.py:161-220, distmult.py:100-146, complex.py:160-219, analogy.py:66-70 + its full sorts).
+ * Bilinear scorers: score = <query(h, r), tail> -- one hw_gemm_f32 of the query rows with the candidate table.  TransE and
+ * hopwise's RotatE (an L2 norm over the 2 d (re, im) differences, rotate.py:61-69): ||q - t||^2 = ||q||^2 + ||t||^2 - 2 <q, t>,
+ * the same product followed by hw_kge_dist_finish.
+ *
+ * hw_kge_query_rows: out[i, :] = the folded query of (h_idx[i], r_idx[i] or r_fixed) -- the model's query slots side by side,
+ * [n, NQ * dim] with NQ = 1 (TransE: h + r; DistMult: h * r), 2 (RotatE: the rotated head (re | im); ComplEx: complex.py:54-59
+ * with the reference's t_im in the last term), 3 (Analogy); ld >= NQ * dim.  sqnorm (nullable) [n] receives ||query||^2.
+ * Replaces the torch gathers / products / cat in front of the product.  Other models: HW_ERR_UNSUPPORTED. */
+int hw_kge_query_rows(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed, int64_t n,
+                      float* out, int64_t ld, float* sqnorm, int32_t* oob_counter, void* stream);
+/* out[j] = sum_k x[j, k]^2 for the n_rows rows of x [n_rows, k] (leading dimension ld): ||t||^2 of the candidate rows. */
+int hw_rows_sqnorm(const float* x, int64_t ld, int64_t n_rows, int32_t k, float* out, void* stream);
+/* In place on c [m, n] (leading dimension ldc) holding <q_i, t_j>:  c[i, j] = base - sqrt(max(qn[i] + tn[j] - 2 c[i, j], 0))
+ * (base = margin for RotatE, 0 for TransE).  Where the expansion cancels -- d^2 < rescore_frac * (qn[i] + tn[j]) -- the entry
+ * is recomputed as sum_k (q[i, k] - t[j, k])^2 from the rows, so that every score is fp32-accurate (a few 1e-6 relative).
+ * mask_column0: column 0 = -inf (trainer.py:733).  n_rescored (nullable): counter of recomputed entries.  m <= 65535. */
+int hw_kge_dist_finish(float* c, int64_t ldc, int64_t m, int64_t n, const float* q, int64_t ldq, const float* t,
+                       int64_t ldt, int32_t k, const float* qn, const float* tn, float base, float rescore_frac,
+                       int32_t mask_column0, int32_t* n_rescored, void* stream);
+/* hw_mask_scores_ex on rows with a leading dimension (a padded score matrix). */
+int hw_mask_scores_ld(float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, const int64_t* hist_rows,
+                      const int64_t* hist_cols, int64_t n_hist, int32_t mask_column0, void* stream);
+/* Exact top-k from c <= 64 candidates per row: cand_idx [m, c] columns (top-c of an approximate score matrix; -1 = none),
+ * cand_approx [m, c] their approximate scores (-inf = masked column: stays -inf), cand_exact [m, c] the same candidates
+ * re-scored exactly.  Writes the k best by (exact value desc, column asc) -- the order of hw_topk_rows -- and ORs 1 into
+ * *unverified when a row cannot prove that no column outside its candidate set belongs to its top-k: proven when the exact
+ * k-th value > min(cand_approx) + rel_slack * |min(cand_approx)| + abs_slack (a column outside the set has an approximate
+ * score <= that minimum), or when the set holds every unmasked column. */
+int hw_topk_rerank(const int64_t* cand_idx, const float* cand_approx, const float* cand_exact, int64_t m, int32_t c,
+                   int32_t k, float rel_slack, float abs_slack, float* out_val, int64_t* out_idx, int32_t* unverified,
+                   void* stream);
+
 /* Backward of hw_kge_score_grouped: given g[b, j] = dLoss/dscore[b, j] (same strides as `out`),
  * atomically accumulates the row gradients into `grads`.  Replaces autograd through
  * nn.Embedding + <Model>.forward (dense embedding_dense_backward in the reference).
@@ -240,7 +283,7 @@ int hw_topk_rows(const float* scores, int64_t n_rows, int64_t n_cols, int64_t ld
                  float* out_val, int64_t* out_idx, void* stream);
 
 /* The same result (bit for bit, ties included) for long rows in two stages: the row is cut into chunks of 4096 columns,
- * each read once and reduced to its k best, then the k best of those.  Taken when n_cols >= 8192 and k <= 64; otherwise the
+ * each read once and reduced to its k best, then the k best of those.  Taken when n_cols >= 1024 and k <= 64; otherwise the
  * call is hw_topk_rows and needs no workspace (hw_topk_rows_workspace_bytes returns 0).  workspace: 8-byte aligned,
  * n_rows * ceil(n_cols / 4096) * k * 8 bytes; HW_ERR_WORKSPACE when smaller. */
 int64_t hw_topk_rows_workspace_bytes(int64_t n_rows, int64_t n_cols, int32_t k);

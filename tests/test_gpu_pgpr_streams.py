@@ -224,8 +224,9 @@ def test_first_multi_stream_evaluation_after_an_optimizer_step_reads_finished_ca
     # 2. after optimizer steps (FusedAdam writes through raw pointers and bumps the version counters: the caches are stale)
     opt = FusedAdam(m.parameters(), lr=5e-2)
     for step in range(3):
-        for p in m.parameters():
-            p.grad = torch.randn_like(p)
+        for p in m.parameters():  # FusedAdam's gradient sinks are the persistent p.grad buffers: written in place
+            p.grad.copy_(torch.randn_like(p))
+        opt.mark_touched()
         opt.step()
         ref = sequential_copy()
         got = m.full_sort_predict(inter)  # multi-stream FIRST, on cold caches

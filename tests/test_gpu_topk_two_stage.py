@@ -17,7 +17,11 @@ def _lexsort_topk(a, k):
 
 
 @pytest.mark.parametrize("rows,cols,ld,k", [
-    (3, 8192, 8192, 10),        # the first size the two-stage form takes: two full chunks
+    (3, 8192, 8192, 10),        # two full chunks
+    (4, 1024, 1024, 10),        # the first size the two-stage form takes (round 5; 8 192 before): a quarter of one chunk
+    (9, 2985, 3008, 16),        # ml-1m-small's items in padded, 16-byte aligned rows (the float4 form of the chunk kernel)
+    (9, 2985, 2985, 16),        # ... and unaligned
+    (3, 4097, 4100, 32),        # one column into a second chunk, aligned padded rows
     (5, 8193, 8200, 1),         # one column into a third chunk, padded rows
     (2, 45539, 45539, 64),      # Yelp2018's item count, the largest k of the two-stage form
     (7, 100001, 100003, 10),
@@ -75,7 +79,7 @@ def test_small_workspace_is_refused():
     rc = lib.hw_topk_rows_ws(s.data_ptr(), 2, 9000, 9000, 4, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), 64, None)
     assert rc == -4
     # short rows: the call is hw_topk_rows and takes no workspace
-    assert lib.hw_topk_rows_workspace_bytes(2, 5000, 4) == 0
-    assert lib.hw_topk_rows_ws(s.data_ptr(), 2, 5000, 9000, 4, val.data_ptr(), idx.data_ptr(), None, 0, None) == 0
+    assert lib.hw_topk_rows_workspace_bytes(2, 1000, 4) == 0
+    assert lib.hw_topk_rows_ws(s.data_ptr(), 2, 1000, 9000, 4, val.data_ptr(), idx.data_ptr(), None, 0, None) == 0
     torch.cuda.synchronize()
     assert idx[0].tolist() == [0, 1, 2, 3]
