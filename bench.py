@@ -25,7 +25,8 @@ weak scaling, no data-path collective -- DESIGN.md §5); the line also carries t
 row gradients + all-reduce of the replicated relation tables inside the timed step), which is what exercises xGMI.
 
 Legs in the JSON line: `roofline` (the scorer kernel: HBM-resident variant as the roofline of record, the configs[1]
-launch against the L2 gather ceiling, the entity-tail variants), `cpu_baseline` (oracle/kge_ref.c on the host
+launch against the L2 gather ceiling, the entity-tail variants, `other_scorers` = the same launch shape for TransE d=64 / d=200,
+DistMult d=200, ComplEx d=256 on >= 4 GB tables), `configs0` (TransE d=64 in the reference's layout), `cpu_baseline` (oracle/kge_ref.c on the host
 cores), `sharded` (configs[3]), `tucker` (configs[4], N = 1), `reference_layout` (configs[1] in the reference's batch
 layout through the model class, N = 1), `pgpr` (configs[2]).
 """
@@ -117,9 +118,10 @@ def launch_ranks(args, argv):
             line = ln
         else:
             print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)  # kept whatever the exit code: a timed-out sharded leg still leaves the replica numbers
     if p.returncode != 0 or line is None:
         sys.exit(f"bench.py: the {args.gpus}-rank run failed (exit code {p.returncode})")
-    print(line)
 
 
 class Dist:
@@ -568,11 +570,14 @@ def leg_roofline_variants(D, args, out, ctx):
                     "against the L2 gather ceiling instead.  The roofline of record is the instantiation the timed region "
                     "launches (fused_instantiation); plain_scorer is the same kernel without sampler and loss",
         "gather_ceiling_note": "the guide's measured random-row gather from HBM is 5.5-5.8 TB/s (1.1-2.3 KB rows)",
-        "traffic_note": "traffic / algorithmic = 1.14: an 800-byte row (d = 200 floats) always occupies 7 lines of 128 B "
-                        "(6.25 needed) whatever its alignment, and RotatE reads two such rows (re, im tables) per tail: 14 lines "
-                        "for 1 600 B = 1.12x, plus the id matrix and the scores.  Not re-reads, and not what bounds the launch: "
-                        "with re | im interleaved in one 1 600-byte row (13 lines; row-strided descriptor, measured) the same "
-                        "launch takes the same 153.8 us (DESIGN.md \u00a78)",
+        "traffic_source": ctx["traffic"].get("source"),
+        "traffic_note": (f"traffic / algorithmic = {head['traffic'] / abytes:.3f} (PMC pass: {ctx['traffic'].get('source')}): "
+                         if head["traffic"] else "no PMC pass on file: ") +
+                        "an 800-byte row (d = 200 floats) always occupies 7 lines of 128 B (6.25 needed) whatever its "
+                        "alignment, and RotatE reads two such rows (re, im tables) per tail: 14 lines for 1 600 B = 1.12x, plus the "
+                        "id matrix and the scores.  Not re-reads, and not what bounds the launch: with re | im interleaved in one "
+                        "1 600-byte row (13 lines; row-strided descriptor, measured) the same launch takes the same time "
+                        "(DESIGN.md \u00a78)",
     }
     # the same launches alternating over two streams (what the timed region of the headline does): aggregate rate only --
     # the roofline of record stays the lone launch above
@@ -608,6 +613,122 @@ def leg_roofline_variants(D, args, out, ctx):
     out["roofline"] = {**rec, "configs1_launch": cfg1, "entity_tails": ent}
     del big_re, big_im, bidx, t_big, bused
     torch.cuda.empty_cache()
+
+
+SCORER_MODEL_ID = {"TransE": 0, "RotatE": 1, "ComplEx": 2, "DistMult": 3}
+
+
+def scorer_algorithmic_bytes_per_triple(model, dim, k=K_NEG):
+    """SURVEY.md \u00a78(d): tail rows NT*d*4 + tail id 8 + score 4 + the group's shared (NH + NR) rows and 2 ids over its K + 1 triples."""
+    nh, nr, nt = {"TransE": (1, 1, 1), "DistMult": (1, 1, 1), "RotatE": (2, 1, 2), "ComplEx": (2, 2, 2)}[model]
+    return nt * dim * 4 + 8 + 4 + ((nh + nr) * dim * 4 + 16) / (k + 1)
+
+
+def leg_scorer_rooflines(D, args, traffic):
+    """HBM rooflines of the other three named scorers (north star: TransE / RotatE / ComplEx / DistMult forward) and of
+    configs[0]'s width: the grouped launch of the headline's shape (2048 groups x (1 + 256) tails, pre-drawn ids) on tail
+    tables of >= 4 GB, tails ~ randint over all rows -- every tail row an HBM miss, as for the RotatE roofline of record."""
+    torch, dev = D.torch, D.dev
+    from hopwise_amd import ops
+
+    gen = torch.Generator(device=dev).manual_seed(77)
+    res = {"shape": f"{B_POS} groups x (1 + {K_NEG}) tails per launch, ids pre-drawn, tail tables >= 4 GB",
+           "traffic_source": traffic.get("source")}
+    tpb = B_POS * (1 + K_NEG)
+    n_head, n_rel = 6041, 13
+    for tag, model, dim in (("transe_d64", "TransE", 64), ("transe_d200", "TransE", 200), ("distmult_d200", "DistMult", 200),
+                            ("complex_d256", "ComplEx", 256)):
+        nh, nr, nt = {"TransE": (1, 1, 1), "DistMult": (1, 1, 1), "ComplEx": (2, 2, 2)}[model]
+        rows = int(math.ceil(4.2e9 / (nt * dim * 4) / 65536) * 65536)
+        tail = tuple(torch.randn(rows, dim, device=dev) * 0.01 for _ in range(nt))
+        head = tuple(torch.randn(n_head, dim, device=dev) * 0.01 for _ in range(nh))
+        rel = tuple(torch.randn(n_rel, dim, device=dev) * 0.01 for _ in range(nr))
+        desc = ops.make_desc(model, head, rel, tail, margin=1.0)
+        users = torch.randint(1, n_head, (B_POS,), device=dev, dtype=torch.int64, generator=gen)
+        idx = torch.randint(1, rows, (B_POS, 1 + K_NEG), device=dev, dtype=torch.int64, generator=gen)
+        shape_g = 16 if dim // 4 <= 16 else (32 if dim // 4 <= 32 else 64)
+        kname = f"kge_score_grouped_kernel<{SCORER_MODEL_ID[model]}, {shape_g}, 4, true, 4, false"
+        ms, reps = _time_kernel(torch, lambda: ops.kge_score_grouped_raw(desc, users, None, n_rel - 1, idx),
+                                tag=f"scorer_hbm_{tag}", kernel=kname)
+        abytes = scorer_algorithmic_bytes_per_triple(model, dim) * tpb
+        ach = abytes / (ms * 1e-3) / 1e9
+        tr = traffic.get(f"scorer_hbm_{tag}_bytes_per_launch")
+        res[tag] = {"bound": "hbm", "kernel": f"kge_score_grouped_kernel<{model}> d={dim}", "kernel_ms": ms, "launches": reps,
+                    "algorithmic_bytes_per_triple": scorer_algorithmic_bytes_per_triple(model, dim),
+                    "algorithmic_bytes_per_launch": abytes, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_over_algorithmic": (tr / abytes if tr else None),
+                    "triples_per_s": tpb / (ms * 1e-3), "table_GB": nt * rows * dim * 4 / 1e9, "tail_rows": rows}
+        del tail, head, rel, desc, idx
+        torch.cuda.empty_cache()
+    res["note"] = ("a row of d floats occupies ceil-ish(4 d / 128) + 1 lines of 128 B at a random 16-byte alignment (d = 64: 256 B = "
+                   "2-3 lines; d = 200: 800 B = 7; d = 256: 1 KB = 8-9), so traffic / algorithmic is largest for the short rows; "
+                   "the launch is bound by row requests in flight (DESIGN.md \u00a74), which is why the short-row scorers sit "
+                   "furthest below the byte peak")
+    return res
+
+
+def leg_configs0(D, args):
+    """BASELINE.json configs[0]: TransE d=64 on the ml-1m-small shape in the layout hopwise's KnowledgeBasedDataLoader yields
+    with the reference's defaults (train_batch_size 2048, one negative per positive): 2048 rec (pos, neg) pairs + 2048 kg pairs
+    = 8 192 scored triples per calculate_loss, through hopwise_amd.model.TransE -- forward, the trainer's step, its graph replay."""
+    import numpy as np
+
+    torch, dev = D.torch, D.dev
+    import hopwise_amd.model as M
+    from hopwise_amd.driver import GraphedTrainStep
+    from hopwise_amd.optim import FusedAdam
+    from tests.helpers import FakeDataset, make_config
+
+    nU, nI, nE, nR, B, d = 6041, 2985, 13805, 13, 2048, 64
+    rng = np.random.default_rng(0)
+    torch.manual_seed(0)
+    m = M.TransE(make_config(dev, d, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    it = {k: torch.from_numpy(v).to(dev) for k, v in dict(
+        user_id=rng.integers(1, nU, B), item_id=rng.integers(1, nI, B), neg_item_id=rng.integers(1, nI, B),
+        head_id=rng.integers(1, nE, B), relation_id=rng.integers(1, nR - 1, B), tail_id=rng.integers(1, nE, B),
+        neg_tail_id=rng.integers(1, nE, B)).items()}
+    res = {"metric": "configs[0]: TransE d=64 calculate_loss in the reference's batch layout (8 192 triples per step), model-class path",
+           "triples_per_step": 4 * B}
+
+    def fwd():
+        with torch.no_grad():
+            return m.calculate_loss(it)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = m.calculate_loss(it)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def wall(fn, reps):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    for name, fn in (("forward", fwd), ("forward_backward_adam", step)):
+        dt = wall(fn, 200)
+        res[name] = {"ms": dt * 1e3, "triples_per_s": 4 * B / dt}
+    gstep = GraphedTrainStep(m, opt, it)
+    dt = wall(lambda: gstep(it), 300)
+    res["forward_backward_adam_graph_replay"] = {"ms": dt * 1e3, "triples_per_s": 4 * B / dt}
+    # evaluation of the same model: every user of a 2 048-user batch against the 2 985 items, history mask, top-10
+    users = torch.from_numpy(rng.integers(1, nU, 2048)).to(dev)
+    hist = (torch.from_numpy(rng.integers(0, 2048, 100_000)).to(dev), torch.from_numpy(rng.integers(1, nI, 100_000)).to(dev))
+    with torch.no_grad():
+        dt = wall(lambda: m.full_sort_topk({"user_id": users}, 10, hist), 100)
+    res["evaluation_top10_2048_users"] = {"ms": dt * 1e3, "scores_per_s": 2048 * nI / dt}
+    res["note"] = ("configs[0] is the reference's CPU-runnable plumbing case; BASELINE.md's CPU probe of the reference (8 vCPU) is "
+                   "of the order of 0.5 M triples/s forward")
+    del gstep, m, opt
+    torch.cuda.empty_cache()
+    return res
 
 
 def leg_cpu_baseline(D, args, out, ctx):
@@ -986,6 +1107,7 @@ def main():
         leg_roofline_variants(D, args, out, ctx)
         if D.world == 1 and not args.no_cpu_baseline:
             leg_cpu_baseline(D, args, out, ctx)
+    traffic_tab = ctx["traffic"]
     del ctx
     torch.cuda.empty_cache()
     D.barrier()
@@ -1000,6 +1122,14 @@ def main():
             out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
             torch.cuda.empty_cache()
 
+    if D.world == 1 and not args.no_hbm_variant:
+        # right behind the RotatE variants and ahead of every leg that launches the same kernels through the model classes:
+        # the profile summary splits the kernel trace by the launch log in launch order
+        guarded("scorer_rooflines", lambda: leg_scorer_rooflines(D, args, traffic_tab))
+        if isinstance(out.get("scorer_rooflines"), dict) and isinstance(out.get("roofline"), dict):
+            out["roofline"]["other_scorers"] = out.pop("scorer_rooflines")
+    if D.world == 1 and not args.no_tucker:
+        guarded("configs0", lambda: leg_configs0(D, args))
     if not args.no_sharded and D.world == 1:
         guarded("sharded", lambda: leg_sharded(D, args))
     if D.world == 1 and not args.no_tucker:
@@ -1041,7 +1171,10 @@ def main():
                 out["sharded"] = {"error": f"timed out after {args.sharded_deadline:.0f} s inside the row-sharded leg (a "
                                            "collective did not complete); the replica legs above are unaffected"}
                 print(json.dumps(out), flush=True)
-            os._exit(0)  # every rank: the launcher treats a non-zero worker as a failed run and would drop the line
+            sys.stdout.flush()
+            # a collective that never completed is a FAILED run: every rank leaves with a non-zero code (the line, with the leg
+            # marked as timed out, is already on rank 0's stdout; launch_ranks relays it whatever the exit code)
+            os._exit(3)
 
         threading.Thread(target=on_deadline, daemon=True).start()
         torch.cuda.empty_cache()

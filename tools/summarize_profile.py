@@ -119,7 +119,9 @@ if fetch and write:
                      "entity_tails_plain": "kge_score_grouped_entity_tails_plain_bytes_per_launch",
                      "entity_tails_xcd_partitioned": "kge_score_grouped_entity_tails_xcd_bytes_per_launch"}
             for vt, v in row["variants"].items():
-                if vt in names:
+                if vt.startswith("scorer_hbm_"):  # the other scorers' HBM launches (bench.py: leg_scorer_rooflines)
+                    out[f"{vt}_bytes_per_launch"] = v["bytes_per_launch"]
+                elif vt in names:
                     out[names[vt]] = v["bytes_per_launch"]
                 elif vt == "timed_region_and_single_stream_pass":
                     out["kge_score_grouped_bytes_per_launch"] = v["bytes_per_launch"]
