@@ -32,8 +32,26 @@ def test_default_legs_at_a_tiny_size():
     assert r["configs1_launch"]["bound"] == "l2" and r["configs1_launch"]["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "triples/s"
-    for leg in ("sharded", "tucker", "reference_layout", "pgpr", "cafe"):
+    for leg in ("sharded", "tucker", "reference_layout", "configs0", "pgpr", "cafe"):
         assert leg in d and "error" not in d[leg], (leg, d[leg].get("error"))
     assert d["sharded"]["parity"] and abs(d["sharded"]["parity"]["sharded_loss"] - d["sharded"]["parity"]["plain_loss"]) < 1e-5
     assert d["tucker"]["parity"]["loss_relation_sets"] == d["tucker"]["parity"]["loss_per_row_product"]
     assert d["pgpr"]["roofline"]["frac"] > 0 and d["pgpr"]["parity"]["missing_all_at_ties"] is True
+    # BASELINE-size parity, inside this suite (not only in the driver's bench line):
+    # configs[1] -- every score of a full 2048 x 257 RotatE d=200 launch of the timed region against oracle/kge_ref.c, its loss
+    # against float64, every sampled negative against the used sets
+    par = d["parity"]
+    assert par["triples"] == 2048 * 257 and par["max_rel_score_err"] < 1e-4
+    assert par["one_launch_scores_equal_plain_scorer"] is True and par["loss"]["rel_err"] < 1e-4
+    assert par["negatives"]["drawn"] == 2048 * 256 and par["negatives"]["in_item_range"] and par["negatives"]["in_used_set"] == 0
+    # configs[2] -- the one-user 64/64/64 leaf proof on the ml-1m-shaped graph (~250 k leaves), rule of tests/test_gpu_pgpr.py
+    pg = d["pgpr"]["parity"]
+    assert pg["users"] == 1 and pg["oracle_leaves"] > 200_000 and pg["device_leaves"] >= pg["common"] > 200_000
+    assert pg["safe_leaves"] <= pg["common"]  # every safe oracle leaf was emitted
+    # CAFE -- the users of a 1 024-user call the oracle walked: same items
+    cf = d["cafe"]["parity"]
+    assert cf["users"] >= 1 and cf["common"] >= 0.9 * cf["oracle_items"] > 0 and cf["max_rel_score_diff"] < 1e-4
+    # the other scorers' HBM launches (>= 4 GB tables): present and sane
+    oth = d["roofline"]["other_scorers"]
+    for tag in ("transe_d64", "transe_d200", "distmult_d200", "complex_d256"):
+        assert oth[tag]["bound"] == "hbm" and 0.3 < oth[tag]["frac"] <= 1.0 and oth[tag]["table_GB"] >= 4.0
