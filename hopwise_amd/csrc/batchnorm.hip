@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
                                                       uint64_t offset, float* __restrict__ y) {
     const float inv_keep = 1.f / (1.f - p);
     const int64_t nq = (n + 3) >> 2;
+    offset = philox_offset(offset);
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
         uint32_t w[4];
         philox_bits4(seed, offset, (uint64_t)q, w);

@@ -547,6 +547,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         return;
     }
 #endif
+    if (drop_mode == 2) offset = philox_offset(offset);
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -971,6 +972,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
                                                                  uint64_t seed, uint64_t offset) {
     const int M = m_ptr ? min(m_ptr[0], m_max) : m_max;
     const int64_t total = (int64_t)M * N;
+    if (drop_mode == 2) offset = philox_offset(offset);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int gm = (int)(i / N), gn = (int)(i % N);
         float v = 0.f;

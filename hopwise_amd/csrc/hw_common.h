@@ -43,6 +43,19 @@ __device__ __forceinline__ uint32_t philox_bits(uint64_t seed, uint64_t offset, 
 
 
 
+// Philox offsets that live on the device.  Every entry point that takes a (seed, offset) pair accepts, instead of a plain offset,
+// an INDIRECT one: bit 63 set, bits 0..47 the address of a uint64 in device memory, bits 48..62 a small addend -- the stream
+// offset is then `*address + addend`, read when the kernel RUNS.  A training step captured in a HIP graph freezes its kernel
+// arguments; with indirect offsets each replay still draws fresh masks / actions: the graph's last node bumps the word
+// (hopwise_amd.philox.PhiloxCounter, driver.GraphedTrainStep).  Kernels resolve the offset once, on entry.
+__device__ __forceinline__ uint64_t philox_offset(uint64_t offset) {
+    if (offset >> 63) {  // wave-uniform: a kernel argument
+        const uint64_t* p = reinterpret_cast<const uint64_t*>(offset & 0x0000FFFFFFFFFFFFull);
+        return *p + ((offset >> 48) & 0x7FFFull);
+    }
+    return offset;
+}
+
 // All four words of block `blk` of the same stream: philox_bits(seed, offset, 4 * blk + k) == w[k].  For code that walks
 // four consecutive positions starting at a multiple of 4 -- one Philox evaluation instead of four.
 __device__ __forceinline__ void philox_bits4(uint64_t seed, uint64_t offset, uint64_t blk, uint32_t (&w)[4]) {

@@ -28,6 +28,7 @@ extern "C" int hw_kge_score_grouped_sampled(const hw_kge_desc* desc, const int64
                                             int64_t value_num, uint64_t seed, uint64_t offset, float* out,
                                             int64_t o_stride_b, int64_t o_stride_j, int32_t* oob_counter, void* stream) {
     if (!desc || !used_ptr || !keys || !t_idx || n_key_space < 1 || value_num < 2) return HW_ERR_INVALID_ARG;
+    if (offset >> 63) return HW_ERR_UNSUPPORTED;  // device-indirect Philox offsets (hw_common.h): hw_neg_sample, then the scorer
     if (HW_FAMILY_OF(desc->model) != 0) return HW_ERR_UNSUPPORTED;  // caller: sample, then score
     SamplerArgs sa;
     sa.used_ptr = used_ptr, sa.used_idx = used_idx, sa.keys = keys, sa.n_key_space = n_key_space;
@@ -48,7 +49,7 @@ static int selfadv_launch(const hw_kge_desc* desc, const int64_t* h_idx, const i
         return HW_ERR_INVALID_ARG;
     if (prev_group_loss && (!prev_loss_out || prev_n_groups < 1 || prev_n_groups > INT32_MAX || prev_group_loss == group_loss_ws))
         return HW_ERR_INVALID_ARG;
-    if (HW_FAMILY_OF(desc->model) != 0) return HW_ERR_UNSUPPORTED;
+    if (HW_FAMILY_OF(desc->model) != 0 || (offset >> 63)) return HW_ERR_UNSUPPORTED;
     SamplerArgs sa;
     sa.used_ptr = used_ptr, sa.used_idx = used_idx, sa.keys = keys, sa.n_key_space = n_key_space;
     sa.value_num = value_num, sa.seed = seed, sa.offset = offset, sa.words = value_num <= 65536 ? (int)((value_num + 31) / 32) : 0, sa.stagger = scorer_stagger();  // 0: no LDS bitmap, binary search in the sorted used slice

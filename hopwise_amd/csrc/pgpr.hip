@@ -877,6 +877,7 @@ __global__ __launch_bounds__(256) void pgpr_layer1_lookup_kernel(L1Tables t, con
                                                                  const float* __restrict__ drop_mask, int drop_mode,
                                                                  uint64_t seed, uint64_t offset, float* __restrict__ out,
                                                                  int64_t ld, int run) {
+    if (drop_mode == 2) offset = philox_offset(offset);
     const int n_rows = n_rows_ptr[0];
     const int lane = threadIdx.x & 63;
     const bool keep = H <= L1_MAX_H;

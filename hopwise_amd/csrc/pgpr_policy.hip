@@ -495,6 +495,7 @@ extern "C" int hw_pgpr_policy_fused(const float* const* slot_tables, const float
     if (state_history < 0 || state_history > 2) return HW_ERR_INVALID_ARG;
     if (!(drop_mode == 0 || drop_mode == 1 || drop_mode == 3) || (drop_mode == 1 && (!mask1 || !mask2)))
         return HW_ERR_INVALID_ARG;
+    if (drop_mode == 3 && ((offset1 | offset2) >> 63)) return HW_ERR_UNSUPPORTED;  // plain offsets only (evaluation path)
     if (ld < PF_A || (ld & 3) || (((uintptr_t)logits | (uintptr_t)b1 | (uintptr_t)ba_padded | (uintptr_t)planes |
                                    (uintptr_t)zero_row) & 15))
         return HW_ERR_INVALID_ARG;

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(64) void action_dropout_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ n_rows, int32_t act_dim,
                                                             double dropout, uint64_t seed, uint64_t offset,
                                                             uint8_t* __restrict__ mask) {
+    offset = philox_offset(offset);
     __shared__ uint32_t keys[TRAIN_MAX_ACT_DIM];
     const int64_t row = blockIdx.x;
     if (n_rows && row >= n_rows[0]) return;
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(64) void policy_sample_kernel(const float* __restri
                                                            uint64_t offset, float* __restrict__ probs,
                                                            int32_t* __restrict__ acts, float* __restrict__ logp,
                                                            float* __restrict__ entropy, float* __restrict__ value) {
+    if (!forced_acts) offset = philox_offset(offset);
     __shared__ float e[TRAIN_MAX_ACT_DIM];
     const int64_t row = blockIdx.x;
     if (n_rows && row >= n_rows[0]) return;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void act_dropout_backward_kernel(const float* 
                                                                   int64_t m_rows, int64_t n, int32_t act,
                                                                   const float* __restrict__ drop_mask, int32_t drop_mode,
                                                                   uint64_t seed, uint64_t offset, float* __restrict__ dx) {
+    if (drop_mode == 2) offset = philox_offset(offset);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m_rows * n) return;
     float m = 1.f;

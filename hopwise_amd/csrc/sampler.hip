@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void neg_sample_kernel(
     const float* __restrict__ alias_prob, const int64_t* __restrict__ alias_keys,
     const int64_t* __restrict__ alias_alias, int64_t n_alias, uint64_t seed, uint64_t offset,
     int64_t* __restrict__ out, int64_t out_stride_key, int64_t out_stride_draw, int32_t* oob) {
+    offset = philox_offset(offset);
     const int64_t tpos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tpos >= total) return;
     // Thread -> (key i, draw j): follow the OUTPUT layout so that stores coalesce and, in the row-per-key layout, a wave
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void neg_sample_bitmap_kernel(
     const int64_t* __restrict__ used_ptr, const int64_t* __restrict__ used_idx, int64_t n_key_space,
     const int64_t* __restrict__ keys, int64_t n_keys, int num, int64_t value_num, uint64_t seed, uint64_t offset,
     int64_t* __restrict__ out, int64_t out_stride_key, int64_t out_stride_draw, int32_t* oob) {
+    offset = philox_offset(offset);
     __shared__ uint32_t bits[SAMPLER_BITMAP_WORDS];
     const int chunks = (num + 255) / 256;
     const int64_t i = blockIdx.x / chunks;

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void tucker_contract_fwd_kernel(const float* _
                                                                   float* __restrict__ out, int64_t w_stride,
                                                                   const int64_t* __restrict__ w_index,
                                                                   uint32_t* __restrict__ keep_out, int64_t batch) {
+    if constexpr (MODE == 2) offset = philox_offset(offset);
     // one thread per (batch row, column), numbered flat over the batch: with a block per row, d = 200 filled three waves and an
     // eighth of the fourth, and the kernel is bound by the Philox rounds its lanes execute (2 x 10^7 blocks per call)
     const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void tucker_contract_bwd_kernel(const float* _
                                                                   uint64_t seed, uint64_t offset,
                                                                   float* __restrict__ gx, float* __restrict__ gw,
                                                                   int64_t w_stride, const int64_t* __restrict__ w_index) {
+    if constexpr (MODE == 2) offset = philox_offset(offset);
     const int b = blockIdx.x;
     const int wave = wave_in_block(), lane = threadIdx.x & 63;
     const float* __restrict__ wb = w + (size_t)(w_index ? w_index[b] : b) * w_stride;
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(256) void tucker_gw_shared_kernel(const float* __re
                                                                const float* __restrict__ go, int64_t batch, int d,
                                                                float drop_p, uint64_t seed, uint64_t offset,
                                                                float* __restrict__ partial) {
+    if constexpr (MODE == 2) offset = philox_offset(offset);
     const int q = blockIdx.x, c = blockIdx.y;
     const int nq = (d + 3) >> 2;
     const float inv_keep = 1.f / (1.f - drop_p);
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(256) void tucker_gw_indexed_kernel(const float* __r
                                                                 const int64_t* __restrict__ w_index, int64_t n_mats,
                                                                 int64_t batch, int d, float drop_p, uint64_t seed,
                                                                 uint64_t offset, float* __restrict__ gw) {
+    if constexpr (MODE == 2) offset = philox_offset(offset);
     const int q = blockIdx.x, c = blockIdx.y;
     const int nq = (d + 3) >> 2;
     const float inv_keep = 1.f / (1.f - drop_p);

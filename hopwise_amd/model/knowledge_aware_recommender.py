@@ -30,6 +30,7 @@ from torch import nn
 from .. import ops
 from .. import pgpr_ops as P
 from ..lazy import LazyList
+from ..philox import PhiloxCounter
 from ..stream_cache import FencedValue
 from ..utils import InputType, seed_for_rank
 from .abstract_recommender import ExplainableRecommender, KnowledgeRecommender
@@ -180,7 +181,9 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         self.l2 = nn.Linear(self.hidden_sizes[0], self.hidden_sizes[1])
         self.actor = nn.Linear(self.hidden_sizes[1], self.act_dim)
         self.critic = nn.Linear(self.hidden_sizes[1], 1)
-        self._drop_calls = 0  # Philox offset of the policy dropout / action draws; rides in the checkpoint (other_parameter)
+        # Philox offsets of the policy dropout / action draws: four per call (layer 1, layer 2, action dropout, action draw);
+        # the call count rides in the checkpoint as `_drop_calls` (other_parameter); philox.py for the captured-step form
+        self._philox = PhiloxCounter(stride=4)
         self._seed = seed_for_rank(_cfg(config, "seed", 2020))
 
         # training (pgpr.py:40-46, 90-104)
@@ -199,6 +202,22 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 pats.append([1 + len(names)] + [int(rel2id.get(n, -2)) for n in names] + [-2] * (3 - len(names)))
         self._patterns = torch.tensor(pats, dtype=torch.int32, device=dev).view(-1, 4) if pats else None
         self.last_loss_parts = None
+
+    def capture_error_flags(self, device):
+        """Device flags a captured training step may raise (driver.GraphedTrainStep allocates them before the capture and
+        the epoch loops read them once per epoch): {name: (bool tensor [1], message)}."""
+        if self.__dict__.get("_pad_user_flag") is None or self._pad_user_flag.device != torch.device(device):
+            self.__dict__["_pad_user_flag"] = torch.zeros(1, dtype=torch.bool, device=device)
+        return {"pad_user": (self._pad_user_flag, "a batch of a captured PGPR step held the [PAD] user 0, which the eager "
+                                                   "step filters out (pgpr.py:189-203): its episode went into the loss")}
+
+    @property
+    def _drop_calls(self):
+        return self._philox.calls
+
+    @_drop_calls.setter
+    def _drop_calls(self, v):
+        self._philox.calls = int(v)
 
     # ------------------------------------------------------------------------------------------------
     def _alloc(self, B, hops, compact_leaves=False, acts_u16=False, mlp_buffers=True, topk_buffers=True):
@@ -280,7 +299,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 modes.append((None, 2))
             else:
                 modes.append((None, 0))
-        self._drop_calls += 1
+        call = self._philox.next()
+        off1, off2 = self._philox.offset(call, 0), self._philox.offset(call, 1)
         if paths is not None and self.fused_policy and P.policy_fused_supported(self.hidden_sizes, self.act_dim):
             # lookup -> l2 -> actor in one launch (csrc/pgpr_policy.hip); its Philox dropout stream packs 128 keep bits per
             # block (drop_mode 3), the three-launch form below keeps hw_common.h:philox_bits' stream (drop_mode 2)
@@ -288,16 +308,16 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             P.policy_fused(self._l1_slot_tables(), zero_row, self.l1.bias.detach(), planes, self.l2.bias.detach(), ba_pad,
                            self.act_dim, self.state_history, paths, n_rows, rmax, buf["logits"],
                            drop_mode={0: 0, 1: 1, 2: 3}[modes[0][1]], mask1=modes[0][0], mask2=modes[1][0],
-                           seed=self._seed, offset1=2 * self._drop_calls, offset2=2 * self._drop_calls + 1)
+                           seed=self._seed, offset1=off1, offset2=off2)
             return
         if paths is not None:
             P.layer1_lookup(self._l1_slot_tables(), self.l1.bias.detach(), self.state_history, paths, n_rows, rmax,
-                            buf["x1"], modes[0][0], modes[0][1], self._seed, 2 * self._drop_calls)
+                            buf["x1"], modes[0][0], modes[0][1], self._seed, off1)
         else:
             P.mlp_layer(buf["state"], self.l1.weight, self.l1.bias, buf["x1"], n_rows, rmax, True, modes[0][0],
-                        modes[0][1], self._seed, 2 * self._drop_calls)
+                        modes[0][1], self._seed, off1)
         P.mlp_layer(buf["x1"], self.l2.weight, self.l2.bias, buf["x2"], n_rows, rmax, True, modes[1][0], modes[1][1],
-                    self._seed, 2 * self._drop_calls + 1)
+                    self._seed, off2)
         P.mlp_layer(buf["x2"], self.actor.weight, self.actor.bias, buf["logits"], n_rows, rmax, False)
 
     @torch.no_grad()
@@ -450,19 +470,19 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             paths, n_rows = ep["paths"][t], nr[t : t + 1]
             P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, B, self.max_acts,
                       self.fix_scores_sorting_bug, acts_buf, n_acts, scratch, start_user_revisitable=True)
-            self._drop_calls += 1
-            call = self._drop_calls
+            call = self._philox.next()
+            off = [self._philox.offset(call, j) for j in range(4)]
             ep["calls"].append(call)
             ep["n_acts"][sl].copy_(n_acts)
             if act_masks is not None:
                 ep["mask"][sl].copy_(act_masks[t])
             else:
-                P.action_dropout(n_acts, n_rows, B, A, self.action_dropout, self._seed, 4 * call + 2, ep["mask"][sl])
+                P.action_dropout(n_acts, n_rows, B, A, self.action_dropout, self._seed, off[2], ep["mask"][sl])
             P.state(g, U32, E32, R32, self.state_history, paths, n_rows, B, ep["state"][sl])
             if drops is not None:
                 modes = [(drops[t][0], 1, 0), (drops[t][1], 1, 0)]
             elif self.policy_dropout == "reference":
-                modes = [(None, 2, 4 * call), (None, 2, 4 * call + 1)]
+                modes = [(None, 2, off[0]), (None, 2, off[1])]
             else:
                 modes = [(None, 0, 0), (None, 0, 0)]
             ep["drop"].append(modes)
@@ -472,7 +492,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                         modes[1][1], self._seed, modes[1][2])
             P.mlp_layer(ep["x2"][sl], head_w, head_b, ep["head"][sl], n_rows, B, False)
             P.policy_sample(ep["head"][sl], A, ep["mask"][sl], n_rows, B, ep["probs"][sl], ep["acts"][sl], ep["logp"][sl],
-                            ep["entropy"][sl], ep["value"][sl], self._seed, 4 * call + 3,
+                            ep["entropy"][sl], ep["value"][sl], self._seed, off[3],
                             None if forced_acts is None else forced_acts[t].contiguous())
             P.expand(g, paths, probs3[t % 2], acts_buf, A, n_acts, n_rows, B, ep["acts"][sl].view(B, 1),
                      ep["logp"][sl].view(B, 1), 1, offsets, ep["paths"][t + 1], probs3[(t + 1) % 2], nr[t + 1 : t + 2], B)
@@ -518,7 +538,15 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
     def calculate_loss(self, interaction):
         """pgpr.py:189-203: roll out, update(); the float64 loss carries a grad_fn over the eight policy tensors."""
         users = interaction[self.USER_ID]
-        users = users[users != 0]
+        if users.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a captured step has one shape: the [PAD] filter below (a host read) cannot run.  hopwise's train loaders never
+            # yield user 0; should one appear the flag is raised on the device and driver.graphed_trainer / train_epoch_graphed
+            # refuse the epoch when they read it (capture_error_flags)
+            if self.__dict__.get("_pad_user_flag") is None or self._pad_user_flag.device != users.device:
+                raise RuntimeError("PGPR: build the step with driver.GraphedTrainStep (it prepares the capture's flags)")
+            self._pad_user_flag.logical_or_((users == 0).any())
+        else:
+            users = users[users != 0]
         if users.numel() == 0:
             return sum(p.sum() for p in self.parameters()).double() * 0.0
         params = (self.l1.weight, self.l1.bias, self.l2.weight, self.l2.bias, self.actor.weight, self.actor.bias,

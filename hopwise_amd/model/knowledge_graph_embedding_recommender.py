@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..philox import PhiloxCounter
 from ..stream_cache import FencedValue
 from ..utils import InputType, seed_for_rank
 from .abstract_recommender import KnowledgeRecommender
@@ -672,7 +673,16 @@ class TuckER(ops.DropoutCounters, KnowledgeRecommender):
         self.forced_masks = None  # tests: {"rec": (m0 [B,d], m1 [B,d,d], m2 [B,d]), "kg": (...)} multiplicative masks
         # False: the per-row mm(r, W) of the reference; True (default): one matrix per distinct relation (see _features)
         self.share_relation_matrices = bool(_cfg(config, "share_relation_matrices", True))
-        self._seed, self._drop_calls = seed_for_rank(_cfg(config, "seed", 2020)), 0
+        self._seed = seed_for_rank(_cfg(config, "seed", 2020))
+        self._philox = PhiloxCounter()  # hidden_dropout1's offsets (one per contraction); `_drop_calls` in the checkpoint
+
+    @property
+    def _drop_calls(self):
+        return self._philox.calls
+
+    @_drop_calls.setter
+    def _drop_calls(self, v):
+        self._philox.calls = int(v)
 
     def _drop(self, module, x, forced):
         if forced is not None:
@@ -705,8 +715,8 @@ class TuckER(ops.DropoutCounters, KnowledgeRecommender):
                 rows, index = self.relation_embedding.weight, r_idx.clamp(0, n_rel - 1)
             w_set = ops.matmul_nn(rows, self.weights.view(d, d * d)).view(-1, d, d)
             if fm[1] is None and self.training and self.hidden_dropout1.p > 0:
-                self._drop_calls += 1
-                x = ops.tucker_contract_shared(x, w_set, index, None, self.hidden_dropout1.p, self._seed, self._drop_calls)
+                off = self._philox.offset(self._philox.next())
+                x = ops.tucker_contract_shared(x, w_set, index, None, self.hidden_dropout1.p, self._seed, off)
             else:
                 x = ops.tucker_contract_shared(x, w_set, index, fm[1])
             return self._drop(self.hidden_dropout2, self.bn1(x), fm[2])
@@ -714,8 +724,8 @@ class TuckER(ops.DropoutCounters, KnowledgeRecommender):
         w_mat = ops.matmul_nn(r, self.weights.view(d, d * d)).view(-1, d, d)
         if fm[1] is None and self.training and self.hidden_dropout1.p > 0:
             # hidden_dropout1 over the [B, d, d] tensor is drawn inside the contraction (Philox), never materialised
-            self._drop_calls += 1
-            x = ops.tucker_contract_dropout(x, w_mat, self.hidden_dropout1.p, self._seed, self._drop_calls)
+            off = self._philox.offset(self._philox.next())
+            x = ops.tucker_contract_dropout(x, w_mat, self.hidden_dropout1.p, self._seed, off)
         else:
             x = ops.tucker_contract(x, w_mat, fm[1])
         return self._drop(self.hidden_dropout2, self.bn1(x), fm[2])
@@ -731,9 +741,10 @@ class TuckER(ops.DropoutCounters, KnowledgeRecommender):
         head, rel, tail = interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], interaction[self.TAIL_ENTITY_ID]
         dev = user.device
         item_flag = torch.zeros(self.n_users + self.n_items, dtype=torch.uint8, device=dev)
-        item_flag[item + self.n_users] = 1
+        # index_fill_, not `flag[idx] = 1`: index_put_ stages its scalar through the host, which a captured step may not do
+        item_flag.index_fill_(0, item + self.n_users, 1)
         tail_flag = torch.zeros(self.n_entities, dtype=torch.uint8, device=dev)
-        tail_flag[tail] = 1
+        tail_flag.index_fill_(0, tail, 1)
         if self.label_smoothing:
             s_rec, a_rec = 1.0 - self.label_smoothing, 1.0 / self.n_items
             s_kg, a_kg = 1.0 - self.label_smoothing, 1.0 / self.n_entities
@@ -862,9 +873,10 @@ class ConvE(ops.DropoutCounters, KnowledgeRecommender):
         head, rel, tail = interaction[self.HEAD_ENTITY_ID], interaction[self.RELATION_ID], interaction[self.TAIL_ENTITY_ID]
         dev = user.device
         item_flag = torch.zeros(self.n_users + self.n_items, dtype=torch.uint8, device=dev)
-        item_flag[item + self.n_users] = 1
+        # index_fill_, not `flag[idx] = 1`: index_put_ stages its scalar through the host, which a captured step may not do
+        item_flag.index_fill_(0, item + self.n_users, 1)
         tail_flag = torch.zeros(self.n_entities, dtype=torch.uint8, device=dev)
-        tail_flag[tail] = 1
+        tail_flag.index_fill_(0, tail, 1)
         if self.label_smoothing:
             s, a_rec, a_kg = 1.0 - self.label_smoothing, 1.0 / self.n_items, 1.0 / self.n_entities
         else:

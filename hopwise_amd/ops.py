@@ -1181,7 +1181,17 @@ class Dropout(torch.nn.Dropout):
 
             stream = 1000 + zlib.crc32(stream.encode())
         self._seed = (seed_for_rank(seed) + 0x632BE59BD9B4E019 * (int(stream) + 1)) & 0xFFFFFFFFFFFFFFFF
-        self.calls = 0
+        from .philox import PhiloxCounter
+
+        self._philox = PhiloxCounter()  # one offset per call; bound to a device word while a step is captured (philox.py)
+
+    @property
+    def calls(self):
+        return self._philox.calls
+
+    @calls.setter
+    def calls(self, v):
+        self._philox.calls = int(v)
 
     def forward(self, x):
         if not self.training or self.p == 0.0:
@@ -1190,8 +1200,7 @@ class Dropout(torch.nn.Dropout):
         if (not (x.is_cuda and x.dtype == torch.float32) or self.p >= 1.0
                 or torch.nn.functional.dropout is not _TORCH_F_DROPOUT):
             return super().forward(x)
-        self.calls += 1
-        return _DropoutFn.apply(x, self.p, self._seed, self.calls)
+        return _DropoutFn.apply(x, self.p, self._seed, self._philox.offset(self._philox.next()))
 
 
 class DropoutCounters:

@@ -417,6 +417,16 @@ int hw_pgpr_policy_fused(const float* const* slot_tables, const float* zero_row,
                          int32_t drop_mode, const float* mask1, const float* mask2, uint64_t seed, uint64_t offset1,
                          uint64_t offset2, float* logits, int64_t ld, void* stream);
 
+/* ---- Philox offsets that live on the device -----------------------------------------------------------------------------
+ * Every `offset` of a (seed, offset) pair below may be INDIRECT: bit 63 set, bits 0..47 the address of a uint64 in device
+ * memory, bits 48..62 a small addend; the stream offset is then *address + addend, read when the kernel runs.  A training
+ * step captured in a HIP graph freezes its kernel arguments; with indirect offsets every replay still draws fresh dropout
+ * masks / actions once the graph's last node has bumped the word (hopwise_amd/philox.py, driver.GraphedTrainStep) -- the
+ * reference draws from torch's generator, whose Philox offset CUDA graphs advance the same way.  Accepted by hw_dropout,
+ * hw_gemm_f32 / hw_pgpr_mlp_layer (drop_mode 2), hw_pgpr_layer1_lookup, hw_pgpr_action_dropout, hw_pgpr_policy_sample,
+ * hw_pgpr_act_dropout_backward, the hw_tucker_contract_* family and hw_neg_sample.  HW_ERR_UNSUPPORTED from the entry
+ * points that do not resolve it: hw_kge_score_grouped_sampled*, hw_pgpr_policy_fused (evaluation paths). */
+
 /* General fp32 MFMA GEMM: c[m, n] = f(op(a)[m, :] . op(b)[:, n] + bias[n]).  a is [m, k] row-major when
  * a_k_contiguous, else stored transposed [k, m]; b is [n, k] row-major (nn.Linear weight) when b_k_contiguous, else
  * [k, n].  Replaces torch.mm / torch.bmm / nn.Linear on the dense paths (tucker.py:74-82, pgpr.py:175-187).

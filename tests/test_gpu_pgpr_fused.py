@@ -79,8 +79,8 @@ def test_fused_policy_philox_dropout_stream():
     got = _logits(m, rec, n_rows, n, None, fused=True)
     call = m._drop_calls  # advanced by _policy_logits
     h1, h2 = m.hidden_sizes
-    k1 = keep_bits_packed(m._seed, 2 * call, n * h1).reshape(n, h1).astype(np.float64) * 2
-    k2 = keep_bits_packed(m._seed, 2 * call + 1, n * h2).reshape(n, h2).astype(np.float64) * 2
+    k1 = keep_bits_packed(m._seed, 4 * call, n * h1).reshape(n, h1).astype(np.float64) * 2
+    k2 = keep_bits_packed(m._seed, 4 * call + 1, n * h2).reshape(n, h2).astype(np.float64) * 2
     d1, d2 = torch.from_numpy(k1.astype(np.float32)).to(dev()), torch.from_numpy(k2.astype(np.float32)).to(dev())
     want = _logits(m, rec, n_rows, n, [(d1, d2)], fused=False)  # the goldens-pinned form with those masks handed in
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6 * np.abs(want).max())
