@@ -527,9 +527,13 @@ def gen_convkb(out_dir):
         print("convkb", d, float(out["eval.loss"]), float(out["train.loss"]), len(rec.masks))
 
 
-def gen_cafe(out_dir):
+CAFE_VARIANTS = {"default": {}, "shallow": {"deep_module": False}, "nodropout": {"use_dropout": False}}
+
+
+def gen_cafe(out_dir, tag="default"):
     """CAFE inference on the reference fixture: module outputs, infer_with_path for every (user, metapath), executor +
-    run_program with the child permutation patched to the identity, eval mode."""
+    run_program with the child permutation patched to the identity, eval mode.  ``tag``: "default" (CAFE.yaml: DeepRelationModule
+    with dropout), "shallow" (deep_module: False -> RelationModule, cafe.py:645-667), "nodropout" (use_dropout: False)."""
     import pickle
 
     from hopwise.config import Config
@@ -541,7 +545,7 @@ def gen_cafe(out_dir):
     os.chdir("/tmp/scratch")
     config = Config(model="CAFE", dataset="test", config_file_list=["/root/reference/tests/model/test_model.yaml"],
                     config_dict={"data_path": "/root/reference/tests/test_data/", "user_inter_num_interval": [1, 10],
-                                 "device": "cpu", "checkpoint_dir": "/tmp/scratch/saved"})
+                                 "device": "cpu", "checkpoint_dir": "/tmp/scratch/saved", **CAFE_VARIANTS[tag]})
     init_seed(config["seed"], config["reproducibility"])
     dataset = create_dataset(config)
     train_data, valid_data, test_data = data_preparation(config, dataset)
@@ -638,8 +642,9 @@ def gen_cafe(out_dir):
     for k, v in model.state_dict().items():
         if "running" in k and any(k.startswith(f"model.{r}.") for r, _ in model.metapaths[mpid][1:]):
             out[f"train.after.{k}"] = v.numpy().copy()
-    np.savez_compressed(os.path.join(out_dir, "cafe_default.npz"), **out)
-    print("cafe", len(infer), out["infer.paths"].shape, scores.shape, len(collected), "train", mpid, pos_paths.shape,
+    out["deep_module"], out["use_dropout"] = np.bool_(config["deep_module"]), np.bool_(config["use_dropout"])
+    np.savez_compressed(os.path.join(out_dir, f"cafe_{tag}.npz"), **out)
+    print("cafe", tag, len(infer), out["infer.paths"].shape, scores.shape, len(collected), "train", mpid, pos_paths.shape,
           float(reg_loss), float(rank_loss), len(rec.masks))
 
 
@@ -652,7 +657,10 @@ if __name__ == "__main__":
     if what in ("sampler", "all"):
         gen_sampler(HERE)
     if what in ("cafe", "all"):
-        gen_cafe(HERE)
+        for tag in CAFE_VARIANTS:
+            gen_cafe(HERE, tag)
+    if what.startswith("cafe:"):
+        gen_cafe(HERE, what[5:])
     if what in ("convkb", "all"):
         gen_convkb(HERE)
     if what in ("conve", "all"):

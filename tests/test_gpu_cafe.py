@@ -8,7 +8,7 @@ import torch
 
 from oracle import cafe as oc
 from tests.helpers import FIELDS, FakeKGDataset
-from tests.test_oracle_golden_cafe import check_collected, load
+from tests.test_oracle_golden_cafe import TAGS, check_collected, load, train_masks
 
 pytestmark = pytest.mark.gpu
 
@@ -22,19 +22,19 @@ class IdentityRng:
         return np.arange(n)
 
 
-def build():
+def build(tag="default"):
     from hopwise_amd.model import CAFE
 
-    z, orc, rid, ui = load()
+    z, orc, rid, ui = load(tag)
     ds = FakeKGDataset(int(z["n_users"]), int(z["n_items"]), int(z["n_entities"]), len(rid), int(z["ui_relation"]),
                        z["inter_users"], z["inter_items"], z["heads"], z["rels"], z["tails"], z["positives"],
                        z["user_emb"], z["entity_emb"], np.zeros((len(rid), z["user_emb"].shape[1]), np.float32))
     ds.ui_relation = ui
     ds.field2token_id = {"relation_id": dict(rid)}
     metapaths = [[[None, "user"]] + [[str(r), "entity"] for r in mp] for mp in z["metapaths"]]
-    cfg = dict(FIELDS, device=dev(), path_constraint=metapaths, rank_weight=10.0, deep_module=True, use_dropout=True,
-               topk_candidates=10, sample_size=500, topk_paths=int(z["topk_paths"]), max_user_trials=50,
-               load_embeddings=True)
+    cfg = dict(FIELDS, device=dev(), path_constraint=metapaths, rank_weight=10.0, deep_module=bool(z["deep_module"]),
+               use_dropout=bool(z["use_dropout"]), topk_candidates=10, sample_size=500, topk_paths=int(z["topk_paths"]),
+               max_user_trials=50, load_embeddings=True)
     m = CAFE(cfg, ds).to(dev())
     # relation names contain dots, which nn.Module.load_state_dict cannot route ("model.film.actor.film.fc1.weight"):
     # assign tensor by tensor instead
@@ -55,10 +55,11 @@ def build():
     return z, orc, m
 
 
-def test_modules_and_log_softmax():
+@pytest.mark.parametrize("tag", TAGS)
+def test_modules_and_log_softmax(tag):
     from hopwise_amd import pgpr_ops as P
 
-    z, orc, m = build()
+    z, orc, m = build(tag)
     ev, uv = torch.from_numpy(z["mod.inputs_e"]).to(dev()), torch.from_numpy(z["mod.inputs_u"]).to(dev())
     with torch.no_grad():
         for k in z.files:
@@ -70,8 +71,9 @@ def test_modules_and_log_softmax():
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
 
 
-def test_infer_paths_vs_reference():
-    z, orc, m = build()
+@pytest.mark.parametrize("tag", TAGS)
+def test_infer_paths_vs_reference(tag):
+    z, orc, m = build(tag)
     pred = m._infer_paths(torch.from_numpy(z["users"]))
     keys, off = z["infer.keys"], z["infer.off"]
     n = 0
@@ -86,8 +88,20 @@ def test_infer_paths_vs_reference():
     assert n > 20
 
 
-def test_run_program_vs_reference():
-    z, orc, m = build()
+@pytest.mark.parametrize("tag", TAGS)
+def test_run_program_vs_reference(tag, monkeypatch):
+    """The reference's run_program on its own fixture -- DeepRelationModule (CAFE.yaml), RelationModule (deep_module: False,
+    cafe.py:645-667) and the deep module built without dropout -- through every form of the module loop: one fused launch per
+    level (the default), the C++ launch-per-layer loop, the Python loop."""
+    z, orc, m = build(tag)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("HW_CAFE_MODULES", mode)
+        sc, cl = m.run_program(torch.from_numpy(z["users"]))
+        fin = np.isfinite(z["run.scores"])
+        assert np.array_equal(np.isfinite(sc.numpy()), fin)
+        np.testing.assert_allclose(sc.numpy()[fin], z["run.scores"][fin], rtol=1e-4)
+        check_collected(cl, z)
+    monkeypatch.setenv("HW_CAFE_MODULES", "2")
     scores, col = m.run_program(torch.from_numpy(z["users"]))
     res = scores.numpy()
     finite = np.isfinite(z["run.scores"])
@@ -110,16 +124,18 @@ class ReplayDropout:
         return x * m
 
 
-def test_training_forward_backward_vs_reference(monkeypatch):
+@pytest.mark.parametrize("tag", TAGS)
+def test_training_forward_backward_vs_reference(tag, monkeypatch):
     """SymbolicNetwork.forward in train mode on the reference's sampled batch: both losses, every module gradient, the
     BatchNorm running statistics afterwards."""
     import torch.nn.functional as F
 
-    z, orc, m = build()
+    z, orc, m = build(tag)
     m.train()
     mpid = int(z["train.mpid"])
-    masks = [torch.from_numpy(z[f"train.mask{i}"]).to(dev()) for i in range(6)]
-    monkeypatch.setattr(F, "dropout", ReplayDropout(masks))
+    if bool(z["use_dropout"]):
+        masks = [torch.from_numpy(mk).to(dev()) for mk in train_masks(z)]
+        monkeypatch.setattr(F, "dropout", ReplayDropout(masks))
     m.zero_grad()
     reg, rank = m.model(m.metapaths[mpid], torch.from_numpy(z["train.pos_paths"]).to(dev()),
                         torch.from_numpy(z["train.neg_pids"]).to(dev()), m.embeddings)
@@ -144,7 +160,7 @@ def test_training_forward_backward_vs_reference(monkeypatch):
         # bound is relative to the tensor's scale
         np.testing.assert_allclose(got, z[k], rtol=3e-4, atol=2e-4 * scale + 1e-9, err_msg=k)
         n_checked += 1
-    assert n_checked >= 30
+    assert n_checked >= (30 if bool(z["deep_module"]) else 18)
 
 
 def test_level_loss_kernels_vs_numpy():
@@ -342,33 +358,12 @@ def test_module_loop_in_cpp_equals_the_python_loop(monkeypatch):
 
 
 def test_shallow_relation_modules_fused_equals_the_python_loop(monkeypatch):
-    """RelationModule (deep_module = False: fc1 -> bn1 -> fc2 + eh, cafe.py:645-667) has no reference golden here; the three
-    forms of the module loop must agree on it as they do on the deep one: C++ launch-per-layer == Python loop bit for bit,
-    fused one-launch-per-level == them to fp32 rounding with the same items and paths.  Batch-norm statistics are perturbed
-    so that the evaluation-mode affine is not the identity."""
-    from hopwise_amd.model import CAFE
-
-    z, orc, rid, ui = load()
-    ds = FakeKGDataset(int(z["n_users"]), int(z["n_items"]), int(z["n_entities"]), len(rid), int(z["ui_relation"]),
-                       z["inter_users"], z["inter_items"], z["heads"], z["rels"], z["tails"], z["positives"],
-                       z["user_emb"], z["entity_emb"], np.zeros((len(rid), z["user_emb"].shape[1]), np.float32))
-    ds.ui_relation = ui
-    ds.field2token_id = {"relation_id": dict(rid)}
-    metapaths = [[[None, "user"]] + [[str(r), "entity"] for r in mp] for mp in z["metapaths"]]
-    cfg = dict(FIELDS, device=dev(), path_constraint=metapaths, rank_weight=10.0, deep_module=False, use_dropout=True,
-               topk_candidates=10, sample_size=500, topk_paths=int(z["topk_paths"]), max_user_trials=50, load_embeddings=True)
-    torch.manual_seed(3)
-    m = CAFE(cfg, ds).to(dev())
-    g = torch.Generator(device="cpu").manual_seed(5)
-    with torch.no_grad():
-        for rel in sorted(m.relation_info):
-            mod = m._module(rel)
-            assert not hasattr(mod, "fc3")
-            mod.bn1.running_mean.copy_(torch.randn(mod.bn1.running_mean.shape, generator=g) * 0.1)
-            mod.bn1.running_var.copy_(torch.rand(mod.bn1.running_var.shape, generator=g) + 0.5)
-            mod.bn1.weight.copy_(torch.rand(mod.bn1.weight.shape, generator=g) + 0.5)
-            mod.bn1.bias.copy_(torch.randn(mod.bn1.bias.shape, generator=g) * 0.1)
-    m.eval()
+    """RelationModule (deep_module = False: fc1 -> bn1 -> fc2 + eh, cafe.py:645-667) on the reference's own run of it
+    (cafe_shallow.npz, pinned in test_run_program_vs_reference above): the three forms of the module loop agree on it as they
+    do on the deep one -- C++ launch-per-layer == Python loop bit for bit, fused one-launch-per-level == them to fp32 rounding
+    with the same items and paths -- under a random visiting order too."""
+    z, orc, m = build("shallow")
+    assert all(not hasattr(m._module(rel), "fc3") for rel in m.relation_info)
     users = torch.from_numpy(z["users"])
     out = {}
     for mode in ("2", "1", "0"):

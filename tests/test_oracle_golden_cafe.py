@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from oracle import cafe as oc
 from oracle.pgpr import CKG
@@ -10,8 +11,11 @@ from oracle.pgpr import CKG
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def load():
-    z = np.load(os.path.join(GOLDEN, "cafe_default.npz"))
+TAGS = ("default", "shallow", "nodropout")  # CAFE.yaml; deep_module: False (RelationModule, cafe.py:645-667); use_dropout: False
+
+
+def load(tag="default"):
+    z = np.load(os.path.join(GOLDEN, f"cafe_{tag}.npz"))
     p = {k[2:]: z[k] for k in z.files if k.startswith("p.")}
     names = [str(x) for x in z["relation_names"]]
     rid = {n: i for i, n in enumerate(names)}
@@ -19,20 +23,33 @@ def load():
     g = CKG(int(z["n_users"]), int(z["n_entities"]), int(z["ui_relation"]), z["inter_users"], z["inter_items"], z["heads"],
             z["rels"], z["tails"], ui_bidirectional=False)
     metapaths = [[(None, "user")] + [(str(r), "entity") for r in mp] for mp in z["metapaths"]]
-    orc = oc.CafeOracle(g, p, z["user_emb"], z["entity_emb"], rid, ui_name, int(z["n_items"]), z["positives"], metapaths)
+    orc = oc.CafeOracle(g, p, z["user_emb"], z["entity_emb"], rid, ui_name, int(z["n_items"]), z["positives"], metapaths,
+                        deep=bool(z["deep_module"]))
     return z, orc, rid, ui_name
 
 
-def test_modules():
-    z, orc, rid, ui = load()
+def train_masks(z):
+    """The multiplicative dropout masks of the recorded training step in call order (one per dropout call: two per level for
+    the deep module, one for the shallow one; none recorded with use_dropout: False -> ones)."""
+    n_levels, per = 3, 2 if bool(z["deep_module"]) else 1
+    if not bool(z["use_dropout"]):
+        return [np.float32(1.0)] * (n_levels * per)
+    return [z[f"train.mask{i}"] for i in range(n_levels * per)]
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_modules(tag):
+    z, orc, rid, ui = load(tag)
+    assert ("model." + str(z["metapaths"][0][0]) + ".fc3.weight" in orc.p) == bool(z["deep_module"])
     for k in z.files:
         if k.startswith("mod.") and not k.startswith("mod.inputs"):
-            got = oc.module_forward(orc.p, k[4:], z["mod.inputs_e"], z["mod.inputs_u"])
+            got = oc.module_forward(orc.p, k[4:], z["mod.inputs_e"], z["mod.inputs_u"], deep=bool(z["deep_module"]))
             np.testing.assert_allclose(got, z[k], rtol=2e-5, atol=2e-6)
 
 
-def test_infer_with_path():
-    z, orc, rid, ui = load()
+@pytest.mark.parametrize("tag", TAGS)
+def test_infer_with_path(tag):
+    z, orc, rid, ui = load(tag)
     keys, off = z["infer.keys"], z["infer.off"]
     n_nonempty = 0
     for t, (u, mpid) in enumerate(keys):
@@ -46,8 +63,9 @@ def test_infer_with_path():
     assert n_nonempty > 20
 
 
-def test_run_program():
-    z, orc, rid, ui = load()
+@pytest.mark.parametrize("tag", TAGS)
+def test_run_program(tag):
+    z, orc, rid, ui = load(tag)
     res, col = orc.run_program(z["users"])
     finite = np.isfinite(z["run.scores"])
     assert np.array_equal(np.isfinite(res), finite)
@@ -72,13 +90,13 @@ def check_collected(col, z):
             assert got_order[k] == ref_order[k], k
 
 
-def test_training_forward_loss():
+@pytest.mark.parametrize("tag", TAGS)
+def test_training_forward_loss(tag):
     """SymbolicNetwork.forward in train mode on the reference's sampled batch (recorded dropout masks)."""
-    z, orc, rid, ui = load()
+    z, orc, rid, ui = load(tag)
     mp = orc.metapaths[int(z["train.mpid"])]
-    masks = [z[f"train.mask{i}"] for i in range(6)]
     reg, rank = oc.symbolic_forward_loss(orc.p, mp, z["train.pos_paths"], z["train.neg_pids"],
-                                         {"user": orc.U, "entity": orc.E}, masks)
+                                         {"user": orc.U, "entity": orc.E}, train_masks(z), deep=bool(z["deep_module"]))
     np.testing.assert_allclose(reg, float(z["train.reg_loss"]), rtol=2e-5)
     np.testing.assert_allclose(rank, float(z["train.rank_loss"]), rtol=2e-5)
     # every sampled path is a walk of SOME metapath (the reference draws a metapath per user and scores the whole batch

@@ -46,6 +46,27 @@ for B in (64, 1024, 4096):
 
     ms = timed(step, 20)
     out[f"pgpr_B{B}"] = {"ms_per_step": round(ms, 3), "users_per_s": round(B / ms * 1e3), "episode_steps": m.max_path_len}
+    # the same step replayed from a HIP graph (driver.GraphedTrainStep: the Philox offsets of the policy dropout, the action
+    # dropout and the action draws live on the device during the capture), FusedAdam as in driver.graphed_trainer
+    from hopwise_amd.driver import GraphedTrainStep
+    from hopwise_amd.optim import FusedAdam
+
+    fopt = FusedAdam(m.parameters(), lr=1e-4)
+    it = {m.USER_ID: users}
+
+    def fstep():
+        fopt.zero_grad(set_to_none=True)
+        loss = m.calculate_loss(it)
+        loss.backward()
+        fopt.step()
+
+    ms_f = timed(fstep, 20)
+    g = GraphedTrainStep(m, fopt, it)
+    ms_g = timed(lambda: g(it), 50)
+    g.check_flags()
+    out[f"pgpr_B{B}"].update(ms_per_step_fused_adam=round(ms_f, 3), ms_per_step_graph_replay=round(ms_g, 3),
+                             users_per_s_graph_replay=round(B / ms_g * 1e3))
+    del g, fopt
 print(json.dumps(out), flush=True)
 del m
 torch.cuda.empty_cache()
@@ -70,4 +91,37 @@ for B in (64, 512, 4096):
 
     ms = timed(step, 20)
     out[f"cafe_B{B}"] = {"ms_per_step": round(ms, 3), "paths_per_s": round(B / ms * 1e3), "metapath_levels": len(mp) - 1}
+print(json.dumps(out), flush=True)
+
+# TuckER (configs[4] width) and ConvE: eager trainer step against its graph replay (three / four dropouts per side, Philox offsets
+# on the device during the capture)
+del m
+torch.cuda.empty_cache()
+import hopwise_amd.model as M
+from hopwise_amd.driver import GraphedTrainStep
+from hopwise_amd.optim import FusedAdam
+from tests.helpers import FakeDataset, make_config
+
+nU, nI, nE, nR, Bt = 6041, 2985, 13805, 13, 2048
+for name, cfg in (("TuckER", dict(embedding_size=200, label_smoothing=0.1, input_dropout=0.3, input_dropout1=0.4, input_dropout2=0.5)),):
+    torch.manual_seed(0)
+    c = make_config(dev, cfg.pop("embedding_size"), 1.0, **cfg)
+    tm = getattr(M, name)(c, FakeDataset(nU, nI, nE, nR)).to(dev).train()
+    it = {k: torch.from_numpy(v).to(dev) for k, v in dict(
+        user_id=rng.integers(1, nU, Bt), item_id=rng.integers(1, nI, Bt), head_id=rng.integers(1, nE, Bt),
+        relation_id=rng.integers(1, nR - 1, Bt), tail_id=rng.integers(1, nE, Bt)).items()}
+    topt = FusedAdam(tm.parameters(), lr=1e-4)
+
+    def tstep():
+        topt.zero_grad(set_to_none=True)
+        loss = tm.calculate_loss(it)
+        loss.backward()
+        topt.step()
+
+    ms_e = timed(tstep, 20)
+    g = GraphedTrainStep(tm, topt, it)
+    ms_g = timed(lambda: g(it), 50)
+    out[f"{name.lower()}_B{Bt}"] = {"ms_per_step_eager": round(ms_e, 3), "ms_per_step_graph_replay": round(ms_g, 3)}
+    del g, topt, tm
+    torch.cuda.empty_cache()
 print(json.dumps(out), flush=True)

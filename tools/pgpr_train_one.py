@@ -6,7 +6,7 @@ dev = torch.device("cuda", 0)
 kg, ds, m = bench_pgpr.make_model(dev)
 m.train()
 rng = np.random.default_rng(0)
-users = torch.from_numpy(rng.integers(1, kg.n_users, 2048)).to(dev)
+users = torch.from_numpy(rng.integers(1, kg.n_users, int(os.environ.get("HW_TRAIN_B", "2048")))).to(dev)
 opt = torch.optim.Adam(m.parameters(), lr=1e-4)
 def step():
     opt.zero_grad(set_to_none=True)
