@@ -134,6 +134,9 @@ def graphed_trainer_protocol(yaml):
                     self.calls += 1
                     return self.t._eager_step(inter)
 
+                def check_flags(self):  # read once per epoch by the trainer: nothing a CPU stand-in could have raised
+                    pass
+
             class cls(graphed_trainer(base)):  # noqa: N801
                 def _graph_safe(self, loss_func):
                     return loss_func is None
