@@ -183,6 +183,49 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         except Exception:
             traffic = None
     ms = dt / steps * 1e3
+    # ---- roofline of the dominant kernel: the policy launch of the LAST hop (55-60 % of a search) -------------------------
+    # It is matrix / issue bound, not bandwidth bound: per beam row two dense layers (H1 x 256 and 256 x 256 multiply-adds:
+    # pgpr.py:175-187) evaluated as three-way bf16 splits -- six bf16 MFMAs per fp32 product, so the pipe's fp32 roof is the dense
+    # bf16 rate / 6.  The slot-table rows it gathers are L2-served (PMC traffic of a whole search is BELOW the bytes the
+    # algorithm addresses), so bytes are no lower bound for it; they are reported for the search as a whole (search_bytes).
+    rows_last = int(counts[-1][len(HOPS) - 1].item()) if len(counts) else 0  # beam rows entering the last hop
+    h1, h2 = m.hidden_sizes
+    flops = 2.0 * rows_last * (h1 * h2 + h2 * 256)  # the actor layer is computed over 256 padded action slots
+    pol_ms = stage_ms.get(f"policy.hop{len(HOPS)}", 0.0)
+    mfma_peak = 2500.0 / 6.0
+    tail_ms = stage_ms.get(f"expand.hop{len(HOPS)}", 0.0)
+    n_leaves = int(counts[-1][len(HOPS)].item()) if len(counts) else 0
+    roofline = {
+        "bound": "mfma", "kernel": f"pgpr_policy_fused_kernel<{2 + 2 * m.state_history}, 3>, last hop ({rows_last} beam rows)",
+        "achieved": (flops / (pol_ms * 1e-3) / 1e12) if pol_ms else 0.0, "peak": mfma_peak, "unit": "TFLOP/s",
+        "frac": (flops / (pol_ms * 1e-3) / 1e12 / mfma_peak) if pol_ms else 0.0, "traffic": None,
+        "kernel_ms": pol_ms, "flops_per_launch": flops,
+        "peak_note": "dense bf16 MFMA 2 500 TFLOP/s / 6: every fp32 product is six bf16 MFMAs of the exact three-way splits "
+                     "(fp32-level error, as the reference's fp32 policy network needs for its top-k cuts); kernel_ms from HIP "
+                     "events around the launch on its stream (stage_ms_by_hop)",
+        "leaf_writes": {"bound": "hbm", "kernel": "pgpr_topk_expand_kernel<true, true>, last hop", "kernel_ms": tail_ms,
+                        "algorithmic_bytes_per_launch": 16.0 * n_leaves + 1280.0 * rows_last,
+                        "achieved": ((16.0 * n_leaves + 1280.0 * rows_last) / (tail_ms * 1e-3) / 1e9) if tail_ms else 0.0,
+                        "peak": 8000.0, "unit": "GB/s",
+                        "frac": ((16.0 * n_leaves + 1280.0 * rows_last) / (tail_ms * 1e-3) / 1e9 / 8000.0) if tail_ms else 0.0,
+                        "note": "16 B per leaf written + 1 KB of logits and <= 256 B of action offsets read per beam row; the "
+                                "kernel is bound by vector-instruction issue (358 wave instructions per row: ranking), not by "
+                                "these bytes (profiles/r4/pmc_pgpr_r4.txt)"},
+        "search_bytes": {
+            "achieved_GBps": abytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": abytes / (ms * 1e-3) / 1e9 / 8000.0,
+            "algorithmic_bytes_per_search": abytes, "traffic": traffic, "per_hop": per_hop,
+            "note": "a REPORTED figure, not a roofline: bytes this algorithm addresses (CSR slice deg * 8 + 2 float64 "
+                    "trim-score lookups per candidate of an over-full row + one 2 KB slot-table row per state slot + 60 B per "
+                    "child, 16 B per child of the last hop; bench_pgpr.algorithmic_bytes) over the wall time of the whole "
+                    "search.  Counter traffic (fabric-side bytes of all kernels of one search, FETCH_SIZE / WRITE_SIZE passes) is "
+                    "below it: the slot-table rows are served by L2"},
+        "stage_ms": {k: round(v, 4) for k, v in sorted(by_stage.items())},
+        "stage_ms_by_hop": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
+        "note": "stage_ms: HIP events between the stages of a search (5 untimed searches; with the one-launch tail the top-k has "
+                "no launch of its own and is inside 'expand'); leaf_layout: the collector on the compact leaves and a full rebuild "
+                "of all 60-byte records, timed once outside the timed region; per-kernel durations: profiles/<round>/"
+                "pgpr_kernel_stats_*.csv",
+    }
     out = {
         "metric": "PGPR paths expanded per second (3-hop beam 64/64/64, d=100, max_acts=250)",
         "value": expanded / dt, "unit": "paths/s", "users_per_step": n_users, "steps": steps, "timed_seconds": dt,
@@ -194,24 +237,7 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         "tail": ("softmax + top-k + expand in one launch per hop (hw_pgpr_topk_expand)" if m.fused_tail
                  else "top-k and expand as two launches per hop"),
         "leaf_layout": leaf_layout,
-        "roofline": {
-            "bound": "hbm", "achieved": abytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-            "frac": abytes / (ms * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes_per_search": abytes, "traffic": traffic,
-            "per_hop": per_hop,
-            "stage_ms": {k: round(v, 4) for k, v in sorted(by_stage.items())},
-            "stage_ms_by_hop": {k: round(v, 4) for k, v in sorted(stage_ms.items())},
-            "note": "bytes this algorithm must move (CSR slice deg * 8 + 2 float64 trim-score lookups per candidate of an "
-                    "over-full row + one 2 KB slot-table row per state slot + 60 B per child, 16 B per child of the last hop when it "
-                    "leaves as a compact leaf {parent row, relation, node, value}; bench_pgpr.algorithmic_bytes) / "
-                    "wall time of the whole search.  The search is not one bandwidth-bound kernel: the policy network is "
-                    "MFMA / issue bound and the action kernels are L2-gather bound (DESIGN.md §4), so this fraction is a "
-                    "reported figure, not a target.  stage_ms: HIP events between the stages of a search (5 untimed "
-                    "searches; with the one-launch tail the top-k has no launch of its own and is inside 'expand'); "
-                    "leaf_layout: the collector on the compact leaves and a full rebuild of all 60-byte records, timed once "
-                    "outside the timed region; per-kernel durations: profiles/r4/pgpr_kernel_stats_*.csv; traffic: fabric-side "
-                    "bytes of all "
-                    "kernels of one search from the FETCH_SIZE / WRITE_SIZE passes",
-        },
+        "roofline": roofline,
     }
     if cpu_users > 0:
         from oracle import pgpr as op

@@ -371,15 +371,18 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             rel_code = np.fromiter((code[n] for n in rel_names), np.int64, total)
         par_row = np.where(par_i < 0, -1, node_ptr[row_b] + par_i)
         mods = [self._module(n) for n in names]
-        # parents precede children inside a program: depth, capacity and leaf flags by program position
-        depth = np.ones(total, np.int64)
-        cap = k_of.copy()
-        for pos in range(int(lens.max()) if B else 0):
-            rows = np.nonzero((row_i == pos) & (par_i >= 0))[0]
-            depth[rows] = depth[par_row[rows]] + 1
-            cap[rows] = cap[par_row[rows]] * k_of[rows]
-        is_leaf = np.ones(total, np.int64)
-        is_leaf[par_row[par_row >= 0]] = 0
+        if flat is not None and "depth" in flat:  # run_program: per-order columns, gathered (see _order_tables)
+            depth, cap, is_leaf = flat["depth"], flat["cap"], flat["is_leaf"]
+        else:
+            # parents precede children inside a program: depth, capacity and leaf flags by program position
+            depth = np.ones(total, np.int64)
+            cap = k_of.copy()
+            for pos in range(int(lens.max()) if B else 0):
+                rows = np.nonzero((row_i == pos) & (par_i >= 0))[0]
+                depth[rows] = depth[par_row[rows]] + 1
+                cap[rows] = cap[par_row[rows]] * k_of[rows]
+            is_leaf = np.ones(total, np.int64)
+            is_leaf[par_row[par_row >= 0]] = 0
         cum = np.cumsum(cap)
         slot_ptr = np.concatenate([[0], cum[node_ptr[1:] - 1]]) if total else np.zeros(B + 1, np.int64)
         slot_off = cum - cap - slot_ptr[row_b]
@@ -389,18 +392,30 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         vec_all = torch.empty((max(total, 1), d), dtype=torch.float32, device=dev)
         # every index column of stages 1 and 2 goes to the device in ONE copy (they were three pageable host-to-device copies
         # per (level, relation) pair -- ~45 per call, each a stall of the launching thread in a leg that is host-bound)
-        et_of = np.array([m.et_name for m in mods])[rel_code] if total else np.zeros(0, "<U6")
+        # the (level, relation) groups in (level, relation) order, rows ascending inside a group: ONE stable sort by the
+        # group key instead of a mask + nonzero per pair (~50 passes over the node columns per call, most of the host time
+        # of a 1 024-user run_program)
         plan, c_eh, c_uv, c_row = [], [], [], []
-        for dep in range(1, int(depth.max()) + 1 if total else 1):
-            at_dep = depth == dep
-            for j in range(len(mods)):
-                rows = np.nonzero(at_dep & (rel_code == j))[0]
-                if len(rows):
-                    plan.append((dep, j, len(rows)))
-                    c_eh.append(np.where(par_row[rows] < 0, row_b[rows], B + par_row[rows]))
-                    c_uv.append(row_b[rows])
-                    c_row.append(rows)
-        et_rows = [(et, np.nonzero(et_of == et)[0]) for et in np.unique(et_of)]
+        if total:
+            n_mods = len(mods)
+            key = depth * n_mods + rel_code
+            order = np.argsort(key, kind="stable")
+            sizes = np.bincount(key, minlength=(int(depth.max()) + 1) * n_mods)
+            plan = [(int(k // n_mods), int(k % n_mods), int(n)) for k, n in enumerate(sizes.tolist()) if n]
+            pr = par_row[order]
+            c_eh, c_uv, c_row = [np.where(pr < 0, row_b[order], B + pr)], [row_b[order]], [order]
+        # rows per tail-entity type, types in name order (integer codes: a string column per node and np.unique over it were
+        # a millisecond of a 1 024-user call)
+        et_rows = []
+        if total:
+            et_name_of_mod = [m.et_name for m in mods]
+            used_mods = np.nonzero(sizes.reshape(-1, n_mods).sum(0))[0].tolist()
+            ets = sorted({et_name_of_mod[j] for j in used_mods})
+            if len(ets) == 1:
+                et_rows = [(ets[0], np.arange(total))]
+            else:
+                et_code = np.array([ets.index(n) if n in ets else -1 for n in et_name_of_mod], np.int64)[rel_code]
+                et_rows = [(et, np.nonzero(et_code == e)[0]) for e, et in enumerate(ets)]
         # the interpreter's node table (host-only inputs: built here so that it rides in the same copy)
         nodes = np.zeros(total, P.CAFE_NODE_DTYPE)
         nodes["parent"], nodes["k"], nodes["is_leaf"], nodes["depth"] = par_i, k_of, is_leaf, depth
@@ -585,11 +600,15 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             index_of_chain = {_chain_of(e["order"], i): i for i in range(len(e["order"]))}
             e["leaf_row"] = np.asarray([index_of_chain.get(chain, -1) for chain in leaves] or [-1], np.int32)
         if e.get("topk") != manual_topk:  # capacity of a node = product of k along its chain
-            cap = np.ones(len(e["order"]), np.int64)
+            n = len(e["order"])
+            cap, depth, is_leaf = np.ones(n, np.int64), np.ones(n, np.int64), np.ones(n, np.int64)
             for i, (par, _, _) in enumerate(e["order"]):
                 cap[i] = manual_topk * (cap[par] if par >= 0 else 1)
+                if par >= 0:
+                    depth[i], is_leaf[par] = depth[par] + 1, 0
             sel = e["leaf_row"][e["leaf_row"] >= 0]
             e["topk"], e["max_rec"] = manual_topk, int(cap[sel].sum())
+            e["cap"], e["depth"], e["is_leaf"] = cap, depth, is_leaf
 
     def _order_tables(self, B, manual_topk, leaves, code):
         """Single branching node with at most 7 children (<= 5 040 visiting orders): every order enumerated once, its columns
@@ -621,7 +640,9 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             srt = np.argsort(codes)
             T = tabs[manual_topk] = dict(
                 codes=codes[srt], par=np.stack([ents[i]["par_i"] for i in srt]), rel=np.stack([ents[i]["rel_code"] for i in srt]),
-                leaf=np.stack([ents[i]["leaf_row"] for i in srt]), max_rec=np.asarray([ents[i]["max_rec"] for i in srt], np.int64))
+                leaf=np.stack([ents[i]["leaf_row"] for i in srt]), max_rec=np.asarray([ents[i]["max_rec"] for i in srt], np.int64),
+                depth=np.stack([ents[i]["depth"] for i in srt]), cap=np.stack([ents[i]["cap"] for i in srt]),
+                is_leaf=np.stack([ents[i]["is_leaf"] for i in srt]))
         perms = self.rng.permuted(np.tile(fast["base"], (B, 1)), axis=1)
         return np.searchsorted(T["codes"], perms @ fast["weights"]), T
 
@@ -695,7 +716,8 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         if got is not None:  # the usual layout: columns gathered from the per-order tables
             oid, T = got
             flat = dict(lens=np.full(B, T["par"].shape[1], np.int64), par_i=T["par"][oid].ravel(),
-                        rel_code=T["rel"][oid].ravel(), names=names)
+                        rel_code=T["rel"][oid].ravel(), names=names, depth=T["depth"][oid].ravel(),
+                        cap=T["cap"][oid].ravel(), is_leaf=T["is_leaf"][oid].ravel())
             leaf_nodes = T["leaf"][oid]
             max_rec_all = int(T["max_rec"][oid].max())
         else:
