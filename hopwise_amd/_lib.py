@@ -221,7 +221,7 @@ SIGNATURES = {
     ),
     "hw_kge_query_rows": (
         C.c_int,
-        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, c_f32p, c_i32p, C.c_void_p],
+        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int32, c_i32p, C.c_void_p],
     ),
     "hw_rows_sqnorm": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int32, c_f32p, C.c_void_p]),
     "hw_kge_dist_finish": (
@@ -233,7 +233,8 @@ SIGNATURES = {
         C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_int32, C.c_void_p]),
     "hw_topk_rerank": (
         C.c_int,
-        [c_i64p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, c_f32p, c_i64p, c_i32p, C.c_void_p],
+        [c_i64p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, c_f32p, C.c_float, C.c_float, c_f32p,
+         c_i64p, c_i32p, C.c_void_p],
     ),
     "hw_mask_scores": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_void_p]),
     "hw_mask_scores_ex": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_int32, C.c_void_p]),

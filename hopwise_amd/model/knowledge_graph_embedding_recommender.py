@@ -249,6 +249,27 @@ class _GatherKGE(KnowledgeRecommender):
         slot = ("sqnorm",) + tuple(t.data_ptr() for t in tail)
         return self._table_cache(slot).get(tuple(t._version for t in tail), lambda: ops.rows_sqnorm(self._cat_tables(tail)))
 
+    def _aug_table(self, tail):
+        """([rows, K + 4] candidate rows [t | -||t||^2 / 2 | 0 0 0], max ||t||^2): the table side of the distance form's ranking
+        product (hw_kge_query_rows ``append_one``), cached per table version like the plain side-by-side copy."""
+        slot = ("aug",) + tuple(t.data_ptr() for t in tail)
+
+        def build():
+            t = self._cat_tables(tail)
+            tn = self._tail_sqnorm(tail)
+            aug = torch.zeros((t.shape[0], t.shape[1] + ops.AUG_PAD), dtype=torch.float32, device=t.device)
+            aug[:, : t.shape[1]] = t
+            aug[:, t.shape[1]] = -0.5 * tn
+            return aug, tn.max().reshape(1)
+
+        aug, tmax = self._table_cache(slot).get(tuple(t._version for t in tail), build)
+        cache = self.__dict__.setdefault("_aug_tn_max", {})
+        key = (slot, tuple(t._version for t in tail))
+        if key not in cache:  # one host read per table version (the re-rank kernel takes the bound by value)
+            cache.clear()
+            cache[key] = float(tmax.item())
+        return aug, cache[key]
+
     def _full_sort_gemm(self, side, h_idx, r_idx, r_fixed, n, padded=False):
         """[B, n] scores of every candidate.  ``padded``: rows start 256-byte aligned (a view of a wider buffer) so that the
         product's epilogue, the finish pass and the top-k read and write 16 bytes per lane."""
@@ -306,6 +327,22 @@ class _GatherKGE(KnowledgeRecommender):
         if self._use_gemm_full_sort(h_idx.numel(), n):
             c = self._rerank_candidates(k, n)
             rerank = self.gemm_rerank and k <= c
+            if rerank and self.GEMM_FORM == "distance":
+                # ranking needs no scores: with the query extended by a 1 and the candidate rows by -||t||^2 / 2 the product
+                # itself orders the candidates as the score does -- no finish pass over the [B, N] matrix
+                q, qn = ops.kge_query_rows(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=True, margin=self.margin,
+                                           augmented=True)
+                aug, tn_max = self._aug_table(tail)
+                buf = torch.empty((q.shape[0], (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)[:, :n]
+                p = ops.gemm(q, aug[:n], out=buf)
+                ops.mask_scores_(p, history_index)
+                approx, cand = ops.topk_rows(p, c)
+                desc = ops.make_desc(self.MODEL, head, rel, tail, self.margin, 0.0, n)
+                exact = ops.kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, cand)  # c <= n: every candidate is a column
+                val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=1e-5, abs_slack=1e-6, qn=qn,
+                                                 base=self.margin if self.MODEL == "RotatE" else 0.0, tn_max=tn_max)
+                return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, 0, n, k, history_index,
+                                              True, self.margin, run_if=flag, out=(val, idx))
             # the product + mask + top-k on the written matrix beats the fused gather kernel (the matrix is written and
             # re-read, but at a quarter of the scoring time)
             scores = self._full_sort_gemm(side, h_idx, r_idx, r_fixed, n, padded=True)

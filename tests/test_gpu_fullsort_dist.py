@@ -192,6 +192,19 @@ def test_rerank_raises_its_flag_and_the_exact_kernel_takes_over():
     nan = exact.clone()
     nan[0, 0] = float("nan")
     assert int(ops.topk_rerank(idx, approx, nan, k)[2].item()) == 1
+    # the distance form: approximate values are p = <q, t> - ||t||^2 / 2 of the augmented product, the bound is taken on
+    # d^2 = ||q||^2 - 2 p.  Distances 1, 2, ..., 32 (scores -1 ... -32), ||q||^2 = 4:
+    dist = torch.arange(1, 33, device=dev(), dtype=torch.float32).view(1, 32)
+    qn = torch.tensor([4.0], device=dev())
+    p = (qn.view(1, 1) - dist * dist) / 2
+    # k = 10: the k-th exact score is -10, a column outside the set is at distance >= 32 -- proven
+    assert int(ops.topk_rerank(idx[:1], p, -dist, 10, rel_slack=1e-5, qn=qn, base=0.0, tn_max=900.0)[2].item()) == 0
+    # the set's smallest p belongs to a column whose distance is no larger than the k-th one: not proven
+    p_bad = p.clone()
+    p_bad[0, -1] = (4.0 - 9.5 * 9.5) / 2
+    assert int(ops.topk_rerank(idx[:1], p_bad, -dist, 10, rel_slack=1e-5, qn=qn, base=0.0, tn_max=900.0)[2].item()) == 1
+    # with a margin as base (RotatE) the same decision
+    assert int(ops.topk_rerank(idx[:1], p, 6.0 - dist, 10, rel_slack=1e-5, qn=qn, base=6.0, tn_max=900.0)[2].item()) == 0
 
 
 def test_query_rows_kernel_equals_the_torch_fold():

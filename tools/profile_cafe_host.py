@@ -13,7 +13,7 @@ import bench_cafe
 
 dev = torch.device("cuda", 0)
 kg, ds, m, metapaths = bench_cafe.make_model(dev)
-users = torch.from_numpy(np.random.default_rng(1).integers(1, kg.n_users, 256))
+users = torch.from_numpy(np.random.default_rng(1).integers(1, kg.n_users, int(os.environ.get("HW_CAFE_USERS", "1024"))))
 for _ in range(2):
     m.run_program_device(users)
 torch.cuda.synchronize()
