@@ -26,7 +26,7 @@ row gradients + all-reduce of the replicated relation tables inside the timed st
 
 Legs in the JSON line: `roofline` (the scorer kernel: HBM-resident variant as the roofline of record, the configs[1]
 launch against the L2 gather ceiling, the entity-tail variants, `other_scorers` = the same launch shape for TransE d=64 / d=200,
-DistMult d=200, ComplEx d=256 on >= 4 GB tables), `configs0` (TransE d=64 in the reference's layout), `cpu_baseline` (oracle/kge_ref.c on the host
+DistMult d=200, ComplEx d=256 on >= 4 GB tables), `configs0` (TransE d=64 in the reference's layout), `evaluation` (the RotatE full-sort + top-10 step, product form vs gather kernel), `cpu_baseline` (oracle/kge_ref.c on the host
 cores), `sharded` (configs[3]), `tucker` (configs[4], N = 1), `reference_layout` (configs[1] in the reference's batch
 layout through the model class, N = 1), `pgpr` (configs[2]).
 """
@@ -731,6 +731,66 @@ def leg_configs0(D, args):
     return res
 
 
+def leg_evaluation(D, args):
+    """The evaluation step a hopwise trainer runs per batch (trainer.py:716-735 + collector.py:173-183): every user of a 2 048-user
+    batch against every item, history mask, top-10 -- RotatE d=200 (the north-star scorer) at ml-1m-small's 2 985 items and at
+    Yelp2018's 45 539, as one product on the MFMA GEMM with the exact re-rank (the default) against the fused gather kernel;
+    the public full_sort_predict (the [B, N] matrix hopwise's own collector ranks) beside it."""
+    import numpy as np
+
+    torch, dev = D.torch, D.dev
+    import hopwise_amd.model as M
+    from tests.helpers import FakeDataset, make_config
+
+    def wall(fn, reps):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    res = {"metric": "RotatE d=200 evaluation step: 2 048 users x all items -> history mask -> top-10 (ms per step)"}
+    rng = np.random.default_rng(0)
+    B = 2048
+    for tag, (nU, nI, nE, nR) in (("ml1m_2985_items", (6041, 2985, 13805, 13)), ("yelp2018_45539_items", (45920, 45539, 90962, 44))):
+        torch.manual_seed(0)
+        m = M.RotatE(make_config(dev, DIM, 1.0), FakeDataset(nU, nI, nE, nR)).to(dev).eval()
+        users = torch.from_numpy(rng.integers(1, nU, B)).to(dev)
+        hist = (torch.from_numpy(rng.integers(0, B, 50 * B)).to(dev), torch.from_numpy(rng.integers(1, nI, 50 * B)).to(dev))
+        inter = {"user_id": users}
+        r = {"scores_per_step": B * nI}
+        with torch.no_grad():
+            gv, gi = m.full_sort_topk(inter, 10, hist)
+            r["topk_product_form_ms"] = wall(lambda: m.full_sort_topk(inter, 10, hist), 50)
+            r["full_sort_predict_product_form_ms"] = wall(lambda: m.full_sort_predict(inter), 50)
+            m.gemm_full_sort = False
+            kv, ki = m.full_sort_topk(inter, 10, hist)
+            r["topk_gather_kernel_ms"] = wall(lambda: m.full_sort_topk(inter, 10, hist), 20)
+            r["full_sort_predict_gather_kernel_ms"] = wall(lambda: m.full_sort_predict(inter), 20)
+        # parity in the line: the product form's top-10 against the fused gather kernel's (positions may swap only where two
+        # exact scores are within an ulp of each other: the two kernels sum a row in different orders)
+        same = (gi == ki)
+        gap = (kv[:, :-1] - kv[:, 1:]).abs() > 4e-7 * kv[:, :-1].abs() + 1e-7
+        decided = torch.ones_like(same)
+        decided[:, :-1] &= gap
+        decided[:, 1:] &= gap
+        r["parity"] = {"columns_equal": float(same.float().mean()), "columns_equal_where_scores_differ": bool(same[decided].all()),
+                       "max_rel_value_diff": float(((gv - kv).abs() / kv.abs().clamp_min(1e-6)).max())}
+        if not r["parity"]["columns_equal_where_scores_differ"] or r["parity"]["max_rel_value_diff"] > 1e-5:
+            raise AssertionError(f"evaluation parity ({tag}): {r['parity']}")
+        r["scores_per_s_product_form"] = B * nI / (r["topk_product_form_ms"] * 1e-3)
+        res[tag] = r
+        del m
+        torch.cuda.empty_cache()
+    res["note"] = ("product form: hw_kge_query_rows -> hw_gemm_f32 (query [q | 1] x table [t | -||t||^2/2]) -> mask -> top-16 -> exact "
+                   "re-score of the candidates by the gather scorer -> hw_topk_rerank (proof on the device, predicated gather "
+                   "fallback); full_sort_predict: the plain product + hw_kge_dist_finish")
+    return res
+
+
 def leg_cpu_baseline(D, args, out, ctx):
     import numpy as np
 
@@ -1130,6 +1190,7 @@ def main():
             out["roofline"]["other_scorers"] = out.pop("scorer_rooflines")
     if D.world == 1 and not args.no_tucker:
         guarded("configs0", lambda: leg_configs0(D, args))
+        guarded("evaluation", lambda: leg_evaluation(D, args))
     if not args.no_sharded and D.world == 1:
         guarded("sharded", lambda: leg_sharded(D, args))
     if D.world == 1 and not args.no_tucker:

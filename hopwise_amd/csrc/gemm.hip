@@ -521,6 +521,74 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         if (tid == 0) bce.loss_partial[bx + gridDim.x * by] = (red[0] + red[1]) + (red[2] + red[3]);
         return;
     }
+    if constexpr (ACT == 4) {
+        // Distance epilogue (hw_gemm_dist): the tile holds <q_i, t_j>; out = base - sqrt(max(||q_i||^2 + ||t_j||^2 - 2 <q_i, t_j>, 0)).
+        // Arguments reuse the epilogue's slots: bias = ||t||^2 per column, drop_mask = ||q||^2 per row, bce.scale = base,
+        // bce.add = the cancellation threshold.  An entry whose d^2 falls below threshold x (||q||^2 + ||t||^2) -- where the
+        // expansion has lost its digits: the query's nearest neighbours, a handful per row -- is recomputed by its lane as
+        // sum_k (q_k - t_k)^2 from the two operand rows (four partial sums), so every score that leaves is fp32-accurate.
+        const float* __restrict__ tn = bias;
+        const float* __restrict__ qn = drop_mask;
+        const float base = bce.scale, frac = bce.add;
+        const bool interior = m0 + BM <= M && n0 + BN <= N;
+        const bool via_lds = interior && (pipe & 2);
+        float* const slab = lds + wave * 2048;  // every loop ended with a barrier: no wave still reads the tiles
+        const bool vec_rows = vec_a && vec_b && (K & 3) == 0;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int gm0 = m0 + wm + ti * 32 + 4 * (lane >> 5);
+            float qv[16];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) qv[rg] = qn[min(gm0 + (rg & 3) + 8 * (rg >> 2), M - 1)];
+            float v[2][16];
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int gn = n0 + wn + tj * 32 + (lane & 31);
+                const bool col_ok = gn < N;
+                const float tv = col_ok ? tn[gn] : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int gm = gm0 + (rg & 3) + 8 * (rg >> 2);
+                    const float sum = qv[rg] + tv;
+                    float d2 = fmaf(-2.f, acc[ti][tj][rg], sum);
+                    if (col_ok && gm < M && d2 < frac * sum) {
+                        const float* __restrict__ qr = A + (size_t)gm * lda;
+                        const float* __restrict__ tr = B + (size_t)gn * ldb;
+                        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+                        if (vec_rows) {
+                            for (int kk = 0; kk < K; kk += 4) {
+                                const f32x4 a4 = *reinterpret_cast<const f32x4*>(qr + kk);
+                                const f32x4 b4 = *reinterpret_cast<const f32x4*>(tr + kk);
+                                const float e0 = a4.x - b4.x, e1 = a4.y - b4.y, e2 = a4.z - b4.z, e3 = a4.w - b4.w;
+                                p0 = fmaf(e0, e0, p0), p1 = fmaf(e1, e1, p1), p2 = fmaf(e2, e2, p2), p3 = fmaf(e3, e3, p3);
+                            }
+                        } else {
+                            for (int kk = 0; kk < K; ++kk) {
+                                const float e0 = qr[kk] - tr[kk];
+                                p0 = fmaf(e0, e0, p0);
+                            }
+                        }
+                        d2 = (p0 + p1) + (p2 + p3);
+                    }
+                    v[tj][rg] = base - __builtin_amdgcn_sqrtf(fmaxf(d2, 0.f));
+                }
+            }
+            if (via_lds) {
+                store_slab_via_lds(slab, v, C + (size_t)(m0 + wm + ti * 32) * ldc + n0 + wn, ldc, lane);
+            } else {
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const int gn = n0 + wn + tj * 32 + (lane & 31);
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int gm = gm0 + (rg & 3) + 8 * (rg >> 2);
+                        if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v[tj][rg];
+                    }
+                }
+            }
+        }
+        return;
+    }
 #ifndef GEMM_ABL_NO_STORE
     if ((pipe & 2) && drop_mode == 0 && m0 + BM <= M && n0 + BN <= N) {  // interior tile, 16-byte rows: dwordx4 stores
         float* const slab = lds + wave * 2048;  // every loop ended with a barrier: no wave still reads the tiles
@@ -1191,6 +1259,9 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     if (act == 3) {  // fused BCE epilogue: x . E^T only, never split
         if (!(a_kc && b_kc) || splits != 1) return HW_ERR_UNSUPPORTED;
         GO(true, true, 3);
+    } else if (act == 4) {  // distance epilogue (hw_gemm_dist): q . t^T only, never split
+        if (!(a_kc && b_kc) || splits != 1) return HW_ERR_UNSUPPORTED;
+        GO(true, true, 4);
     } else if (a_kc && b_kc) GO3(true, true);
     else if (a_kc && !b_kc) GO3(true, false);
     else if (!a_kc && !b_kc) GO3(false, false);
@@ -1229,6 +1300,22 @@ extern "C" int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, 
     HW_CLEAR_ERR();
     launch_gemm(a, lda, a_k_contiguous != 0, b, ldb, b_k_contiguous != 0, c, ldc, m_rows, m_max, n, k, bias, elu,
                 drop_mask, drop_mode, seed, offset, workspace, workspace ? workspace_floats : 0, (hipStream_t)stream);
+    return HW_LAUNCH_RC();
+}
+
+// c[i, j] = base - ||q_i - t_j|| from ONE product: the distance epilogue of the kernel above (ACT = 4).
+extern "C" int hw_gemm_dist(const float* q, int64_t ldq, const float* t, int64_t ldt, float* c, int64_t ldc, int64_t m,
+                            int64_t n, int64_t k, const float* qn, const float* tn, float base, float rescore_frac,
+                            void* stream) {
+    if (!q || !t || !c || !qn || !tn || m < 0 || n < 1 || k < 1 || ldc < n || ldq < k || ldt < k) return HW_ERR_INVALID_ARG;
+    if (!(rescore_frac >= 0.f && rescore_frac <= 1.f)) return HW_ERR_INVALID_ARG;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (m == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    GemmBce ep{nullptr, base, rescore_frac, 0.f, nullptr};
+    const int rc = launch_gemm(q, ldq, true, t, ldt, true, c, ldc, nullptr, m, n, k, tn, 4, qn, 0, 0, 0, nullptr, 0,
+                               (hipStream_t)stream, ep);
+    if (rc) return rc;
     return HW_LAUNCH_RC();
 }
 

@@ -280,11 +280,10 @@ class _GatherKGE(KnowledgeRecommender):
         out = None
         if padded:
             out = torch.empty((q.shape[0], (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)[:, :n]
-        scores = ops.gemm(q, table, out=out)
-        if dist:
-            base = self.margin if self.MODEL == "RotatE" else 0.0
-            ops.kge_dist_finish_(scores, q, table, qn, self._tail_sqnorm(tail)[:n], base)
-        return scores
+        if dist:  # the product with the distance epilogue: one launch, the dot products never reach memory
+            return ops.gemm_dist(q, table, qn, self._tail_sqnorm(tail)[:n], self.margin if self.MODEL == "RotatE" else 0.0,
+                                 out=out)
+        return ops.gemm(q, table, out=out)
 
     def _use_gemm_full_sort(self, n_queries, n=None):
         if (self.GEMM_FORM is None or not self.gemm_full_sort or n_queries <= 0 or "_tables" in self.__dict__

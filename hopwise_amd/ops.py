@@ -623,6 +623,24 @@ def kge_dist_finish_(dots, q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRA
     return dots
 
 
+def gemm_dist(q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRAC, out=None):
+    """out[i, j] = base - ||q_i - t_j||: the product with the distance epilogue (hw_gemm_dist), one launch."""
+    lib = _lib.load()
+    q, t = _dev(q, torch.float32, "q"), _dev(t, torch.float32, "t")
+    qn, tn = _dev(qn, torch.float32, "qn").contiguous(), _dev(tn, torch.float32, "tn").contiguous()
+    if q.dim() != 2 or t.dim() != 2 or q.stride(1) != 1 or t.stride(1) != 1 or q.shape[1] != t.shape[1]:
+        raise ValueError("q [m, k] and t [n, k] with unit inner stride")
+    m, n = q.shape[0], t.shape[0]
+    if qn.numel() != m or tn.numel() != n:
+        raise ValueError("qn / tn: one value per row")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=q.device)
+    if m and n:
+        check(lib.hw_gemm_dist(_ptr(q), q.stride(0), _ptr(t), t.stride(0), _ptr(out), out.stride(0), m, n, q.shape[1],
+                               _ptr(qn), _ptr(tn), float(base), float(rescore_frac), _stream()), "hw_gemm_dist")
+    return out
+
+
 def topk_rerank(cand_idx, cand_approx, cand_exact, k, rel_slack=5e-5, abs_slack=1e-6, unverified=None, qn=None, base=0.0,
                 tn_max=0.0):
     """(values [R, k], indices [R, k], unverified int32 [1]): the exact top-k out of c <= 64 re-scored candidates per row

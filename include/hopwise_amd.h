@@ -188,6 +188,11 @@ int hw_rows_sqnorm(const float* x, int64_t ld, int64_t n_rows, int32_t k, float*
 int hw_kge_dist_finish(float* c, int64_t ldc, int64_t m, int64_t n, const float* q, int64_t ldq, const float* t,
                        int64_t ldt, int32_t k, const float* qn, const float* tn, float base, float rescore_frac,
                        int32_t mask_column0, int32_t* n_rescored, void* stream);
+/* The product and the finish in ONE launch: c[i, j] = base - ||q_i - t_j|| for q [m, k], t [n, k] (K-contiguous rows), with the
+ * same recomputation from the rows where the expansion cancels (the lane that owns the entry sums (q_k - t_k)^2 itself).  What
+ * full_sort_predict / full_sort_predict_kg of the distance scorers run (transe.py:112-154, rotate.py:161-220). */
+int hw_gemm_dist(const float* q, int64_t ldq, const float* t, int64_t ldt, float* c, int64_t ldc, int64_t m, int64_t n,
+                 int64_t k, const float* qn, const float* tn, float base, float rescore_frac, void* stream);
 /* hw_mask_scores_ex on rows with a leading dimension (a padded score matrix). */
 int hw_mask_scores_ld(float* scores, int64_t n_rows, int64_t n_cols, int64_t ld, const int64_t* hist_rows,
                       const int64_t* hist_cols, int64_t n_hist, int32_t mask_column0, void* stream);

@@ -32,7 +32,7 @@ def test_default_legs_at_a_tiny_size():
     assert r["configs1_launch"]["bound"] == "l2" and r["configs1_launch"]["frac"] <= 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "triples/s"
-    for leg in ("sharded", "tucker", "reference_layout", "configs0", "pgpr", "cafe"):
+    for leg in ("sharded", "tucker", "reference_layout", "configs0", "evaluation", "pgpr", "cafe"):
         assert leg in d and "error" not in d[leg], (leg, d[leg].get("error"))
     assert d["sharded"]["parity"] and abs(d["sharded"]["parity"]["sharded_loss"] - d["sharded"]["parity"]["plain_loss"]) < 1e-5
     assert d["tucker"]["parity"]["loss_relation_sets"] == d["tucker"]["parity"]["loss_per_row_product"]
@@ -55,3 +55,6 @@ def test_default_legs_at_a_tiny_size():
     oth = d["roofline"]["other_scorers"]
     for tag in ("transe_d64", "transe_d200", "distmult_d200", "complex_d256"):
         assert oth[tag]["bound"] == "hbm" and 0.3 < oth[tag]["frac"] <= 1.0 and oth[tag]["table_GB"] >= 4.0
+    ev = d["evaluation"]
+    for tag in ("ml1m_2985_items", "yelp2018_45539_items"):
+        assert ev[tag]["parity"]["columns_equal_where_scores_differ"] is True and ev[tag]["topk_product_form_ms"] > 0

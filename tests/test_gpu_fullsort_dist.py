@@ -114,6 +114,12 @@ def test_finish_pass_recomputes_where_the_expansion_cancels(model):
             assert float(err_raw[list(rows), list(cols)].max()) > 50 * float(err_fixed[list(rows), list(cols)].max() + 1e-9)
             # the query itself: distance exactly 0
             assert float(fixed[0, 1]) == 0.0
+            # the fused form (hw_gemm_dist: the same recomputation inside the product's epilogue) on the same inputs
+            out = torch.empty((B, (nI + 63) // 64 * 64), dtype=torch.float32, device=dev())[:, :nI] if padded else None
+            fused = ops.gemm_dist(q, table, qn, tn, base=0.0, out=out)
+            err_fused = ((-fused.double()) - want).abs()
+            assert bool((err_fused <= tol).all()), float((err_fused - tol).max())
+            assert float(fused[0, 1]) == 0.0
         # column 0 masked in the same pass
         masked = ops.kge_dist_finish_(ops.gemm(q, table), q, table, qn, tn, base=m.margin, mask_column0=True)
         assert bool(torch.isinf(masked[:, 0]).all()) and bool(torch.isfinite(masked[:, 1:]).all())
@@ -200,8 +206,7 @@ def test_rerank_raises_its_flag_and_the_exact_kernel_takes_over():
     # k = 10: the k-th exact score is -10, a column outside the set is at distance >= 32 -- proven
     assert int(ops.topk_rerank(idx[:1], p, -dist, 10, rel_slack=1e-5, qn=qn, base=0.0, tn_max=900.0)[2].item()) == 0
     # the set's smallest p belongs to a column whose distance is no larger than the k-th one: not proven
-    p_bad = p.clone()
-    p_bad[0, -1] = (4.0 - 9.5 * 9.5) / 2
+    p_bad = p.clamp_min((4.0 - 9.5 * 9.5) / 2)  # every candidate looked at least as near as 9.5: so may a column outside
     assert int(ops.topk_rerank(idx[:1], p_bad, -dist, 10, rel_slack=1e-5, qn=qn, base=0.0, tn_max=900.0)[2].item()) == 1
     # with a margin as base (RotatE) the same decision
     assert int(ops.topk_rerank(idx[:1], p, 6.0 - dist, 10, rel_slack=1e-5, qn=qn, base=6.0, tn_max=900.0)[2].item()) == 0

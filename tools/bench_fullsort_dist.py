@@ -60,6 +60,7 @@ for nU, nI, nE, nR in ((6041, 2985, 13805, 13), (45920, 45539, 90962, 44)):
                 out["query_rows_ms"] = round(timed(lambda: ops.kge_query_rows(name, head, rel, tail, users, None, m._rec_rel_full_sort(), sqnorm=True)), 4)
                 out["gemm_ms"] = round(timed(lambda: ops.gemm(q, table, out=buf)), 4)
                 out["finish_ms"] = round(timed(lambda: ops.kge_dist_finish_(buf, q, table, qn, tn, 0.0)), 4)
+                out["gemm_dist_ms"] = round(timed(lambda: ops.gemm_dist(q, table, qn, tn, 0.0, out=buf)), 4)
                 out["topk32_ms"] = round(timed(lambda: ops.topk_rows(buf, 32)), 4)
                 out["topk10_ms"] = round(timed(lambda: ops.topk_rows(buf, 10)), 4)
                 m.gemm_full_sort = False
