@@ -11,7 +11,7 @@ i0,i1=key[-11],key[-1]
 seg=rows[i0:i1]
 agg=collections.defaultdict(lambda:[0,0])
 for r in seg:
-    k=r["Kernel_Name"].split("(")[0][:60]
+    k=r["Kernel_Name"].split("(")[0][:60] if "at::native" not in r["Kernel_Name"] else r["Kernel_Name"][:230]
     agg[k][0]+=1; agg[k][1]+=int(r["End_Timestamp"])-int(r["Start_Timestamp"])
 steps=10
 tot=sum(v[1] for v in agg.values())
