@@ -350,6 +350,10 @@ SIGNATURES = {
         C.c_int,
         [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_float, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_void_p],
     ),
+    "hw_pgpr_policy_grad_scaled": (
+        C.c_int,
+        [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_float, c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_void_p],
+    ),
     "hw_act_dropout_backward": (
         C.c_int,
         [c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int32, c_f32p, C.c_int32, C.c_uint64, C.c_uint64, c_f32p, C.c_void_p],

@@ -117,10 +117,10 @@ class _EpisodeLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        grads = ctx.model._episode_backward(ctx.ep)
-        scale = grad_out.to(torch.float32)
+        # the upstream gradient of the scalar loss enters at d loss / d head: every gradient behind it is linear in it
+        grads = ctx.model._episode_backward(ctx.ep, upstream=grad_out.to(torch.float32).reshape(1))
         ctx.ep = None
-        return (None, None) + tuple(g * scale for g in grads)
+        return (None, None) + tuple(grads)
 
 
 class PGPR(KnowledgeRecommender, ExplainableRecommender):
@@ -427,8 +427,14 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
 
     # -- training: one REINFORCE episode per batch (pgpr.py:120-203, 335-396) ---------------------------------------
     def _head_params(self):
-        return (torch.cat([self.actor.weight, self.critic.weight], 0).detach().contiguous(),
-                torch.cat([self.actor.bias, self.critic.bias], 0).detach().contiguous())
+        """(actor | critic) weights and biases stacked for the one head product of a step; rebuilt when a parameter moves."""
+        ps = (self.actor.weight, self.critic.weight, self.actor.bias, self.critic.bias)
+        build = lambda: (torch.cat([self.actor.weight, self.critic.weight], 0).detach().contiguous(),
+                         torch.cat([self.actor.bias, self.critic.bias], 0).detach().contiguous())
+        if ps[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            return build()  # a captured step must hold the stacking itself: a replay moves the weights without running this
+        key = tuple((t._version, t.data_ptr()) for t in ps)
+        return self._fenced("_head_cache").get(key, build)
 
     @torch.no_grad()
     def episode_device(self, users, forced_acts=None, act_masks=None, drops=None):
@@ -453,7 +459,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                   paths=[i32(B, P.ROW_INTS) for _ in range(T + 1)])
         probs3 = [f32(B, 3) for _ in range(2)]
         nr = torch.zeros(T + 1, dtype=torch.int32, device=dev)
-        acts_buf, n_acts, offsets = i32(B, A, 2), i32(B), i32(B)
+        acts_buf, offsets = i32(B, A, 2), i32(B)
         scratch = None
         if g.max_degree > P.ACT_LDS_KEYS:
             scratch = torch.empty((min(2048, B), g.max_degree), dtype=torch.int64, device=dev)
@@ -468,12 +474,12 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
             paths, n_rows = ep["paths"][t], nr[t : t + 1]
+            n_acts = ep["n_acts"][sl]  # the step's action counts land in the episode record directly
             P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, B, self.max_acts,
                       self.fix_scores_sorting_bug, acts_buf, n_acts, scratch, start_user_revisitable=True)
             call = self._philox.next()
             off = [self._philox.offset(call, j) for j in range(4)]
             ep["calls"].append(call)
-            ep["n_acts"][sl].copy_(n_acts)
             if act_masks is not None:
                 ep["mask"][sl].copy_(act_masks[t])
             else:
@@ -507,7 +513,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         return ep
 
     @torch.no_grad()
-    def _episode_backward(self, ep):
+    def _episode_backward(self, ep, upstream=None):
         """Gradients of update()'s loss w.r.t. (l1.w, l1.b, l2.w, l2.b, actor.w, actor.b, critic.w, critic.b): the
         head gradient per row, then one stacked GEMM pass over all T * B rows."""
         from ..ops import gemm
@@ -515,7 +521,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         B, T, A = ep["B"], ep["T"], self.act_dim
         n = T * B
         dhead = torch.empty_like(ep["head"])
-        P.policy_grad(ep["probs"], A, ep["acts"], ep["coef_actor"], self.weight_factor / B, ep["dvalue"], n, dhead)
+        P.policy_grad(ep["probs"], A, ep["acts"], ep["coef_actor"], self.weight_factor / B, ep["dvalue"], n, dhead, upstream)
         g_head_w = gemm(dhead, ep["x2"], a_k_contiguous=False, b_k_contiguous=False)
         g_head_b = P.colsum(dhead)
         dx2 = gemm(dhead, ep["head_w"], b_k_contiguous=False)  # [n, H2]

@@ -519,12 +519,13 @@ def policy_sample(head, act_dim, mask, n_rows, max_rows, probs, acts, logp, entr
     )
 
 
-def policy_grad(probs, act_dim, acts, coef_actor, coef_entropy, dvalue, n_rows, dhead):
+def policy_grad(probs, act_dim, acts, coef_actor, coef_entropy, dvalue, n_rows, dhead, upstream=None):
+    """``upstream``: float32 [1] on the device, the gradient arriving at the scalar loss (None = 1): dhead comes out scaled."""
     lib = _lib.load()
     check(
-        lib.hw_pgpr_policy_grad(_ptr(probs), int(act_dim), _ptr(acts), _ptr(coef_actor), float(coef_entropy),
-                                _ptr(dvalue), int(n_rows), _ptr(dhead), dhead.stride(0), _stream()),
-        "hw_pgpr_policy_grad",
+        lib.hw_pgpr_policy_grad_scaled(_ptr(probs), int(act_dim), _ptr(acts), _ptr(coef_actor), float(coef_entropy),
+                                       _ptr(dvalue), int(n_rows), _ptr(dhead), dhead.stride(0), _ptr(upstream), _stream()),
+        "hw_pgpr_policy_grad_scaled",
     )
 
 

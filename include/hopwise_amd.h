@@ -621,6 +621,11 @@ int hw_pgpr_policy_sample(const float* head, int64_t ld, int32_t act_dim, const 
 int hw_pgpr_policy_grad(const float* probs, int32_t act_dim, const int32_t* acts, const float* coef_actor,
                         float coef_entropy, const float* dvalue, int64_t n_rows, float* dhead, int64_t ld,
                         void* stream);
+/* The same times upstream[0] (a device float: the gradient arriving at the scalar loss, pgpr.py:189-203 `loss.backward()`);
+ * NULL = 1.  Everything behind dhead is linear in it, so the eight parameter gradients come out scaled. */
+int hw_pgpr_policy_grad_scaled(const float* probs, int32_t act_dim, const int32_t* acts, const float* coef_actor,
+                               float coef_entropy, const float* dvalue, int64_t n_rows, float* dhead, int64_t ld,
+                               const float* upstream, void* stream);
 
 /* dx = dy * d/dpre[dropout(act(pre))] recovered from y = dropout(act(pre)) (act 1 ELU, 2 ReLU, 0 none; drop modes as
  * hw_gemm_f32, mode 2 regenerates the Philox mask of the forward call with the same seed / offset). */
