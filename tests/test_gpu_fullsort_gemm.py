@@ -78,3 +78,34 @@ def test_cached_side_by_side_table_follows_the_weights():
         c = m.full_sort_predict(inter).view_as(b)
     assert float((a - b).abs().max()) > 1e-3
     np.testing.assert_allclose(b.cpu().numpy(), c.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(c.abs().max()))
+
+
+@pytest.mark.parametrize("model", ["DistMult", "ComplEx", "Analogy"])
+def test_bilinear_topk_with_the_exact_rerank_is_the_gather_paths(model):
+    """``gemm_rerank: True`` on a bilinear scorer (off by default there: the product's own scores are fp32-accurate): the
+    evaluation top-k of the product form re-scored by the gather scorer and ranked exactly -- the gather path's columns, and
+    values that are predict()'s bit for bit."""
+    for dim, nE, nI, B, k in ((64, 1003, 700, 5, 10), (24, 5000, 4600, 70, 20)):
+        nU, nR = 50, 6
+        tables = random_tables(model, nU, nE, nR, dim, seed=dim + B)
+        m = build(model, tables, dim, nU, nI, nE, nR, gemm_rerank=True)
+        assert m.gemm_rerank and m.GEMM_FORM == "bilinear"
+        rng = np.random.default_rng(B)
+        users = torch.from_numpy(rng.integers(0, nU, B)).to(dev())
+        hist = (torch.from_numpy(rng.integers(0, B, 40)).to(dev()), torch.from_numpy(rng.integers(0, nI, 40)).to(dev()))
+        inter = {"user_id": users}
+        with torch.no_grad():
+            gv, gi = m.full_sort_topk(inter, k, hist)
+            m.gemm_full_sort = False
+            kv, ki = m.full_sort_topk(inter, k, hist)
+            m.gemm_full_sort = True
+            flat = {"user_id": users.repeat_interleave(k), "item_id": gi.reshape(-1)}
+            np.testing.assert_array_equal(m.predict(flat).view(B, k).cpu().numpy(), gv.cpu().numpy())
+        kvn, kin, gin = kv.cpu().numpy(), ki.cpu().numpy(), gi.cpu().numpy()
+        scale = float(np.abs(kvn).max())
+        np.testing.assert_allclose(gv.cpu().numpy(), kvn, rtol=1e-5, atol=1e-6 * scale)
+        gap_ok = np.ones_like(kin, bool)
+        gaps = kvn[:, :-1] - kvn[:, 1:]
+        gap_ok[:, :-1] &= gaps > 2e-6 * scale
+        gap_ok[:, 1:] &= gaps > 2e-6 * scale
+        assert (kin == gin)[gap_ok].all() and gap_ok.mean() > 0.8
