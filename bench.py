@@ -785,7 +785,7 @@ def leg_evaluation(D, args):
         res[tag] = r
         del m
         torch.cuda.empty_cache()
-    res["note"] = ("product form: hw_kge_query_rows -> hw_gemm_f32 (query [q | 1] x table [t | -||t||^2/2]) -> mask -> top-16 -> exact "
+    res["note"] = ("product form: hw_kge_query_rows -> hw_gemm_f32 (bias -||t||^2/2) -> mask -> top-16 -> exact "
                    "re-score of the candidates by the gather scorer -> hw_topk_rerank (proof on the device, predicated gather "
                    "fallback); full_sort_predict: the plain product + hw_kge_dist_finish")
     return res

@@ -221,7 +221,7 @@ SIGNATURES = {
     ),
     "hw_kge_query_rows": (
         C.c_int,
-        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int32, c_i32p, C.c_void_p],
+        [C.POINTER(KgeDesc), c_i64p, c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, c_f32p, c_i32p, C.c_void_p],
     ),
     "hw_rows_sqnorm": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int32, c_f32p, C.c_void_p]),
     "hw_kge_dist_finish": (

@@ -13,9 +13,9 @@
 //     the squared distance is a small fraction of that sum the entry is recomputed directly as sum_k (q_k - t_k)^2 from
 //     the rows (a wave per such entry, rare: the query's nearest neighbours) -- every score the pass leaves behind is
 //     within a few 1e-6 relative of the fp32 reference formula;
-//   * the evaluation top-k needs no finish pass at all: with the query extended by a 1 and every candidate row by
-//     -||t||^2 / 2 (one more column of the cached table) the product itself is p = <q, t> - ||t||^2 / 2, and ranking by p IS
-//     ranking by score (score = base - sqrt(||q||^2 - 2 p), monotone);
+//   * the evaluation top-k needs no finish pass at all: with -||t||^2 / 2 as the product's per-column bias (hw_gemm_f32's
+//     bias epilogue) the product itself is p = <q, t> - ||t||^2 / 2, and ranking by p IS ranking by score
+//     (score = base - sqrt(||q||^2 - 2 p), monotone);
 //   * topk_rerank_kernel: the top-k of an evaluation stays EXACT.  The caller takes the top-c (c > k) of the finished
 //     matrix, re-scores those c candidates with the gather scorer (the kernel `predict` runs), and this kernel ranks them
 //     by (exact value desc, index asc).  It also proves the candidate set was large enough: a column outside the set has
@@ -32,8 +32,7 @@ template <int MODEL, int G, int NE, bool VEC>
 __global__ __launch_bounds__(256) void kge_query_rows_kernel(hw_kge_desc d, const int64_t* __restrict__ h_idx,
                                                              const int64_t* __restrict__ r_idx, int64_t r_fixed,
                                                              int64_t n, float* __restrict__ out, int64_t ld,
-                                                             float* __restrict__ sqnorm, int vec_store, int append_one,
-                                                             int32_t* oob) {
+                                                             float* __restrict__ sqnorm, int vec_store, int32_t* oob) {
     using SC = Scorer<MODEL, G, NE, VEC>;
     using MT = ModelTraits<MODEL>;
     using R = Row<G, NE, VEC>;
@@ -75,10 +74,6 @@ __global__ __launch_bounds__(256) void kge_query_rows_kernel(hw_kge_desc d, cons
     }
     s = group_sum<G>(s);
     if (sqnorm && live && gl == 0) sqnorm[i] = s;
-    if (append_one && live) {  // [q | 1 | 0 ...]: the query side of the augmented product (see hw_kge_query_rows)
-        const int k0 = MT::NQ * d.dim;
-        for (int c = k0 + gl; c < ld; c += G) row[c] = c == k0 ? 1.f : 0.f;
-    }
 }
 
 // out[j] = sum_k x[j, k]^2, a wave per row
@@ -243,7 +238,7 @@ __global__ __launch_bounds__(256) void topk_rerank_kernel(const int64_t* __restr
     } else {
         const float e_k = __shfl(ex, __builtin_ctzll(kth), 64);
         if (qn) {
-            // distance form: the approximate values are p = <q, t> - ||t||^2 / 2 (the augmented product), so a column outside
+            // distance form: the approximate values are p = <q, t> - ||t||^2 / 2 (the biased product), so a column outside
             // the set has p <= lo, i.e. d^2 = ||q||^2 - 2 p >= ||q||^2 - 2 lo, less the product's error (rel_slack of
             // ||q||^2 + max ||t||^2): its score is at most base - sqrt of that
             const float q2 = qn[r];
@@ -271,8 +266,7 @@ __global__ __launch_bounds__(256) void topk_rerank_kernel(const int64_t* __restr
     } while (0)
 
 extern "C" int hw_kge_query_rows(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed,
-                                 int64_t n, float* out, int64_t ld, float* sqnorm, int32_t append_one, int32_t* oob_counter,
-                                 void* stream) {
+                                 int64_t n, float* out, int64_t ld, float* sqnorm, int32_t* oob_counter, void* stream) {
     int rc = check_desc(desc);
     if (rc) return rc;
     if (!h_idx || !out || n < 0) return HW_ERR_INVALID_ARG;
@@ -285,7 +279,7 @@ extern "C" int hw_kge_query_rows(const hw_kge_desc* desc, const int64_t* h_idx, 
         case HW_ANALOGY: nq = 3; break;
         default: return HW_ERR_UNSUPPORTED;
     }
-    if (ld < (int64_t)nq * desc->dim + (append_one ? 1 : 0)) return HW_ERR_INVALID_ARG;
+    if (ld < (int64_t)nq * desc->dim) return HW_ERR_INVALID_ARG;
     if (n == 0) return HW_OK;
     const RowShape shape = row_shape(desc->dim, tables_aligned16(desc));
     const int NS = HW_WAVE / shape.G;
@@ -296,7 +290,7 @@ extern "C" int hw_kge_query_rows(const hw_kge_desc* desc, const int64_t* h_idx, 
     HW_CLEAR_ERR();
 #define CALL(MODEL, G_, NE_, VEC_)                                                                                    \
     hipLaunchKernelGGL((kge_query_rows_kernel<MODEL, G_, NE_, VEC_>), dim3((unsigned)n_blocks), dim3(256), 0, st, *desc, \
-                       h_idx, r_idx, r_fixed, n, out, ld, sqnorm, vec_store, (int)(append_one != 0), oob_counter)
+                       h_idx, r_idx, r_fixed, n, out, ld, sqnorm, vec_store, oob_counter)
     HW_QUERY_MODELS(desc->model, shape, CALL);
 #undef CALL
     return HW_LAUNCH_RC();

@@ -249,26 +249,22 @@ class _GatherKGE(KnowledgeRecommender):
         slot = ("sqnorm",) + tuple(t.data_ptr() for t in tail)
         return self._table_cache(slot).get(tuple(t._version for t in tail), lambda: ops.rows_sqnorm(self._cat_tables(tail)))
 
-    def _aug_table(self, tail):
-        """([rows, K + 4] candidate rows [t | -||t||^2 / 2 | 0 0 0], max ||t||^2): the table side of the distance form's ranking
-        product (hw_kge_query_rows ``append_one``), cached per table version like the plain side-by-side copy."""
-        slot = ("aug",) + tuple(t.data_ptr() for t in tail)
+    def _rank_bias(self, tail):
+        """(-||t||^2 / 2 per candidate row, max ||t||^2): the per-column bias that turns the product into the distance form's
+        ranking value, and the bound the re-rank's proof needs; cached per table version."""
+        slot = ("rankbias",) + tuple(t.data_ptr() for t in tail)
+        ver = tuple(t._version for t in tail)
 
         def build():
-            t = self._cat_tables(tail)
             tn = self._tail_sqnorm(tail)
-            aug = torch.zeros((t.shape[0], t.shape[1] + ops.AUG_PAD), dtype=torch.float32, device=t.device)
-            aug[:, : t.shape[1]] = t
-            aug[:, t.shape[1]] = -0.5 * tn
-            return aug, tn.max().reshape(1)
+            return tn * -0.5, tn.max().reshape(1)
 
-        aug, tmax = self._table_cache(slot).get(tuple(t._version for t in tail), build)
-        cache = self.__dict__.setdefault("_aug_tn_max", {})
-        key = (slot, tuple(t._version for t in tail))
-        if key not in cache:  # one host read per table version (the re-rank kernel takes the bound by value)
+        bias, tmax = self._table_cache(slot).get(ver, build)
+        cache = self.__dict__.setdefault("_tn_max_host", {})
+        if (slot, ver) not in cache:  # one host read per table version (the re-rank kernel takes the bound by value)
             cache.clear()
-            cache[key] = float(tmax.item())
-        return aug, cache[key]
+            cache[(slot, ver)] = float(tmax.item())
+        return bias, cache[(slot, ver)]
 
     def _full_sort_gemm(self, side, h_idx, r_idx, r_fixed, n, padded=False):
         """[B, n] scores of every candidate.  ``padded``: rows start 256-byte aligned (a view of a wider buffer) so that the
@@ -327,13 +323,12 @@ class _GatherKGE(KnowledgeRecommender):
             c = self._rerank_candidates(k, n)
             rerank = self.gemm_rerank and k <= c
             if rerank and self.GEMM_FORM == "distance":
-                # ranking needs no scores: with the query extended by a 1 and the candidate rows by -||t||^2 / 2 the product
-                # itself orders the candidates as the score does -- no finish pass over the [B, N] matrix
-                q, qn = ops.kge_query_rows(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=True, margin=self.margin,
-                                           augmented=True)
-                aug, tn_max = self._aug_table(tail)
+                # ranking needs no scores: with -||t||^2 / 2 as the product's per-column bias the product itself orders the
+                # candidates as the score does -- no finish pass over the [B, N] matrix
+                q, qn = ops.kge_query_rows(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=True, margin=self.margin)
+                bias, tn_max = self._rank_bias(tail)
                 buf = torch.empty((q.shape[0], (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)[:, :n]
-                p = ops.gemm(q, aug[:n], out=buf)
+                p = ops.gemm(q, self._cat_tables(tail)[:n], bias=bias[:n], out=buf)
                 ops.mask_scores_(p, history_index)
                 approx, cand = ops.topk_rows(p, c)
                 desc = ops.make_desc(self.MODEL, head, rel, tail, self.margin, 0.0, n)

@@ -571,25 +571,20 @@ GEMM_QUERY_MODELS = ("TransE", "DistMult", "RotatE", "ComplEx", "Analogy")
 DIST_RESCORE_FRAC = 1.0 / 16.0  # d^2 below this fraction of ||q||^2 + ||t||^2: recomputed from the rows (cancellation)
 
 
-AUG_PAD = 4  # columns the augmented product adds: [.. | 1 | 0 0 0] x [.. | -||t||^2 / 2 | 0 0 0] (rows stay 16-byte aligned)
-
-
-def kge_query_rows(model, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=False, margin=0.0, augmented=False):
-    """(query rows [B, NQ * dim], ||query||^2 [B] or None): the folded queries of a full sort as a dense matrix.
-    ``augmented``: rows [q | 1 | 0 0 0] ([B, NQ * dim + 4]) for the product with a table whose extra column holds
-    -||t||^2 / 2 (the distance form's ranking product, hw_kge_query_rows)."""
+def kge_query_rows(model, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=False, margin=0.0):
+    """(query rows [B, NQ * dim], ||query||^2 [B] or None): the folded queries of a full sort as a dense matrix."""
     lib = _lib.load()
     desc = make_desc(model, head, rel, tail, margin, 0.0)
     h_idx = _idx(h_idx, "h_idx").contiguous()
     if r_idx is not None:
         r_idx = _idx(r_idx, "r_idx").contiguous()
     B = h_idx.shape[0]
-    K = len(tail) * desc.dim + (AUG_PAD if augmented else 0)
+    K = len(tail) * desc.dim
     out = torch.empty((B, K), dtype=torch.float32, device=h_idx.device)
     qn = torch.empty(B, dtype=torch.float32, device=h_idx.device) if sqnorm else None
     if B:
         check(lib.hw_kge_query_rows(C.byref(desc), _ptr(h_idx), _ptr(r_idx), int(r_fixed), B, _ptr(out), K, _ptr(qn),
-                                    int(bool(augmented)), _ptr(_OobCounter.get(h_idx.device)), _stream()), "hw_kge_query_rows")
+                                    _ptr(_OobCounter.get(h_idx.device)), _stream()), "hw_kge_query_rows")
     return out, qn
 
 
@@ -645,7 +640,8 @@ def topk_rerank(cand_idx, cand_approx, cand_exact, k, rel_slack=5e-5, abs_slack=
                 tn_max=0.0):
     """(values [R, k], indices [R, k], unverified int32 [1]): the exact top-k out of c <= 64 re-scored candidates per row
     (hw_topk_rerank), with the device-side proof that the candidate set sufficed.  ``qn`` [R] (+ ``base``, ``tn_max``):
-    ``cand_approx`` are values of the augmented product of the distance form and the proof is made in the distance domain."""
+    ``cand_approx`` are values <q, t> - ||t||^2 / 2 of the distance form's ranking product and the proof is made in the distance
+    domain."""
     lib = _lib.load()
     ci = _idx(cand_idx, "cand_idx").contiguous()
     ca = _dev(cand_approx, torch.float32, "cand_approx").contiguous()

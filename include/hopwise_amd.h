@@ -173,12 +173,12 @@ int hw_kge_full_sort_topk_if(const hw_kge_desc* desc, const int64_t* h_idx, cons
  * hw_kge_query_rows: out[i, :] = the folded query of (h_idx[i], r_idx[i] or r_fixed) -- the model's query slots side by side,
  * [n, NQ * dim] with NQ = 1 (TransE: h + r; DistMult: h * r), 2 (RotatE: the rotated head (re | im); ComplEx: complex.py:54-59
  * with the reference's t_im in the last term), 3 (Analogy); ld >= NQ * dim.  sqnorm (nullable) [n] receives ||query||^2.
- * append_one: out[i, NQ * dim] = 1 and the rest of the row up to ld = 0 -- the query side of the AUGMENTED product of the
- * distance form: against candidate rows [t | -||t||^2 / 2 | 0 ...] it yields p = <q, t> - ||t||^2 / 2, which orders the
- * candidates exactly as the score does (score = base - sqrt(||q||^2 - 2 p)): an evaluation's top-k needs no finish pass.
+ * Evaluation of the distance form: hw_gemm_f32 of these rows with the candidate table and bias[j] = -||t_j||^2 / 2 yields
+ * p = <q, t> - ||t||^2 / 2, which orders the candidates exactly as the score does (score = base - sqrt(||q||^2 - 2 p)): an
+ * evaluation's top-k needs no finish pass.
  * Replaces the torch gathers / products / cat in front of the product.  Other models: HW_ERR_UNSUPPORTED. */
 int hw_kge_query_rows(const hw_kge_desc* desc, const int64_t* h_idx, const int64_t* r_idx, int64_t r_fixed, int64_t n,
-                      float* out, int64_t ld, float* sqnorm, int32_t append_one, int32_t* oob_counter, void* stream);
+                      float* out, int64_t ld, float* sqnorm, int32_t* oob_counter, void* stream);
 /* out[j] = sum_k x[j, k]^2 for the n_rows rows of x [n_rows, k] (leading dimension ld): ||t||^2 of the candidate rows. */
 int hw_rows_sqnorm(const float* x, int64_t ld, int64_t n_rows, int32_t k, float* out, void* stream);
 /* In place on c [m, n] (leading dimension ldc) holding <q_i, t_j>:  c[i, j] = base - sqrt(max(qn[i] + tn[j] - 2 c[i, j], 0))
@@ -202,7 +202,7 @@ int hw_mask_scores_ld(float* scores, int64_t n_rows, int64_t n_cols, int64_t ld,
  * *unverified when a row cannot prove that no column outside its candidate set belongs to its top-k: proven when the exact
  * k-th value > min(cand_approx) + rel_slack * |min(cand_approx)| + abs_slack (a column outside the set has an approximate
  * score <= that minimum), or when the set holds every unmasked column.
- * qn != NULL: cand_approx are values p of the augmented product (hw_kge_query_rows append_one), qn [m] = ||q||^2, and the
+ * qn != NULL: cand_approx are values p = <q, t> - ||t||^2 / 2 of the biased product (above), qn [m] = ||q||^2, and the
  * bound is taken in the distance domain: a column outside the set has d^2 >= qn - 2 min(p) - rel_slack * (qn + tn_max)
  * (tn_max = the largest ||t||^2 of the table), i.e. a score <= base - sqrt(that). */
 int hw_topk_rerank(const int64_t* cand_idx, const float* cand_approx, const float* cand_exact, int64_t m, int32_t c,

@@ -198,7 +198,7 @@ def test_rerank_raises_its_flag_and_the_exact_kernel_takes_over():
     nan = exact.clone()
     nan[0, 0] = float("nan")
     assert int(ops.topk_rerank(idx, approx, nan, k)[2].item()) == 1
-    # the distance form: approximate values are p = <q, t> - ||t||^2 / 2 of the augmented product, the bound is taken on
+    # the distance form: approximate values are p = <q, t> - ||t||^2 / 2 of the biased product, the bound is taken on
     # d^2 = ||q||^2 - 2 p.  Distances 1, 2, ..., 32 (scores -1 ... -32), ||q||^2 = 4:
     dist = torch.arange(1, 33, device=dev(), dtype=torch.float32).view(1, 32)
     qn = torch.tensor([4.0], device=dev())
