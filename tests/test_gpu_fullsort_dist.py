@@ -310,3 +310,58 @@ def test_product_form_against_the_reference_goldens(path):
                 checked += 1
             np.testing.assert_allclose(tv[r, c], ref_v[r, c], rtol=RTOL, atol=ATOL)
     assert checked > 0
+
+
+def test_edges_of_the_product_form():
+    """Empty batches, k beyond the re-rank's 64 candidates, k = n, a single candidate column, a history that masks almost a whole
+    row (fewer live columns than k): the product form returns what the gather form returns."""
+    from hopwise_amd import ops
+
+    model, dim, nU, nE, nI, nR = "RotatE", 32, 40, 600, 500, 5
+    tables = random_tables(model, nU, nE, nR, dim, seed=2)
+    m = build(model, tables, dim, nU, nI, nE, nR, gemm_min_scores=0)
+    users = torch.arange(1, 20, device=dev())
+    inter = {"user_id": users}
+    B = users.numel()
+
+    def both(k, hist=None):
+        with torch.no_grad():
+            m.gemm_full_sort = True
+            g = m.full_sort_topk(inter, k, hist)
+            m.gemm_full_sort = False
+            r = m.full_sort_topk(inter, k, hist)
+            m.gemm_full_sort = True
+        return g, r
+
+    for k in (1, 58, 64, 70, 128):  # 58 -> 64 candidates; 70, 128: beyond the re-rank, the finished scores are ranked
+        (gv, gi), (kv, ki) = both(k)
+        np.testing.assert_allclose(gv.cpu().numpy(), kv.cpu().numpy(), rtol=2e-5, atol=1e-6)
+        assert (gi == ki).float().mean() > 0.98
+    # a row with three live columns only: the rest of its top-10 is -inf, as the gather form reports it
+    cols = torch.arange(0, nI, device=dev())
+    keep = torch.tensor([7, 99, 320], device=dev())
+    dead = cols[~torch.isin(cols, keep)]
+    hist = (torch.full_like(dead, 4), dead)
+    (gv, gi), (kv, ki) = both(10, hist)
+    assert torch.equal(gi[4, :3].sort().values, keep) and torch.isinf(gv[4, 3:]).all() and torch.isinf(kv[4, 3:]).all()
+    assert torch.equal(gi[:4], ki[:4]) and torch.equal(gi[5:], ki[5:])
+    # empty batch
+    with torch.no_grad():
+        ev, ei = m.full_sort_topk({"user_id": users[:0]}, 10)
+        assert ev.shape == (0, 10) and ei.shape == (0, 10)
+        assert m.full_sort_predict({"user_id": users[:0]}).shape[0] == 0
+    # the entry points on nothing
+    head, rel, tail = m._tables("rec")
+    q, qn = ops.kge_query_rows(model, head, rel, tail, users[:0], None, m._rec_rel_full_sort(), sqnorm=True)
+    assert q.shape == (0, 2 * dim) and qn.shape == (0,)
+    t = m._cat_tables(tail)[:nI]
+    assert ops.gemm_dist(q, t, qn, m._tail_sqnorm(tail)[:nI]).shape == (0, nI)
+    z = torch.zeros((0, 16), device=dev())
+    v, i, flag = ops.topk_rerank(z.long(), z, z, 10)
+    assert v.shape == (0, 10) and int(flag.item()) == 0
+    # one candidate column
+    one = build(model, tables, dim, nU, 1, nE, nR, gemm_min_scores=0)
+    with torch.no_grad():
+        s = one.full_sort_predict(inter)
+        one.gemm_full_sort = False
+        np.testing.assert_allclose(s.cpu().numpy(), one.full_sort_predict(inter).view_as(s).cpu().numpy(), rtol=2e-5, atol=1e-6)
