@@ -38,6 +38,7 @@ from .knowledge_graph_embedding_recommender import _cfg
 
 
 _SEARCH_STREAMS = {}  # (device type, index) -> side streams of PGPR._search_and_collect
+_ACTION_STREAMS = {}  # (device index, caller stream handle) -> the stream a search's action kernels run on beside its policy launch
 
 
 class BeamResult:
@@ -154,6 +155,8 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         # evaluation batches larger than user_chunk: consecutive searches are dealt over this many HIP streams (a search's
         # policy launch is matrix-bound, its action / ranking launches are not: +15 % on the bench); 1 = one after another
         self.search_streams = max(1, int(_cfg(config, "search_streams", os.environ.get("HW_PGPR_STREAMS", "3"))))
+        # beam search: a hop's action kernels on a stream of their own beside its policy launch (HW_PGPR_OVERLAP=0: in line)
+        self.overlap_actions = bool(_cfg(config, "overlap_actions", os.environ.get("HW_PGPR_OVERLAP", "1") != "0"))
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         dev = torch.device(self.device)
 
@@ -322,7 +325,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
 
     @torch.no_grad()
     def beam_search_device(self, users, hops=None, drops=None, keep_trace=False, keep_buffers=False, stage_events=None,
-                           fused_tail=None, compact_leaves=None):
+                           fused_tail=None, compact_leaves=None, overlap_actions=None):
         """Expand ``users`` (int64 tensor on the device) hop by hop; returns a :class:`BeamResult` of leaf rows.
         ``drops``: optional per hop (mask1 [rows, h0], mask2 [rows, h1]) multiplicative masks.
         ``fused_tail`` (default: config ``fused_topk_expand`` / HW_PGPR_TAIL, on): softmax + top-k + expand of a hop as one
@@ -374,6 +377,17 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 ev.record()
                 stage_events.append((stage, hop, ev))
 
+        # stage marks time the stages one after another; a trace reads buffers between them
+        # (``overlap_actions``: a caller that already runs several searches side by side passes False -- their kernels fill
+        # each other's gaps, and the extra stream only adds to the queue: 4.97 -> 4.64 ms for a lone search, 4.20 = 4.31 for three)
+        overlap = ((self.overlap_actions if overlap_actions is None else bool(overlap_actions)) and stage_events is None
+                   and not keep_trace and users.is_cuda and not torch.cuda.is_current_stream_capturing())
+        if overlap:
+            dev = users.device
+            cur = torch.cuda.current_stream(dev)
+            side = _ACTION_STREAMS.get((dev.index, cur.cuda_stream))
+            if side is None:
+                side = _ACTION_STREAMS[(dev.index, cur.cuda_stream)] = torch.cuda.Stream(device=dev)
         mark("start", -1)
         for hop, k in enumerate(hops):
             rmax = buf["rows"][hop]
@@ -382,11 +396,22 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
                 # the reference refreshes state_pool at the end of hops 0 and 1 only (pgpr.py:481); with at most
                 # three hops every hop sees a fresh state, which is the same thing.
                 P.state(g, U32, E32, R32, self.state_history, paths, n_rows, rmax, buf["state"])
-            P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, rmax, self.max_acts,
-                      self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"], u16=acts_u16)
-            mark("actions", hop)
-            self._policy_logits(buf, n_rows, rmax, drops, hop, paths if lookup else None)
-            mark("policy", hop)
+            if overlap:
+                # the action lists and the policy logits of a hop both depend on the hop's path rows only -- and on different
+                # units (the action kernels are scalar- / vector-issue bound, the policy launch matrix- and L2-bound): the action
+                # kernels go to a stream of their own, the tail below waits for both
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, rmax, self.max_acts,
+                              self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"], u16=acts_u16)
+                self._policy_logits(buf, n_rows, rmax, drops, hop, paths if lookup else None)
+                cur.wait_stream(side)
+            else:
+                P.actions(g, score_user, score_entity, self._score_rel_entity, paths, n_rows, rmax, self.max_acts,
+                          self.fix_scores_sorting_bug, buf["acts"], buf["n_acts"], buf["scratch"], u16=acts_u16)
+                mark("actions", hop)
+                self._policy_logits(buf, n_rows, rmax, drops, hop, paths if lookup else None)
+                mark("policy", hop)
             if fused_tail and P.topk_expand_supported(self.act_dim, k):
                 last = hop == len(hops) - 1
                 mark("topk", hop)  # no launch of its own: the stage is part of "expand"
@@ -664,7 +689,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         outs = []
         for i, chunk in enumerate(chunks):
             with torch.cuda.stream(side[i % n_streams]):
-                res = self.beam_search_device(chunk)
+                res = self.beam_search_device(chunk, overlap_actions=False)
                 scores, sel = self.collect_scores_device(chunk, res)
             outs.append((chunk, res, scores, sel))
         for st in side[:n_streams]:
