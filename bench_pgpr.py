@@ -258,10 +258,10 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         _, _, m_id = make_model(dev, dropout="identity")
         m_id.load_state_dict(m.state_dict())
         gp, gq = m_id.beam_search_device(torch.from_numpy(users).to(dev)).numpy()
-        got = {tuple(int(x) for x in r) for r in gp}
+        got = {tuple(int(x) for x in r[:11]) for r in gp}  # without the record's last word, the user's index in the batch
 
-        def rec_of(path):  # oracle path [(rel, type, id) x n] -> the device's 12-int record
-            r = [int(path[0][2]), len(path)] + [0] * 10
+        def rec_of(path):  # oracle path [(rel, type, id) x n] -> the first 11 ints of the device's record
+            r = [int(path[0][2]), len(path)] + [0] * 9
             for j, (rel, typ, nid) in enumerate(path[1:]):
                 r[2 + 3 * j : 5 + 3 * j] = [int(rel), int(typ), int(nid)]
             return tuple(r)

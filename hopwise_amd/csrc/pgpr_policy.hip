@@ -18,6 +18,8 @@
 //     the [rows, H] activation: block idx >> 7, word (idx >> 5) & 3, bit idx & 31) -- 6 Philox evaluations per beam row for
 //     both layers; the unfused kernels' stream (hw_common.h:philox_bits, one block per 4 elements) costs 192 per row, about
 //     as many cycles as the matrix products.  Mode 1 (explicit masks, the parity tests) and mode 0 (identity) as before.
+#include <type_traits>
+
 #include "hw_common.h"
 
 namespace hw {
@@ -107,9 +109,22 @@ __device__ __forceinline__ float pf_elu(float x) {
     return x > 0.f ? x : u;
 }
 
-#ifndef PF_INTERLEAVE
-#define PF_INTERLEAVE 1
-#endif
+// Register budget and the weight path.  The kernel runs one wave per SIMD and its accumulators alone are 256 registers per
+// lane, so what the rest of the loop keeps live decides two things: whether the fragment reads get registers of their own
+// (a first form staged the weight chunks through 48 registers per lane and kept two gather buffers; hipcc then recycled ONE
+// register quad for most fragment reads -- read, wait a full LDS round trip, multiply, read ... -- and SQ_WAIT_INST_ANY was
+// 43 % of the wave cycles), and how many registers per SIMD are left for OTHER kernels' waves: the beam search's action and
+// selection kernels run beside this one on other streams, and a wave of theirs can only become resident on a SIMD whose
+// register file has room for it (432 of 512 taken: none of the trim kernels fits; 376 taken: they do -- the three-stream search
+// went from 4.25 to 3.9 ms with nothing else changed, profiles/r5/policy_kernel_experiments_r5.txt).  Hence:
+//   * the weight chunks travel global -> LDS directly (global_load_lds_dwordx4: no vector registers, no ds_write pass);
+//   * ONE gather buffer; the gathers of chunk c + 2 are issued in the middle of trip c, right behind the last piece of chunk
+//     c + 1's operand preparation (which empties the buffer).
+// Rules followed for the DMA (cdna_hip_programming.md 5, 'Pipelining across barriers'): the LDS image is lane-linear per wave
+// instruction; no __syncthreads() while a DMA is in flight (it would wait vmcnt(0)) -- a counted s_waitcnt vmcnt(N) that
+// leaves the younger gathers in flight, lgkmcnt(0), raw s_barrier; the DMAs are issued BEFORE the gathers of the same trip,
+// so that the vmcnt(0) hipcc puts in front of the gathers' first use never waits for a DMA younger than them.
+// tools/pf_abl/policy_pipe.hip keeps the other forms tried (three stages, sixteen one-tile steps per trip) behind flags.
 
 template <int NPARTS, int MODE>
 __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, const float* __restrict__ b1, int H1,
@@ -119,13 +134,12 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
                                                                    const int32_t* __restrict__ paths,
                                                                    const int32_t* __restrict__ n_rows_ptr, PfDrop dr,
                                                                    float* __restrict__ logits, int64_t ld) {
-    constexpr int PF_STAGES = 2;
     // ONE __shared__ object: a second one beside an array that direct-to-LDS loads write makes hipcc wait vmcnt(0) before the
     // first ds_read of every k-step (cdna_hip_programming.md, 'Projection GEMM at M = 256' item 4(a))
-    __shared__ __attribute__((aligned(16))) uint8_t lds[PF_STAGES * PF_CHUNK + (1024 + PF_H2) * 4];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * PF_CHUNK + (1024 + PF_H2) * 4];
     // the two hidden biases: read per chunk inside the MFMA shadow, where a global load would have to be waited for with a
     // vmcnt that also drains the weight prefetch issued before it (vector-memory operations return in order)
-    float* const bias_lds = reinterpret_cast<float*>(lds + PF_STAGES * PF_CHUNK);
+    float* const bias_lds = reinterpret_cast<float*>(lds + 2 * PF_CHUNK);
     const int n_rows = n_rows_ptr[0];
     const int row0 = blockIdx.x * PF_ROWS;
     if (row0 >= n_rows) return;
@@ -178,39 +192,34 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         }
     }
 
-    // ---- weight chunk pipeline: global -> registers -> LDS stage (q & 1) ----
-    pf_u32x4 wreg[12];
-    auto w_fetch = [&](int q) {
-#ifdef PF_ABL_NO_W
-        return;
-#endif
-        const pf_u32x4* s = reinterpret_cast<const pf_u32x4*>(planes + (size_t)q * PF_CHUNK);
+    // ---- weight chunk pipeline: global -> LDS stage (q & 1), no registers in between ----
+    const int wave_u = wave_in_block();  // wave-uniform for the compiler too: the DMA's LDS base travels in M0
+    auto w_glds = [&](int q) {  // chunk q -> stage q & 1: twelve 1-KB pieces per wave, destination = base + lane * 16
+        typedef __attribute__((address_space(1))) const void gptr_t;
+        typedef __attribute__((address_space(3))) void lptr_t;
+        const uint8_t* src = planes + (size_t)q * PF_CHUNK + (size_t)tid * 16;
+        uint8_t* dst = lds + (q & 1) * PF_CHUNK + wave_u * 1024;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) wreg[i] = s[tid + 256 * i];
+        for (int i = 0; i < 12; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(src + 4096 * i), (lptr_t*)(dst + 4096 * i), 16, 0, 0);
     };
-    auto w_put = [&](int q) {
-#ifdef PF_ABL_NO_W
-        return;
-#endif
-        pf_u32x4* d = reinterpret_cast<pf_u32x4*>(lds + (q & 1) * PF_CHUNK);
-#pragma unroll
-        for (int i = 0; i < 12; ++i) d[tid + 256 * i] = wreg[i];
+    // end of a trip: the DMAs of this trip have landed (counted wait: the N younger vector loads -- this trip's gathers -- stay
+    // in flight), this wave's own LDS reads are done, then the block meets.
+    auto trip_sync = [&](auto n_younger) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(decltype(n_younger)::value) : "memory");
     };
 
     // ---- x1 chunk of this lane: 16 values k = 32 c + 16 g + 0..15, as gathered sums (before ELU) ----
-    // Two gather buffers and two operand sets: while the matrix pipe works on chunk c, the same wave turns the gathered rows
-    // of chunk c + 1 into MFMA operands (ELU, dropout, split: ~600 vector instructions against 96 MFMAs of 32 cycles -- with
-    // one wave per SIMD nothing else can fill the MFMA shadow) and the gathers of chunk c + 2 are in flight.
-    f32x4 xs[2][NPARTS][4];
-    f32x4 xm[2][4];  // explicit mask (mode 1)
+    // One gather buffer and two operand sets: while the matrix pipe works on chunk c, the same wave turns the gathered rows of
+    // chunk c + 1 into MFMA operands (ELU, dropout, split: ~600 vector instructions against 96 MFMAs of 32 cycles -- with one
+    // wave per SIMD nothing else can fill the MFMA shadow); the gathers of chunk c + 2 are issued in the MIDDLE of trip c, as
+    // soon as that preparation has emptied the buffer, and have the second half of the trip plus the first quarter of the next
+    // one (~3 000 cycles) to arrive.
+    f32x4 xs[NPARTS][4];
+    f32x4 xm[4];  // explicit mask (mode 1)
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xm[u][i] = f32x4{1.f, 1.f, 1.f, 1.f};
+    for (int i = 0; i < 4; ++i) xm[i] = f32x4{1.f, 1.f, 1.f, 1.f};
     auto x_fetch = [&](int c, f32x4 (&xq)[NPARTS][4], f32x4 (&mq)[4]) {
-#ifdef PF_ABL_NO_X
-        return;
-#endif
         const int k0 = PF_KC * c + 16 * g;
 #pragma unroll
         for (int q = 0; q < NPARTS; ++q)
@@ -240,9 +249,6 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         return keep;
     };
     auto x_piece = [&](int c, int t, uint32_t keep, const f32x4 (&xq)[NPARTS][4], const f32x4 (&mq)[4], pf_bf16x8 (&out)[2][3]) {
-#ifdef PF_ABL_NO_X
-        return;
-#endif
         const int k0 = PF_KC * c + 16 * g;
         float e[8];
 #pragma unroll
@@ -275,9 +281,6 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     };
     // a quarter of a chunk's matrix work: k-step t, tiles T = 4 half .. 4 half + 3 (12 fragment reads, 24 MFMAs)
     auto mma_group = [&](const uint8_t* stage, f32x16 (&acc)[8], const pf_bf16x8 (&bop)[2][3], int t, int half) {
-#ifdef PF_ABL_NO_MMA
-        return;
-#endif
         pf_bf16x8 fa[4][3];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -295,33 +298,15 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         PF_TERM(0, 0)
 #undef PF_TERM
     };
-    // one chunk of matrix work: acc[T] += W[chunk] (rows 32 T ..) . B operands, T = 0..7, both k-steps
-    auto mma_chunk = [&](const uint8_t* stage, f32x16 (&acc)[8], const pf_bf16x8 (&bop)[2][3]) {
-#ifdef PF_ABL_NO_MMA  // timing experiment: one FMA per (tile, step) instead of six MFMAs, operands still read
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const pf_u32x4 w = *reinterpret_cast<const pf_u32x4*>(stage + pf_off(32 * i + b, 2 * g + t));
-                acc[i][0] = fmaf(__uint_as_float(w.x), __uint_as_float(__builtin_bit_cast(pf_u32x4, bop[t][0]).x), acc[i][0]);
-            }
-        return;
-#endif
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int half = 0; half < 2; ++half) mma_group(stage, acc, bop, t, half);
-    };
     f32x16 acc2[8];
 #pragma unroll
     for (int T = 0; T < 8; ++T) acc2[T] = f32x16{0};
 
-    w_fetch(0);
-    x_fetch(0, xs[0], xm[0]);
-    x_fetch(1, xs[1], xm[1]);  // n2 >= 4
-    w_put(0);
-    __syncthreads();  // weight chunk 0 and the biases are in LDS
-    x_finish(0, 0, xs[0], xm[0], xb[0]);
+    w_glds(0);
+    x_fetch(0, xs, xm);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk 0 and the biases are in LDS
+    x_finish(0, 0, xs, xm, xb[0]);
+    x_fetch(1, xs, xm);
     for (int c0 = 0; c0 < n2; c0 += 4) {  // n2 % 4 == 0; unrolled by four so that buffer parity and `fresh` are static
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -329,37 +314,26 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
             // no test around the gathers (a load that leaves its block through a phi is waited for at the end of that
             // block, i.e. in front of the MFMAs): the last trips re-read the last chunk and throw the result away
             const int c2 = c + 2 < n2 ? c + 2 : n2 - 1, c1 = c + 1 < n2 ? c + 1 : n2 - 1;
-#if PF_INTERLEAVE
             {
-                // ONE scheduling region per trip, in the order wanted: the weight loads of chunk c + 1 and the gathers of
-                // chunk c + 2 ride in the first MFMA groups, the finish of chunk c + 1 in the middle ones, the LDS stores
-                // of the weights (the other stage: every wave left it at the barrier that ended the previous trip) in the last.
-                // The compiler's own order inside the region is kept: sched_group_barrier patterns measured slower (2.82 vs 2.51 ms).
+                // ONE scheduling region per trip, in the order wanted: the operand preparation of chunk c + 1 between the first
+                // MFMA groups, then the DMAs of weight chunk c + 1 (the other stage: every wave left it at the barrier that
+                // ended the previous trip) and the gathers of chunk c + 2 under the remaining groups.  The compiler's own
+                // order inside the region is kept: sched_group_barrier patterns measured slower (2.82 vs 2.51 ms).
                 const uint8_t* st = lds + (u & 1) * PF_CHUNK;
                 const uint32_t keep = x_keep(c1, (u + 1) & 3);
                 mma_group(st, acc2, xb[u & 1], 0, 0);
-                w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
-                x_fetch(c2, xs[u & 1], xm[u & 1]);  // two chunks ahead; the finish of the previous trip emptied this buffer
-                x_piece(c1, 0, keep, xs[(u + 1) & 1], xm[(u + 1) & 1], xb[(u + 1) & 1]);
+                x_piece(c1, 0, keep, xs, xm, xb[(u + 1) & 1]);
                 mma_group(st, acc2, xb[u & 1], 0, 1);
-                x_piece(c1, 1, keep, xs[(u + 1) & 1], xm[(u + 1) & 1], xb[(u + 1) & 1]);
+                x_piece(c1, 1, keep, xs, xm, xb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);  // the gathers below overwrite what the two pieces above read
+                w_glds(c + 1);  // chunk n2 is the first actor chunk: always exists; before the gathers: older than them on
+                                // the vector-memory counter
+                x_fetch(c2, xs, xm);
                 mma_group(st, acc2, xb[u & 1], 1, 0);
-                w_put(c + 1);
                 mma_group(st, acc2, xb[u & 1], 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-#else
-            w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
-            x_fetch(c2, xs[u & 1], xm[u & 1]);  // two chunks ahead; x_finish of the previous trip emptied this buffer
-            __builtin_amdgcn_sched_barrier(0);
-            x_finish(c1, (u + 1) & 3, xs[(u + 1) & 1], xm[(u + 1) & 1], xb[(u + 1) & 1]);
-            mma_chunk(lds + (u & 1) * PF_CHUNK, acc2, xb[u & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            w_put(c + 1);
-#endif
-#ifndef PF_ABL_NO_SYNC
-            __syncthreads();
-#endif
+            trip_sync(std::integral_constant<int, NPARTS * 4 + (MODE == 1 ? 4 : 0)>{});
         }
     }
 
@@ -407,18 +381,16 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
         const int q = n2 + T;
-#if PF_INTERLEAVE
         {  // one scheduling region per trip, as in the hidden-layer loop
             const uint8_t* st = lds + (q & 1) * PF_CHUNK;
             mma_group(st, acc3, hb[T & 1], 0, 0);
             if (T + 1 < 8) {
-                w_fetch(q + 1);
+                w_glds(q + 1);
                 const uint32_t word = h_word(T + 1);
                 h_piece(T + 1, 0, word, hb[(T + 1) & 1]);
                 mma_group(st, acc3, hb[T & 1], 0, 1);
                 h_piece(T + 1, 1, word, hb[(T + 1) & 1]);
                 mma_group(st, acc3, hb[T & 1], 1, 0);
-                w_put(q + 1);
                 mma_group(st, acc3, hb[T & 1], 1, 1);
             } else {
                 mma_group(st, acc3, hb[T & 1], 0, 1);
@@ -427,24 +399,7 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (T + 1 < 8) {
-#ifndef PF_ABL_NO_SYNC
-            __syncthreads();
-#endif
-        }
-#else
-        if (T + 1 < 8) w_fetch(q + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (T + 1 < 8) h_make(T + 1, hb[(T + 1) & 1]);
-        mma_chunk(lds + (q & 1) * PF_CHUNK, acc3, hb[T & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (T + 1 < 8) {
-            w_put(q + 1);
-#ifndef PF_ABL_NO_SYNC
-            __syncthreads();
-#endif
-        }
-#endif
+        if (T + 1 < 8) trip_sync(std::integral_constant<int, 0>{});
     }
 
     // ---- logits: lane (b, g) holds actions a = 32 Ta + 8 (v >> 2) + 4 g + (v & 3) of its beam row ----
@@ -519,16 +474,12 @@ extern "C" int hw_pgpr_policy_fused(const float* const* slot_tables, const float
 #define PF_GO(NP, MD)                                                                                                   \
     hipLaunchKernelGGL((pgpr_policy_fused_kernel<NP, MD>), dim3((unsigned)grid), dim3(256), 0, st, t, b1, hidden1,      \
                        (const uint8_t*)planes, b2, ba_padded, act_dim, paths, n_rows, dr, logits, ld)
-#ifdef PF_ONLY_43
-#define PF_BY_MODE(NP) PF_GO(4, 3)
-#else
 #define PF_BY_MODE(NP)                 \
     do {                               \
         if (drop_mode == 0) PF_GO(NP, 0);      \
         else if (drop_mode == 1) PF_GO(NP, 1); \
         else PF_GO(NP, 3);                     \
     } while (0)
-#endif
     if (state_history == 0) PF_BY_MODE(2);
     else if (state_history == 1) PF_BY_MODE(4);
     else PF_BY_MODE(6);

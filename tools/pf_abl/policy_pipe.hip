@@ -1,9 +1,12 @@
-// EXPERIMENT (round 5), not part of the product build: csrc/pgpr_policy.hip with three more forms of its main loop behind
-// flags -- PF_SINGLE_X (one gather buffer), PF_GLDS (weight chunks by global_load_lds DMA, counted vmcnt + raw s_barrier),
-// PF_NSTAGE=3 (DMAs two chunks ahead), PF_PIPE (sixteen one-tile steps per trip with the fragments of the next step read a
-// step ahead, the operand preparation in two-value slices).  Every form is bit-identical to the product kernel; on 1 M
-// synthetic rows they measure 2.38-2.47 ms against 2.51-2.56 (tools/pf_abl/run.py), in the real 64/64/64 search the policy
-// stage stays at 2.78-2.82 ms (bench_pgpr.py): DESIGN.md section 8 has the numbers and the reading.
+// EXPERIMENT (round 5), not part of the product build: the forms of the policy kernel's main loop behind flags.  The default
+// (PF_GLDS: weight chunks by global_load_lds DMA with counted vmcnt + raw s_barrier, one gather buffer) IS the product kernel
+// (csrc/pgpr_policy.hip carries it with the switches resolved); -DPF_GLDS=0 is the round-4 form (weights staged through 48
+// registers, two gather buffers), PF_SINGLE_X its one-buffer variant, PF_NSTAGE=3 DMAs two chunks ahead, PF_PIPE sixteen
+// one-tile steps per trip with the fragments of the next step read a step ahead and the operand preparation in two-value
+// slices; the PF_ABL_* switches take parts of the work out for timing.  Every form computes the same bits.  On 1 M synthetic
+// rows they measure 2.38-2.47 ms against 2.51-2.56 for the round-4 form (tools/pf_abl/run.py); in the real 64/64/64 search
+// the lone policy stage stays at 2.78-2.82 ms, and what the smaller register footprint buys is room for other kernels' waves
+// beside it (three-stream search 4.25 -> 3.9 ms, tools/pf_abl/ab_streams.sh): DESIGN.md section 8 has the numbers.
 // PGPR policy network of one beam-search hop in ONE launch (pgpr.py:175-187 + the state of :296-333):
 //   first layer as a slot-table lookup (hw_pgpr_layer1_lookup's sum) -> ELU -> dropout -> [rows, H1] x W2^T on the bf16 matrix
 //   pipes (three-way split = fp32-level error, gemm.hip) -> ELU -> dropout -> x Wa^T -> logits.
