@@ -169,6 +169,11 @@ SIGNATURES = {
         [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_i64p, c_i64p, c_i64p, C.c_float, C.c_float, c_f32p, C.c_int64,
          C.c_void_p],
     ),
+    "hw_cafe_level_loss_grad_dev": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_i64p, c_i64p, c_i64p, c_f32p, c_f32p, c_f32p, C.c_int64,
+         C.c_void_p],
+    ),
     "hw_conv2d_1ch_workspace_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "hw_conv2d_1ch_forward": (
         C.c_int,

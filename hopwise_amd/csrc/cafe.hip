@@ -140,8 +140,14 @@ __global__ __launch_bounds__(256) void level_loss_grad_kernel(const float* __res
                                                               const int64_t* __restrict__ target,
                                                               const int64_t* __restrict__ pos,
                                                               const int64_t* __restrict__ neg, int64_t n_rows,
-                                                              float g_ce, float g_rank, float* __restrict__ dx,
-                                                              int64_t ldd) {
+                                                              float g_ce, float g_rank,
+                                                              const float* __restrict__ g_ce_dev,
+                                                              const float* __restrict__ g_rank_dev,
+                                                              float* __restrict__ dx, int64_t ldd) {
+    // upstream gradients as device scalars when given (a captured step cannot read them on the host, and the eager step
+    // saves two host reads per level)
+    if (g_ce_dev) g_ce = g_ce_dev[0];
+    if (g_rank_dev) g_rank = g_rank_dev[0];
     const int64_t row = blockIdx.x;
     const float* __restrict__ r = x + (size_t)row * ld;
     float* __restrict__ o = dx + (size_t)row * ldd;
@@ -380,7 +386,22 @@ extern "C" int hw_cafe_level_loss_grad(const float* logits, int64_t ld, int64_t 
         return HW_ERR_INVALID_ARG;
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(level_loss_grad_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, logits, ld,
-                       (int)n_cols, lse, target, pos, neg, n_rows, g_ce, g_rank, dlogits, ldd);
+                       (int)n_cols, lse, target, pos, neg, n_rows, g_ce, g_rank, (const float*)nullptr,
+                       (const float*)nullptr, dlogits, ldd);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_cafe_level_loss_grad_dev(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const float* lse,
+                                           const int64_t* target, const int64_t* pos, const int64_t* neg,
+                                           const float* g_ce, const float* g_rank, float* dlogits, int64_t ldd,
+                                           void* stream) {
+    if (!logits || !lse || !target || !dlogits || !g_ce || n_rows < 1 || n_cols < 1 || n_cols > INT32_MAX || ld < n_cols ||
+        ldd < n_cols || (!pos) != (!neg) || (pos && !g_rank))
+        return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(level_loss_grad_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                       (int)n_cols, lse, target, pos, neg, n_rows, 0.f, 0.f, g_ce, pos ? g_rank : (const float*)nullptr,
+                       dlogits, ldd);
     return HW_LAUNCH_RC();
 }
 

@@ -243,6 +243,8 @@ __device__ __forceinline__ void store_slab_via_lds(float* __restrict__ slab, con
     }
 }
 
+#include "gemm_small.h"
+
 template <bool A_KC, bool B_KC, int ACT, bool SPLIT = false>
 __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                           const float* __restrict__ B, int64_t ldb,
@@ -1089,6 +1091,33 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
                        int64_t ldc, const int32_t* m_rows, int64_t m_max, int64_t n, int64_t k, const float* bias,
                        int act, const float* drop_mask, int drop_mode, uint64_t seed, uint64_t offset,
                        float* workspace, int64_t workspace_floats, hipStream_t st, GemmBce bce = GemmBce{}) {
+    {
+        // short products on few tiles (gemm_small.h): a latency chain on the 128-wide tiles, 64 x 64 tiles with the whole K (or
+        // two chunks of it) in flight here.  Measured on MI355X, CAFE's module products at 512 paths: [512, 200] x [256, 200]^T
+        // 26 -> 7 us, its weight gradient (K = 512) 33 -> 9 us (tools/bench_gemm_small.py).
+        const char* sme = getenv("HW_GEMM_SMALL");
+        const char* se2 = getenv("HW_GEMM_SPLIT");
+        const bool on = (sme ? atoi(sme) != 0 : true) && (se2 ? atoi(se2) != 0 : true);
+        const int64_t big_tiles = ((m_max + BM - 1) / BM) * ((n + BN - 1) / BN);
+        if (on && act >= 0 && act <= 2 && drop_mode >= 0 && drop_mode <= 2 && k >= 4 && k <= 1024 && big_tiles <= 32 && aligned16(a, lda) &&
+            aligned16(b, ldb) && (a_kc || m_max >= 4) && (b_kc || n >= 4)) {
+            dim3 grid((unsigned)((m_max + SM_T - 1) / SM_T), (unsigned)((n + SM_T - 1) / SM_T));
+#define GOS(AK, BK_, ACT_) hipLaunchKernelGGL((gemm_small_kernel<AK, BK_, ACT_>), grid, dim3(256), 0, st, a, lda, b, ldb, c, ldc, m_rows, (int)m_max, (int)n, (int)k, bias, drop_mask, drop_mode, seed, offset)
+#define GOS3(AK, BK_)                     \
+    do {                                  \
+        if (act == 1) GOS(AK, BK_, 1);      \
+        else if (act == 2) GOS(AK, BK_, 2); \
+        else GOS(AK, BK_, 0);               \
+    } while (0)
+            if (a_kc && b_kc) GOS3(true, true);
+            else if (a_kc && !b_kc) GOS3(true, false);
+            else if (!a_kc && !b_kc) GOS3(false, false);
+            else GOS3(false, true);
+#undef GOS3
+#undef GOS
+            return HW_OK;
+        }
+    }
     // narrow-N products (TuckER / ConvE backward: N = d = 200): whole-row tiles of 16x16x4 MFMAs, see gemm_f32_n208_kernel
     {
         // Measured on MI355X (tools/bench_gemm_tucker.py, iFashion shapes): with an M-contiguous A (dE = dS^T . x) the

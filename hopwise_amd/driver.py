@@ -170,56 +170,68 @@ class GraphedTrainStep:
     model's counters (philox.PhiloxCounter) are bound to device words and hand the kernels INDIRECT offsets; the graph's last
     node bumps the words, the host counts follow after every replay: replays and eager steps draw one and the same stream
     (tests/test_gpu_graph_philox.py), and a checkpoint (``other_parameter``) resumes it.
-    Still refused: CAFE (its path sampler is host code that runs inside every step, cafe.py:143-198); batches of any other
-    shape than the captured one run eagerly.  A capture that holds a memset node is refused too: on this HIP runtime such a
+    CAFE, whose path sampler is host code that runs inside every step (cafe.py:143-198), is replayed by
+    :class:`GraphedStagedTrainStep` (``make_graphed_step`` picks the class); batches of any other shape than the captured one
+    run eagerly.  A capture that holds a memset node is refused too: on this HIP runtime such a
     node replays a stale pattern; the engine itself only launches kernels.  A capture that cannot be
     inspected (no ``keep_graph``, or the runtime's graph API not reachable) is refused unless ``allow_unverified_capture``."""
 
-    REFUSED = ("CAFE",)
+    REFUSED = ()  # models no capture can hold (none since CAFE's step is replayed by GraphedStagedTrainStep)
 
     def __init__(self, model, optimizer, example, clip_grad_norm=None, allow_unverified_capture=False,
                  assume_zero_initialised_state=None):
-        if type(model).__name__ in self.REFUSED:
-            raise ValueError(f"{type(model).__name__} runs host code inside every step (its path sampler): not graph-safe")
-        for grp in optimizer.param_groups:
-            if not grp.get("capturable", False):
-                raise ValueError("the optimizer must be constructed with capturable=True (e.g. torch.optim.Adam)")
+        if hasattr(model, "graph_host_stage") and not isinstance(self, GraphedStagedTrainStep):
+            raise ValueError(f"{type(model).__name__} runs host code inside every step (its path sampler): one capture of "
+                             "calculate_loss would freeze it -- use GraphedStagedTrainStep (make_graphed_step picks it)")
+        self._setup(model, optimizer, clip_grad_norm, allow_unverified_capture, assume_zero_initialised_state)
         from .philox import DeviceCounters
 
-        self.model, self.opt, self.clip = model, optimizer, clip_grad_norm
         self.keys = sorted(k for k in example if torch.is_tensor(example[k]))  # dict or Interaction: iterate field names
         self.static = {k: example[k].clone() for k in self.keys}
         self.shapes = {k: tuple(v.shape) for k, v in self.static.items()}
+        self.counters = DeviceCounters(model, self._params[0].device)
+        self.graph, self.loss, self.verified_no_memset_nodes = self._capture(self._step, self.counters)
+
+    def _setup(self, model, optimizer, clip_grad_norm, allow_unverified_capture, assume_zero_initialised_state):
+        if type(model).__name__ in self.REFUSED:
+            raise ValueError(f"{type(model).__name__}: not graph-safe")
+        for grp in optimizer.param_groups:
+            if not grp.get("capturable", False):
+                raise ValueError("the optimizer must be constructed with capturable=True (e.g. torch.optim.Adam)")
+        self.model, self.opt, self.clip = model, optimizer, clip_grad_norm
+        self._allow_unverified = bool(allow_unverified_capture)
         self._params = [p for grp in optimizer.param_groups for p in grp["params"]]
         self._zero_state = _zero_initialised_state(optimizer) if assume_zero_initialised_state is None else bool(
             assume_zero_initialised_state)
-        dev = self._params[0].device
-        self.counters = DeviceCounters(model, dev)
         # device flags the captured step may raise instead of a host-side check it cannot run (read by check_flags)
-        self.flags = model.capture_error_flags(dev) if hasattr(model, "capture_error_flags") else {}
-        saved = self._snapshot()
+        self.flags = model.capture_error_flags(self._params[0].device) if hasattr(model, "capture_error_flags") else {}
+
+    def _capture(self, step_fn, counters, pool=None):
+        """Two warm-up steps undone in place, then ``step_fn`` recorded into a graph -> (graph, its loss tensor, whether the
+        graph was inspected and holds no memset node)."""
+        saved = self._snapshot(counters)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up: lazy state of the optimizer, workspace caches
             for _ in range(2):
-                self._step()
+                step_fn()
         torch.cuda.current_stream().wait_stream(side)
         # the warm-up steps were real optimizer steps on the example batch: undo them in place (the capture below records
         # pointers), so that the first replay IS the first step on this batch, as in Trainer._train_epoch
-        self._restore(saved)
+        self._restore(saved, counters)
         try:  # keep the captured hipGraph_t so that it can be inspected before it is instantiated
-            self.graph, kept = torch.cuda.CUDAGraph(keep_graph=True), True
+            graph, kept = torch.cuda.CUDAGraph(keep_graph=True), True
         except TypeError:  # a torch without keep_graph
-            self.graph, kept = torch.cuda.CUDAGraph(), False
+            graph, kept = torch.cuda.CUDAGraph(), False
         self.opt.zero_grad(set_to_none=True)
-        self.counters.begin_capture()
+        counters.begin_capture()
         try:
-            with torch.cuda.graph(self.graph):
-                self.loss = self._step()
-                self.counters.bump_in_graph()
+            with torch.cuda.graph(graph, pool=pool):
+                loss = step_fn()
+                counters.bump_in_graph()
         finally:
-            self.counters.end_capture()
-        n_memset = count_memset_nodes(self.graph) if kept else None
+            counters.end_capture()
+        n_memset = count_memset_nodes(graph) if kept else None
         if n_memset:
             raise ValueError(
                 f"the captured training step holds {n_memset} memset node(s) (a hipMemsetAsync / cudaMemsetAsync issued by "
@@ -227,17 +239,17 @@ class GraphedTrainStep:
                 "value on the first launch of the graph only and a stale staging pattern afterwards (DESIGN.md section "
                 "2, tools/memset_pattern_probe.py): replaying this step would be silently wrong.  Fill with a kernel "
                 "(tensor.zero_(), hopwise_amd.ops.fill_bytes_) or run the step eagerly")
-        if n_memset is None and not allow_unverified_capture:
+        if n_memset is None and not self._allow_unverified:
             raise ValueError(
                 "the captured training step could not be inspected for memset nodes (this torch has no "
                 "CUDAGraph(keep_graph=True), or the HIP runtime's graph API could not be reached through the library mapped "
                 "into this process): a memset node would replay a stale pattern silently (DESIGN.md section 2).  Pass "
                 "allow_unverified_capture=True to replay it regardless, or run the step eagerly")
         if kept:
-            self.graph.instantiate()
-        self.verified_no_memset_nodes = n_memset == 0
+            graph.instantiate()
+        return graph, loss, n_memset == 0
 
-    def _snapshot(self):
+    def _snapshot(self, counters):
         """Copies of everything a warm-up step changes: parameters, module buffers, the optimizer's per-parameter state, the
         models' Philox call counts."""
         state = {}
@@ -246,10 +258,10 @@ class GraphedTrainStep:
             if st:
                 state[p] = {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
         return ([p.detach().clone() for p in self._params], [b.detach().clone() for b in self.model.buffers()], state,
-                self.counters.snapshot())
+                counters.snapshot())
 
     @torch.no_grad()
-    def _restore(self, saved):
+    def _restore(self, saved, counters):
         """Put the snapshot back IN PLACE.  State tensors the warm-up created (the optimizer's lazy initialisation: step
         counters and moments, all of which start at zero in torch's Adam and in FusedAdam) are zeroed."""
         params, buffers, state, counts = saved
@@ -257,7 +269,7 @@ class GraphedTrainStep:
             p.copy_(v)
         for b, v in zip(self.model.buffers(), buffers):
             b.copy_(v)
-        self.counters.restore(counts)
+        counters.restore(counts)
         for p in self._params:
             before = state.get(p, {})
             for k, v in self.opt.state.get(p, {}).items():
@@ -274,12 +286,19 @@ class GraphedTrainStep:
                             "(the state then exists and is restored exactly), or pass assume_zero_initialised_state=True")
 
     def _step(self):
+        return self._step_of(lambda: self.model.calculate_loss(self.static))
+
+    def _step_of(self, loss_fn):
         self.opt.zero_grad(set_to_none=True)
-        losses = self.model.calculate_loss(self.static)
+        losses = loss_fn()
         loss = sum(losses) if isinstance(losses, tuple) else losses
         loss.backward()
         if self.clip:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), **self.clip)
+        # the parameters this step moves (torch.optim.Adam: those with a gradient; FusedAdam: those a backward reached) --
+        # asked BEFORE the optimizer runs, which forgets it
+        self._last_stepped = ([p for grp in self.opt.param_groups for p in self.opt._stepped(grp)]
+                              if hasattr(self.opt, "_stepped") else [p for p in self._params if p.grad is not None])
         self.opt.step()
         return loss.detach()
 
@@ -306,6 +325,102 @@ class GraphedTrainStep:
         return self.loss
 
 
+class GraphedStagedTrainStep(GraphedTrainStep):
+    """A training step with host code in front of its device work, replayed from one HIP graph PER FORM of that device work.
+
+    CAFE's ``calculate_loss`` (cafe.py:329-340) samples a metapath, positive paths and negative items on the host
+    (cafe.py:143-198: numpy draws, neighbour walks, a replay memory) and then runs the symbolic network of THAT metapath -- a
+    different chain of relation modules, hence a different set of parameters the optimizer steps, from batch to batch.  The
+    model exposes the two halves (``graph_host_stage(interaction) -> (key, host tensors)``, ``graph_device_stage(key,
+    tensors) -> losses``; ``calculate_loss`` is the one after the other); here the host half runs as it is on every call and the
+    device half -- zero_grad, network, backward, clip, optimizer -- is captured once per key (metapath id, rows of the batch)
+    the first time the key shows up, then replayed: ~25 kernel nodes instead of ~150 launches from Python (the eager step is
+    launch-bound: 2.2 ms at 64 and at 512 paths alike).
+
+    The captures share one memory pool (replays are stream-ordered on the caller's stream and nothing a capture allocates has
+    to outlive its replay: gradients are rewritten from scratch, the loss is consumed by the caller before the next step) and
+    one set of device Philox words (philox.DeviceCounters ``share``): the dropout streams run on through replays of different
+    metapaths exactly as through eager steps.  FusedAdam keeps one device step counter per group of parameters that have always
+    been stepped together and splits a group when a new metapath steps only part of it -- a capture made before such a split
+    would go on advancing the old counter.  So the optimizer is told the partition up front (``model.optimizer_step_groups()``
+    -> ``FusedAdam.pin_step_groups``: one counter per relation module, never merged), and as a second line every capture
+    remembers the counters it was recorded with and is thrown away (captured again on its next use) should the optimizer have
+    moved one of its parameters to another counter all the same."""
+
+    MAX_CAPTURES = 64  # distinct (metapath, batch rows) forms kept; a form beyond that runs eagerly
+
+    def __init__(self, model, optimizer, example=None, clip_grad_norm=None, allow_unverified_capture=False,
+                 assume_zero_initialised_state=None):
+        if not (hasattr(model, "graph_host_stage") and hasattr(model, "graph_device_stage")):
+            raise ValueError(f"{type(model).__name__} has no graph_host_stage / graph_device_stage: use GraphedTrainStep")
+        self._setup(model, optimizer, clip_grad_norm, allow_unverified_capture, assume_zero_initialised_state)
+        if hasattr(optimizer, "pin_step_groups") and hasattr(model, "optimizer_step_groups"):
+            optimizer.pin_step_groups(model.optimizer_step_groups())  # no regrouping of step counters under the captures
+        self.captures = {}
+        self.counters = None  # the first capture's DeviceCounters: owner of the shared device words
+        self._pool = None
+        self.n_captured = self.n_replayed = self.n_eager = 0
+        self.verified_no_memset_nodes = True
+
+    def matches(self, interaction):
+        return True  # a form that cannot be replayed runs eagerly inside __call__
+
+    def _counter_refs(self, params):
+        return [(p, self.opt.state[p]["step"]) for p in params if "step" in self.opt.state.get(p, {})]
+
+    def _eager(self, key, dev_tensors):
+        self.n_eager += 1
+        return self._step_of(lambda: self.model.graph_device_stage(key, dev_tensors))
+
+    def _new_capture(self, key, host):
+        from .philox import DeviceCounters
+
+        dev = self._params[0].device
+        static = {k: v.to(dev).clone() for k, v in host.items()}
+        counters = DeviceCounters(self.model, dev, share=self.counters)
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        step_fn = lambda: self._step_of(lambda: self.model.graph_device_stage(key, static))
+        graph, loss, verified = self._capture(step_fn, counters, pool=self._pool)
+        if self.counters is None:
+            self.counters = counters
+        self.verified_no_memset_nodes = self.verified_no_memset_nodes and verified
+        stepped = list(self._last_stepped)
+        cap = dict(graph=graph, loss=loss, static=static, counters=counters, stepped=stepped,
+                   refs=self._counter_refs(stepped))
+        self.n_captured += 1
+        return cap
+
+    def __call__(self, interaction):
+        key, host = self.model.graph_host_stage(interaction)
+        rows = next(iter(host.values())).shape[0] if host else 0
+        cap = self.captures.get(key)
+        if cap is not None and any(self.opt.state[p].get("step") is not s for p, s in cap["refs"]):
+            del self.captures[key]  # the optimizer regrouped its step counters since: record this form again
+            cap = None
+        if cap is None:
+            if rows == 0 or len(self.captures) >= self.MAX_CAPTURES:
+                dev = self._params[0].device
+                return self._eager(key, {k: v.to(dev) if v.is_cuda else v.pin_memory().to(dev, non_blocking=True)
+                                         for k, v in host.items()})
+            cap = self.captures[key] = self._new_capture(key, host)
+        for k, v in host.items():  # pinned staging (caching host allocator): no pin-on-the-fly for the larger batches
+            cap["static"][k].copy_(v if v.is_cuda else v.pin_memory(), non_blocking=True)
+        cap["counters"].before_replay()
+        cap["graph"].replay()
+        cap["counters"].after_replay()
+        torch.autograd.graph.increment_version(cap["stepped"])
+        self.n_replayed += 1
+        return cap["loss"]
+
+
+def make_graphed_step(model, optimizer, example, clip_grad_norm=None, **kw):
+    """The replayed training step for ``model``: one capture of calculate_loss, or one per form of its device half when the
+    model runs host code inside the step (CAFE)."""
+    cls = GraphedStagedTrainStep if hasattr(model, "graph_host_stage") else GraphedTrainStep
+    return cls(model, optimizer, example, clip_grad_norm, **kw)
+
+
 def train_epoch_graphed(model, batches, optimizer, clip_grad_norm=None, device=None, step=None):
     """train_epoch with the steady-state batches replayed from one HIP graph; returns (summed loss, GraphedTrainStep)
     so the next epoch can reuse the capture."""
@@ -315,7 +430,7 @@ def train_epoch_graphed(model, batches, optimizer, clip_grad_norm=None, device=N
         if device is not None:
             interaction = interaction.to(device)
         if step is None:
-            step = GraphedTrainStep(model, optimizer, interaction, clip_grad_norm)
+            step = make_graphed_step(model, optimizer, interaction, clip_grad_norm)
         if step.matches(interaction):
             loss = step(interaction)
         else:  # ragged last batch
@@ -348,8 +463,9 @@ def graphed_trainer(base):
         so the NaN check (trainer.py:337-339) fires at the end of the epoch instead of at the offending batch;
       * a batch whose shapes differ from the captured one (the ragged last batch) runs eagerly, as the base class would.
     Anything the graph cannot hold falls back to the base class for the whole epoch: a custom ``loss_func``, AMP, DDP
-    (``single_spec`` false), CAFE (host path sampler inside the step).  TuckER / ConvE / ConvKB / PGPR / TPRec replay since
-    round 5: their Philox offsets live on the device during a capture (philox.py)."""
+    (``single_spec`` false).  TuckER / ConvE / ConvKB / PGPR / TPRec replay since round 5: their Philox offsets live on the
+    device during a capture (philox.py); CAFE's host path sampler runs as it is and the device half of its step is replayed
+    from one capture per metapath (GraphedStagedTrainStep)."""
 
     # KGTrainer._train_epoch picks the loader state and then calls super()._train_epoch (trainer.py:647-666): the replayed
     # loop has to sit BELOW it, in the place of Trainer._train_epoch.  So the override lives in a class derived from the
@@ -378,7 +494,7 @@ def graphed_trainer(base):
             return all(g.get("capturable", False) for g in self.optimizer.param_groups)
 
         def _make_step(self, interaction):
-            return GraphedTrainStep(self.model, self.optimizer, interaction, getattr(self, "clip_grad_norm", None))
+            return make_graphed_step(self.model, self.optimizer, interaction, getattr(self, "clip_grad_norm", None))
 
         def _eager_step(self, interaction):
             self.optimizer.zero_grad()

@@ -325,7 +325,7 @@ class KgeScoreGrouped(torch.autograd.Function):
                         grads_out.append(None)  # shared buffer already returned for an earlier slot
                     elif (sink := _live_sink(t)) is not None and torch.is_grad_enabled() is False:
                         bufs[key] = sink[0]  # accumulate straight into p.grad; autograd gets nothing to add
-                        sink[1].touch(t.data_ptr())
+                        sink[1].touch(t.data_ptr(), sink=True)
                         grads_out.append(None)
                     else:
                         bufs[key] = torch.zeros_like(t)
@@ -380,7 +380,7 @@ def _grad_slots(desc_tables, needs, bufs, grads_out_by_pos, positions):
                 sink = _live_sink(t) if not torch.is_grad_enabled() else None
                 if sink is not None:
                     bufs[key] = sink[0]
-                    sink[1].touch(t.data_ptr())
+                    sink[1].touch(t.data_ptr(), sink=True)
                 else:
                     bufs[key] = torch.zeros_like(t)
                     grads_out_by_pos[p] = bufs[key]
@@ -1307,9 +1307,12 @@ class LevelLoss(torch.autograd.Function):
         pos, neg = (ctx.saved_tensors[3], ctx.saved_tensors[4]) if ctx.has_rank else (None, None)
         d = torch.empty_like(logits)
         n, v = logits.shape
-        check(lib.hw_cafe_level_loss_grad(_ptr(logits), logits.stride(0), n, v, _ptr(lse), _ptr(target), _ptr(pos),
-                                          _ptr(neg), float(g_ce), float(g_rank) if ctx.has_rank else 0.0, _ptr(d),
-                                          d.stride(0), _stream()), "hw_cafe_level_loss_grad")
+        # the upstream gradients stay on the device: no host read per level, and the launch can be captured
+        g_ce = g_ce.to(torch.float32).contiguous()
+        g_rank = g_rank.to(torch.float32).contiguous() if ctx.has_rank else None
+        check(lib.hw_cafe_level_loss_grad_dev(_ptr(logits), logits.stride(0), n, v, _ptr(lse), _ptr(target), _ptr(pos),
+                                              _ptr(neg), _ptr(g_ce), _ptr(g_rank), _ptr(d), d.stride(0), _stream()),
+              "hw_cafe_level_loss_grad_dev")
         return d, None, None, None
 
 

@@ -29,18 +29,31 @@ class _SinkState:
     """Bookkeeping of the gradient sinks of one optimizer: whether anything accumulated since the last step (``dirty``),
     WHICH parameters did (``touched``: torch.optim.Adam skips a parameter whose ``.grad`` is None, i.e. one no backward
     reached -- its moments do not decay and weight decay is not applied; the sink buffers are never None, so that is
-    tracked here), and whether writing straight into ``p.grad`` is safe under torch.distributed."""
+    tracked here), and whether writing straight into ``p.grad`` is safe under torch.distributed.
 
-    __slots__ = ("dirty", "touched", "caller_syncs")
+    ``used`` / ``plain``: a persistent gradient buffer only pays for a parameter some gradient kernel writes into directly
+    (the embedding tables of the scorers).  For every other parameter -- Linear / BatchNorm weights, whose gradient arrives
+    through autograd's AccumulateGrad -- it costs an ``add`` launch per parameter per step (AccumulateGrad adds into an existing
+    ``.grad`` and takes the incoming tensor as it is when ``.grad`` is None): 30 launches of a CAFE step, 120 of a TuckER step.
+    So a parameter that has been stepped without any kernel having used its buffer (``used``) becomes ``plain``: from then on
+    ``zero_grad`` drops its gradient like torch's ``set_to_none`` does, and the kernels fall back to handing autograd their
+    gradient should such a parameter ever reach them."""
+
+    __slots__ = ("dirty", "touched", "caller_syncs", "used", "plain")
 
     def __init__(self, caller_syncs=False):
         self.dirty = True
         self.touched = set()
         self.caller_syncs = caller_syncs
+        self.used = set()
+        self.plain = set()
 
-    def touch(self, data_ptr):
+    def touch(self, data_ptr, sink=False):
         self.dirty = True
         self.touched.add(data_ptr)
+        if sink:
+            self.used.add(data_ptr)
+            self.plain.discard(data_ptr)
 
     def check_distributed(self):
         """Sinks bypass autograd's AccumulateGrad, so DistributedDataParallel's reducer hooks never fire for these
@@ -74,6 +87,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._decoupled = bool(decoupled_weight_decay)
         self._launch_cache = {}
         self._counter_members, self._counter_keepalive = {}, {}
+        self._pinned = set()  # ids of the step counters pin_step_groups made: never merged with another group's
         devices = set()
         for group in self.param_groups:
             for p in group["params"]:
@@ -104,7 +118,7 @@ class FusedAdam(torch.optim.Optimizer):
             return
         for group in self.param_groups:
             for p in (group["params"] if params is None else params):
-                self._sinks.touch(p.data_ptr())
+                self._sinks.touch(p.data_ptr(), sink=True)  # written by hand: keep the persistent buffer
             if params is not None:
                 break
 
@@ -114,11 +128,17 @@ class FusedAdam(torch.optim.Optimizer):
         if self._sinks is None:
             return super().zero_grad(set_to_none)
         dirty = []
+        plain = self._sinks.plain
         for group in self.param_groups:
             for p in group["params"]:
                 if not p.requires_grad:
                     continue
-                if p.grad is None:  # dropped behind our back (e.g. module.zero_grad()): put a cleared buffer back
+                if p.data_ptr() in plain:  # no kernel writes into this one: let AccumulateGrad take the gradient as it comes
+                    if set_to_none:
+                        p.grad = None
+                    elif p.grad is not None and self._sinks.dirty:
+                        dirty.append(p.grad)
+                elif p.grad is None:  # dropped behind our back (e.g. module.zero_grad()): put a cleared buffer back
                     p.grad = torch.zeros_like(p)
                 elif self._sinks.dirty:
                     dirty.append(p.grad)
@@ -137,6 +157,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._launch_cache.clear()
         self._counter_members.clear()
         self._counter_keepalive.clear()
+        self._pinned.clear()
 
     def _state_of(self, p):
         st = self.state[p]
@@ -148,6 +169,36 @@ class FusedAdam(torch.optim.Optimizer):
             st["step"] = st["step"].to(device=p.device, dtype=torch.int64)
         return st
 
+    def pin_step_groups(self, groups):
+        """``groups``: lists of parameters that are always stepped together -- the parameters of one module of a model whose
+        steps use different modules from batch to batch (CAFE: one relation module per metapath level).  Each list (in
+        chunks of 16, what one launch updates) gets ONE device step counter now and keeps it: counters of different groups are
+        never merged however equal their values, so no later step regroups them -- which a captured step relies on, its
+        launches hold the counters' addresses (driver.GraphedStagedTrainStep throws a capture away when the optimizer moved one
+        of its parameters to another counter; with pinned groups that never happens).  The update rule is untouched: every
+        parameter's step count is what torch.optim.Adam's would be.  A group whose members have been stepped a different number
+        of times already is left alone."""
+        for params in groups:
+            params = [p for p in params if p.requires_grad]
+            for lo in range(0, len(params), _lib.ADAM_MAX_SEGS):
+                chunk = params[lo : lo + _lib.ADAM_MAX_SEGS]
+                states = [self._state_of(p) for p in chunk]
+                if len({int(st["step"]) for st in states}) != 1:
+                    continue
+                ids = {id(p) for p in chunk}
+                if all(id(st["step"]) in self._pinned and self._counter_members.get(id(st["step"])) == ids for st in states):
+                    continue  # pinned by an earlier call
+                counter = states[0]["step"].clone()
+                for st in states:
+                    old = self._counter_members.get(id(st["step"]))
+                    if old is not None:
+                        old -= ids
+                    st["step"] = counter
+                self._counter_members[id(counter)] = set(ids)
+                self._counter_keepalive[id(counter)] = counter
+                self._pinned.add(id(counter))
+        self._launch_cache.clear()
+
     def _stepped(self, group):
         """The group's parameters this step updates: those with a gradient and, with sinks, those a backward reached since
         the last step (as torch.optim.Adam skips ``grad is None``)."""
@@ -157,15 +208,15 @@ class FusedAdam(torch.optim.Optimizer):
         return ps
 
     def _launches(self, group):
-        """[(AdamArgs, step tensor)] for the group's parameters that have a gradient, 16 per launch; cached per
-        composition on the identity of every buffer involved.
+        """[(AdamArgs, step tensor, parameters)] for the group's parameters that have a gradient, 16 per launch; cached per
+        composition on the identity of every persistent buffer involved (the gradient pointers are filled in per step).
 
         A launch reads ONE device step counter, so parameters share a counter only while they are always stepped
         together: a parameter that sits a step out (untouched, see _SinkState) is split off with its own counter."""
         ps = self._stepped(group)
         states = [self._state_of(p) for p in ps]
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
-                     s["step"].data_ptr()) for p, s in zip(ps, states))
+        key = tuple((p.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), s["step"].data_ptr())
+                    for p, s in zip(ps, states))
         cache = self._launch_cache.setdefault(id(group), {})
         hit = cache.get(key)
         if hit is not None:
@@ -182,16 +233,28 @@ class FusedAdam(torch.optim.Optimizer):
             owners = self._counter_members.get(cid)
             if owners is not None and not owners <= present:
                 fresh = members[0][1]["step"].clone()
+                self._pinned.discard(cid)  # a pinned group stepped in part: its counter is an ordinary one from here on
                 for _, s in members:
                     s["step"] = fresh
                 self._counter_members[cid] = owners - {id(p) for p, _ in members}
                 self._counter_members[id(fresh)] = {id(p) for p, _ in members}
         # 2. counters at the same value that only serve parameters of this composition are merged: one counter per launch
         #    (the kernel advances the counter it is given, so the 16-segment chunks of a long list each own one)
-        by_value = {}
+        by_value, by_pin = {}, {}
         for p, s in zip(ps, states):
-            by_value.setdefault(int(s["step"]), []).append((p, s))  # device read: composition changes only
+            if id(s["step"]) in self._pinned:
+                by_pin.setdefault(id(s["step"]), []).append((p, s))
+            else:
+                by_value.setdefault(int(s["step"]), []).append((p, s))  # device read: composition changes only
         out = []
+        for members in by_pin.values():  # a pinned group (whole: a partial one was split and unpinned above): one launch
+            args = _lib.AdamArgs()
+            args.n_segs = len(members)
+            for i, (p, s) in enumerate(members):
+                args.seg[i].p, args.seg[i].g = p.data_ptr(), p.grad.data_ptr()
+                args.seg[i].m, args.seg[i].v = s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()
+                args.seg[i].n = p.numel()
+            out.append((args, members[0][1]["step"], [p for p, _ in members]))
         for _, members in sorted(by_value.items()):
             for lo in range(0, len(members), _lib.ADAM_MAX_SEGS):
                 chunk = members[lo : lo + _lib.ADAM_MAX_SEGS]
@@ -217,10 +280,10 @@ class FusedAdam(torch.optim.Optimizer):
                     args.seg[i].p, args.seg[i].g = p.data_ptr(), p.grad.data_ptr()
                     args.seg[i].m, args.seg[i].v = s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr()
                     args.seg[i].n = p.numel()
-                out.append((args, shared))
+                out.append((args, shared, [p for p, _ in chunk]))
         # the merge may have changed step pointers: file the result under the key the NEXT identical call will compute
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(),
-                     s["step"].data_ptr()) for p, s in zip(ps, states))
+        key = tuple((p.data_ptr(), s["exp_avg"].data_ptr(), s["exp_avg_sq"].data_ptr(), s["step"].data_ptr())
+                    for p, s in zip(ps, states))
         cache[key] = out
         return out
 
@@ -258,13 +321,17 @@ class FusedAdam(torch.optim.Optimizer):
             stepped = self._stepped(group)
             if stepped:
                 torch.autograd.graph.increment_version(stepped)
-            for args, step in self._launches(group):
+            for args, step, members in self._launches(group):
+                for i, p in enumerate(members):  # plain parameters get a new gradient tensor every step
+                    args.seg[i].g = p.grad.data_ptr()
                 rc = lib.hw_adam_step(C.byref(args), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                       float(group["weight_decay"]), C.c_void_p(step.data_ptr()),
                                       (1 if self._sinks is not None else 0) | (2 if self._decoupled else 0),
                                       ops._stream())
                 _lib.check(rc, "hw_adam_step")
         if self._sinks is not None:
+            # a parameter stepped without a kernel having written into its buffer gets no persistent buffer from here on
+            self._sinks.plain.update(self._sinks.touched - self._sinks.used)
             self._sinks.dirty = False
             self._sinks.touched.clear()
         return loss

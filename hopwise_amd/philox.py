@@ -76,15 +76,31 @@ def counters_of(model):
 
 
 class DeviceCounters:
-    """The device words of a model's counters for one captured step."""
+    """The device words of a model's counters for one captured step.
 
-    def __init__(self, model, device):
-        self.entries = counters_of(model)
+    ``share``: another DeviceCounters of the same model -- the two use ONE set of device words (and one record of the host
+    counts the words stand for), each with its own per-step increments: the captures of a step that comes in several forms
+    (driver.GraphedStagedTrainStep: one capture per metapath of CAFE) then hand the stream on to each other on the device, with
+    no host copy between replays of different forms."""
+
+    def __init__(self, model, device, share=None):
+        if share is None:
+            self.entries = counters_of(model)
+            self.words = torch.zeros(max(len(self.entries), 1), dtype=torch.int64, device=device)
+            self._sh = {"expect": None}
+        else:
+            self.entries, self.words, self._sh = share.entries, share.words, share._sh
         n = max(len(self.entries), 1)
-        self.words = torch.zeros(n, dtype=torch.int64, device=device)
         self.inc = torch.zeros(n, dtype=torch.int64, device=device)   # filled after the capture: stride * calls per step
         self.per_step = [0] * len(self.entries)
-        self._expect = None
+
+    @property
+    def _expect(self):
+        return self._sh["expect"]
+
+    @_expect.setter
+    def _expect(self, v):
+        self._sh["expect"] = v
 
     def _host_values(self):
         return [c.stride * c.calls for _, c in self.entries]

@@ -728,6 +728,12 @@ int hw_cafe_level_loss(const float* logits, int64_t ld, int64_t n_rows, int64_t 
 int hw_cafe_level_loss_grad(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const float* lse,
                             const int64_t* target, const int64_t* pos, const int64_t* neg, float g_ce, float g_rank,
                             float* dlogits, int64_t ldd, void* stream);
+/* The same with the upstream gradients as device scalars (g_ce required; g_rank required when pos / neg are given): what
+ * autograd hands the backward of the level loss already lives on the device -- no host read, and the launch can sit in a
+ * captured training step (driver.GraphedStagedTrainStep). */
+int hw_cafe_level_loss_grad_dev(const float* logits, int64_t ld, int64_t n_rows, int64_t n_cols, const float* lse,
+                                const int64_t* target, const int64_t* pos, const int64_t* neg, const float* g_ce,
+                                const float* g_rank, float* dlogits, int64_t ldd, void* stream);
 
 /* Interpret every task's program: for each node in order and each parent path in order, candidates = distinct
  * neighbours of the path's tail under node.rel, minus ids already picked at this node, minus (leaves) the excluded

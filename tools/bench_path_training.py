@@ -91,6 +91,27 @@ for B in (64, 512, 4096):
 
     ms = timed(step, 20)
     out[f"cafe_B{B}"] = {"ms_per_step": round(ms, 3), "paths_per_s": round(B / ms * 1e3), "metapath_levels": len(mp) - 1}
+    # the same device half replayed from its capture (driver.GraphedStagedTrainStep; the host half here hands over the same
+    # batch: what is timed is the replay path -- host tensors into the static buffers, one graph launch, counters)
+    from hopwise_amd.driver import make_graphed_step
+    from hopwise_amd.optim import FusedAdam
+
+    m._get_batch_by_user = lambda users, pos=pos, neg=neg_t.cpu().numpy(): (0, pos, neg)
+    fopt = FusedAdam(m.parameters(), lr=1e-4)
+    it = {m.USER_ID: torch.from_numpy(pos[:, 0].copy())}  # user ids as the loader hands them over: on the host
+
+    def fstep():
+        fopt.zero_grad()
+        reg, rank = m.calculate_loss(it)
+        (reg + rank).backward()
+        fopt.step()
+
+    ms_f = timed(fstep, 20)
+    g = make_graphed_step(m, fopt, None)
+    ms_g = timed(lambda: g(it), 50)
+    out[f"cafe_B{B}"].update(ms_per_step_fused_adam=round(ms_f, 3), ms_per_step_graph_replay=round(ms_g, 3),
+                             paths_per_s_graph_replay=round(B / ms_g * 1e3), captures=g.n_captured)
+    del g, fopt
 print(json.dumps(out), flush=True)
 
 # TuckER (configs[4] width) and ConvE: eager trainer step against its graph replay (three / four dropouts per side, Philox offsets

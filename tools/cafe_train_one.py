@@ -20,6 +20,14 @@ def step():
     reg, rank = m.model(mp, pos_t, neg_t, m.embeddings)
     (reg + rank * m.rank_weight).backward()
     opt.step()
+if len(sys.argv) > 2 and sys.argv[2] == "graph":  # the same step through driver.GraphedStagedTrainStep (host ids stay on the host)
+    from hopwise_amd.driver import make_graphed_step
+    from hopwise_amd.optim import FusedAdam
+    neg = neg_t.cpu().numpy()
+    m._get_batch_by_user = lambda users: (0, pos, neg)
+    g = make_graphed_step(m, FusedAdam(m.parameters(), lr=1e-4), None)
+    it = {m.USER_ID: torch.from_numpy(pos[:, 0].copy())}
+    step = lambda: g(it)
 for _ in range(5): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
