@@ -426,8 +426,9 @@ def train_epoch_graphed(model, batches, optimizer, clip_grad_norm=None, device=N
     so the next epoch can reuse the capture."""
     model.train()
     total = None
+    staged = hasattr(model, "graph_host_stage")  # its host half wants the ids where the loader has them
     for interaction in batches:
-        if device is not None:
+        if device is not None and not staged:
             interaction = interaction.to(device)
         if step is None:
             step = make_graphed_step(model, optimizer, interaction, clip_grad_norm)
@@ -511,8 +512,9 @@ def graphed_trainer(base):
                 return super()._train_epoch(train_data, epoch_idx, loss_func=loss_func, show_progress=show_progress)
             self.model.train()
             total = None
+            staged = hasattr(self.model, "graph_host_stage")  # CAFE: the ids are wanted on the host, where the loader has them
             for batch_interaction in train_data:
-                interaction = batch_interaction.to(self.device)
+                interaction = batch_interaction if staged else batch_interaction.to(self.device)
                 if self._graph_step is None:
                     self._graph_step = self._make_step(interaction)
                 loss = self._graph_step(interaction) if self._graph_step.matches(interaction) else self._eager_step(interaction)

@@ -147,7 +147,7 @@ class SymbolicNetwork(nn.Module):
         x, reg_loss, rank_loss = user_vec, 0, None
         for i, module in enumerate(modules):
             x = module((x, user_vec)).view(pos_paths.shape[0], -1)
-            logits = ops.matmul_nt(x, embeddings[module.et_name])
+            logits = ops.matmul_nt(x, embeddings[module.et_name], padded=True)  # level_loss takes a row pitch
             last = i == len(modules) - 1
             ce, rk = ops.level_loss(logits, pos_paths[:, i + 1], pos_paths[:, -1] if last else None,
                                     neg_pids if last else None)

@@ -1017,28 +1017,42 @@ def gemm(a, b, a_k_contiguous=True, b_k_contiguous=True, bias=None, elu=False, o
     return out
 
 
+def _unit_rows(t):
+    """``t`` as a 2-D operand the kernels take: unit inner stride, rows at any 4-byte-aligned pitch (no copy for a padded view)."""
+    return t if t.dim() == 2 and t.stride(1) == 1 else t.contiguous()
+
+
+def padded_rows(m, n, device, dtype=torch.float32):
+    """An [m, n] matrix whose rows start 16 bytes apart-aligned (pitch n rounded up to 4 elements): what the split GEMM and the
+    row kernels want of an operand whose width is whatever a vocabulary happens to be (13 805 entities: every second row of
+    the contiguous matrix starts off a 16-byte boundary, and the product that reads it falls back to the exact-FMA loop)."""
+    return torch.empty((m, (n + 3) & ~3), dtype=dtype, device=device)[:, :n]
+
+
 class MatMul(torch.autograd.Function):
-    """y = x @ w^T (w in nn.Linear layout [N, K]) with both gradients on the same MFMA kernel."""
+    """y = x @ w^T (w in nn.Linear layout [N, K]) with both gradients on the same MFMA kernel.  ``padded``: y is a padded-pitch
+    view when N is no multiple of 4 (see :func:`padded_rows`; for callers whose consumers take a row pitch)."""
 
     @staticmethod
-    def forward(ctx, x, w):
+    def forward(ctx, x, w, padded=False):
         ctx.save_for_backward(x, w)
-        return gemm(x.contiguous(), w.contiguous(), True, True)
+        x, w = x.contiguous(), w.contiguous()
+        return gemm(x, w, True, True, out=padded_rows(x.shape[0], w.shape[0], x.device) if padded else None)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        gy = gy.contiguous()
+        gy = _unit_rows(gy)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = gemm(gy, w.contiguous(), True, False)  # [M, N] @ [N, K]
         if ctx.needs_input_grad[1]:
             gw = gemm(gy, x.contiguous(), False, False)  # gy^T [N, M] @ x [M, K]
-        return gx, gw
+        return gx, gw, None
 
 
-def matmul_nt(x, w):
-    return MatMul.apply(x, w)
+def matmul_nt(x, w, padded=False):
+    return MatMul.apply(x, w, padded)
 
 
 class MatMulNN(torch.autograd.Function):
@@ -1286,7 +1300,7 @@ class LevelLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, pos, neg):
         lib = _lib.load()
-        logits = _dev(logits, torch.float32, "logits").contiguous()
+        logits = _unit_rows(_dev(logits, torch.float32, "logits"))
         n, v = logits.shape
         target = _idx(target, "target").contiguous()
         pos = None if pos is None else _idx(pos, "pos").contiguous()
@@ -1305,8 +1319,8 @@ class LevelLoss(torch.autograd.Function):
         lib = _lib.load()
         logits, lse, target = ctx.saved_tensors[:3]
         pos, neg = (ctx.saved_tensors[3], ctx.saved_tensors[4]) if ctx.has_rank else (None, None)
-        d = torch.empty_like(logits)
         n, v = logits.shape
+        d = padded_rows(n, v, logits.device)  # the product that consumes it (dX = d . E) wants 16-byte row starts
         # the upstream gradients stay on the device: no host read per level, and the launch can be captured
         g_ce = g_ce.to(torch.float32).contiguous()
         g_rank = g_rank.to(torch.float32).contiguous() if ctx.has_rank else None
