@@ -266,7 +266,12 @@ def leg_kge(D, args, out):
         return ln
 
     n_lanes = max(1, args.streams)
-    lanes = [make_lane(torch.cuda.current_stream() if n_lanes == 1 else torch.cuda.Stream()) for _ in range(n_lanes)]
+    # lanes on streams that were probed to sit on different hardware queues (hopwise_amd/stream_pool.py: torch's pooled streams
+    # share four queues, and two lanes that take turns on one queue are one lane)
+    from hopwise_amd.stream_pool import concurrent_streams
+
+    lane_streams = [torch.cuda.current_stream()] if n_lanes == 1 else concurrent_streams(n_lanes, dev)
+    lanes = [make_lane(s) for s in lane_streams]
     solo = lanes[0] if n_lanes == 1 else make_lane(torch.cuda.current_stream())  # single-stream launches (calibration, later legs)
     torch.cuda.synchronize()
     if fused_loss and lib.hw_kge_score_grouped_sampled_selfadv(*solo.fused_args, C.c_uint64(0), *solo.loss_tail) != 0:
@@ -581,7 +586,9 @@ def leg_roofline_variants(D, args, out, ctx):
     }
     # the same launches alternating over two streams (what the timed region of the headline does): aggregate rate only --
     # the roofline of record stays the lone launch above
-    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    from hopwise_amd.stream_pool import concurrent_streams
+
+    st = concurrent_streams(2, dev)  # two streams on two hardware queues
     torch.cuda.synchronize()
 
     def pair(n):

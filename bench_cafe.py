@@ -79,7 +79,10 @@ def _timed(fn, min_seconds, reps0=3, streams=None):
 def run(dev, n_users=256, n_metapaths=6, cpu_users=0, min_seconds=0.5, rank=0, streams=1):
     kg, ds, m, metapaths = make_model(dev, n_metapaths)
     users = torch.from_numpy(np.random.default_rng(1 + rank).integers(1, kg.n_users, n_users))
-    side = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
+    # streams that were probed to sit on different hardware queues (hopwise_amd/stream_pool.py)
+    from hopwise_amd.stream_pool import concurrent_streams
+
+    side = concurrent_streams(streams, dev) if streams > 1 else None
     t_dev, reps, (scores, rec, leaves, _) = _timed(lambda: m.run_program_device(users), min_seconds, streams=side)
     t_all, reps_all, (sc_cpu, lists) = _timed(lambda: (lambda s, p: (s, len(p) and p))(*m.run_program(users)), min_seconds / 2)
     # paths the interpreter emitted in one call: the node counts of every user's program

@@ -126,7 +126,10 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         steps = max(5, int(np.ceil(1.1 * min_seconds / max((time.perf_counter() - t0) / 3, 1e-4))))
     user_batches = [batch(i) for i in range(steps)]  # ids resident on the device before the clock starts
     counts = []
-    side = [torch.cuda.Stream(device=dev) for _ in range(streams)] if streams > 1 else None
+    # streams that were probed to sit on different hardware queues (hopwise_amd/stream_pool.py)
+    from hopwise_amd.stream_pool import concurrent_streams
+
+    side = concurrent_streams(streams, dev) if streams > 1 else None
     if side is not None:  # one untimed search per stream: its allocator pool is filled before the clock starts
         for st in side:
             with torch.cuda.stream(st):
