@@ -347,7 +347,7 @@ class GraphedStagedTrainStep(GraphedTrainStep):
     remembers the counters it was recorded with and is thrown away (captured again on its next use) should the optimizer have
     moved one of its parameters to another counter all the same."""
 
-    MAX_CAPTURES = 64  # distinct (metapath, batch rows) forms kept; a form beyond that runs eagerly
+    MAX_CAPTURES = 64  # distinct (metapath, batch rows) forms kept; beyond that the one used longest ago is dropped
 
     def __init__(self, model, optimizer, example=None, clip_grad_norm=None, allow_unverified_capture=False,
                  assume_zero_initialised_state=None):
@@ -399,11 +399,16 @@ class GraphedStagedTrainStep(GraphedTrainStep):
             del self.captures[key]  # the optimizer regrouped its step counters since: record this form again
             cap = None
         if cap is None:
-            if rows == 0 or len(self.captures) >= self.MAX_CAPTURES:
+            if rows == 0:
                 dev = self._params[0].device
                 return self._eager(key, {k: v.to(dev) if v.is_cuda else v.pin_memory().to(dev, non_blocking=True)
                                          for k, v in host.items()})
-            cap = self.captures[key] = self._new_capture(key, host)
+            if len(self.captures) >= self.MAX_CAPTURES:  # the form used longest ago makes room (dicts keep insertion order)
+                del self.captures[next(iter(self.captures))]
+            cap = self._new_capture(key, host)
+        else:
+            del self.captures[key]
+        self.captures[key] = cap  # most recently used last
         for k, v in host.items():  # pinned staging (caching host allocator): no pin-on-the-fly for the larger batches
             cap["static"][k].copy_(v if v.is_cuda else v.pin_memory(), non_blocking=True)
         cap["counters"].before_replay()

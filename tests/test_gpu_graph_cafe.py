@@ -102,3 +102,19 @@ def test_cafe_replays_draw_fresh_dropout_masks():
     for (_, c), v in zip(counters_of(m), counts):  # an eager interruption (here: putting the counts back) is followed
         c.calls = v
     assert float(step(u)) == b
+
+
+def test_more_forms_than_kept_captures_drop_the_oldest():
+    from hopwise_amd.driver import make_graphed_step
+    from hopwise_amd.optim import FusedAdam
+
+    z, eager, graphed = _pair()
+    o1, o2 = FusedAdam(eager.parameters(), lr=2e-3), FusedAdam(graphed.parameters(), lr=2e-3)
+    step = make_graphed_step(graphed, o2, None)
+    step.MAX_CAPTURES = 2
+    l1, l2 = [], []
+    for u in _batches(z, 12):
+        l1.append(float(_eager(eager, o1, {eager.USER_ID: u})))
+        l2.append(float(step({graphed.USER_ID: u})))
+    assert len(step.captures) == 2 and step.n_captured > 2 and step.n_eager == 0
+    np.testing.assert_allclose(l2, l1, rtol=2e-5)
