@@ -1108,19 +1108,25 @@ __device__ __forceinline__ void sort64(uint32_t& key, int lane) {
 // and counting compares.  The sum of a row's exps is taken in a different order in the two forms (an ulp of p): every
 // kernel that ranks a row picks the form by the same rule (rank_slots), so they still agree bit for bit.
 __device__ __forceinline__ int rank_slots(int na) { return na <= 128 ? 2 : 4; }
+// the row's raw logits in the blocked layout of NPL slots per lane (element j = lane * NPL + i; clamped index, select
+// afterwards: the loads are issued together)
 template <int NPL>
-__device__ __forceinline__ void row_softmax_keys(const float* __restrict__ lr, int act_dim, int na, int lane,
-                                                 float* __restrict__ probs_row, uint32_t (&key)[NPL], bool& row_has_two) {
+__device__ __forceinline__ void row_logits_load(const float* __restrict__ lr, int act_dim, int lane, float (&x)[NPL]) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int j = lane * NPL + i;
+        x[i] = lr[j < act_dim ? j : act_dim - 1];
+    }
+}
+
+// ranking keys of a row from its raw logits (row_logits_load's registers)
+template <int NPL>
+__device__ __forceinline__ void row_softmax_keys_of(float (&x)[NPL], int act_dim, int na, int lane,
+                                                    float* __restrict__ probs_row, uint32_t (&key)[NPL], bool& row_has_two) {
     // p is rounded to float32 before the + 1 (probs + mask.float() on a float32 tensor, pgpr.py:453): no fused multiply-add,
     // or the same row would rank differently depending on which kernel the function was inlined into
 #pragma clang fp contract(off)
-    float x[NPL];
     float mx = -INFINITY;
-#pragma unroll
-    for (int i = 0; i < NPL; ++i) {  // clamped index, select afterwards: the four loads are issued together
-        const int j = lane * NPL + i;  // blocked layout: element j of the row
-        x[i] = lr[j < act_dim ? j : act_dim - 1];
-    }
 #pragma unroll
     for (int i = 0; i < NPL; ++i) {
         const int j = lane * NPL + i;
@@ -1149,6 +1155,14 @@ __device__ __forceinline__ void row_softmax_keys(const float* __restrict__ lr, i
         key[i] = valid ? ((mant << 8) | (uint32_t)(255 - j)) + 0x80000000u : 0u;
     }
     row_has_two = __any(two);
+}
+
+template <int NPL>
+__device__ __forceinline__ void row_softmax_keys(const float* __restrict__ lr, int act_dim, int na, int lane,
+                                                 float* __restrict__ probs_row, uint32_t (&key)[NPL], bool& row_has_two) {
+    float x[NPL];
+    row_logits_load<NPL>(lr, act_dim, lane, x);
+    row_softmax_keys_of<NPL>(x, act_dim, na, lane, probs_row, key, row_has_two);
 }
 
 __device__ __forceinline__ void decode_topk_key(uint32_t kk, bool row_has_two, int& idx, float& v) {
@@ -1412,39 +1426,83 @@ __global__ __launch_bounds__(256) void pgpr_topk_expand_kernel(
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int n_rows = n_rows_ptr[0];
     const int lane = threadIdx.x & 63, w = wave_in_block();
-    for (int row_v = blockIdx.x * 4 + w; row_v < n_rows; row_v += gridDim.x * 4) {
-        const int row = __builtin_amdgcn_readfirstlane(row_v);
-        const int na = n_acts[row];
-        // A16: everything the tail of the row needs that does not depend on the ranking is requested BEFORE it -- the row's whole
-        // offset list (<= 256 x 2 bytes: four entries per lane; the chosen entry is picked out of the lanes' registers
-        // afterwards) and the current node's CSR base -- and pinned there: left to itself the scheduler sinks these loads to
-        // their first use, behind the ranking, where each adds a dependent memory round trip to a chain that is all latency
-        // (last hop of the 64/64/64 bench, one card: 0.91 ms with the entry gathered after the ranking, 0.85 ms this way)
-        uint2 a16 = make_uint2(0u, 0u);
-        int64_t lo_pref = 0;
+    const int stride = gridDim.x * 4;
+    const int first = blockIdx.x * 4 + w;
+    if (first >= n_rows) return;  // no block-wide barrier below: a wave may leave alone
+    // A row is a chain of dependent round trips -- counts and parent record (scalar unit) -> logits, offset list, CSR base ->
+    // ranking -> edge -> leaf -- and the launch spent two thirds of its wave cycles in s_waitcnt with ten waves per SIMD
+    // (profiles/r5/pmc_pgpr_r5b.txt: SQ_WAIT_ANY 8.2e8 of 1.25e9).  So everything that does not depend on a row's ranking is
+    // requested AHEAD of the row, branch-free (clamped indices: the last row is simply requested again):
+    //   two rows ahead  the scalar reads: action count, the 48-byte parent record, the output offset;
+    //   one row ahead   the vector reads that need those: the raw logits (their layout follows the count: rank_slots), and with
+    //                   A16 the row's whole offset list (<= 256 x 2 bytes: four entries per lane; the chosen entry is picked
+    //                   out of the lanes' registers afterwards) and the current node's CSR base.
+    // Within a row the pre-ranking requests had already been hoisted above the ranking (0.91 -> 0.85 ms for the last hop of
+    // the 64/64/64 bench in round 4).
+    static_assert(PATH_INTS == 12, "three 16-byte pieces");
+    struct RowScalars {
+        int row, na;
+        i32x4 q0, q1, q2;  // the parent record
+        int o0;            // first output slot
+    };
+    auto read_scalars = [&](int row) {  // row is wave-uniform: scalar loads
+        RowScalars r;
+        r.row = row;
+        r.na = n_acts[row];
+        const i32x4* pr = reinterpret_cast<const i32x4*>(paths + (size_t)row * PATH_INTS);
+        r.q0 = pr[0], r.q1 = pr[1], r.q2 = pr[2];
+        r.o0 = offsets[row];
+        return r;
+    };
+    auto request = [&](const RowScalars& r, float (&x)[4], uint2& a16, int64_t& lo_pref) {
+        const int npl = rank_slots(r.na);  // wave-uniform: 2 or 4
+        const float* __restrict__ lr = logits + (size_t)r.row * ld;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int j = lane * npl + (i < npl ? i : npl - 1);  // slots 2, 3 of a two-slot row repeat slot 1
+            x[i] = lr[j < act_dim ? j : act_dim - 1];
+        }
         if constexpr (A16) {
             const int ld16 = act16_ld(act_dim);
-            const uint2* arow = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(acts) + (size_t)row * ld16);
+            const uint2* arow = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(acts) + (size_t)r.row * ld16);
             a16 = arow[lane * 4 < ld16 ? lane : 0];  // clamped: lanes past the row re-read its first piece
-            const int32_t* prec = paths + (size_t)row * PATH_INTS;
-            const int plen = prec[1];
-            const int pt = plen == 1 ? T_USER : prec[2 + 3 * (plen - 2) + 1];
-            const int pn = plen == 1 ? prec[0] : prec[2 + 3 * (plen - 2) + 2];
+            const int plen = r.q0.y;
+            const int pt = plen == 1 ? T_USER : (plen == 2 ? r.q0.w : (plen == 3 ? r.q1.z : r.q2.y));
+            const int pn = plen == 1 ? r.q0.x : (plen == 2 ? r.q1.x : (plen == 3 ? r.q1.w : r.q2.z));
             lo_pref = g.ptr[pt == T_USER ? pn : (int64_t)g.n_users + pn];
-            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    auto clamp_next = [&](int row) { return row + stride < n_rows ? row + stride : row; };
+    RowScalars s1 = read_scalars(__builtin_amdgcn_readfirstlane(first));
+    RowScalars s2 = read_scalars(clamp_next(s1.row));
+    float xn[4];
+    uint2 a16n = make_uint2(0u, 0u);
+    int64_t lon = 0;
+    request(s1, xn, a16n, lon);
+    for (bool more = true; more;) {
+        const RowScalars cur = s1;
+        const int row = cur.row, na = cur.na;
+        float xr[4] = {xn[0], xn[1], xn[2], xn[3]};
+        const uint2 a16 = a16n;
+        const int64_t lo_pref = lon;
+        more = row + stride < n_rows;  // wave-uniform
+        s1 = s2;
+        s2 = read_scalars(clamp_next(s1.row));
+        request(s1, xn, a16n, lon);
+        __builtin_amdgcn_sched_barrier(0);  // the requests stay above the ranking
         bool row_has_two;
         uint32_t one;
         if (rank_slots(na) == 2) {  // wave-uniform
             uint32_t key[2];
-            row_softmax_keys<2>(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key, row_has_two);
+            float x2[2] = {xr[0], xr[1]};
+            row_softmax_keys_of<2>(x2, act_dim, na, lane, nullptr, key, row_has_two);
             one = select_sort_topk<2>(key, k, lane, surv_all[w]);
         } else {
             uint32_t key[4];
-            row_softmax_keys<4>(logits + (size_t)row * ld, act_dim, na, lane, nullptr, key, row_has_two);
+            row_softmax_keys_of<4>(xr, act_dim, na, lane, nullptr, key, row_has_two);
             one = select_sort_topk<4>(key, k, lane, surv_all[w]);
         }
-        const int64_t o0 = offsets[row];
+        const int64_t o0 = cur.o0;
         const int64_t room = cap - o0;  // children past the output capacity are dropped, as in pgpr_expand_kernel
         const int n_child = min(k, na);
         const int n_live = (int)(room < (int64_t)n_child ? (room < 0 ? 0 : room) : (int64_t)n_child);  // wave-uniform
@@ -1453,10 +1511,8 @@ __global__ __launch_bounds__(256) void pgpr_topk_expand_kernel(
         int idx;
         float v;
         decode_topk_key(one, row_has_two, idx, v);
-        // the parent record, once per row, through the scalar unit (the row index is wave-uniform)
-        static_assert(PATH_INTS == 12, "three 16-byte pieces");
-        const i32x4* pr = reinterpret_cast<const i32x4*>(paths + (size_t)row * PATH_INTS);
-        const i32x4 q0 = pr[0], q1 = pr[1], q2 = pr[2];
+        // the parent record: read once per row through the scalar unit, two rows ago
+        const i32x4 q0 = cur.q0, q1 = cur.q1, q2 = cur.q2;
         const int len = q0.y;
         const int cur_t = len == 1 ? T_USER : (len == 2 ? q0.w : (len == 3 ? q1.z : q2.y));
         int rel, node;
