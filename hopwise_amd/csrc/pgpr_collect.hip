@@ -188,33 +188,79 @@ __global__ __launch_bounds__(256) void collect_mark_parents_kernel(hw_pgpr_graph
     __syncthreads();
     const int slot0 = slot0_sh;
     const int wave = wave_in_block(), lane = threadIdx.x & 63;
-    for (int p = p0 + wave; p < p1; p += 4) {  // everything up to the child loads is wave-uniform
-        const int32_t* __restrict__ pr = parents + (size_t)p * CPATH_INTS;
-        if (pr[1] != n_nodes - 1) continue;
-        bool okp = true;
-        for (int j = 1; j < n_nodes - 1; ++j) okp &= pr[2 + 3 * (j - 1)] != -1;  // no self loop after the root
-        if (!okp) continue;
-        const int cur_t = n_nodes == 2 ? 0 : pr[2 + 3 * (n_nodes - 3) + 1];
-        const int uid = pr[0];
-        const int slot = first_idx[pr[11]];
+    // A parent is a chain of dependent reads -- record, probabilities, child range (scalar unit) -> user slot, the children
+    // (vector) -> positives bit -> LDS max -- and a wave walks 128 parents one after the other.  The reads are therefore issued
+    // AHEAD of the parent that needs them, branch-free (clamped indices; a wave's last parent is simply requested again):
+    // the scalar reads two parents ahead, the user slot and the children one ahead (as in pgpr.hip: pgpr_topk_expand_kernel).
+    static_assert(CPATH_INTS == 12, "three 16-byte pieces");
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    struct Par {
+        int p;
+        i32x4 q0, q1, q2;   // the record
+        float f0, f1, f2;   // its probability prefix
+        int c0, c1;         // child range
+    };
+    auto read_scalars = [&](int p) {  // p is wave-uniform: scalar loads
+        Par r;
+        r.p = p;
+        const i32x4* pr = reinterpret_cast<const i32x4*>(parents + (size_t)p * CPATH_INTS);
+        r.q0 = pr[0], r.q1 = pr[1], r.q2 = pr[2];
         const float* __restrict__ q = parent_probs + (size_t)p * 3;
-        float prefix = n_nodes == 2 ? 1.f : q[0];  // reduce(mul) in float32, the leaf's own value last (leaf_key's order)
-        for (int j = 1; j < n_nodes - 2; ++j) prefix = prefix * q[j];
-        const int c0 = child_offsets[p];
-        int c1 = p + 1 < n_par ? child_offsets[p + 1] : n_leaf;
-        c1 = c1 < n_leaf ? c1 : n_leaf;
-        const int i = c0 + lane;
-        if (i >= c1) continue;
-        const int4 lf = cleaf[i];
-        const int lt = (cur_t == 1 && lf.y == g.ui_relation) ? 0 : 1;  // pgpr.py:209-213
-        const int pid = lf.z;
-        if (lf.y == -1 || lt != 1 || pid >= g.n_items) continue;       // a self loop / not an item
-        if (bit_test(pos_bits, pos_words, uid, pid)) continue;         // already a train positive
-        const float v = __uint_as_float((uint32_t)lf.w);
-        const float pp = n_nodes == 2 ? v : prefix * v;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(pp) << 32) | (uint32_t)(~(uint32_t)i);
-        if (slot == slot0) atomicMax(&lds_best[pid], key);
-        else atomicMax(best + (size_t)slot * g.n_items + pid, key);
+        r.f0 = q[0], r.f1 = q[1], r.f2 = q[2];
+        r.c0 = child_offsets[p];
+        r.c1 = child_offsets[p + 1 < n_par ? p + 1 : p];  // the last parent's range ends at n_leaf (below)
+        return r;
+    };
+    auto clamp_next = [&](int p) { return p + 4 < p1 ? p + 4 : p; };
+    auto request = [&](const Par& r, int& slot, int4& lf) {
+        slot = first_idx[r.q2.w];  // record word 11: the user's index in the batch
+        const int i = r.c0 + lane;
+        lf = cleaf[i < n_leaf ? i : (n_leaf > 0 ? n_leaf - 1 : 0)];
+    };
+    const int pw = p0 + wave;
+    if (pw < p1 && n_leaf > 0) {
+        Par s1 = read_scalars(__builtin_amdgcn_readfirstlane(pw));
+        Par s2 = read_scalars(clamp_next(s1.p));
+        int slot_n;
+        int4 lf_n;
+        request(s1, slot_n, lf_n);
+        for (bool more = true; more;) {
+            const Par cur = s1;
+            const int slot = slot_n;
+            const int4 lf = lf_n;
+            more = cur.p + 4 < p1;  // wave-uniform
+            s1 = s2;
+            s2 = read_scalars(clamp_next(s1.p));
+            request(s1, slot_n, lf_n);
+            __builtin_amdgcn_sched_barrier(0);
+            // the tests that do not depend on the child, on values (selects, no loads)
+            const int len = cur.q0.y;
+            const int rel1 = cur.q0.z, rel2 = cur.q1.y, rel3 = cur.q2.x;  // relations of hops 1..3
+            bool okp = len == n_nodes - 1;
+            if (n_nodes - 1 > 1) okp = okp && rel1 != -1;  // no self loop after the root
+            if (n_nodes - 1 > 2) okp = okp && rel2 != -1;
+            if (n_nodes - 1 > 3) okp = okp && rel3 != -1;
+            if (!okp) continue;  // wave-uniform
+            // type of the parent's last node (hop n_nodes - 2)
+            const int cur_t = n_nodes == 2 ? 0 : (n_nodes == 3 ? cur.q0.w : (n_nodes == 4 ? cur.q1.z : cur.q2.y));
+            const int uid = cur.q0.x;
+            float prefix = n_nodes == 2 ? 1.f : cur.f0;  // reduce(mul) in float32, the leaf's own value last (leaf_key's order)
+            if (n_nodes - 2 > 1) prefix = prefix * cur.f1;
+            if (n_nodes - 2 > 2) prefix = prefix * cur.f2;
+            int c1 = cur.p + 1 < n_par ? cur.c1 : n_leaf;
+            c1 = c1 < n_leaf ? c1 : n_leaf;
+            const int i = cur.c0 + lane;
+            if (i >= c1) continue;
+            const int lt = (cur_t == 1 && lf.y == g.ui_relation) ? 0 : 1;  // pgpr.py:209-213
+            const int pid = lf.z;
+            if (lf.y == -1 || lt != 1 || pid >= g.n_items) continue;       // a self loop / not an item
+            if (bit_test(pos_bits, pos_words, uid, pid)) continue;         // already a train positive
+            const float v = __uint_as_float((uint32_t)lf.w);
+            const float pp = n_nodes == 2 ? v : prefix * v;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(pp) << 32) | (uint32_t)(~(uint32_t)i);
+            if (slot == slot0) atomicMax(&lds_best[pid], key);
+            else atomicMax(best + (size_t)slot * g.n_items + pid, key);
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < g.n_items; c += 256) {
