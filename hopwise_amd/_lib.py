@@ -234,6 +234,10 @@ SIGNATURES = {
         [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int32, c_f32p, c_f32p,
          C.c_float, C.c_float, C.c_int32, c_i32p, C.c_void_p],
     ),
+    "hw_gemm_rank": (
+        C.c_int,
+        [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p],
+    ),
     "hw_gemm_dist": (
         C.c_int,
         [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_f32p, C.c_float,

@@ -336,11 +336,16 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
             const uint8_t* Ai = img + cur * SPLIT_STAGE;
             const uint8_t* Bi = Ai + OA;
             uint8_t* An = img + (cur ^ 1) * SPLIT_STAGE;
+            // ACT == 5, the ranking product (hw_gemm_rank): the three largest terms only -- hi.hi, hi.mid, mid.hi -- for products
+            // whose consumer re-scores its candidates exactly (hw_topk_rerank); the lo planes are not read.  Dropped: mid.mid,
+            // hi.lo, lo.hi <= 3 x 2^-18 |a b| per product (round-to-nearest splits).
+            constexpr bool LITE = ACT == 5;
+            constexpr int NPLANES = LITE ? 2 : 3;
             bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NPLANES; ++p) {
 #ifdef GEMM_ABL_NO_READ
                     fa[t][p] = fb[t][p] = __builtin_bit_cast(bf16x8, f32x4{(float)lane, (float)t, (float)p, (float)cur});
 #else
@@ -363,24 +368,43 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
 #else
 #define HW_PIECE(KC_, V_, I_, OFF_) put_piece_split<KC_, FULL>(V_, I_, k_end, k0 + BK, An + OFF_);
 #endif
-            HW_SPLIT_TERM(1, 1)
-            if constexpr (FETCH_IN) fetch_next();
-            HW_PIECE(A_KC, na[0], 0, 0)
-            HW_SPLIT_TERM(2, 0)
-            HW_PIECE(A_KC, na[1], 1, 0)
-            HW_SPLIT_TERM(0, 2)
-            HW_PIECE(B_KC, nb[0], 0, OA)
-            HW_SPLIT_TERM(1, 0)
-            HW_PIECE(B_KC, nb[1], 1, OA)
-            HW_SPLIT_TERM(0, 1)
-            HW_SPLIT_TERM(0, 0)
-            // the scheduler's order: per MFMA up to four vector instructions of the conversion, every other one an LDS store
+            if constexpr (LITE) {
+                HW_SPLIT_TERM(1, 0)
+                if constexpr (FETCH_IN) fetch_next();
+                HW_PIECE(A_KC, na[0], 0, 0)
+                HW_PIECE(A_KC, na[1], 1, 0)
+                HW_SPLIT_TERM(0, 1)
+                HW_PIECE(B_KC, nb[0], 0, OA)
+                HW_PIECE(B_KC, nb[1], 1, OA)
+                HW_SPLIT_TERM(0, 0)
+                // half the MFMAs carry the same conversion: eight vector instructions and an LDS store per MFMA
 #pragma unroll
-            for (int q = 0; q < 24; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                if (FETCH_IN && q >= 1 && q <= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                for (int q = 0; q < 12; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    if (FETCH_IN && q >= 1 && q <= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            } else {
+                HW_SPLIT_TERM(1, 1)
+                if constexpr (FETCH_IN) fetch_next();
+                HW_PIECE(A_KC, na[0], 0, 0)
+                HW_SPLIT_TERM(2, 0)
+                HW_PIECE(A_KC, na[1], 1, 0)
+                HW_SPLIT_TERM(0, 2)
+                HW_PIECE(B_KC, nb[0], 0, OA)
+                HW_SPLIT_TERM(1, 0)
+                HW_PIECE(B_KC, nb[1], 1, OA)
+                HW_SPLIT_TERM(0, 1)
+                HW_SPLIT_TERM(0, 0)
+                // the scheduler's order: per MFMA up to four vector instructions of the conversion, every other one an LDS store
+#pragma unroll
+                for (int q = 0; q < 24; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    if (FETCH_IN && q >= 1 && q <= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (q % 2 == 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #undef HW_SPLIT_TERM
@@ -1216,7 +1240,7 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     const int64_t gm = (m_max + BM - 1) / BM, gn = (n + BN - 1) / BN;
     // split-K when the output grid cannot fill the chip and K is long (e.g. dX = dY [2048, 144779] . E [144779, 200])
     int splits = 1;
-    if (act != 3 && workspace && gm * gn < 256 && k >= 16 * BK) {
+    if (act < 3 && workspace && gm * gn < 256 && k >= 16 * BK) {
         // also the short-K, few-row products of a beam search's first hops: a lone tile walks its K / 16 steps at one
         // load latency each (75 us for [64, 512] x [256, 512]^T), so the chain is cut into splits of >= 4 steps
         int64_t want = (768 + gm * gn - 1) / (gm * gn);
@@ -1291,6 +1315,9 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     } else if (act == 4) {  // distance epilogue (hw_gemm_dist): q . t^T only, never split
         if (!(a_kc && b_kc) || splits != 1) return HW_ERR_UNSUPPORTED;
         GO(true, true, 4);
+    } else if (act == 5) {  // ranking product (hw_gemm_rank): q . t^T + bias from the three largest split terms, never split
+        if (!(a_kc && b_kc) || splits != 1 || !split) return HW_ERR_UNSUPPORTED;
+        GO(true, true, 5);
     } else if (a_kc && b_kc) GO3(true, true);
     else if (a_kc && !b_kc) GO3(true, false);
     else if (!a_kc && !b_kc) GO3(false, false);
@@ -1329,6 +1356,21 @@ extern "C" int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, 
     HW_CLEAR_ERR();
     launch_gemm(a, lda, a_k_contiguous != 0, b, ldb, b_k_contiguous != 0, c, ldc, m_rows, m_max, n, k, bias, elu,
                 drop_mask, drop_mode, seed, offset, workspace, workspace ? workspace_floats : 0, (hipStream_t)stream);
+    return HW_LAUNCH_RC();
+}
+
+// c[i, j] = <q_i, t_j> + bias[j] to ~2^-16 relative accuracy per product (three of the six split terms: half the matrix
+// work): candidate generation for a consumer that re-scores exactly (hw_topk_rerank).  |error| <= 1.2e-5 sum_k |q_ik t_jk|.
+extern "C" int hw_gemm_rank(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc,
+                            int64_t m, int64_t n, int64_t k, void* stream) {
+    if (!q || !t || !c || m < 0 || n < 1 || k < 4 || ldc < n || ldq < k || ldt < k) return HW_ERR_INVALID_ARG;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if (!aligned16(q, ldq) || !aligned16(t, ldt)) return HW_ERR_UNSUPPORTED;  // the split loop's operands
+    if (m == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    const int rc = launch_gemm(q, ldq, true, t, ldt, true, c, ldc, nullptr, m, n, k, bias, 5, nullptr, 0, 0, 0, nullptr, 0,
+                               (hipStream_t)stream);
+    if (rc != HW_OK) return rc;
     return HW_LAUNCH_RC();
 }
 

@@ -150,6 +150,19 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     for (int i = tid; i < H1; i += 256) bias_lds[i] = b1[i];
     bias_lds[1024 + tid] = b2[tid];  // 256 threads, PF_H2 = 256
 
+    // ---- weight chunk pipeline: global -> LDS stage (q & 1), no registers in between ----
+    const int wave_u = wave_in_block();  // wave-uniform for the compiler too: the DMA's LDS base travels in M0
+    auto w_glds = [&](int q) {  // chunk q -> stage q & 1: twelve 1-KB pieces per wave, destination = base + lane * 16
+        typedef __attribute__((address_space(1))) const void gptr_t;
+        typedef __attribute__((address_space(3))) void lptr_t;
+        const uint8_t* src = planes + (size_t)q * PF_CHUNK + (size_t)tid * 16;
+        uint8_t* dst = lds + (q & 1) * PF_CHUNK + wave_u * 1024;
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t*)(src + 4096 * i), (lptr_t*)(dst + 4096 * i), 16, 0, 0);
+    };
+    w_glds(0);  // first of all: the chunk travels while the path records are read and turned into row addresses
+
     // ---- slot-table rows of this lane's beam row (pgpr_layer1_lookup_kernel's selection, per lane) ----
     const float* src[NPARTS];
     {
@@ -192,17 +205,6 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         }
     }
 
-    // ---- weight chunk pipeline: global -> LDS stage (q & 1), no registers in between ----
-    const int wave_u = wave_in_block();  // wave-uniform for the compiler too: the DMA's LDS base travels in M0
-    auto w_glds = [&](int q) {  // chunk q -> stage q & 1: twelve 1-KB pieces per wave, destination = base + lane * 16
-        typedef __attribute__((address_space(1))) const void gptr_t;
-        typedef __attribute__((address_space(3))) void lptr_t;
-        const uint8_t* src = planes + (size_t)q * PF_CHUNK + (size_t)tid * 16;
-        uint8_t* dst = lds + (q & 1) * PF_CHUNK + wave_u * 1024;
-#pragma unroll
-        for (int i = 0; i < 12; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(src + 4096 * i), (lptr_t*)(dst + 4096 * i), 16, 0, 0);
-    };
     // end of a trip: the DMAs of this trip have landed (counted wait: the N younger vector loads -- this trip's gathers -- stay
     // in flight), this wave's own LDS reads are done, then the block meets.
     auto trip_sync = [&](auto n_younger) {
@@ -302,7 +304,6 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #pragma unroll
     for (int T = 0; T < 8; ++T) acc2[T] = f32x16{0};
 
-    w_glds(0);
     x_fetch(0, xs, xm);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // chunk 0 and the biases are in LDS
     x_finish(0, 0, xs, xm, xb[0]);

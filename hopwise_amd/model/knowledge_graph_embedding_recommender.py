@@ -89,6 +89,8 @@ class _GatherKGE(KnowledgeRecommender):
         rr = _cfg(config, "gemm_rerank", os.environ.get("HW_FULLSORT_RERANK"))
         self.gemm_rerank = (self.GEMM_FORM == "distance") if rr is None else str(rr).lower() not in ("0", "false")
         self.gemm_min_scores = int(_cfg(config, "gemm_min_scores", os.environ.get("HW_FULLSORT_GEMM_MIN", self.GEMM_MIN_SCORES)))
+        # split terms of the evaluation top-k's ranking product (distance scorers, with the exact re-rank): 3 (hw_gemm_rank) or 6
+        self.gemm_rank_terms = 6 if str(_cfg(config, "gemm_rank_terms", os.environ.get("HW_FULLSORT_RANK_TERMS", "3"))) == "6" else 3
         self.apply(xavier_normal_initialization)
 
     def REL_ROW_FACTOR(self):
@@ -328,12 +330,18 @@ class _GatherKGE(KnowledgeRecommender):
                 q, qn = ops.kge_query_rows(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=True, margin=self.margin)
                 bias, tn_max = self._rank_bias(tail)
                 buf = torch.empty((q.shape[0], (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)[:, :n]
-                p = ops.gemm(q, self._cat_tables(tail)[:n], bias=bias[:n], out=buf)
+                # ... and no exact one either: the candidates are re-scored below, so the product runs on the three largest of
+                # its six split terms (hw_gemm_rank: half the matrix work).  Its error bound, 1.2e-5 sum |q_k t_k| <= 0.6e-5
+                # (||q||^2 + ||t||^2), doubles in d^2 = ||q||^2 - 2 p: the re-rank's proof carries 2e-5 (||q||^2 + max ||t||^2)
+                # for it (1e-5 with the six-term product, whose own error is ~1e-7)
+                lite = self.gemm_rank_terms == 3
+                table = self._cat_tables(tail)[:n]
+                p = ops.gemm_rank(q, table, bias[:n], out=buf) if lite else ops.gemm(q, table, bias=bias[:n], out=buf)
                 ops.mask_scores_(p, history_index)
                 approx, cand = ops.topk_rows(p, c)
                 desc = ops.make_desc(self.MODEL, head, rel, tail, self.margin, 0.0, n)
                 exact = ops.kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, cand)  # c <= n: every candidate is a column
-                val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=1e-5, abs_slack=1e-6, qn=qn,
+                val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=2e-5 if lite else 1e-5, abs_slack=1e-6, qn=qn,
                                                  base=self.margin if self.MODEL == "RotatE" else 0.0, tn_max=tn_max)
                 return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, 0, n, k, history_index,
                                               True, self.margin, run_if=flag, out=(val, idx))

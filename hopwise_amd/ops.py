@@ -618,6 +618,26 @@ def kge_dist_finish_(dots, q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRA
     return dots
 
 
+RANK_PRODUCT_REL_ERR = 1.2e-5  # hw_gemm_rank: |error| <= this x sum_k |q_k t_k| (three split terms of six)
+
+
+def gemm_rank(q, t, bias=None, out=None):
+    """out[M, N] = q @ t^T + bias from the three largest split terms (``hw_gemm_rank``): a ranking product for callers that
+    re-score their candidates exactly.  Falls back to the six-term product where the split loop does not apply."""
+    lib = _lib.load()
+    q = _unit_rows(_dev(q, torch.float32, "q"))
+    t = _unit_rows(_dev(t, torch.float32, "t"))
+    M, K = q.shape
+    N = t.shape[0]
+    if out is None:
+        out = padded_rows(M, N, q.device)
+    rc = lib.hw_gemm_rank(_ptr(q), q.stride(0), _ptr(t), t.stride(0), _ptr(bias), _ptr(out), out.stride(0), M, N, K, _stream())
+    if rc == -2:  # HW_ERR_UNSUPPORTED: operands the split loop does not take, or HW_GEMM_SPLIT=0
+        return gemm(q, t, bias=bias, out=out)
+    check(rc, "hw_gemm_rank")
+    return out
+
+
 def gemm_dist(q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRAC, out=None):
     """out[i, j] = base - ||q_i - t_j||: the product with the distance epilogue (hw_gemm_dist), one launch."""
     lib = _lib.load()

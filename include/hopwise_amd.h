@@ -188,6 +188,14 @@ int hw_rows_sqnorm(const float* x, int64_t ld, int64_t n_rows, int32_t k, float*
 int hw_kge_dist_finish(float* c, int64_t ldc, int64_t m, int64_t n, const float* q, int64_t ldq, const float* t,
                        int64_t ldt, int32_t k, const float* qn, const float* tn, float base, float rescore_frac,
                        int32_t mask_column0, int32_t* n_rescored, void* stream);
+/* c[i, j] = <q_i, t_j> + bias[j] (bias may be NULL) from the three largest of the six split terms (hi.hi, hi.mid, mid.hi):
+ * half the matrix work of hw_gemm_f32, |error| <= 1.2e-5 * sum_k |q_ik t_jk| per entry.  For candidate generation only -- the
+ * evaluation top-k of the distance scorers ranks by it and re-scores the candidates exactly (hw_topk_rerank, whose slack covers
+ * this bound; rotate.py:161-220, transe.py:112-154).  q [m, k] and t [n, k] row-major, 16-byte aligned rows (ld % 4 == 0);
+ * HW_ERR_UNSUPPORTED otherwise or with HW_GEMM_SPLIT=0. */
+int hw_gemm_rank(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc, int64_t m,
+                 int64_t n, int64_t k, void* stream);
+
 /* The product and the finish in ONE launch: c[i, j] = base - ||q_i - t_j|| for q [m, k], t [n, k] (K-contiguous rows), with the
  * same recomputation from the rows where the expansion cancels (the lane that owns the entry sums (q_k - t_k)^2 itself).  What
  * full_sort_predict / full_sort_predict_kg of the distance scorers run (transe.py:112-154, rotate.py:161-220). */

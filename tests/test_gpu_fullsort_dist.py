@@ -365,3 +365,38 @@ def test_edges_of_the_product_form():
         s = one.full_sort_predict(inter)
         one.gemm_full_sort = False
         np.testing.assert_allclose(s.cpu().numpy(), one.full_sort_predict(inter).view_as(s).cpu().numpy(), rtol=2e-5, atol=1e-6)
+
+
+def test_ranking_product_error_bound_and_the_topk_it_feeds():
+    """hw_gemm_rank (three split terms of six): every entry within 1.2e-5 sum |q_k t_k| of the float64 product -- the bound the
+    re-rank's proof is given -- and the evaluation top-k that ranks by it returns what the six-term path and the gather
+    kernel return."""
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(4)
+    for M, N, K in ((130, 1003, 400), (64, 4600, 128), (7, 300, 64)):
+        q = (rng.standard_normal((M, K)) * rng.uniform(0.1, 3.0, (M, 1))).astype(np.float32)
+        t = (rng.standard_normal((N, K)) * rng.uniform(0.1, 3.0, (N, 1))).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        got = ops.gemm_rank(torch.from_numpy(q).to(dev()), torch.from_numpy(t).to(dev()), torch.from_numpy(b).to(dev()))
+        want = q.astype(np.float64) @ t.astype(np.float64).T + b
+        bound = ops.RANK_PRODUCT_REL_ERR * (np.abs(q).astype(np.float64) @ np.abs(t).astype(np.float64).T)
+        err = np.abs(got.cpu().numpy() - want)
+        assert (err <= bound + 1e-6 * np.abs(want) + 1e-6).all(), float((err / (bound + 1e-12)).max())
+        assert err.max() > 1e-7 * np.abs(want).max()  # and it IS the cheaper product: not the six-term one
+    for model in ("RotatE", "TransE"):
+        dim, nU, nI, nE, nR, B, k = 64, 60, 4600, 5000, 6, 70, 10
+        tables = random_tables(model, nU, nE, nR, dim, seed=3)
+        m3 = build(model, tables, dim, nU, nI, nE, nR, gemm_min_scores=0)
+        m6 = build(model, tables, dim, nU, nI, nE, nR, gemm_min_scores=0, gemm_rank_terms=6)
+        assert m3.gemm_rank_terms == 3 and m6.gemm_rank_terms == 6
+        users = torch.from_numpy(rng.integers(0, nU, B)).to(dev())
+        hist = (torch.from_numpy(rng.integers(0, B, 60)).to(dev()), torch.from_numpy(rng.integers(0, nI, 60)).to(dev()))
+        with torch.no_grad():
+            v3, i3 = m3.full_sort_topk({"user_id": users}, k, hist)
+            v6, i6 = m6.full_sort_topk({"user_id": users}, k, hist)
+            m6.gemm_full_sort = False
+            vk, ik = m6.full_sort_topk({"user_id": users}, k, hist)
+        np.testing.assert_array_equal(i3.cpu().numpy(), i6.cpu().numpy())
+        np.testing.assert_array_equal(v3.cpu().numpy(), v6.cpu().numpy())
+        np.testing.assert_array_equal(i3.cpu().numpy(), ik.cpu().numpy())
