@@ -29,9 +29,13 @@ export HW_BENCH_LAUNCH_LOG=$OUT/launch_log_write.json
 $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.log 2>&1
 echo "write done" >> $OUT/progress.txt
 unset HW_BENCH_LAUNCH_LOG
+# the search's kernels one after another (HW_PGPR_OVERLAP=0): a lone search otherwise runs its action kernels beside the policy
+# launch, and a kernel's duration in the trace then includes what ran beside it (bench_pgpr's roofline.kernel_ms is the lone launch)
+export HW_PGPR_OVERLAP=0
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pgpr_trace -- python3 $ROOT/bench_pgpr.py --users 256 --steps 10 > $OUT/pgpr_trace.log 2>&1
 $T rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pgpr_fetch -- python3 $ROOT/bench_pgpr.py --users 256 --steps 3 > $OUT/pgpr_fetch.log 2>&1
 $T rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pgpr_write -- python3 $ROOT/bench_pgpr.py --users 256 --steps 3 > $OUT/pgpr_write.log 2>&1
+unset HW_PGPR_OVERLAP
 echo "pgpr done" >> $OUT/progress.txt
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tucker_trace -- python3 $ROOT/tools/bench_tucker.py --reps 10 > $OUT/tucker_trace.log 2>&1
 $T rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/tucker_mfma -- python3 $ROOT/tools/bench_tucker.py --reps 2 > $OUT/tucker_mfma.log 2>&1
