@@ -118,3 +118,57 @@ def test_more_forms_than_kept_captures_drop_the_oldest():
         l2.append(float(step({graphed.USER_ID: u})))
     assert len(step.captures) == 2 and step.n_captured > 2 and step.n_eager == 0
     np.testing.assert_allclose(l2, l1, rtol=2e-5)
+
+
+def test_graphed_trainer_mixin_on_cafe_takes_the_loaders_host_batches():
+    """driver.graphed_trainer(<a Trainer>) with CAFE: the epoch loop hands the staged step the loader's HOST batch (the path sampler
+    wants the ids there), the device half replays per metapath, the epoch ends with the plain loop's loss and parameters."""
+    from hopwise_amd.driver import GraphedStagedTrainStep, graphed_trainer
+    from hopwise_amd.optim import FusedAdam
+
+    z, plain_m, graph_m = _pair()
+
+    class Batch(dict):
+        moved = 0
+
+        def to(self, device):
+            Batch.moved += 1
+            return Batch({k: v.to(device) for k, v in self.items()})
+
+    epoch = [Batch({plain_m.USER_ID: u.cpu()}) for u in _batches(z, 10)]
+
+    class Base:
+        def __init__(self, config, model):
+            self.config, self.model, self.device, self.clip_grad_norm = config, model, dev(), None
+            self.optimizer = FusedAdam(model.parameters(), lr=config["learning_rate"])
+
+        def _check_nan(self, loss):
+            if torch.isnan(loss):
+                raise ValueError("Training loss is nan")
+
+        def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+            self.model.train()
+            total = 0.0
+            for inter in train_data:
+                inter = inter.to(self.device)
+                self.optimizer.zero_grad()
+                losses = (loss_func or self.model.calculate_loss)(inter)
+                loss = sum(losses)  # the trainer sums the (reg, rank) tuple (trainer.py:245-249)
+                total += loss.item()
+                self._check_nan(loss)
+                loss.backward()
+                self.optimizer.step()
+            return total
+
+    cfg = {"learning_rate": 2e-3, "learner": "adam", "single_spec": True}
+    plain, graphed = Base(cfg, plain_m), graphed_trainer(Base)(cfg, graph_m)
+    for ep in range(2):
+        lp = plain._train_epoch(epoch, ep)
+        moved = Batch.moved
+        lg = graphed._train_epoch(epoch, ep)
+        assert Batch.moved == moved  # the replayed loop left the batches on the host
+        np.testing.assert_allclose(lg, lp, rtol=2e-5)
+    step = graphed._graph_step
+    assert isinstance(step, GraphedStagedTrainStep) and step.n_replayed == 20 and step.n_captured == len(step.captures)
+    for (k, a), (_, c) in zip(plain_m.state_dict().items(), graph_m.state_dict().items()):
+        np.testing.assert_allclose(c.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
