@@ -236,7 +236,17 @@ SIGNATURES = {
     ),
     "hw_gemm_rank": (
         C.c_int,
-        [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p],
+        [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+         c_f32p, C.c_int64, C.c_void_p],
+    ),
+    "hw_mask_bits_words": (C.c_int64, [C.c_int64]),
+    "hw_mask_bits": (
+        C.c_int,
+        [c_i64p, c_i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
+    "hw_topk_from_tile_max": (
+        C.c_int,
+        [c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int32, c_f32p, c_i64p, c_i32p, C.c_void_p],
     ),
     "hw_gemm_dist": (
         C.c_int,

@@ -221,6 +221,14 @@ struct GemmBce {
     const uint8_t* flag;
     float scale, add, inv_numel;
     float* loss_partial;
+    // ACT == 5 (ranking product, hw_gemm_rank), both optional:
+    //   rank_mask      bit (row, col) set = the entry leaves as -inf (a user's history): [rows, rank_mask_ld] 32-bit words
+    //   rank_tile_max  the maximum of every 64-column stretch of every (masked) row: [rows, rank_tile_ld] floats -- what
+    //                  hw_topk_from_tile_max needs to find a row's best columns while reading a few of its stretches only
+    const uint32_t* rank_mask;
+    int64_t rank_mask_ld;
+    float* rank_tile_max;
+    int64_t rank_tile_ld;
 };
 
 // Epilogue: one wave's 32-row x 64-column slab (accumulator tiles [ti][0], [ti][1]) leaves through a wave-private 8 KB LDS
@@ -608,6 +616,70 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
 #pragma unroll
                     for (int rg = 0; rg < 16; ++rg) {
                         const int gm = gm0 + (rg & 3) + 8 * (rg >> 2);
+                        if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v[tj][rg];
+                    }
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (ACT == 5) {
+        // ranking product: + bias, the history mask and the per-stretch maxima on the way out.  A wave's slab is 32 rows x 64
+        // columns = exactly one 64-column stretch of 32 rows (n0 + wn is a multiple of 64), its two 32-column halves one mask
+        // word each: lane l of the wave fetches the word of (row l >> 1, half l & 1) -- one load for the slab -- and every lane
+        // picks its rows' words out of the wave with readlane.
+        const bool interior = m0 + BM <= M && n0 + BN <= N;
+        const bool via_lds = interior && (pipe & 2);
+        float* const slab = lds + wave * 2048;  // every loop ended with a barrier: no wave still reads the tiles
+        const int g5 = lane >> 5;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int gm0 = m0 + wm + ti * 32;
+            uint32_t mword = 0u;
+            if (bce.rank_mask) {
+                const int mr = gm0 + (lane >> 1);
+                const int64_t wcol = ((int64_t)(n0 + wn) >> 5) + (lane & 1);
+                if (mr < M && wcol < bce.rank_mask_ld) mword = bce.rank_mask[(size_t)mr * bce.rank_mask_ld + wcol];
+            }
+            float v[2][16];
+            float rmax[16];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) rmax[rg] = -INFINITY;
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj) {
+                const int gn = n0 + wn + tj * 32 + (lane & 31);
+                const float bv = (bias && gn < N) ? bias[gn] : 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int r0 = (rg & 3) + 8 * (rg >> 2);  // the row of the lanes with g5 == 0; g5 == 1: r0 + 4
+                    const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)mword, 2 * r0 + tj);
+                    const uint32_t wb = (uint32_t)__builtin_amdgcn_readlane((int)mword, 2 * (r0 + 4) + tj);
+                    const uint32_t wsel = g5 ? wb : wa;
+                    float x = acc[ti][tj][rg] + bv;
+                    if ((wsel >> (lane & 31)) & 1u) x = -INFINITY;
+                    v[tj][rg] = x;
+                    rmax[rg] = fmaxf(rmax[rg], gn < N ? x : -INFINITY);
+                }
+            }
+            if (bce.rank_tile_max && n0 + wn < N) {  // a stretch that starts inside the row
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {  // max over the 32 lanes that hold the row's 64 columns
+                    float mx = rmax[rg];
+#pragma unroll
+                    for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                    const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
+                    if ((lane & 31) == 0 && gm < M) bce.rank_tile_max[(size_t)gm * bce.rank_tile_ld + ((n0 + wn) >> 6)] = mx;
+                }
+            }
+            if (via_lds) {
+                store_slab_via_lds(slab, v, C + (size_t)gm0 * ldc + n0 + wn, ldc, lane);
+            } else {
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) {
+                    const int gn = n0 + wn + tj * 32 + (lane & 31);
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
                         if (gm < M && gn < N) C[(size_t)gm * ldc + gn] = v[tj][rg];
                     }
                 }
@@ -1362,14 +1434,18 @@ extern "C" int hw_gemm_f32(const float* a, int64_t lda, int32_t a_k_contiguous, 
 // c[i, j] = <q_i, t_j> + bias[j] to ~2^-16 relative accuracy per product (three of the six split terms: half the matrix
 // work): candidate generation for a consumer that re-scores exactly (hw_topk_rerank).  |error| <= 1.2e-5 sum_k |q_ik t_jk|.
 extern "C" int hw_gemm_rank(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc,
-                            int64_t m, int64_t n, int64_t k, void* stream) {
+                            int64_t m, int64_t n, int64_t k, const uint32_t* mask_bits, int64_t mask_ld, float* tile_max,
+                            int64_t tile_ld, void* stream) {
     if (!q || !t || !c || m < 0 || n < 1 || k < 4 || ldc < n || ldq < k || ldt < k) return HW_ERR_INVALID_ARG;
     if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if ((mask_bits && mask_ld < (n + 31) / 32) || (tile_max && tile_ld < (n + 63) / 64)) return HW_ERR_INVALID_ARG;
     if (!aligned16(q, ldq) || !aligned16(t, ldt)) return HW_ERR_UNSUPPORTED;  // the split loop's operands
     if (m == 0) return HW_OK;
     HW_CLEAR_ERR();
+    GemmBce rk{};
+    rk.rank_mask = mask_bits, rk.rank_mask_ld = mask_ld, rk.rank_tile_max = tile_max, rk.rank_tile_ld = tile_ld;
     const int rc = launch_gemm(q, ldq, true, t, ldt, true, c, ldc, nullptr, m, n, k, bias, 5, nullptr, 0, 0, 0, nullptr, 0,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, rk);
     if (rc != HW_OK) return rc;
     return HW_LAUNCH_RC();
 }

@@ -28,6 +28,14 @@ using namespace hw;
 
 namespace {
 
+// hw_topk_rows' key: (orderable image of the value) << 32 | ~column -- unique per column
+__device__ __forceinline__ uint64_t topk_key_u(float v, uint32_t idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((uint64_t)u << 32) | (uint32_t)(~idx);
+}
+
+
 template <int MODEL, int G, int NE, bool VEC>
 __global__ __launch_bounds__(256) void kge_query_rows_kernel(hw_kge_desc d, const int64_t* __restrict__ h_idx,
                                                              const int64_t* __restrict__ r_idx, int64_t r_fixed,
@@ -251,6 +259,121 @@ __global__ __launch_bounds__(256) void topk_rerank_kernel(const int64_t* __restr
     if (!ok && lane == 0) atomicOr(unverified, 1);
 }
 
+
+// ---- evaluation top-k from per-stretch maxima ----------------------------------------------------------------------------------
+// The ranking product (hw_gemm_rank) leaves, next to the masked score matrix, the maximum of every 64-column stretch of every row.
+// The k-th largest stretch maximum of a row, T, is a lower bound of the row's k-th largest score (k stretches hold a score >= T),
+// so the row's k best columns all lie in the stretches whose maximum is >= T -- k of them plus ties.  One wave per row: T by a
+// bitwise search over the images of the <= 16 maxima a lane holds (ballot counts, no cross-lane reduction), the qualifying
+// stretches' 64 scores each, the scores >= T into a list in LDS, the k largest keys of the list in order.  A row of 45 539 columns
+// is found from 712 maxima + ~16 x 256 bytes instead of its 182 KB (the two-stage top-k reads the whole matrix: 0.13-0.16 ms for
+// 2 048 such rows).  Keys, order and the exhausted-row convention are hw_topk_rows' (value desc, column asc; -inf / -1).  Rows
+// whose qualifying stretches or candidates outgrow the LDS lists (many equal scores) raise `overflow` instead of answering.
+constexpr int TM_MAX_PER_LANE = 16;   // stretches per lane: n_cols <= 64 * 64 * 16 = 65 536
+constexpr int TM_QUAL = 128;          // qualifying stretches kept per row
+constexpr int TM_LIST = 512;          // candidate keys kept per row
+
+__device__ __forceinline__ uint32_t tm_image(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void topk_tile_max_kernel(const float* __restrict__ s, int64_t ld, int64_t n_rows,
+                                                            int64_t n_cols, const float* __restrict__ tile_max,
+                                                            int64_t tile_ld, int k, float* __restrict__ out_val,
+                                                            int64_t* __restrict__ out_idx, int32_t* __restrict__ overflow) {
+    __shared__ uint64_t list[4][TM_LIST];
+    __shared__ int qual[4][TM_QUAL];
+    const int lane = threadIdx.x & 63, w = wave_in_block();
+    const int64_t row = (int64_t)blockIdx.x * 4 + w;
+    if (row >= n_rows) return;  // no block-wide barrier below
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const int n_tiles = (int)((n_cols + 63) / 64);
+    const float* __restrict__ tm = tile_max + row * tile_ld;
+    uint32_t img[TM_MAX_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < TM_MAX_PER_LANE; ++i) {  // stretch t = 64 i + lane; 0 = no such stretch (a real image is never 0)
+        const int t = 64 * i + lane;
+        img[i] = t < n_tiles ? tm_image(tm[t < n_tiles ? t : 0]) : 0u;
+    }
+    // T = the k-th largest image, counted with multiplicity (0 when the row has fewer than k stretches)
+    uint32_t T = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t c = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < TM_MAX_PER_LANE; ++i) cnt += __popcll(__ballot(img[i] >= c));
+        if (cnt >= k) T = c;  // wave-uniform
+    }
+    // the qualifying stretches, in stretch order
+    int n_qual = 0;
+#pragma unroll
+    for (int i = 0; i < TM_MAX_PER_LANE; ++i) {
+        const bool q = img[i] != 0u && img[i] >= T;
+        const unsigned long long b = __ballot(q);
+        const int pos = n_qual + __popcll(b & lt_mask);
+        if (q && pos < TM_QUAL) qual[w][pos] = 64 * i + lane;
+        n_qual += __popcll(b);
+    }
+    bool over = n_qual > TM_QUAL;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const float* __restrict__ srow = s + row * ld;
+    int n_list = 0;
+    const int nq = over ? 0 : n_qual;
+    for (int q = 0; q < nq; ++q) {  // wave-uniform trips
+        const int64_t col = (int64_t)qual[w][q] * 64 + lane;
+        const bool in = col < n_cols;
+        const float x = in ? srow[col] : -INFINITY;
+        const bool pass = in && tm_image(x) >= T;
+        const unsigned long long b = __ballot(pass);
+        const int pos = n_list + __popcll(b & lt_mask);
+        if (pass && pos < TM_LIST) list[w][pos] = topk_key_u(x, (uint32_t)col);
+        n_list += __popcll(b);
+    }
+    over = over || n_list > TM_LIST;
+    if (over) {  // no answer for this row: the flag says so, the outputs stay harmless (column 0, -inf)
+        if (lane == 0) atomicOr(overflow, 1);
+        for (int r = lane; r < k; r += 64) out_val[row * k + r] = -INFINITY, out_idx[row * k + r] = 0;
+        return;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint64_t bound = ~0ull;
+    for (int round = 0; round < k; ++round) {
+        uint64_t best = 0;
+        for (int j = lane; j < n_list; j += 64) {
+            const uint64_t x = list[w][j];
+            best = (x < bound && x > best) ? x : best;
+        }
+        best = wave_max_u64(best);
+        if (lane == 0) {
+            const int64_t o = row * k + round;
+            if (best == 0) {
+                out_val[o] = -INFINITY;
+                out_idx[o] = -1;
+            } else {
+                const uint32_t idx = ~(uint32_t)(best & 0xffffffffu);
+                out_val[o] = srow[idx];
+                out_idx[o] = idx;
+            }
+        }
+        bound = best;
+    }
+}
+
+// history pairs -> the bit matrix hw_gemm_rank masks with: bit (row, col) of a zeroed [n_rows, words] array of 32-bit words
+__global__ __launch_bounds__(256) void mask_bits_kernel(const int64_t* __restrict__ hr, const int64_t* __restrict__ hc,
+                                                        int64_t n_hist, int64_t n_rows, int64_t n_cols, int64_t words,
+                                                        int mask_column0, uint32_t* __restrict__ bits) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (mask_column0 && i < n_rows) atomicOr(bits + i * words, 1u);
+    if (i < n_hist) {
+        const int64_t r = hr[i], c = hc[i];
+        if (r >= 0 && r < n_rows && c >= 0 && c < n_cols) atomicOr(bits + r * words + (c >> 5), 1u << (c & 31));
+    }
+}
+
 }  // namespace
 
 #define HW_QUERY_MODELS(model, shape, CALL)                                                 \
@@ -354,5 +477,39 @@ extern "C" int hw_topk_rerank(const int64_t* cand_idx, const float* cand_approx,
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(topk_rerank_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, cand_idx, cand_approx,
                        cand_exact, m, (int)c, (int)k, rel_slack, abs_slack, qn, base, tn_max, out_val, out_idx, unverified);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int64_t hw_mask_bits_words(int64_t n_cols) { return n_cols < 1 ? 0 : (n_cols + 31) / 32; }
+
+extern "C" int hw_mask_bits(const int64_t* hist_rows, const int64_t* hist_cols, int64_t n_hist, int64_t n_rows, int64_t n_cols,
+                            int32_t mask_column0, uint32_t* bits, int64_t words_per_row, void* stream) {
+    if (!bits || n_rows < 0 || n_cols < 1 || words_per_row < (n_cols + 31) / 32 || n_hist < 0 ||
+        (n_hist > 0 && (!hist_rows || !hist_cols)))
+        return HW_ERR_INVALID_ARG;
+    if (n_rows == 0) return HW_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (hw::fill_bytes_async(bits, 0, sizeof(uint32_t) * (size_t)(n_rows * words_per_row), st) != hipSuccess) return HW_ERR_LAUNCH;
+    const int64_t n = (mask_column0 && n_rows > n_hist) ? n_rows : n_hist;
+    if (n == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(mask_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hist_rows, hist_cols, n_hist, n_rows,
+                       n_cols, words_per_row, (int)(mask_column0 != 0), bits);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_topk_from_tile_max(const float* scores, int64_t ld, int64_t n_rows, int64_t n_cols, const float* tile_max,
+                                     int64_t tile_ld, int32_t k, float* out_val, int64_t* out_idx, int32_t* overflow,
+                                     void* stream) {
+    if (!scores || !tile_max || !out_val || !out_idx || !overflow || n_rows < 0 || n_cols < 1 || ld < n_cols || k < 1 || k > 64 ||
+        tile_ld < (n_cols + 63) / 64)
+        return HW_ERR_INVALID_ARG;
+    if (n_cols > (int64_t)64 * 64 * TM_MAX_PER_LANE) return HW_ERR_UNSUPPORTED;
+    if (n_rows == 0) return HW_OK;
+    const int64_t n_blocks = (n_rows + 3) / 4;
+    if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(topk_tile_max_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, scores, ld, n_rows, n_cols,
+                       tile_max, tile_ld, (int)k, out_val, out_idx, overflow);
     return HW_LAUNCH_RC();
 }

@@ -334,15 +334,28 @@ class _GatherKGE(KnowledgeRecommender):
                 # its six split terms (hw_gemm_rank: half the matrix work).  Its error bound, 1.2e-5 sum |q_k t_k| <= 0.6e-5
                 # (||q||^2 + ||t||^2), doubles in d^2 = ||q||^2 - 2 p: the re-rank's proof carries 2e-5 (||q||^2 + max ||t||^2)
                 # for it (1e-5 with the six-term product, whose own error is ~1e-7)
+                # The history mask and the maximum of every 64-column stretch leave the product's epilogue with the scores: the
+                # candidates are then found from the maxima and the few stretches that can hold them (hw_topk_from_tile_max)
+                # instead of by a pass over the whole [B, N] matrix.
                 lite = self.gemm_rank_terms == 3
                 table = self._cat_tables(tail)[:n]
-                p = ops.gemm_rank(q, table, bias[:n], out=buf) if lite else ops.gemm(q, table, bias=bias[:n], out=buf)
-                ops.mask_scores_(p, history_index)
-                approx, cand = ops.topk_rows(p, c)
+                p = flag = None
+                if lite and 128 * c <= n <= 65536:  # at least 2 c stretches: the k-th largest stretch maximum means something
+                    bits = ops.mask_bits(history_index, q.shape[0], n, device=q.device)  # column 0 and the history pairs
+                    tmax = torch.empty((q.shape[0], (n + 63) // 64), dtype=torch.float32, device=q.device)
+                    p = ops.gemm_rank(q, table, bias[:n], out=buf, mask=bits, tile_max=tmax)
+                    if p is not None:
+                        approx, cand, flag = ops.topk_from_tile_max(p, tmax, c)
+                if p is None:  # six terms asked for, a very wide table, or operands the split loop does not take
+                    lite = False
+                    p = ops.gemm(q, table, bias=bias[:n], out=buf)
+                    ops.mask_scores_(p, history_index)
+                    approx, cand = ops.topk_rows(p, c)
                 desc = ops.make_desc(self.MODEL, head, rel, tail, self.margin, 0.0, n)
                 exact = ops.kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, cand)  # c <= n: every candidate is a column
-                val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=2e-5 if lite else 1e-5, abs_slack=1e-6, qn=qn,
-                                                 base=self.margin if self.MODEL == "RotatE" else 0.0, tn_max=tn_max)
+                val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=2e-5 if lite else 1e-5, abs_slack=1e-6,
+                                                 unverified=flag, qn=qn, base=self.margin if self.MODEL == "RotatE" else 0.0,
+                                                 tn_max=tn_max)
                 return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, 0, n, k, history_index,
                                               True, self.margin, run_if=flag, out=(val, idx))
             # the product + mask + top-k on the written matrix beats the fused gather kernel (the matrix is written and

@@ -621,9 +621,28 @@ def kge_dist_finish_(dots, q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRA
 RANK_PRODUCT_REL_ERR = 1.2e-5  # hw_gemm_rank: |error| <= this x sum_k |q_k t_k| (three split terms of six)
 
 
-def gemm_rank(q, t, bias=None, out=None):
+def mask_bits(history_index, n_rows, n_cols, column0=True, device=None):
+    """What ``mask_scores_`` would set to -inf -- column 0 (the [PAD] item) and the evaluation's history pairs -- as the bit
+    matrix ``gemm_rank`` masks with: int32 [n_rows, words] (``hw_mask_bits``)."""
+    lib = _lib.load()
+    hr = hc = None
+    n_hist = 0
+    if history_index is not None:
+        hr, hc = (_idx(x, "history_index").contiguous() for x in history_index)
+        n_hist = hr.numel()
+        device = hr.device
+    words = int(lib.hw_mask_bits_words(int(n_cols)))
+    bits = torch.empty((int(n_rows), words), dtype=torch.int32, device=device)
+    check(lib.hw_mask_bits(_ptr(hr), _ptr(hc), n_hist, int(n_rows), int(n_cols), int(bool(column0)), _ptr(bits), words,
+                           _stream()), "hw_mask_bits")
+    return bits
+
+
+def gemm_rank(q, t, bias=None, out=None, mask=None, tile_max=None):
     """out[M, N] = q @ t^T + bias from the three largest split terms (``hw_gemm_rank``): a ranking product for callers that
-    re-score their candidates exactly.  Falls back to the six-term product where the split loop does not apply."""
+    re-score their candidates exactly.  ``mask`` (``mask_bits``): those entries leave as -inf; ``tile_max`` [M, ceil(N / 64)]
+    receives every 64-column stretch's maximum (for ``topk_from_tile_max``).  Returns None when the split loop does not apply
+    to the operands (the caller takes its six-term route)."""
     lib = _lib.load()
     q = _unit_rows(_dev(q, torch.float32, "q"))
     t = _unit_rows(_dev(t, torch.float32, "t"))
@@ -631,11 +650,28 @@ def gemm_rank(q, t, bias=None, out=None):
     N = t.shape[0]
     if out is None:
         out = padded_rows(M, N, q.device)
-    rc = lib.hw_gemm_rank(_ptr(q), q.stride(0), _ptr(t), t.stride(0), _ptr(bias), _ptr(out), out.stride(0), M, N, K, _stream())
+    rc = lib.hw_gemm_rank(_ptr(q), q.stride(0), _ptr(t), t.stride(0), _ptr(bias), _ptr(out), out.stride(0), M, N, K,
+                          _ptr(mask), 0 if mask is None else mask.stride(0), _ptr(tile_max),
+                          0 if tile_max is None else tile_max.stride(0), _stream())
     if rc == -2:  # HW_ERR_UNSUPPORTED: operands the split loop does not take, or HW_GEMM_SPLIT=0
-        return gemm(q, t, bias=bias, out=out)
+        return None
     check(rc, "hw_gemm_rank")
     return out
+
+
+def topk_from_tile_max(scores, tile_max, k, overflow=None):
+    """(values [R, k], columns [R, k], overflow int32 [1]) = topk_rows(scores, k) answered from the 64-column stretch maxima
+    ``gemm_rank`` left (``hw_topk_from_tile_max``); ``overflow`` != 0: some row could not be answered (the caller falls back)."""
+    lib = _lib.load()
+    scores = _unit_rows(_dev(scores, torch.float32, "scores"))
+    R, N = scores.shape
+    val = torch.empty((R, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((R, k), dtype=torch.int64, device=scores.device)
+    if overflow is None:
+        overflow = torch.zeros(1, dtype=torch.int32, device=scores.device)
+    check(lib.hw_topk_from_tile_max(_ptr(scores), scores.stride(0), R, N, _ptr(tile_max), tile_max.stride(0), int(k), _ptr(val),
+                                    _ptr(idx), _ptr(overflow), _stream()), "hw_topk_from_tile_max")
+    return val, idx, overflow
 
 
 def gemm_dist(q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRAC, out=None):

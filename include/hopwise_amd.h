@@ -192,9 +192,26 @@ int hw_kge_dist_finish(float* c, int64_t ldc, int64_t m, int64_t n, const float*
  * half the matrix work of hw_gemm_f32, |error| <= 1.2e-5 * sum_k |q_ik t_jk| per entry.  For candidate generation only -- the
  * evaluation top-k of the distance scorers ranks by it and re-scores the candidates exactly (hw_topk_rerank, whose slack covers
  * this bound; rotate.py:161-220, transe.py:112-154).  q [m, k] and t [n, k] row-major, 16-byte aligned rows (ld % 4 == 0);
- * HW_ERR_UNSUPPORTED otherwise or with HW_GEMM_SPLIT=0. */
+ * HW_ERR_UNSUPPORTED otherwise or with HW_GEMM_SPLIT=0.  Optional, on the way out of the product's epilogue:
+ *   mask_bits [m, mask_ld] 32-bit words (hw_mask_bits): entry (i, j) leaves as -inf where bit j of row i is set -- the
+ *             evaluation's history mask (trainer.py:731-734) without a pass of its own;
+ *   tile_max  [m, tile_ld] floats: the maximum of every 64-column stretch of every (masked) row, for hw_topk_from_tile_max. */
 int hw_gemm_rank(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc, int64_t m,
-                 int64_t n, int64_t k, void* stream);
+                 int64_t n, int64_t k, const uint32_t* mask_bits, int64_t mask_ld, float* tile_max, int64_t tile_ld,
+                 void* stream);
+/* History pairs -> the bit matrix hw_gemm_rank masks with: bits [n_rows, words_per_row] (words_per_row >= hw_mask_bits_words(n_cols))
+ * is zeroed, then bit (hist_rows[i], hist_cols[i]) set for every pair inside the matrix (and column 0 of every row with
+ * mask_column0: the [PAD] item, trainer.py:731). */
+int64_t hw_mask_bits_words(int64_t n_cols);
+int hw_mask_bits(const int64_t* hist_rows, const int64_t* hist_cols, int64_t n_hist, int64_t n_rows, int64_t n_cols,
+                 int32_t mask_column0, uint32_t* bits, int64_t words_per_row, void* stream);
+/* hw_topk_rows (same order, values and exhausted-row convention) of a score matrix whose 64-column stretch maxima are known
+ * (hw_gemm_rank's tile_max): a row is answered from its maxima and the few stretches that can hold one of its k best columns
+ * instead of from all its columns.  k <= 64, n_cols <= 65 536 (else HW_ERR_UNSUPPORTED).  Rows with so many equal scores that
+ * the qualifying stretches / candidates outgrow the kernel's lists set *overflow (an int32 the caller zeroed) and leave
+ * (-inf, column 0) behind: the caller falls back (hw_kge_full_sort_topk_if takes the flag as its predicate). */
+int hw_topk_from_tile_max(const float* scores, int64_t ld, int64_t n_rows, int64_t n_cols, const float* tile_max, int64_t tile_ld,
+                          int32_t k, float* out_val, int64_t* out_idx, int32_t* overflow, void* stream);
 
 /* The product and the finish in ONE launch: c[i, j] = base - ||q_i - t_j|| for q [m, k], t [n, k] (K-contiguous rows), with the
  * same recomputation from the rows where the expansion cancels (the lane that owns the entry sums (q_k - t_k)^2 itself).  What

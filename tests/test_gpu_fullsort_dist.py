@@ -400,3 +400,50 @@ def test_ranking_product_error_bound_and_the_topk_it_feeds():
         np.testing.assert_array_equal(i3.cpu().numpy(), i6.cpu().numpy())
         np.testing.assert_array_equal(v3.cpu().numpy(), v6.cpu().numpy())
         np.testing.assert_array_equal(i3.cpu().numpy(), ik.cpu().numpy())
+
+
+def test_mask_bits_tile_maxima_and_the_topk_from_them():
+    """hw_gemm_rank with its two by-products -- the history mask applied in the epilogue, the maximum of every 64-column stretch --
+    and hw_topk_from_tile_max: the top-k of the masked matrix, bit for bit what mask + hw_topk_rows give on the same matrix (ties,
+    -inf rows, ragged widths), and the overflow flag where a row's equal scores outgrow the kernel's lists."""
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(9)
+    for M, N, K, k in ((130, 4600, 64, 16), (300, 45539, 32, 16), (33, 9000, 128, 24), (64, 8191, 16, 64), (5, 2048, 8, 10)):
+        q = rng.standard_normal((M, K)).astype(np.float32)
+        t = rng.standard_normal((N, K)).astype(np.float32)
+        t[N // 3] = t[N // 3 + 7]  # equal scores in every row: the tie goes to the smaller column
+        b = rng.standard_normal(N).astype(np.float32)
+        b[N // 3] = b[N // 3 + 7]
+        qd, td, bd = (torch.from_numpy(x).to(dev()) for x in (q, t, b))
+        hr = torch.from_numpy(rng.integers(0, M, 5 * M)).to(dev())
+        hc = torch.from_numpy(rng.integers(0, N, 5 * M)).to(dev())
+        keep0 = rng.choice(N, 400, replace=False)  # row 0: everything masked but 400 columns (in more than k stretches)
+        gone = np.setdiff1d(np.arange(N), keep0)
+        hr = torch.cat([hr, torch.zeros(len(gone), dtype=torch.int64, device=dev())])
+        hc = torch.cat([hc, torch.from_numpy(gone).to(dev())])
+        bits = ops.mask_bits((hr, hc), M, N)
+        tmax = torch.full((M, (N + 63) // 64), 123.0, device=dev())
+        p = ops.gemm_rank(qd, td, bd, mask=bits, tile_max=tmax)
+        plain = ops.gemm_rank(qd, td, bd).clone()
+        ops.mask_scores_(plain, (hr, hc))
+        np.testing.assert_array_equal(p.cpu().numpy(), plain.cpu().numpy())
+        pn = p.cpu().numpy()
+        want_max = np.stack([pn[:, 64 * j : 64 * j + 64].max(1) for j in range((N + 63) // 64)], 1)
+        np.testing.assert_array_equal(tmax.cpu().numpy(), want_max)
+        v, i, over = ops.topk_from_tile_max(p, tmax, k)
+        rv, ri = ops.topk_rows(p.contiguous(), k)
+        assert int(over.item()) == 0
+        np.testing.assert_array_equal(i.cpu().numpy(), ri.cpu().numpy())
+        np.testing.assert_array_equal(v.cpu().numpy(), rv.cpu().numpy())
+    # a row of equal scores (a user whose every item is masked: all -inf): more candidates than the kernel's lists hold -> the
+    # flag, harmless outputs
+    same = torch.full((3, 8192), -float("inf"), device=dev())
+    same[2] = 0.0
+    same[1] = torch.from_numpy(rng.standard_normal(8192).astype(np.float32)).to(dev())
+    tm = same.view(3, 128, 64).max(2).values.contiguous()
+    v, i, over = ops.topk_from_tile_max(same, tm, 16)
+    assert int(over.item()) == 1
+    rv, ri = ops.topk_rows(same, 16)
+    np.testing.assert_array_equal(i[1].cpu().numpy(), ri[1].cpu().numpy())  # the other rows are answered
+    assert int(i[0].min()) >= 0 and int(i[0].max()) < 8192
