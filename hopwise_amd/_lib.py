@@ -239,6 +239,13 @@ SIGNATURES = {
         [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
          c_f32p, C.c_int64, C.c_void_p],
     ),
+    "hw_rank_planes_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "hw_rank_planes": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "hw_gemm_rank_planes": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_void_p, C.c_int64, c_f32p,
+         C.c_int64, C.c_void_p],
+    ),
     "hw_mask_bits_words": (C.c_int64, [C.c_int64]),
     "hw_mask_bits": (
         C.c_int,

@@ -163,7 +163,7 @@ __device__ __forceinline__ int split_off(int r, int half) { return r * 32 + ((ha
 
 // registers of fetch_tile<KC> -> the three plane images of one operand.  KC: rows f >> 2, four consecutive k at (f & 3) * 4;
 // k-major: k = f >> 5, four consecutive rows at (f & 31) * 4.  FULL: the whole k-tile lies below K (no zeroing).
-template <bool KC, bool FULL>
+template <bool KC, bool FULL, bool TWO_PLANES = false>
 __device__ __forceinline__ void put_piece_split(const f32x4& v, int i, int K, int k0, uint8_t* __restrict__ img) {
     const int tid = threadIdx.x;
     constexpr int PLANE = SplitImg<KC>::PLANE;
@@ -186,7 +186,8 @@ __device__ __forceinline__ void put_piece_split(const f32x4& v, int i, int K, in
     split_pair(x2, x3, h1, m1, l1);
     *reinterpret_cast<uint2*>(dst) = uint2{h0, h1};
     *reinterpret_cast<uint2*>(dst + PLANE) = uint2{m0, m1};
-    *reinterpret_cast<uint2*>(dst + 2 * PLANE) = uint2{l0, l1};
+    // the ranking product never reads the lo plane (the compiler drops the second residual with the store)
+    if constexpr (!TWO_PLANES) *reinterpret_cast<uint2*>(dst + 2 * PLANE) = uint2{l0, l1};
 }
 
 template <bool KC, bool FULL>
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
 #ifdef GEMM_ABL_NO_PUT
 #define HW_PIECE(KC_, V_, I_, OFF_) asm volatile("" ::"v"(V_), "v"(An));
 #else
-#define HW_PIECE(KC_, V_, I_, OFF_) put_piece_split<KC_, FULL>(V_, I_, k_end, k0 + BK, An + OFF_);
+#define HW_PIECE(KC_, V_, I_, OFF_) put_piece_split<KC_, FULL, ACT == 5>(V_, I_, k_end, k0 + BK, An + OFF_);
 #endif
             if constexpr (LITE) {
                 HW_SPLIT_TERM(1, 0)

@@ -90,6 +90,7 @@ class _GatherKGE(KnowledgeRecommender):
         self.gemm_rerank = (self.GEMM_FORM == "distance") if rr is None else str(rr).lower() not in ("0", "false")
         self.gemm_min_scores = int(_cfg(config, "gemm_min_scores", os.environ.get("HW_FULLSORT_GEMM_MIN", self.GEMM_MIN_SCORES)))
         # split terms of the evaluation top-k's ranking product (distance scorers, with the exact re-rank): 3 (hw_gemm_rank) or 6
+        self.gemm_rank_planes = str(_cfg(config, "gemm_rank_planes", os.environ.get("HW_FULLSORT_RANK_PLANES", "1"))).lower() not in ("0", "false")
         self.gemm_rank_terms = 6 if str(_cfg(config, "gemm_rank_terms", os.environ.get("HW_FULLSORT_RANK_TERMS", "3"))) == "6" else 3
         self.apply(xavier_normal_initialization)
 
@@ -251,6 +252,14 @@ class _GatherKGE(KnowledgeRecommender):
         slot = ("sqnorm",) + tuple(t.data_ptr() for t in tail)
         return self._table_cache(slot).get(tuple(t._version for t in tail), lambda: ops.rows_sqnorm(self._cat_tables(tail)))
 
+    RANK_PLANES_MIN_K = 128  # from this inner width on the plane-image product beats the one that splits on the fly
+
+    def _rank_planes(self, tail, n):
+        """The first ``n`` candidate rows as (hi, mid) bf16 plane images for the ranking product (ops.rank_planes), cached per
+        table version: an evaluation epoch scores every batch against the same table."""
+        slot = ("rankplanes", n) + tuple(t.data_ptr() for t in tail)
+        return self._table_cache(slot).get(tuple(t._version for t in tail), lambda: ops.rank_planes(self._cat_tables(tail)[:n]))
+
     def _rank_bias(self, tail):
         """(-||t||^2 / 2 per candidate row, max ||t||^2): the per-column bias that turns the product into the distance form's
         ranking value, and the bound the re-rank's proof needs; cached per table version."""
@@ -343,7 +352,12 @@ class _GatherKGE(KnowledgeRecommender):
                 if lite and 128 * c <= n <= 65536:  # at least 2 c stretches: the k-th largest stretch maximum means something
                     bits = ops.mask_bits(history_index, q.shape[0], n, device=q.device)  # column 0 and the history pairs
                     tmax = torch.empty((q.shape[0], (n + 63) // 64), dtype=torch.float32, device=q.device)
-                    p = ops.gemm_rank(q, table, bias[:n], out=buf, mask=bits, tile_max=tmax)
+                    if q.shape[1] >= self.RANK_PLANES_MIN_K and q.shape[0] >= 512 and self.gemm_rank_planes:
+                        # operands split once (the table per weight version, the queries per call), 256 x 256 tiles fed by DMA
+                        p = ops.gemm_rank_planes(ops.rank_planes(q), self._rank_planes(tail, n), q.shape[0], n, q.shape[1],
+                                                 bias[:n], out=buf, mask=bits, tile_max=tmax)
+                    else:
+                        p = ops.gemm_rank(q, table, bias[:n], out=buf, mask=bits, tile_max=tmax)
                     if p is not None:
                         approx, cand, flag = ops.topk_from_tile_max(p, tmax, c)
                 if p is None:  # six terms asked for, a very wide table, or operands the split loop does not take

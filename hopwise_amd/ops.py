@@ -659,6 +659,27 @@ def gemm_rank(q, t, bias=None, out=None, mask=None, tile_max=None):
     return out
 
 
+def rank_planes(x):
+    """The (hi, mid) bf16 plane images of an fp32 matrix [rows, K] for ``gemm_rank_planes`` (``hw_rank_planes``): uint8 tensor."""
+    lib = _lib.load()
+    x = _unit_rows(_dev(x, torch.float32, "x"))
+    rows, K = x.shape
+    planes = torch.empty(int(lib.hw_rank_planes_bytes(rows, K)), dtype=torch.uint8, device=x.device)
+    check(lib.hw_rank_planes(_ptr(x), x.stride(0), rows, K, _ptr(planes), _stream()), "hw_rank_planes")
+    return planes
+
+
+def gemm_rank_planes(q_planes, t_planes, m, n, k, bias=None, out=None, mask=None, tile_max=None):
+    """``gemm_rank(q, t, ...)`` from the operands' plane images (``rank_planes``): same values, no conversion in the product."""
+    lib = _lib.load()
+    if out is None:
+        out = padded_rows(m, n, q_planes.device)
+    check(lib.hw_gemm_rank_planes(_ptr(q_planes), _ptr(t_planes), int(m), int(n), int(k), _ptr(bias), _ptr(out), out.stride(0),
+                                  _ptr(mask), 0 if mask is None else mask.stride(0), _ptr(tile_max),
+                                  0 if tile_max is None else tile_max.stride(0), _stream()), "hw_gemm_rank_planes")
+    return out
+
+
 def topk_from_tile_max(scores, tile_max, k, overflow=None):
     """(values [R, k], columns [R, k], overflow int32 [1]) = topk_rows(scores, k) answered from the 64-column stretch maxima
     ``gemm_rank`` left (``hw_topk_from_tile_max``); ``overflow`` != 0: some row could not be answered (the caller falls back)."""

@@ -199,6 +199,16 @@ int hw_kge_dist_finish(float* c, int64_t ldc, int64_t m, int64_t n, const float*
 int hw_gemm_rank(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc, int64_t m,
                  int64_t n, int64_t k, const uint32_t* mask_bits, int64_t mask_ld, float* tile_max, int64_t tile_ld,
                  void* stream);
+/* hw_gemm_rank on operands split ONCE (csrc/gemm_rank.hip): hw_rank_planes turns an fp32 matrix [rows, k] (row pitch ld) into the
+ * (hi, mid) bf16 plane images the product's DMA loads straight into LDS -- the item table once per weight version, a batch's query
+ * rows once per call; hw_rank_planes_bytes sizes the buffer (16-byte aligned).  hw_gemm_rank_planes: the same c, mask and
+ * tile_max as hw_gemm_rank(q, t, ...) on the matrices the images were made from, bit for bit, on 256 x 256 tiles with no
+ * conversion in the main loop (the evaluation's [2 048, 400] x [45 539, 400]^T: 0.38 -> see DESIGN.md section 4). */
+int64_t hw_rank_planes_bytes(int64_t rows, int64_t k);
+int hw_rank_planes(const float* x, int64_t ld, int64_t rows, int64_t k, void* planes, void* stream);
+int hw_gemm_rank_planes(const void* q_planes, const void* t_planes, int64_t m, int64_t n, int64_t k, const float* bias, float* c,
+                        int64_t ldc, const uint32_t* mask_bits, int64_t mask_ld, float* tile_max, int64_t tile_ld, void* stream);
+
 /* History pairs -> the bit matrix hw_gemm_rank masks with: bits [n_rows, words_per_row] (words_per_row >= hw_mask_bits_words(n_cols))
  * is zeroed, then bit (hist_rows[i], hist_cols[i]) set for every pair inside the matrix (and column 0 of every row with
  * mask_column0: the [PAD] item, trainer.py:731). */

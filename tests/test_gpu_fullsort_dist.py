@@ -447,3 +447,60 @@ def test_mask_bits_tile_maxima_and_the_topk_from_them():
     rv, ri = ops.topk_rows(same, 16)
     np.testing.assert_array_equal(i[1].cpu().numpy(), ri[1].cpu().numpy())  # the other rows are answered
     assert int(i[0].min()) >= 0 and int(i[0].max()) < 8192
+
+
+def test_ranking_product_from_plane_images_equals_the_one_from_fp32_operands():
+    """hw_gemm_rank_planes (operands split once into bf16 plane images, 256 x 256 tiles fed by DMA) against hw_gemm_rank on the
+    matrices the images were made from: scores, masked entries and stretch maxima bit for bit, ragged shapes included."""
+    from hopwise_amd import ops
+
+    rng = np.random.default_rng(12)
+    for M, N, K in ((300, 1000, 400), (2048, 4600, 200), (17, 257, 64), (256, 256, 16), (1, 70, 20), (513, 777, 130)):
+        q = rng.standard_normal((M, K)).astype(np.float32)
+        t = rng.standard_normal((N, K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        Kp = (K + 3) & ~3
+        qd = torch.zeros((M, Kp), device=dev())[:, :K]
+        qd.copy_(torch.from_numpy(q))
+        td = torch.zeros((N, Kp), device=dev())[:, :K]
+        td.copy_(torch.from_numpy(t))
+        bd = torch.from_numpy(b).to(dev())
+        hist = (torch.from_numpy(rng.integers(0, M, 3 * M)).to(dev()), torch.from_numpy(rng.integers(0, N, 3 * M)).to(dev()))
+        bits = ops.mask_bits(hist, M, N)
+        nt = (N + 63) // 64
+        tm1, tm2 = torch.full((M, nt), 5.0, device=dev()), torch.full((M, nt), 7.0, device=dev())
+        want = ops.gemm_rank(qd, td, bd, mask=bits, tile_max=tm1)
+        assert want is not None
+        got = ops.gemm_rank_planes(ops.rank_planes(qd), ops.rank_planes(td), M, N, K, bd, mask=bits, tile_max=tm2)
+        np.testing.assert_array_equal(got.cpu().numpy(), want.cpu().numpy(), err_msg=f"{M} {N} {K}")
+        np.testing.assert_array_equal(tm2.cpu().numpy(), tm1.cpu().numpy())
+        plain = ops.gemm_rank_planes(ops.rank_planes(qd), ops.rank_planes(td), M, N, K)
+        np.testing.assert_array_equal(plain.cpu().numpy(), ops.gemm_rank(qd, td).cpu().numpy())
+
+
+def test_evaluation_topk_through_the_plane_image_product_is_the_gather_paths():
+    """B >= 512 and K >= 128: the evaluation top-k takes the plane-image product (cached table planes, per-call query planes);
+    columns and scores equal the gather kernel's, and follow the weights after an optimizer step."""
+    from hopwise_amd.optim import FusedAdam
+
+    rng = np.random.default_rng(21)
+    model, dim, nU, nI, nE, nR, B, k = "RotatE", 64, 700, 4600, 5000, 6, 600, 10
+    m = build(model, random_tables(model, nU, nE, nR, dim, seed=5), dim, nU, nI, nE, nR, gemm_min_scores=0)
+    assert m.gemm_rank_planes and 2 * dim >= m.RANK_PLANES_MIN_K
+    users = torch.from_numpy(rng.integers(0, nU, B)).to(dev())
+    hist = (torch.from_numpy(rng.integers(0, B, 3000)).to(dev()), torch.from_numpy(rng.integers(0, nI, 3000)).to(dev()))
+    for step in range(2):
+        with torch.no_grad():
+            v, i = m.full_sort_topk({"user_id": users}, k, hist)
+            assert any(s[0] == "rankplanes" for s in m._gemm_tables)
+            m.gemm_full_sort = False
+            vk, ik = m.full_sort_topk({"user_id": users}, k, hist)
+            m.gemm_full_sort = True
+        np.testing.assert_array_equal(i.cpu().numpy(), ik.cpu().numpy())
+        np.testing.assert_array_equal(v.cpu().numpy(), vk.cpu().numpy())
+        opt = FusedAdam(m.parameters(), lr=0.05)  # move the tables: the cached planes must follow
+        g = torch.Generator().manual_seed(step)
+        for p in m.parameters():
+            p.grad.copy_(torch.randn(p.shape, generator=g).to(p.device))
+        opt.mark_touched()
+        opt.step()
