@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "hw_common.h"
+#include "rank_epilogue.h"
 
 namespace hw {
 
@@ -663,14 +664,10 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
                 }
             }
             if (bce.rank_tile_max && n0 + wn < N) {  // a stretch that starts inside the row
-#pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {  // max over the 32 lanes that hold the row's 64 columns
-                    float mx = rmax[rg];
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-                    const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
-                    if ((lane & 31) == 0 && gm < M) bce.rank_tile_max[(size_t)gm * bce.rank_tile_ld + ((n0 + wn) >> 6)] = mx;
-                }
+                int rg;
+                const float mx = half_wave_row_max(rmax, lane, rg);  // rank_epilogue.h
+                const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
+                if ((lane & 1) == 0 && gm < M) bce.rank_tile_max[(size_t)gm * bce.rank_tile_ld + ((n0 + wn) >> 6)] = mx;
             }
             if (via_lds) {
                 store_slab_via_lds(slab, v, C + (size_t)gm0 * ldc + n0 + wn, ldc, lane);

@@ -9,13 +9,16 @@
 //   * both operands arrive as bf16 PLANE IMAGES (hi, mid), split once -- the item table once per weight version (an evaluation epoch
 //     scores thousands of batches against the same table), the batch's query rows once per call -- and stored in LDS image order,
 //     so a k-step's 32 KB travel global -> LDS by DMA (global_load_lds): no conversion, no staging registers in the main loop;
-//   * 256 x 256 tiles (eight waves of 64 x 128): half the L2 bytes per multiply of the 128 x 128 tiles;
-//   * four LDS stages, DMAs three k-steps ahead, one barrier per k-step of 24 MFMAs per wave (counted vmcnt, raw s_barrier: the
-//     rules of pgpr_policy.hip's weight path).
+//   * 128 x 256 tiles (four waves of 64 x 128), two blocks per CU (HW_GEMM_RANK_TILE=256: 256 x 256 tiles, one block per CU: least
+//     L2 traffic per multiply, 300 against 284 us); XCD-aware block order (the blocks of one item tile on one XCD);
+//   * three (four) LDS stages, DMAs two (three) k-steps ahead, one barrier per k-step of 24 MFMAs per wave (counted vmcnt, raw
+//     s_barrier: the rules of pgpr_policy.hip's weight path).
 // Same terms in the same order per accumulator and k ascending: the sums are hw_gemm_rank's.
+#include <cstdlib>
 #include <type_traits>
 
 #include "hw_common.h"
+#include "rank_epilogue.h"
 
 namespace hw {
 namespace {
@@ -28,8 +31,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int RK_T = 256;                  // tile rows of either operand
 constexpr int RK_PLANE = RK_T * 32;        // [256 rows][16 k] bf16: 8 KB
 constexpr int RK_OPERAND = 2 * RK_PLANE;   // hi, mid
-constexpr int RK_STAGE = 2 * RK_OPERAND;   // A and B: 32 KB
-constexpr int RK_STAGES = 4;
 
 // byte offset of fragment half h (8 k = 16 B) of row r inside a plane image: gemm.hip's split_off
 __device__ __host__ __forceinline__ int rk_off(int r, int half) { return r * 32 + ((half ^ ((r >> 3) & 1)) << 4); }
@@ -70,30 +71,54 @@ __global__ __launch_bounds__(256) void rank_planes_kernel(const float* __restric
     *reinterpret_cast<uint2*>(dst + RK_PLANE) = uint2{mid[0], mid[1]};
 }
 
-__global__ __launch_bounds__(512, 1) void gemm_rank_planes_kernel(const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb,
-                                                                  int n_ks, float* __restrict__ C, int64_t ldc, int M, int N,
-                                                                  const float* __restrict__ bias,
-                                                                  const uint32_t* __restrict__ mask, int64_t mask_ld,
-                                                                  float* __restrict__ tile_max, int64_t tile_ld, int vec_c) {
+// TA = rows of the query tile: 256 (eight waves, one block per CU) or 128 (four waves, 72 KB of LDS: two blocks per CU).  The item
+// tile is 256 rows either way; a wave owns 64 x 128.  Measured (2 048 x 45 539 x 400, tools/bench_gemm_rank.py): 284 us (128) /
+// 300 us (256), of which ~65 us are the 373 MB of stores (the same kernel without them: 200 us; a device fill of the matrix:
+// 55 us) and the main loop ~0.45 us per k -- about half the matrix pipes' rate: what was tried on top without effect is listed in
+// DESIGN.md section 8 (a half-tile phase shift between the two blocks of a CU; item tiles fastest in the block order).
+template <int TA>
+__global__ __launch_bounds__(TA * 2, TA == 128 ? 2 : 1) void gemm_rank_planes_kernel(
+    const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb, int n_ks, float* __restrict__ C, int64_t ldc, int M, int N,
+    const float* __restrict__ bias, const uint32_t* __restrict__ mask, int64_t mask_ld, float* __restrict__ tile_max,
+    int64_t tile_ld, int vec_c) {
+    constexpr int NW = TA / 32;                     // waves
+    constexpr int A_PLANE = TA * 32;                // the tile's rows of one plane image
+    constexpr int STAGE = 2 * A_PLANE + RK_OPERAND; // A (hi, mid) then B (hi, mid)
+    constexpr int STAGES = TA == 128 ? 3 : 4;
+    constexpr int PIECES = STAGE / 1024, A_PIECES = 2 * A_PLANE / 1024, PER_WAVE = PIECES / NW;
+    static_assert(PIECES % NW == 0, "whole pieces per wave");
     // ONE __shared__ object (a second one beside an array that direct-to-LDS loads write makes hipcc wait vmcnt(0) before LDS reads)
-    __shared__ __attribute__((aligned(16))) uint8_t lds[RK_STAGES * RK_STAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t lds[STAGES * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = wave_in_block();
     const int wr = wave >> 1, wc = wave & 1;  // wave tile: rows 64 wr .., columns 128 wc ..
-    const int m0 = blockIdx.x * RK_T, n0 = blockIdx.y * RK_T;
-    const uint8_t* __restrict__ a_img = pa + (size_t)blockIdx.x * n_ks * RK_OPERAND;
-    const uint8_t* __restrict__ b_img = pb + (size_t)blockIdx.y * n_ks * RK_OPERAND;
-    // k-step s -> stage s & 3: 32 one-KB pieces (16 of A's two planes, 16 of B's), four per wave, destination = base + lane * 16
+    // XCD-aware block order (gemm.hip): workgroups go to the 8 XCDs round-robin by linear id, so the blocks that read the SAME
+    // item tile (all query tiles of one column of the grid) are renumbered onto ONE XCD -- the tile is then fetched from HBM into
+    // one L2 instead of eight (73 MB of item planes instead of 584 MB per product).  gridDim.y is a multiple of 8.
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned bm = j % gridDim.x, bn = (j / gridDim.x) * 8u + xcd;
+    const int m0 = bm * TA, n0 = bn * RK_T;
+    if (n0 >= N) return;  // the padding of gridDim.y (whole block: before any barrier)
+    // the query tile's rows inside their 256-row plane image: rows (m0 % 256) .. + TA, contiguous in image order
+    const uint8_t* __restrict__ a_img = pa + (size_t)(m0 / RK_T) * n_ks * RK_OPERAND + (m0 % RK_T) * 32;
+    const uint8_t* __restrict__ b_img = pb + (size_t)bn * n_ks * RK_OPERAND;
+    // k-step s -> stage s % STAGES, in one-KB pieces (destination = base + lane * 16), PER_WAVE per wave
     auto dma = [&](int s) {
         typedef __attribute__((address_space(1))) const void gptr_t;
         typedef __attribute__((address_space(3))) void lptr_t;
         const int sc = s < n_ks ? s : n_ks - 1;  // past the end: the last step again, into a stage nobody reads any more
-        uint8_t* dst = lds + (s & (RK_STAGES - 1)) * RK_STAGE;
+        uint8_t* dst = lds + (s % STAGES) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int piece = wave * 4 + i;  // 0..15: A, 16..31: B
-            const uint8_t* src = (piece < 16 ? a_img : b_img) + (size_t)sc * RK_OPERAND + (piece & 15) * 1024 + lane * 16;
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst + piece * 1024), 16, 0, 0);
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int piece = wave * PER_WAVE + i;
+            const uint8_t* src;
+            if (piece < A_PIECES) {  // plane piece / (A_PIECES / 2), KB piece % (A_PIECES / 2) of the tile's rows
+                src = a_img + (size_t)sc * RK_OPERAND + (piece / (A_PIECES / 2)) * RK_PLANE + (piece % (A_PIECES / 2)) * 1024;
+            } else {
+                src = b_img + (size_t)sc * RK_OPERAND + (piece - A_PIECES) * 1024;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t*)(src + lane * 16), (lptr_t*)(dst + piece * 1024), 16, 0, 0);
         }
     };
     f32x16 acc[2][4];
@@ -101,23 +126,22 @@ __global__ __launch_bounds__(512, 1) void gemm_rank_planes_kernel(const uint8_t*
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x16{0};
-    dma(0);
-    dma(1);
-    dma(2);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) dma(s);
     for (int s = 0; s < n_ks; ++s) {
-        // step s has landed (the eight younger DMAs of steps s + 1, s + 2 may still fly), every wave is done with step s - 1
-        asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        dma(s + 3);  // into the stage step s - 1 was read from
-        const uint8_t* st = lds + (s & (RK_STAGES - 1)) * RK_STAGE;
+        // step s has landed (the younger DMAs of the steps after it may still fly), every wave is done with step s - 1
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"((STAGES - 2) * PER_WAVE) : "memory");
+        dma(s + STAGES - 1);  // into the stage step s - 1 was read from
+        const uint8_t* st = lds + (s % STAGES) * STAGE;
         bf16x8 fa[2][2], fb[4][2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                fa[t][p] = *reinterpret_cast<const bf16x8*>(st + p * RK_PLANE + rk_off(64 * wr + 32 * t + (lane & 31), lane >> 5));
+                fa[t][p] = *reinterpret_cast<const bf16x8*>(st + p * A_PLANE + rk_off(64 * wr + 32 * t + (lane & 31), lane >> 5));
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                fb[t][p] = *reinterpret_cast<const bf16x8*>(st + RK_OPERAND + p * RK_PLANE +
+                fb[t][p] = *reinterpret_cast<const bf16x8*>(st + 2 * A_PLANE + p * RK_PLANE +
                                                             rk_off(128 * wc + 32 * t + (lane & 31), lane >> 5));
         }
         // smallest terms first, as gemm_f32_kernel<.., 5, ..>: (mid, hi), (hi, mid), (hi, hi)
@@ -132,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rank_planes_kernel(const uint8_t*
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the stages become the store slabs
 
     // ---- epilogue: gemm_f32_kernel's ACT == 5 branch per 32-row x 64-column slab ----
-    float* const slab = reinterpret_cast<float*>(lds) + wave * 2048;  // 8 KB per wave
+    float* const slab = reinterpret_cast<float*>(lds) + wave * 2048;  // 8 KB per wave (NW x 8 KB <= the stages)
     const int g5 = lane >> 5;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -166,14 +190,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rank_planes_kernel(const uint8_t*
                 }
             }
             if (tile_max) {
-#pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    float mx = rmax[rg];
-#pragma unroll
-                    for (int off = 16; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-                    const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
-                    if ((lane & 31) == 0 && gm < M) tile_max[(size_t)gm * tile_ld + (gn0 >> 6)] = mx;
-                }
+                int rg;
+                const float mx = half_wave_row_max(rmax, lane, rg);  // rank_epilogue.h
+                const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
+                if ((lane & 1) == 0 && gm < M) tile_max[(size_t)gm * tile_ld + (gn0 >> 6)] = mx;
             }
             if (vec_c && gm0 + 32 <= M && gn0 + 64 <= N) {  // whole slab, 16-byte rows: through the wave's LDS slab
                 const int c = lane & 31;
@@ -233,12 +253,19 @@ extern "C" int hw_gemm_rank_planes(const void* q_planes, const void* t_planes, i
     if ((mask_bits && mask_ld < (n + 31) / 32) || (tile_max && tile_ld < (n + 63) / 64)) return HW_ERR_INVALID_ARG;
     if ((((uintptr_t)q_planes) | ((uintptr_t)t_planes)) & 15) return HW_ERR_INVALID_ARG;
     if (m == 0) return HW_OK;
-    const int64_t gm = (m + RK_T - 1) / RK_T, gn = (n + RK_T - 1) / RK_T;
-    if (gm > INT32_MAX || gn > 65535) return HW_ERR_INVALID_ARG;
+    const int64_t gn = (n + RK_T - 1) / RK_T;
+    if (gn > 65535) return HW_ERR_INVALID_ARG;
     const int vec_c = ((((uintptr_t)c) & 15) == 0 && (ldc & 3) == 0) ? 1 : 0;
+    // 128-row query tiles, two blocks per CU (one's epilogue beside the other's main loop), unless told otherwise
+    static const bool big = [] { const char* e = getenv("HW_GEMM_RANK_TILE"); return e && atoi(e) == 256; }();
     HW_CLEAR_ERR();
-    hipLaunchKernelGGL(gemm_rank_planes_kernel, dim3((unsigned)gm, (unsigned)gn), dim3(512), 0, (hipStream_t)stream,
-                       (const uint8_t*)q_planes, (const uint8_t*)t_planes, (int)((k + 15) / 16), c, ldc, (int)m, (int)n, bias,
-                       mask_bits, mask_ld, tile_max, tile_ld, vec_c);
+    if (big)
+        hipLaunchKernelGGL(gemm_rank_planes_kernel<256>, dim3((unsigned)((m + 255) / 256), (unsigned)((gn + 7) / 8 * 8)), dim3(512), 0,
+                           (hipStream_t)stream, (const uint8_t*)q_planes, (const uint8_t*)t_planes, (int)((k + 15) / 16), c, ldc,
+                           (int)m, (int)n, bias, mask_bits, mask_ld, tile_max, tile_ld, vec_c);
+    else
+        hipLaunchKernelGGL(gemm_rank_planes_kernel<128>, dim3((unsigned)((m + 127) / 128), (unsigned)((gn + 7) / 8 * 8)), dim3(256), 0,
+                           (hipStream_t)stream, (const uint8_t*)q_planes, (const uint8_t*)t_planes, (int)((k + 15) / 16), c, ldc,
+                           (int)m, (int)n, bias, mask_bits, mask_ld, tile_max, tile_ld, vec_c);
     return HW_LAUNCH_RC();
 }

@@ -23,5 +23,8 @@ for M, N, K in ((2048, 45539, 400), (2048, 45539, 200), (2048, 45539, 64), (256,
          "six_terms_us": round(t_us(lambda: ops.gemm(q, t, bias=b, out=out)), 1),
          "three_terms_us": round(t_us(lambda: ops.gemm_rank(q, t, b, out=out, mask=bits, tile_max=tm)), 1),
          "planes_us": round(t_us(lambda: ops.gemm_rank_planes(qp, tp, M, N, K, b, out=out, mask=bits, tile_max=tm)), 1),
+         "planes_plain_us": round(t_us(lambda: ops.gemm_rank_planes(qp, tp, M, N, K, None, out=out)), 1),
+         "planes_max_only_us": round(t_us(lambda: ops.gemm_rank_planes(qp, tp, M, N, K, b, out=out, tile_max=tm)), 1),
+         "three_terms_plain_us": round(t_us(lambda: ops.gemm_rank(q, t, None, out=out)), 1),
          "query_planes_us": round(t_us(lambda: ops.rank_planes(q)), 1), "table_planes_us": round(t_us(lambda: ops.rank_planes(t)), 1)}
     print(json.dumps(r), flush=True)
