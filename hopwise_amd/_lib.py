@@ -239,6 +239,11 @@ SIGNATURES = {
         [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
          c_f32p, C.c_int64, C.c_void_p],
     ),
+    "hw_gemm_f32_masked": (
+        C.c_int,
+        [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+         c_f32p, C.c_int64, C.c_void_p],
+    ),
     "hw_rank_planes_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "hw_rank_planes": (C.c_int, [c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "hw_gemm_rank_planes": (
@@ -266,6 +271,11 @@ SIGNATURES = {
         C.c_int,
         [c_i64p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, c_f32p, C.c_float, C.c_float, c_f32p,
          c_i64p, c_i32p, C.c_void_p],
+    ),
+    "hw_topk_rerank_dot": (
+        C.c_int,
+        [c_i64p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_float, c_f32p, C.c_float, c_f32p, c_i64p,
+         c_i32p, C.c_void_p],
     ),
     "hw_mask_scores": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_void_p]),
     "hw_mask_scores_ex": (C.c_int, [c_f32p, C.c_int64, C.c_int64, c_i64p, c_i64p, C.c_int64, C.c_int32, C.c_void_p]),

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
             // ACT == 5, the ranking product (hw_gemm_rank): the three largest terms only -- hi.hi, hi.mid, mid.hi -- for products
             // whose consumer re-scores its candidates exactly (hw_topk_rerank); the lo planes are not read.  Dropped: mid.mid,
             // hi.lo, lo.hi <= 3 x 2^-18 |a b| per product (round-to-nearest splits).
-            constexpr bool LITE = ACT == 5;
+            constexpr bool LITE = ACT == 5;  // ACT == 6: all six terms, the same epilogue (hw_gemm_f32_masked)
             constexpr int NPLANES = LITE ? 2 : 3;
             bf16x8 fa[2][3], fb[2][3];
 #pragma unroll
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
         }
         return;
     }
-    if constexpr (ACT == 5) {
+    if constexpr (ACT == 5 || ACT == 6) {
         // ranking product: + bias, the history mask and the per-stretch maxima on the way out.  A wave's slab is 32 rows x 64
         // columns = exactly one 64-column stretch of 32 rows (n0 + wn is a multiple of 64), its two 32-column halves one mask
         // word each: lane l of the wave fetches the word of (row l >> 1, half l & 1) -- one load for the slab -- and every lane
@@ -1388,6 +1388,9 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
     } else if (act == 5) {  // ranking product (hw_gemm_rank): q . t^T + bias from the three largest split terms, never split
         if (!(a_kc && b_kc) || splits != 1 || !split) return HW_ERR_UNSUPPORTED;
         GO(true, true, 5);
+    } else if (act == 6) {  // the six-term product with the ranking product's epilogue (hw_gemm_f32_masked)
+        if (!(a_kc && b_kc) || splits != 1 || !split) return HW_ERR_UNSUPPORTED;
+        GO(true, true, 6);
     } else if (a_kc && b_kc) GO3(true, true);
     else if (a_kc && !b_kc) GO3(true, false);
     else if (!a_kc && !b_kc) GO3(false, false);
@@ -1443,6 +1446,26 @@ extern "C" int hw_gemm_rank(const float* q, int64_t ldq, const float* t, int64_t
     GemmBce rk{};
     rk.rank_mask = mask_bits, rk.rank_mask_ld = mask_ld, rk.rank_tile_max = tile_max, rk.rank_tile_ld = tile_ld;
     const int rc = launch_gemm(q, ldq, true, t, ldt, true, c, ldc, nullptr, m, n, k, bias, 5, nullptr, 0, 0, 0, nullptr, 0,
+                               (hipStream_t)stream, rk);
+    if (rc != HW_OK) return rc;
+    return HW_LAUNCH_RC();
+}
+
+// hw_gemm_rank's by-products on the full six-term product: c = q . t^T + bias with fp32-level error, history mask applied, stretch
+// maxima written -- the evaluation step of the bilinear scorers (whose product IS the score: no re-rank) without its mask pass
+// and with hw_topk_from_tile_max instead of a top-k over the whole matrix.
+extern "C" int hw_gemm_f32_masked(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c,
+                                  int64_t ldc, int64_t m, int64_t n, int64_t k, const uint32_t* mask_bits, int64_t mask_ld,
+                                  float* tile_max, int64_t tile_ld, void* stream) {
+    if (!q || !t || !c || m < 0 || n < 1 || k < 4 || ldc < n || ldq < k || ldt < k) return HW_ERR_INVALID_ARG;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return HW_ERR_INVALID_ARG;
+    if ((mask_bits && mask_ld < (n + 31) / 32) || (tile_max && tile_ld < (n + 63) / 64)) return HW_ERR_INVALID_ARG;
+    if (!aligned16(q, ldq) || !aligned16(t, ldt)) return HW_ERR_UNSUPPORTED;  // the split loop's operands
+    if (m == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    GemmBce rk{};
+    rk.rank_mask = mask_bits, rk.rank_mask_ld = mask_ld, rk.rank_tile_max = tile_max, rk.rank_tile_ld = tile_ld;
+    const int rc = launch_gemm(q, ldq, true, t, ldt, true, c, ldc, nullptr, m, n, k, bias, 6, nullptr, 0, 0, 0, nullptr, 0,
                                (hipStream_t)stream, rk);
     if (rc != HW_OK) return rc;
     return HW_LAUNCH_RC();

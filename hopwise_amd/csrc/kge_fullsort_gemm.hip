@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void topk_rerank_kernel(const int64_t* __restr
                                                           const float* __restrict__ cand_exact, int64_t m, int c, int k,
                                                           float rel_slack, float abs_slack, const float* __restrict__ qn,
                                                           float base, float tn_max, float* __restrict__ out_val,
-                                                          int64_t* __restrict__ out_idx, int32_t* __restrict__ unverified) {
+                                                          int64_t* __restrict__ out_idx, int32_t* __restrict__ unverified,
+                                                          int dot_form) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + wave_in_block();
     if (r >= m) return;
@@ -245,7 +246,11 @@ __global__ __launch_bounds__(256) void topk_rerank_kernel(const int64_t* __restr
         ok = false;
     } else {
         const float e_k = __shfl(ex, __builtin_ctzll(kth), 64);
-        if (qn) {
+        if (qn && dot_form) {
+            // product form (the bilinear scorers: score = <q, t>): a column outside the set has an approximate product <= lo
+            // and the approximation errs by at most rel_slack ||q|| max ||t|| (hw_gemm_rank: 1.2e-5 sum |q_k t_k|)
+            ok = e_k > lo + rel_slack * __builtin_amdgcn_sqrtf(qn[r] * tn_max) + abs_slack;
+        } else if (qn) {
             // distance form: the approximate values are p = <q, t> - ||t||^2 / 2 (the biased product), so a column outside
             // the set has p <= lo, i.e. d^2 = ||q||^2 - 2 p >= ||q||^2 - 2 lo, less the product's error (rel_slack of
             // ||q||^2 + max ||t||^2): its score is at most base - sqrt of that
@@ -476,7 +481,22 @@ extern "C" int hw_topk_rerank(const int64_t* cand_idx, const float* cand_approx,
     if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
     HW_CLEAR_ERR();
     hipLaunchKernelGGL(topk_rerank_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, cand_idx, cand_approx,
-                       cand_exact, m, (int)c, (int)k, rel_slack, abs_slack, qn, base, tn_max, out_val, out_idx, unverified);
+                       cand_exact, m, (int)c, (int)k, rel_slack, abs_slack, qn, base, tn_max, out_val, out_idx, unverified, 0);
+    return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_topk_rerank_dot(const int64_t* cand_idx, const float* cand_approx, const float* cand_exact, int64_t m,
+                                  int32_t c, int32_t k, float rel_slack, float abs_slack, const float* qn, float tn_max,
+                                  float* out_val, int64_t* out_idx, int32_t* unverified, void* stream) {
+    if (!cand_idx || !cand_approx || !cand_exact || !out_val || !out_idx || !unverified || !qn) return HW_ERR_INVALID_ARG;
+    if (m < 0 || c < 1 || c > 64 || k < 1 || k > c || !(rel_slack >= 0.f) || !(abs_slack >= 0.f) || !(tn_max >= 0.f))
+        return HW_ERR_INVALID_ARG;
+    if (m == 0) return HW_OK;
+    const int64_t n_blocks = (m + 3) / 4;
+    if (n_blocks > INT32_MAX) return HW_ERR_INVALID_ARG;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(topk_rerank_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, cand_idx, cand_approx,
+                       cand_exact, m, (int)c, (int)k, rel_slack, abs_slack, qn, 0.f, tn_max, out_val, out_idx, unverified, 1);
     return HW_LAUNCH_RC();
 }
 

@@ -84,10 +84,13 @@ class _GatherKGE(KnowledgeRecommender):
         self.fused_loss = bool(_cfg(config, "fused_loss", True))
         # bilinear scorers (BILINEAR below): full sorts as one product on the MFMA GEMM (HW_FULLSORT_GEMM=0: the gather kernel)
         self.gemm_full_sort = bool(_cfg(config, "gemm_full_sort", os.environ.get("HW_FULLSORT_GEMM", "1") != "0"))
-        # full_sort_topk of the product form: exact re-rank of the top candidates (None: on for the distance scorers, whose
-        # product scores carry the expansion's rounding; the bilinear products are fp32-accurate as they are)
+        # full_sort_topk of the product form: exact re-rank of the top candidates.  Unset: on for the distance scorers (whose
+        # product scores carry the expansion's rounding) and "auto" for the bilinear ones -- their products are fp32-accurate as
+        # they are, so the re-rank is taken where it is the FASTER route: wide tables, where the three-term ranking product with
+        # its in-epilogue mask and stretch maxima beats the six-term product + mask + top-k (and returns the gather path's scores)
         rr = _cfg(config, "gemm_rerank", os.environ.get("HW_FULLSORT_RERANK"))
-        self.gemm_rerank = (self.GEMM_FORM == "distance") if rr is None else str(rr).lower() not in ("0", "false")
+        self.gemm_rerank = ((True if self.GEMM_FORM == "distance" else "auto") if rr is None
+                            else str(rr).lower() not in ("0", "false"))
         self.gemm_min_scores = int(_cfg(config, "gemm_min_scores", os.environ.get("HW_FULLSORT_GEMM_MIN", self.GEMM_MIN_SCORES)))
         # split terms of the evaluation top-k's ranking product (distance scorers, with the exact re-rank): 3 (hw_gemm_rank) or 6
         self.gemm_rank_planes = str(_cfg(config, "gemm_rank_planes", os.environ.get("HW_FULLSORT_RANK_PLANES", "1"))).lower() not in ("0", "false")
@@ -332,20 +335,24 @@ class _GatherKGE(KnowledgeRecommender):
         head, rel, tail = self._tables(side)
         if self._use_gemm_full_sort(h_idx.numel(), n):
             c = self._rerank_candidates(k, n)
-            rerank = self.gemm_rerank and k <= c
-            if rerank and self.GEMM_FORM == "distance":
-                # ranking needs no scores: with -||t||^2 / 2 as the product's per-column bias the product itself orders the
-                # candidates as the score does -- no finish pass over the [B, N] matrix
+            fast_rank = self.gemm_rank_terms == 3 and 128 * c <= n <= 65536  # the three-term product + stretch maxima apply
+            rerank = (fast_rank if self.gemm_rerank == "auto" else bool(self.gemm_rerank)) and k <= c
+            if rerank and (self.GEMM_FORM == "distance" or fast_rank):
+                # Ranking needs no scores, and no exact ones either: the candidates are re-scored below.
+                #  * distance form: with -||t||^2 / 2 as the product's per-column bias the product itself orders the candidates as
+                #    the score does -- no finish pass over the [B, N] matrix; bilinear form: the product is the score;
+                #  * the product runs on the three largest of its six split terms (hw_gemm_rank: half the matrix work).  Its error
+                #    bound, 1.2e-5 sum |q_k t_k| <= 1.2e-5 ||q|| ||t|| <= 0.6e-5 (||q||^2 + ||t||^2), is what the re-rank's proof is
+                #    given: doubled in d^2 = ||q||^2 - 2 p for the distance form (2e-5 (||q||^2 + max ||t||^2); 1e-5 with the
+                #    six-term product, whose own error is ~1e-7), 2e-5 ||q|| max ||t|| for the bilinear one;
+                #  * the history mask and the maximum of every 64-column stretch leave the product's epilogue with the scores: the
+                #    candidates are then found from the maxima and the few stretches that can hold them (hw_topk_from_tile_max)
+                #    instead of by a pass over the whole [B, N] matrix.
+                dist = self.GEMM_FORM == "distance"
                 q, qn = ops.kge_query_rows(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, sqnorm=True, margin=self.margin)
                 bias, tn_max = self._rank_bias(tail)
+                bias = bias[:n] if dist else None
                 buf = torch.empty((q.shape[0], (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)[:, :n]
-                # ... and no exact one either: the candidates are re-scored below, so the product runs on the three largest of
-                # its six split terms (hw_gemm_rank: half the matrix work).  Its error bound, 1.2e-5 sum |q_k t_k| <= 0.6e-5
-                # (||q||^2 + ||t||^2), doubles in d^2 = ||q||^2 - 2 p: the re-rank's proof carries 2e-5 (||q||^2 + max ||t||^2)
-                # for it (1e-5 with the six-term product, whose own error is ~1e-7)
-                # The history mask and the maximum of every 64-column stretch leave the product's epilogue with the scores: the
-                # candidates are then found from the maxima and the few stretches that can hold them (hw_topk_from_tile_max)
-                # instead of by a pass over the whole [B, N] matrix.
                 lite = self.gemm_rank_terms == 3
                 table = self._cat_tables(tail)[:n]
                 p = flag = None
@@ -353,27 +360,42 @@ class _GatherKGE(KnowledgeRecommender):
                     bits = ops.mask_bits(history_index, q.shape[0], n, device=q.device)  # column 0 and the history pairs
                     tmax = torch.empty((q.shape[0], (n + 63) // 64), dtype=torch.float32, device=q.device)
                     if q.shape[1] >= self.RANK_PLANES_MIN_K and q.shape[0] >= 512 and self.gemm_rank_planes:
-                        # operands split once (the table per weight version, the queries per call), 256 x 256 tiles fed by DMA
+                        # operands split once (the table per weight version, the queries per call), 256-wide tiles fed by DMA
                         p = ops.gemm_rank_planes(ops.rank_planes(q), self._rank_planes(tail, n), q.shape[0], n, q.shape[1],
-                                                 bias[:n], out=buf, mask=bits, tile_max=tmax)
+                                                 bias, out=buf, mask=bits, tile_max=tmax)
                     else:
-                        p = ops.gemm_rank(q, table, bias[:n], out=buf, mask=bits, tile_max=tmax)
+                        p = ops.gemm_rank(q, table, bias, out=buf, mask=bits, tile_max=tmax)
                     if p is not None:
                         approx, cand, flag = ops.topk_from_tile_max(p, tmax, c)
                 if p is None:  # six terms asked for, a very wide table, or operands the split loop does not take
                     lite = False
-                    p = ops.gemm(q, table, bias=bias[:n], out=buf)
+                    p = ops.gemm(q, table, bias=bias, out=buf)
                     ops.mask_scores_(p, history_index)
                     approx, cand = ops.topk_rows(p, c)
                 desc = ops.make_desc(self.MODEL, head, rel, tail, self.margin, 0.0, n)
                 exact = ops.kge_score_grouped_raw(desc, h_idx, r_idx, r_fixed, cand)  # c <= n: every candidate is a column
-                val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=2e-5 if lite else 1e-5, abs_slack=1e-6,
-                                                 unverified=flag, qn=qn, base=self.margin if self.MODEL == "RotatE" else 0.0,
-                                                 tn_max=tn_max)
+                if dist:
+                    val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=2e-5 if lite else 1e-5, abs_slack=1e-6,
+                                                     unverified=flag, qn=qn, base=self.margin if self.MODEL == "RotatE" else 0.0,
+                                                     tn_max=tn_max)
+                else:
+                    # every slack of the product form scales with ||q|| max ||t|| (a DistMult on freshly initialised tables
+                    # scores ~1e-5: an absolute 1e-6 would be a quarter of the gaps it has to resolve)
+                    val, idx, flag = ops.topk_rerank(cand, approx, exact, k, rel_slack=2.2e-5 if lite else 2e-6, abs_slack=0.0,
+                                                     unverified=flag, qn=qn, tn_max=tn_max, dot=True)
                 return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, 0, n, k, history_index,
                                               True, self.margin, run_if=flag, out=(val, idx))
-            # the product + mask + top-k on the written matrix beats the fused gather kernel (the matrix is written and
-            # re-read, but at a quarter of the scoring time)
+            if not rerank and self.GEMM_FORM == "bilinear" and 128 * k <= n <= 65536 and k <= 64:
+                # the product IS the score: mask and stretch maxima in its epilogue, the top-k from the maxima (no mask pass, no
+                # top-k pass over the [B, N] matrix); the gather kernel behind the overflow flag for rows of equal scores
+                q, _ = ops.kge_query_rows(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed)
+                bits = ops.mask_bits(history_index, q.shape[0], n, device=q.device)
+                tmax = torch.empty((q.shape[0], (n + 63) // 64), dtype=torch.float32, device=q.device)
+                p = ops.gemm_rank(q, self._bilinear_table(tail, n), None, mask=bits, tile_max=tmax, exact=True)
+                if p is not None:
+                    val, idx, flag = ops.topk_from_tile_max(p, tmax, k)
+                    return ops.kge_full_sort_topk(self.MODEL, head, rel, tail, h_idx, r_idx, r_fixed, 0, n, k, history_index,
+                                                  True, self.margin, run_if=flag, out=(val, idx))
             scores = self._full_sort_gemm(side, h_idx, r_idx, r_fixed, n, padded=True)
             ops.mask_scores_(scores, history_index)
             if not rerank:

@@ -638,11 +638,12 @@ def mask_bits(history_index, n_rows, n_cols, column0=True, device=None):
     return bits
 
 
-def gemm_rank(q, t, bias=None, out=None, mask=None, tile_max=None):
+def gemm_rank(q, t, bias=None, out=None, mask=None, tile_max=None, exact=False):
     """out[M, N] = q @ t^T + bias from the three largest split terms (``hw_gemm_rank``): a ranking product for callers that
     re-score their candidates exactly.  ``mask`` (``mask_bits``): those entries leave as -inf; ``tile_max`` [M, ceil(N / 64)]
     receives every 64-column stretch's maximum (for ``topk_from_tile_max``).  Returns None when the split loop does not apply
-    to the operands (the caller takes its six-term route)."""
+    to the operands (the caller takes its six-term route).  ``exact``: all six terms (``hw_gemm_f32_masked``: ``gemm``'s values
+    with the same by-products)."""
     lib = _lib.load()
     q = _unit_rows(_dev(q, torch.float32, "q"))
     t = _unit_rows(_dev(t, torch.float32, "t"))
@@ -650,7 +651,8 @@ def gemm_rank(q, t, bias=None, out=None, mask=None, tile_max=None):
     N = t.shape[0]
     if out is None:
         out = padded_rows(M, N, q.device)
-    rc = lib.hw_gemm_rank(_ptr(q), q.stride(0), _ptr(t), t.stride(0), _ptr(bias), _ptr(out), out.stride(0), M, N, K,
+    rc = (lib.hw_gemm_f32_masked if exact else lib.hw_gemm_rank)(
+        _ptr(q), q.stride(0), _ptr(t), t.stride(0), _ptr(bias), _ptr(out), out.stride(0), M, N, K,
                           _ptr(mask), 0 if mask is None else mask.stride(0), _ptr(tile_max),
                           0 if tile_max is None else tile_max.stride(0), _stream())
     if rc == -2:  # HW_ERR_UNSUPPORTED: operands the split loop does not take, or HW_GEMM_SPLIT=0
@@ -714,7 +716,7 @@ def gemm_dist(q, t, qn, tn, base=0.0, rescore_frac=DIST_RESCORE_FRAC, out=None):
 
 
 def topk_rerank(cand_idx, cand_approx, cand_exact, k, rel_slack=5e-5, abs_slack=1e-6, unverified=None, qn=None, base=0.0,
-                tn_max=0.0):
+                tn_max=0.0, dot=False):
     """(values [R, k], indices [R, k], unverified int32 [1]): the exact top-k out of c <= 64 re-scored candidates per row
     (hw_topk_rerank), with the device-side proof that the candidate set sufficed.  ``qn`` [R] (+ ``base``, ``tn_max``):
     ``cand_approx`` are values <q, t> - ||t||^2 / 2 of the distance form's ranking product and the proof is made in the distance
@@ -735,6 +737,11 @@ def topk_rerank(cand_idx, cand_approx, cand_exact, k, rel_slack=5e-5, abs_slack=
             qn = _dev(qn, torch.float32, "qn").contiguous()
             if qn.numel() != R:
                 raise ValueError("qn: one value per row")
+        if dot:  # product scores: the proof in the product's own domain (qn = ||q||^2 per row, tn_max = max ||t||^2)
+            check(lib.hw_topk_rerank_dot(_ptr(ci), _ptr(ca), _ptr(ce), R, c, int(k), float(rel_slack), float(abs_slack),
+                                         _ptr(qn), float(tn_max), _ptr(val), _ptr(idx), _ptr(unverified), _stream()),
+                  "hw_topk_rerank_dot")
+            return val, idx, unverified
         check(lib.hw_topk_rerank(_ptr(ci), _ptr(ca), _ptr(ce), R, c, int(k), float(rel_slack), float(abs_slack), _ptr(qn),
                                  float(base), float(tn_max), _ptr(val), _ptr(idx), _ptr(unverified), _stream()), "hw_topk_rerank")
     return val, idx, unverified

@@ -199,6 +199,12 @@ int hw_kge_dist_finish(float* c, int64_t ldc, int64_t m, int64_t n, const float*
 int hw_gemm_rank(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc, int64_t m,
                  int64_t n, int64_t k, const uint32_t* mask_bits, int64_t mask_ld, float* tile_max, int64_t tile_ld,
                  void* stream);
+/* The same by-products on the FULL six-term product (fp32-level error, hw_gemm_f32's values): the evaluation step of the bilinear
+ * scorers (distmult.py:50-51, complex.py:53-62, analogy.py:66-70), whose product is the score itself. */
+int hw_gemm_f32_masked(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc,
+                       int64_t m, int64_t n, int64_t k, const uint32_t* mask_bits, int64_t mask_ld, float* tile_max,
+                       int64_t tile_ld, void* stream);
+
 /* hw_gemm_rank on operands split ONCE (csrc/gemm_rank.hip): hw_rank_planes turns an fp32 matrix [rows, k] (row pitch ld) into the
  * (hi, mid) bf16 plane images the product's DMA loads straight into LDS -- the item table once per weight version, a batch's query
  * rows once per call; hw_rank_planes_bytes sizes the buffer (16-byte aligned).  hw_gemm_rank_planes: the same c, mask and
@@ -243,6 +249,12 @@ int hw_mask_scores_ld(float* scores, int64_t n_rows, int64_t n_cols, int64_t ld,
 int hw_topk_rerank(const int64_t* cand_idx, const float* cand_approx, const float* cand_exact, int64_t m, int32_t c,
                    int32_t k, float rel_slack, float abs_slack, const float* qn, float base, float tn_max, float* out_val,
                    int64_t* out_idx, int32_t* unverified, void* stream);
+/* The same with the proof made for a PRODUCT score (the bilinear scorers: score = <q, t>, cand_approx from hw_gemm_rank): a
+ * column outside the set has an approximate product <= the set's smallest one, and the approximation errs by at most
+ * rel_slack * ||q|| * max ||t|| (qn[i] = ||q_i||^2, tn_max = max_j ||t_j||^2). */
+int hw_topk_rerank_dot(const int64_t* cand_idx, const float* cand_approx, const float* cand_exact, int64_t m, int32_t c,
+                       int32_t k, float rel_slack, float abs_slack, const float* qn, float tn_max, float* out_val,
+                       int64_t* out_idx, int32_t* unverified, void* stream);
 
 /* Backward of hw_kge_score_grouped: given g[b, j] = dLoss/dscore[b, j] (same strides as `out`),
  * atomically accumulates the row gradients into `grads`.  Replaces autograd through

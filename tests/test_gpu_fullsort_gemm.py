@@ -109,3 +109,35 @@ def test_bilinear_topk_with_the_exact_rerank_is_the_gather_paths(model):
         gap_ok[:, :-1] &= gaps > 2e-6 * scale
         gap_ok[:, 1:] &= gaps > 2e-6 * scale
         assert (kin == gin)[gap_ok].all() and gap_ok.mean() > 0.8
+
+
+@pytest.mark.parametrize("model", ["DistMult", "ComplEx", "Analogy"])
+def test_wide_tables_take_the_ranking_product_and_return_the_gather_paths_topk(model):
+    """Default configuration, a table wide enough for the stretch maxima to mean something (n >= 128 c): the bilinear scorers'
+    evaluation top-k runs the three-term ranking product (plane images from 512 queries on) with mask and maxima in its
+    epilogue, re-scores its candidates with the gather scorer and proves the set in the product's own domain -- columns and
+    values are the gather kernel's, bit for bit; with gemm_rerank: False the product's own values come back."""
+    dim, nU, nI, nE, nR, k = 64, 700, 4600, 5000, 6, 10
+    rng = np.random.default_rng(3)
+    tables = random_tables(model, nU, nE, nR, dim, seed=7)
+    m = build(model, tables, dim, nU, nI, nE, nR)
+    assert m.gemm_rerank == "auto" and m.GEMM_FORM == "bilinear"
+    for B in (70, 600):
+        users = torch.from_numpy(rng.integers(0, nU, B)).to(dev())
+        hist = (torch.from_numpy(rng.integers(0, B, 900)).to(dev()), torch.from_numpy(rng.integers(0, nI, 900)).to(dev()))
+        with torch.no_grad():
+            gv, gi = m.full_sort_topk({"user_id": users}, k, hist)
+            m.gemm_full_sort = False
+            kv, ki = m.full_sort_topk({"user_id": users}, k, hist)
+            m.gemm_full_sort = True
+        np.testing.assert_array_equal(gi.cpu().numpy(), ki.cpu().numpy())
+        np.testing.assert_array_equal(gv.cpu().numpy(), kv.cpu().numpy())
+    plain = build(model, tables, dim, nU, nI, nE, nR, gemm_rerank=False)
+    with torch.no_grad():
+        pv, pi = plain.full_sort_topk({"user_id": users}, k, hist)
+        full = plain.full_sort_predict({"user_id": users}).view(len(users), nI).clone()
+    from hopwise_amd import ops
+    ops.mask_scores_(full, hist)
+    rv, ri = ops.topk_rows(full, k)
+    np.testing.assert_array_equal(pi.cpu().numpy(), ri.cpu().numpy())
+    np.testing.assert_array_equal(pv.cpu().numpy(), rv.cpu().numpy())
