@@ -80,7 +80,7 @@ template <int TA>
 __global__ __launch_bounds__(TA * 2, TA == 128 ? 2 : 1) void gemm_rank_planes_kernel(
     const uint8_t* __restrict__ pa, const uint8_t* __restrict__ pb, int n_ks, float* __restrict__ C, int64_t ldc, int M, int N,
     const float* __restrict__ bias, const uint32_t* __restrict__ mask, int64_t mask_ld, float* __restrict__ tile_max,
-    int64_t tile_ld, int vec_c) {
+    int64_t tile_ld, int vec_c, int group) {
     constexpr int NW = TA / 32;                     // waves
     constexpr int A_PLANE = TA * 32;                // the tile's rows of one plane image
     constexpr int STAGE = 2 * A_PLANE + RK_OPERAND; // A (hi, mid) then B (hi, mid)
@@ -95,9 +95,19 @@ __global__ __launch_bounds__(TA * 2, TA == 128 ? 2 : 1) void gemm_rank_planes_ke
     // XCD-aware block order (gemm.hip): workgroups go to the 8 XCDs round-robin by linear id, so the blocks that read the SAME
     // item tile (all query tiles of one column of the grid) are renumbered onto ONE XCD -- the tile is then fetched from HBM into
     // one L2 instead of eight (73 MB of item planes instead of 584 MB per product).  gridDim.y is a multiple of 8.
+    // Within an XCD, `group` query tiles (not all of them) share an item tile at a time: the blocks of one item tile run in step
+    // and ask for the same bytes, so what an XCD has in flight towards HBM is (resident blocks / blocks per item tile) tiles --
+    // with all 16 query tiles on one item tile, four tiles x two k-steps = 128 KB per XCD, i.e. a stream of ~0.3 TB/s at HBM's
+    // latency: THAT paced the main loop (1.4 us per k-step against 0.37 us of matrix work).  Smaller groups put more distinct
+    // item tiles in flight; the item planes are then read `gridDim.x / group` times (from the Infinity Cache after the first).
     const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
     const unsigned xcd = lin & 7u, j = lin >> 3;
-    const unsigned bm = j % gridDim.x, bn = (j / gridDim.x) * 8u + xcd;
+    const unsigned gx = gridDim.x, n_col = gridDim.y >> 3;  // query tiles; item tiles per XCD
+    const unsigned g = (unsigned)group < gx ? (unsigned)group : gx;
+    const unsigned per_sweep = g * n_col;                   // blocks of one sweep over the XCD's item tiles with g query tiles
+    const unsigned sweep = j / per_sweep, in = j % per_sweep;
+    const unsigned g_here = min(g, gx - sweep * g);         // the last sweep may hold fewer query tiles
+    const unsigned bm = sweep * g + in % g_here, bn = (in / g_here) * 8u + xcd;
     const int m0 = bm * TA, n0 = bn * RK_T;
     if (n0 >= N) return;  // the padding of gridDim.y (whole block: before any barrier)
     // the query tile's rows inside their 256-row plane image: rows (m0 % 256) .. + TA, contiguous in image order
@@ -258,14 +268,15 @@ extern "C" int hw_gemm_rank_planes(const void* q_planes, const void* t_planes, i
     const int vec_c = ((((uintptr_t)c) & 15) == 0 && (ldc & 3) == 0) ? 1 : 0;
     // 128-row query tiles, two blocks per CU (one's epilogue beside the other's main loop), unless told otherwise
     static const bool big = [] { const char* e = getenv("HW_GEMM_RANK_TILE"); return e && atoi(e) == 256; }();
+    static const int group = [] { const char* e = getenv("HW_GEMM_RANK_GROUP"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
     HW_CLEAR_ERR();
     if (big)
         hipLaunchKernelGGL(gemm_rank_planes_kernel<256>, dim3((unsigned)((m + 255) / 256), (unsigned)((gn + 7) / 8 * 8)), dim3(512), 0,
                            (hipStream_t)stream, (const uint8_t*)q_planes, (const uint8_t*)t_planes, (int)((k + 15) / 16), c, ldc,
-                           (int)m, (int)n, bias, mask_bits, mask_ld, tile_max, tile_ld, vec_c);
+                           (int)m, (int)n, bias, mask_bits, mask_ld, tile_max, tile_ld, vec_c, group);
     else
         hipLaunchKernelGGL(gemm_rank_planes_kernel<128>, dim3((unsigned)((m + 127) / 128), (unsigned)((gn + 7) / 8 * 8)), dim3(256), 0,
                            (hipStream_t)stream, (const uint8_t*)q_planes, (const uint8_t*)t_planes, (int)((k + 15) / 16), c, ldc,
-                           (int)m, (int)n, bias, mask_bits, mask_ld, tile_max, tile_ld, vec_c);
+                           (int)m, (int)n, bias, mask_bits, mask_ld, tile_max, tile_ld, vec_c, group);
     return HW_LAUNCH_RC();
 }
