@@ -288,6 +288,16 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
             bz = (j / (gridDim.x * gridDim.y)) * 8u + xcd;
         } else {
             by = (j / gridDim.x) * 8u + xcd;
+            // pipe bits 8..15: `group` row tiles (not all) share a column tile at a time inside the XCD -- the blocks of one
+            // column tile run in step and ask for the same operand bytes, so fewer of them per tile means more distinct tiles
+            // in flight towards HBM (gemm_rank.hip: what paced that product's main loop)
+            const unsigned group = (unsigned)(pipe >> 8) & 255u;
+            if (group && group < gridDim.x) {
+                const unsigned n_col = gridDim.y >> 3, per_sweep = group * n_col;
+                const unsigned sweep = j / per_sweep, in = j % per_sweep;
+                const unsigned g_here = min(group, gridDim.x - sweep * group);
+                bx = sweep * group + in % g_here, by = (in / g_here) * 8u + xcd;
+            }
         }
     }
     const int m0 = bx * BM, n0 = by * BN;
@@ -1345,6 +1355,8 @@ static int launch_gemm(const float* a, int64_t lda, bool a_kc, const float* b, i
             else if (splits == 1 && gn >= 16) {
                 pipe |= 4;
                 grid.y = (unsigned)((gn + 7) / 8 * 8);
+                static const int group = [] { const char* e = getenv("HW_GEMM_GROUP"); return e ? atoi(e) & 255 : 0; }();
+                pipe |= group << 8;
             }
         }
     }
