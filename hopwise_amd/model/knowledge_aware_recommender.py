@@ -156,6 +156,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         # policy launch is matrix-bound, its action / ranking launches are not: +15 % on the bench); 1 = one after another
         self.search_streams = max(1, int(_cfg(config, "search_streams", os.environ.get("HW_PGPR_STREAMS", "3"))))
         # beam search: a hop's action kernels on a stream of their own beside its policy launch (HW_PGPR_OVERLAP=0: in line)
+        self.score_cache_mb = int(_cfg(config, "score_cache_mb", os.environ.get("HW_PGPR_SCORE_CACHE_MB", "2048")))
         self.overlap_actions = bool(_cfg(config, "overlap_actions", os.environ.get("HW_PGPR_OVERLAP", "1") != "0"))
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         dev = torch.device(self.device)
@@ -290,6 +291,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             self._fused_policy_state()
         self._l1_slot_tables()
         ops._OobCounter.get(self._t64[0].device)
+        self._batch_scores(torch.zeros(1, dtype=torch.int64, device=self._t64[0].device))  # the all-users score cache
 
     def _policy_logits(self, buf, n_rows, rmax, drops, hop, paths=None):
         """l1 -> ELU -> dropout -> l2 -> ELU -> dropout -> actor (pgpr.py:175-187), logits into buf['logits'].
@@ -368,7 +370,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         U32, E32, R32 = self._t32
         nr = buf["n_rows"]
         P.init_paths(users, buf["paths"][0], buf["probs"][0], nr[0:1])
-        score_user, score_entity = P.user_scores(g, U64, E64, R64, users, self._user_vec())  # float64 trim tables
+        score_user, score_entity = self._batch_scores(users)  # float64 trim tables
         trace = []
 
         def mark(stage, hop):
@@ -442,6 +444,37 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         res.buffers = buf if keep_buffers else None  # per-hop path rows / action counts (bench_pgpr's byte accounting)
         return res
 
+    def _batch_scores(self, users, plain=False):
+        """(score_user [B, n_users], score_entity [B, n_entities]) float64 of a batch's root users: u . U[n] and (u + r_ui) . E[n]
+        for every node n -- what the trims and the reward read (pgpr.py:268-276, 339-357).  ``plain``: the (U + R_ui) form
+        even when the model swaps the [UI-Relation] row per user (TPRec's u_p_scales, tprec.py:146-149).
+
+        The tables these are products of are frozen (pretrained TransE embeddings loaded at construction), so the scores of
+        EVERY user are computed once -- ``hw_pgpr_user_scores`` over all users in chunks, the same fma chains -- when they fit
+        ``score_cache_mb`` (default 2 048: ml-1m's 6 040 users x 19 845 nodes x 8 B = 0.96 GB), and a batch is two row gathers:
+        0.19 -> 0.03 ms of a 1 024-user training step, 0.10 -> 0.02 ms of a 256-user search."""
+        g = self.graph
+        U64, E64, R64 = self._t64
+        vec = None if plain else self._user_vec()
+        budget = self.score_cache_mb << 20
+        slot = "_score_cache_plain" if vec is None else "_score_cache"
+        if (g.n_users * (g.n_users + g.n_entities) * 8 > budget
+                or (users.is_cuda and torch.cuda.is_current_stream_capturing() and not self._fenced(slot).has(0))):
+            return P.user_scores(g, U64, E64, R64, users, vec)  # too big to keep, or not yet built and no place to build it
+
+        def build():
+            su = torch.empty((g.n_users, g.n_users), dtype=torch.float64, device=U64.device)
+            se = torch.empty((g.n_users, g.n_entities), dtype=torch.float64, device=U64.device)
+            ids = torch.arange(g.n_users, device=U64.device)
+            for lo in range(0, g.n_users, 2048):
+                a, b = P.user_scores(g, U64, E64, R64, ids[lo : lo + 2048], vec)
+                su[lo : lo + 2048], se[lo : lo + 2048] = a, b
+            return su, se
+
+        su, se = self._fenced(slot).get(0, build)
+        rows = users.clamp(0, g.n_users - 1)  # hw_pgpr_user_scores clamps the same way
+        return su.index_select(0, rows), se.index_select(0, rows)
+
     def _user_vec(self):
         """Per-user replacement of the [UI-Relation] row in the trimming / reward scores (None: PGPR; TPRec overrides)."""
         return None
@@ -490,11 +523,11 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             scratch = torch.empty((min(2048, B), g.max_degree), dtype=torch.int64, device=dev)
         head_w, head_b = self._head_params()
         P.init_paths(users, ep["paths"][0], probs3[0], nr[0:1])
-        score_user, score_entity = P.user_scores(g, U64, E64, R64, users, self._user_vec())
+        score_user, score_entity = self._batch_scores(users)
         scales = torch.empty(B, dtype=torch.float64, device=dev)
         own_scales = self._user_vec() is None  # u_p_scales always come from the plain (U + R_ui) tables (tprec.py:146-149)
         if not own_scales:
-            _, plain = P.user_scores(g, U64, E64, R64, users)
+            _, plain = self._batch_scores(users, plain=True)
             P.reward(ep["paths"][0], B, None, plain, self.n_items, scales, True, ep["rewards"][:B])
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)

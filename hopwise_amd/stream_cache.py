@@ -65,6 +65,10 @@ class FencedValue:
                 self._seen.add(st.cuda_stream)
         return self.value
 
+    def has(self, key):
+        """Whether the value for ``key`` is built (no fence taken)."""
+        return self.key is not None and self.key == key
+
     def drop(self):
         self.key = self.value = self._event = None
         self._seen, self._cuda = set(), []
