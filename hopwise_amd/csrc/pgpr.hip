@@ -296,17 +296,19 @@ __device__ __forceinline__ void trim_row_in_registers(const hw_pgpr_graph& g, co
     }
 }
 
+// (bx, nb): this block's index among the nb blocks that share the rows -- blockIdx.x / gridDim.x of the kernel of its own, a slice
+// of the grid in pgpr_actions_trim_kernel
 template <bool A16>
-__global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
-    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+__device__ __forceinline__ void trim_wave_body(
+    const hw_pgpr_graph& g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
     const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
     const int32_t* __restrict__ n_rows_ptr, int max_acts, int flags, int32_t* __restrict__ acts,
-    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len) {
+    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len, int bx, int nb) {
     const int n_rows = list ? list_len[0] : n_rows_ptr[0];
     const int act_dim = max_acts + 1;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int it = blockIdx.x * 4 + wave_in_block(); it < n_rows; it += gridDim.x * 4) {
+    for (int it = bx * 4 + wave_in_block(); it < n_rows; it += nb * 4) {
         const int row = list ? list[it] : it;
         if (n_acts[row] >= 0) continue;  // wave-uniform: finished by the first pass
         PathRec rec;
@@ -439,18 +441,18 @@ __device__ __forceinline__ void trim_row_in_block(const hw_pgpr_graph& g, const 
 }
 
 template <bool A16>
-__global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
-    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+__device__ __forceinline__ void trim_block_body(
+    const hw_pgpr_graph& g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
     const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
     const int32_t* __restrict__ n_rows_ptr, int max_acts, int flags, int32_t* __restrict__ acts,
-    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len) {
+    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len, int bx, int nb) {
     __shared__ int sh_cnt[2][2][4];
     __shared__ int sh_slot[2][32][4];
     const int n_rows = list ? list_len[0] : n_rows_ptr[0];
     const int act_dim = max_acts + 1;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    for (int it = blockIdx.x; it < n_rows; it += gridDim.x) {
+    for (int it = bx; it < n_rows; it += nb) {
         const int row = list ? list[it] : it;
         if (n_acts[row] >= 0) continue;  // block-uniform
         PathRec rec;
@@ -485,6 +487,45 @@ __global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
         __syncthreads();  // every wave has finished the row before it is marked done
         if (threadIdx.x == 0) arow.self_loop(cur_n), n_acts[row] = 1 + max_acts;
     }
+}
+
+// The two trims of a hop as kernels of their own (the rows of a degree class queued by the first pass) ...
+template <bool A16>
+__global__ __launch_bounds__(256, 3) void pgpr_actions_trim_wave_kernel(
+    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+    const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
+    const int32_t* __restrict__ n_rows_ptr, int max_acts, int flags, int32_t* __restrict__ acts,
+    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len) {
+    trim_wave_body<A16>(g, score_user, score_entity, score_rel_entity, paths, n_rows_ptr, max_acts, flags, acts, n_acts, list,
+                        list_len, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <bool A16>
+__global__ __launch_bounds__(256, 3) void pgpr_actions_trim_block_kernel(
+    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+    const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
+    const int32_t* __restrict__ n_rows_ptr, int max_acts, int flags, int32_t* __restrict__ acts,
+    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list, const int32_t* __restrict__ list_len) {
+    trim_block_body<A16>(g, score_user, score_entity, score_rel_entity, paths, n_rows_ptr, max_acts, flags, acts, n_acts, list,
+                         list_len, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ... and as ONE launch: blocks [0, nb_wave) take the wave trim's queue, the rest the block trim's.  The two are independent
+// (different rows); for the few hundred over-full rows of a training batch each is a latency chain of ~30 us that fills a
+// fraction of the chip, so one after the other they cost twice that (a sixth of the replayed 1 024-user step).
+template <bool A16>
+__global__ __launch_bounds__(256, 3) void pgpr_actions_trim_kernel(
+    hw_pgpr_graph g, const double* __restrict__ score_user, const double* __restrict__ score_entity,
+    const double* __restrict__ score_rel_entity, const int32_t* __restrict__ paths,
+    const int32_t* __restrict__ n_rows_ptr, int max_acts, int flags, int32_t* __restrict__ acts,
+    int32_t* __restrict__ n_acts, const int32_t* __restrict__ list_w, const int32_t* __restrict__ len_w,
+    const int32_t* __restrict__ list_b, const int32_t* __restrict__ len_b, int nb_wave, int nb_block) {
+    if ((int)blockIdx.x < nb_wave)
+        trim_wave_body<A16>(g, score_user, score_entity, score_rel_entity, paths, n_rows_ptr, max_acts, flags, acts, n_acts,
+                            list_w, len_w, (int)blockIdx.x, nb_wave);
+    else
+        trim_block_body<A16>(g, score_user, score_entity, score_rel_entity, paths, n_rows_ptr, max_acts, flags, acts, n_acts,
+                             list_b, len_b, (int)blockIdx.x - nb_wave, nb_block);
 }
 
 __global__ __launch_bounds__(256) void pgpr_actions_kernel(
@@ -1735,7 +1776,19 @@ extern "C" int hw_pgpr_actions(const hw_pgpr_graph* graph, const double* score_u
             hipLaunchKernelGGL(pgpr_actions_small_kernel<false>, dim3((unsigned)g1), dim3(256), 0, st, *graph, paths, n_rows,
                                max_acts, fix_scores_sorting_bug, acts, n_acts, work, max_rows);
     }
-    if (!(fix_scores_sorting_bug & 1)) {
+    const bool both_trims = !(fix_scores_sorting_bug & 1) && graph->max_degree > TRIM_WAVE_MAX_DEG && max_rows <= 65536;
+    if (both_trims) {  // small hops and training batches: the two trims side by side in one launch
+        const int g2 = (int)((max_rows + 3) / 4 > 4096 ? 4096 : (max_rows + 3) / 4);
+        const int g3 = (int)(max_rows < 2048 ? max_rows : 2048);
+        if (a16)
+            hipLaunchKernelGGL(pgpr_actions_trim_kernel<true>, dim3((unsigned)(g2 + g3)), dim3(256), 0, st, *graph, score_user,
+                               score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
+                               lists[0], lens[0], lists[1], lens[1], g2, g3);
+        else
+            hipLaunchKernelGGL(pgpr_actions_trim_kernel<false>, dim3((unsigned)(g2 + g3)), dim3(256), 0, st, *graph, score_user,
+                               score_entity, score_rel_entity, paths, n_rows, max_acts, fix_scores_sorting_bug, acts, n_acts,
+                               lists[0], lens[0], lists[1], lens[1], g2, g3);
+    } else if (!(fix_scores_sorting_bug & 1)) {
         int64_t g2 = (max_rows + 3) / 4;
         if (g2 > 4096) g2 = 4096;
         if (a16)
