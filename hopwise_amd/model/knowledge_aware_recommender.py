@@ -444,7 +444,7 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         res.buffers = buf if keep_buffers else None  # per-hop path rows / action counts (bench_pgpr's byte accounting)
         return res
 
-    def _batch_scores(self, users, plain=False):
+    def _batch_scores(self, users, plain=False, all_users=False):
         """(score_user [B, n_users], score_entity [B, n_entities]) float64 of a batch's root users: u . U[n] and (u + r_ui) . E[n]
         for every node n -- what the trims and the reward read (pgpr.py:268-276, 339-357).  ``plain``: the (U + R_ui) form
         even when the model swaps the [UI-Relation] row per user (TPRec's u_p_scales, tprec.py:146-149).
@@ -452,14 +452,17 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
         The tables these are products of are frozen (pretrained TransE embeddings loaded at construction), so the scores of
         EVERY user are computed once -- ``hw_pgpr_user_scores`` over all users in chunks, the same fma chains -- when they fit
         ``score_cache_mb`` (default 2 048: ml-1m's 6 040 users x 19 845 nodes x 8 B = 0.96 GB), and a batch is two row gathers:
-        0.19 -> 0.03 ms of a 1 024-user training step, 0.10 -> 0.02 ms of a 256-user search."""
+        0.19 -> 0.07 ms of a 1 024-user training step, 0.10 -> 0.02 ms of a 256-user search.  ``all_users``: the whole cached
+        tables (None when they are not kept) -- a training episode reads them in place, its records carrying the user's row."""
         g = self.graph
         U64, E64, R64 = self._t64
         vec = None if plain else self._user_vec()
         budget = self.score_cache_mb << 20
         slot = "_score_cache_plain" if vec is None else "_score_cache"
         if (g.n_users * (g.n_users + g.n_entities) * 8 > budget
-                or (users.is_cuda and torch.cuda.is_current_stream_capturing() and not self._fenced(slot).has(0))):
+                or (U64.is_cuda and torch.cuda.is_current_stream_capturing() and not self._fenced(slot).has(0))):
+            if all_users:
+                return None
             return P.user_scores(g, U64, E64, R64, users, vec)  # too big to keep, or not yet built and no place to build it
 
         def build():
@@ -472,8 +475,15 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             return su, se
 
         su, se = self._fenced(slot).get(0, build)
+        if all_users:
+            return su, se
         rows = users.clamp(0, g.n_users - 1)  # hw_pgpr_user_scores clamps the same way
         return su.index_select(0, rows), se.index_select(0, rows)
+
+    def _all_user_scales(self):
+        """u_p_scales of every user (pgpr.py:85-88: the largest item score of the plain tables), next to the score cache."""
+        return self._fenced("_scale_cache").get(
+            0, lambda: self._batch_scores(None, plain=True, all_users=True)[1][:, : self.n_items].max(dim=1).values.contiguous())
 
     def _user_vec(self):
         """Per-user replacement of the [UI-Relation] row in the trimming / reward scores (None: PGPR; TPRec overrides)."""
@@ -523,12 +533,22 @@ class PGPR(KnowledgeRecommender, ExplainableRecommender):
             scratch = torch.empty((min(2048, B), g.max_degree), dtype=torch.int64, device=dev)
         head_w, head_b = self._head_params()
         P.init_paths(users, ep["paths"][0], probs3[0], nr[0:1])
-        score_user, score_entity = self._batch_scores(users)
-        scales = torch.empty(B, dtype=torch.float64, device=dev)
         own_scales = self._user_vec() is None  # u_p_scales always come from the plain (U + R_ui) tables (tprec.py:146-149)
-        if not own_scales:
-            _, plain = self._batch_scores(users, plain=True)
-            P.reward(ep["paths"][0], B, None, plain, self.n_items, scales, True, ep["rewards"][:B])
+        cached = self._batch_scores(None, all_users=True)
+        if cached is not None:
+            # the scores of all users are kept (frozen embeddings): the episode reads them in place -- the records' last word,
+            # which names the row of the score tables, is the user id instead of the slot in the batch (nothing else in an
+            # episode reads that word) -- and the scales come from their cache: no table of the batch is made at all
+            score_user, score_entity = cached
+            scales = self._all_user_scales()
+            ep["paths"][0][:, P.ROW_INTS - 1] = users.clamp(0, g.n_users - 1).to(torch.int32)
+            own_scales = False  # nothing to compute inside the step
+        else:
+            score_user, score_entity = self._batch_scores(users)
+            scales = torch.empty(B, dtype=torch.float64, device=dev)
+            if not own_scales:
+                _, plain = self._batch_scores(users, plain=True)
+                P.reward(ep["paths"][0], B, None, plain, self.n_items, scales, True, ep["rewards"][:B])
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
             paths, n_rows = ep["paths"][t], nr[t : t + 1]
