@@ -97,6 +97,9 @@ def concurrent_streams(n, device=None, beside=None):
     key = (device.index, n, tuple(s.cuda_stream for s in beside))
     hit = _PICKS.get(key)
     if hit is None:
+        if not hasattr(torch.cuda, "_sleep"):  # the probe's spin kernel is a private torch helper: without it, plain streams
+            hit = _PICKS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+            return hit
         pool = _POOLS.get(device.index)
         if pool is None:
             pool = _POOLS[device.index] = _DevicePool(device)
