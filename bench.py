@@ -1210,7 +1210,8 @@ def main():
         torch.cuda.empty_cache()
         pg = bench_pgpr.run(D.dev, n_users=args.pgpr_users, steps=args.pgpr_steps, warmup=1,
                             cpu_users=(1 if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline else 0), rank=D.rank,
-                            streams=args.pgpr_streams)
+                            streams=args.pgpr_streams,
+                            cpu_workers=(8 if D.rank == 0 and D.world == 1 and not args.no_cpu_baseline else 0))
         if D.world > 1:  # whole-job rate on the slowest rank's clock
             tm, tp = D.reduce(pg["ms_per_step"], "max"), D.reduce(pg["paths_per_step"], "sum")
             pg.update(value=tp / (tm * 1e-3), ms_per_step=tm, paths_per_step=tp, n_gpus=D.world)

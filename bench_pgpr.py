@@ -104,7 +104,40 @@ def algorithmic_bytes(m, res, hops):
     return total, per_hop
 
 
-def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5, streams=1):
+def _cpu_workers(kg, ds, m, rng, n_workers, users_per_worker=2):
+    """oracle/pgpr.py's beam search in ``n_workers`` child processes -> the cpu_baseline object, or None when a worker fails."""
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "pgpr_state.npz")
+        W = {"w." + k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+        np.savez(path, n_users=kg.n_users, n_entities=kg.n_entities, n_items=kg.n_items, ui_relation=kg.ui_relation,
+                 inter_users=kg.inter_users, inter_items=kg.inter_items, heads=kg.heads, relations=kg.relations, tails=kg.tails,
+                 user_emb=ds._w["user_embedding_id"], entity_emb=ds._w["entity_embedding_id"],
+                 relation_emb=ds._w["relation_embedding_id"], max_acts=250, state_history=1, **W)
+        env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+        procs = []
+        for _ in range(n_workers):
+            users = [str(int(u)) for u in rng.integers(1, kg.n_users, users_per_worker)]
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.pgpr_worker", path, ",".join(map(str, HOPS)), *users],
+                                          cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        res = []
+        for p in procs:
+            try:
+                o, _ = p.communicate(timeout=300)
+                res.append(json.loads(o.strip().splitlines()[-1]))
+            except Exception:  # noqa: BLE001
+                p.kill()
+                return None
+    paths, slowest = sum(r["paths"] for r in res), max(r["seconds"] for r in res)
+    return {"value": paths / slowest, "unit": "paths/s", "cores": n_workers, "kind": "port",
+            "sample": f"{n_workers} processes x {users_per_worker} users, one thread each, same graph/tables/MLP, oracle/pgpr.py "
+                      f"beam_search; slowest worker {slowest:.1f} s"}
+
+
+def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5, streams=1, cpu_workers=0):
     """steps = 0: as many searches as fill `min_seconds` of timed work (at least 5).  ``streams`` > 1: the timed searches are
     dealt round-robin over that many HIP streams (independent user batches: a search's policy launch is matrix-bound, its
     action / ranking launches are not, and kernels of two searches can share the chip)."""
@@ -256,6 +289,13 @@ def run(dev, n_users=32, steps=0, warmup=1, cpu_users=0, rank=0, min_seconds=0.5
         n = sum(sum(min(k, len(a)) for a in t["acts"]) for t, k in zip(trace, HOPS))
         out["cpu_baseline"] = {"value": n / cdt, "unit": "paths/s", "cores": 1, "kind": "port",
                                "sample": f"{cpu_users} user(s), same graph/tables/MLP, oracle/pgpr.py beam_search in {cdt:.1f} s"}
+        if cpu_workers > 1:
+            # the same oracle on several cores: child processes (numpy only, one BLAS thread each) take two users apiece; the
+            # rate is all their paths over the slowest worker's time.  They start after the timed GPU region: the host is theirs.
+            multi = _cpu_workers(kg, ds, m, rng, cpu_workers)
+            if multi is not None:
+                multi["single_core"] = out["cpu_baseline"]["value"]
+                out["cpu_baseline"] = multi
         # full-size parity, outside the timed region: the same users through the device search with the policy dropout
         # switched to identity (the oracle has none), leaves compared with the rule of tests/test_gpu_pgpr.py
         _, _, m_id = make_model(dev, dropout="identity")
@@ -291,5 +331,6 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=0, help="0: enough searches for 0.5 s of timed work")
     ap.add_argument("--cpu-users", type=int, default=0)
     ap.add_argument("--streams", type=int, default=1)
+    ap.add_argument("--cpu-workers", type=int, default=0, help="CPU baseline on this many processes (with --cpu-users)")
     a = ap.parse_args()
-    print(json.dumps(run(torch.device("cuda", 0), a.users, a.steps, 1, a.cpu_users, streams=a.streams)))
+    print(json.dumps(run(torch.device("cuda", 0), a.users, a.steps, 1, a.cpu_users, streams=a.streams, cpu_workers=a.cpu_workers)))
