@@ -194,8 +194,12 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
     const uint32_t* __restrict__ excluded_init, int64_t bit_words, int grow_excluded,
     int32_t* __restrict__ out_ids, float* __restrict__ out_vals, int32_t* __restrict__ out_count,
     const int64_t* __restrict__ slot_ptr) {
-    __shared__ uint32_t vis[CAFE_BIT_WORDS];
-    __shared__ uint32_t excl[CAFE_BIT_WORDS];
+    // the two id bitmaps, sized by the launch to the graph's entities (dynamic LDS: 2 x bit_words words).  As static arrays of
+    // CAFE_BIT_WORDS they took 64 KB whatever the graph -- two blocks per CU -- while ml-1m's 13 805 entities need 3.4 KB: a
+    // block is a long chain of dependent steps, so how many of them a CU holds is the throughput.
+    extern __shared__ uint32_t cafe_bits[];
+    uint32_t* const vis = cafe_bits;
+    uint32_t* const excl = cafe_bits + bit_words;
     __shared__ int counts[CAFE_MAX_NODES];
     __shared__ uint64_t red2[2][4];
     __shared__ long long pt_base[CAFE_PCHUNK];  // parent table (see the node loop)
@@ -587,7 +591,8 @@ extern "C" int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* n
     if (bit_words > CAFE_BIT_WORDS || max_nodes_per_task > CAFE_MAX_NODES) return HW_ERR_UNSUPPORTED;
     if (n_tasks == 0) return HW_OK;
     HW_CLEAR_ERR();
-    hipLaunchKernelGGL(cafe_execute_kernel, dim3((unsigned)n_tasks), dim3(256), 0, (hipStream_t)stream, *graph, nodes,
+    const size_t bits_bytes = 2 * (size_t)bit_words * sizeof(uint32_t);  // <= 64 KB (bit_words <= CAFE_BIT_WORDS)
+    hipLaunchKernelGGL(cafe_execute_kernel, dim3((unsigned)n_tasks), dim3(256), bits_bytes, (hipStream_t)stream, *graph, nodes,
                        node_ptr, users, logprobs, logprob_ld, excluded_init, bit_words, grow_excluded, out_ids, out_vals,
                        out_count, slot_ptr);
     return HW_LAUNCH_RC();
