@@ -118,13 +118,15 @@ __device__ __forceinline__ float pf_elu(float x) {
 // register file has room for it (432 of 512 taken: none of the trim kernels fits; 376 taken: they do -- the three-stream search
 // went from 4.25 to 3.9 ms with nothing else changed, profiles/r5/policy_kernel_experiments_r5.txt).  Hence:
 //   * the weight chunks travel global -> LDS directly (global_load_lds_dwordx4: no vector registers, no ds_write pass);
-//   * ONE gather buffer; the gathers of chunk c + 2 are issued in the middle of trip c, right behind the last piece of chunk
-//     c + 1's operand preparation (which empties the buffer).
+//   * ONE gather buffer, refilled in halves: the gathers of chunk c + 2's half t are issued in trip c right behind piece t of
+//     chunk c + 1's operand preparation (which empties that half).
 // Rules followed for the DMA (cdna_hip_programming.md 5, 'Pipelining across barriers'): the LDS image is lane-linear per wave
 // instruction; no __syncthreads() while a DMA is in flight (it would wait vmcnt(0)) -- a counted s_waitcnt vmcnt(N) that
-// leaves the younger gathers in flight, lgkmcnt(0), raw s_barrier; the DMAs are issued BEFORE the gathers of the same trip,
-// so that the vmcnt(0) hipcc puts in front of the gathers' first use never waits for a DMA younger than them.
-// tools/pf_abl/policy_pipe.hip keeps the other forms tried (three stages, sixteen one-tile steps per trip) behind flags.
+// leaves the younger gathers in flight, lgkmcnt(0), raw s_barrier, all three as builtins the compiler's counter model can
+// see; the DMAs of a trip are issued behind the trip's last use of a gathered register and land by its closing wait, so that
+// no use of a loaded register ever has a DMA pending in front of it (hipcc answers that with vmcnt(0): trip_sync below).
+// tools/pf_abl/policy_pipe.hip keeps the other forms tried (three stages, sixteen one-tile steps per trip, the whole-buffer
+// refill) behind flags.
 
 template <int NPARTS, int MODE>
 __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, const float* __restrict__ b1, int H1,
@@ -207,16 +209,23 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 
     // end of a trip: the DMAs of this trip have landed (counted wait: the N younger vector loads -- this trip's gathers -- stay
     // in flight), this wave's own LDS reads are done, then the block meets.
+    // The wait is a builtin, not inline assembly, so that hipcc's own counter model sees it: an LDS DMA the compiler believes
+    // pending makes it force vmcnt(0) at the next use of ANY loaded register (its "pending flat" rule -- a DMA counts on both
+    // the vector-memory and the LDS counter), which is how the first form of this loop came to wait for all sixteen gathers of
+    // a chunk a few MFMAs into the trip that uses them.  With the wait visible the uses get counted waits (vmcnt(14) .. (8)).
     auto trip_sync = [&](auto n_younger) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(decltype(n_younger)::value) : "memory");
+        constexpr int n = decltype(n_younger)::value;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (0 << 8) | ((n >> 4) << 14));  // vmcnt(n) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
 
     // ---- x1 chunk of this lane: 16 values k = 32 c + 16 g + 0..15, as gathered sums (before ELU) ----
     // One gather buffer and two operand sets: while the matrix pipe works on chunk c, the same wave turns the gathered rows of
     // chunk c + 1 into MFMA operands (ELU, dropout, split: ~600 vector instructions against 96 MFMAs of 32 cycles -- with one
-    // wave per SIMD nothing else can fill the MFMA shadow); the gathers of chunk c + 2 are issued in the MIDDLE of trip c, as
-    // soon as that preparation has emptied the buffer, and have the second half of the trip plus the first quarter of the next
-    // one (~3 000 cycles) to arrive.
+    // wave per SIMD nothing else can fill the MFMA shadow); the gathers of chunk c + 2 are issued in trip c, half by half, as
+    // soon as that preparation has emptied a half (x_fetch_half below).
     f32x4 xs[NPARTS][4];
     f32x4 xm[4];  // explicit mask (mode 1)
 #pragma unroll
@@ -230,6 +239,21 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         if constexpr (MODE == 1)
 #pragma unroll
             for (int i = 0; i < 4; ++i) mq[i] = *reinterpret_cast<const f32x4*>(dr.mask1 + (size_t)rowc * H1 + k0 + 4 * i);
+    };
+    // the buffer is refilled in halves: the eight values k-step t reads are free as soon as piece t has been prepared, so the
+    // gathers of chunk c + 2's half t go out right there -- 72 (first half: the trip's closing wait is for a DMA younger than
+    // it) and ~94 (second half) MFMAs before their use, against ~45 for sixteen loads issued behind piece 1 (2.60 -> 2.43 ms on
+    // 1 M rows, bit-identical; tools/pf_abl PF_HALFX)
+    auto x_fetch_half = [&](int c, int h, f32x4 (&xq)[NPARTS][4], f32x4 (&mq)[4]) {
+        const int k0 = PF_KC * c + 16 * g;
+#pragma unroll
+        for (int q = 0; q < NPARTS; ++q)
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i) xq[q][i] = *reinterpret_cast<const f32x4*>(src[q] + k0 + 4 * i);
+        if constexpr (MODE == 1)
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i)
+                mq[i] = *reinterpret_cast<const f32x4*>(dr.mask1 + (size_t)rowc * H1 + k0 + 4 * i);
     };
     uint32_t pw[4] = {0u, 0u, 0u, 0u};
     pf_bf16x8 xb[2][2][3];  // B operands: [set][k-step][plane]
@@ -316,25 +340,29 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
             // block, i.e. in front of the MFMAs): the last trips re-read the last chunk and throw the result away
             const int c2 = c + 2 < n2 ? c + 2 : n2 - 1, c1 = c + 1 < n2 ? c + 1 : n2 - 1;
             {
-                // ONE scheduling region per trip, in the order wanted: the operand preparation of chunk c + 1 between the first
-                // MFMA groups, then the DMAs of weight chunk c + 1 (the other stage: every wave left it at the barrier that
-                // ended the previous trip) and the gathers of chunk c + 2 under the remaining groups.  The compiler's own
-                // order inside the region is kept: sched_group_barrier patterns measured slower (2.82 vs 2.51 ms).
+                // The order wanted, pinned by scheduling barriers where a load would overwrite what a piece still reads: piece
+                // t of chunk c + 1's operand preparation behind MFMA group t, the gathers of chunk c + 2's half t right behind
+                // it, the DMAs of weight chunk c + 1 (the other stage: every wave left it at the barrier that ended the previous
+                // trip) behind piece 1 -- behind the LAST read of a gathered register in the trip: a use behind a pending DMA
+                // would be a vmcnt(0) (see trip_sync) -- and older than the second half's gathers, which stay in flight across
+                // the closing wait.  Inside a region the compiler's own order is kept: sched_group_barrier patterns measured
+                // slower (2.82 vs 2.51 ms).
                 const uint8_t* st = lds + (u & 1) * PF_CHUNK;
                 const uint32_t keep = x_keep(c1, (u + 1) & 3);
                 mma_group(st, acc2, xb[u & 1], 0, 0);
                 x_piece(c1, 0, keep, xs, xm, xb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                x_fetch_half(c2, 0, xs, xm);
                 mma_group(st, acc2, xb[u & 1], 0, 1);
                 x_piece(c1, 1, keep, xs, xm, xb[(u + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);  // the gathers below overwrite what the two pieces above read
-                w_glds(c + 1);  // chunk n2 is the first actor chunk: always exists; before the gathers: older than them on
-                                // the vector-memory counter
-                x_fetch(c2, xs, xm);
+                __builtin_amdgcn_sched_barrier(0);
+                w_glds(c + 1);  // chunk n2 is the first actor chunk: always exists
+                x_fetch_half(c2, 1, xs, xm);
                 mma_group(st, acc2, xb[u & 1], 1, 0);
                 mma_group(st, acc2, xb[u & 1], 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
-            trip_sync(std::integral_constant<int, NPARTS * 4 + (MODE == 1 ? 4 : 0)>{});
+            trip_sync(std::integral_constant<int, NPARTS * 2 + (MODE == 1 ? 2 : 0)>{});
         }
     }
 

@@ -118,6 +118,9 @@ __device__ __forceinline__ float pf_elu(float x) {
     return x > 0.f ? x : u;
 }
 
+#ifndef PF_DMA_AUX  // cache policy bits of the weight DMAs (gfx940 family: 1 = sc0, 2 = nt, 16 = sc1)
+#define PF_DMA_AUX 0
+#endif
 #ifndef PF_INTERLEAVE
 #define PF_INTERLEAVE 1
 #endif
@@ -234,6 +237,25 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #pragma unroll
     for (int q = 0; q < NPARTS; ++q) src[q] = tb.zero;
 #endif
+#ifdef PF_ABL_CUR_L1  // timing experiments: which of the gathered parts costs what the all-L1 form saves
+    src[1] = tb.zero;
+#endif
+#ifdef PF_ABL_CUR_L2  // the current node's row from a 512 KB window of its table: distinct rows per lane, L2-resident
+    src[1] = tb.cur_e + (size_t)(rowc & 255) * H1;
+#endif
+#ifdef PF_ABL_USER_L1
+    src[0] = tb.zero;
+#endif
+#ifdef PF_ABL_LAST_L1
+    if constexpr (NPARTS > 2) src[2] = tb.zero;
+#endif
+#ifdef PF_ABL_REL_L1
+    if constexpr (NPARTS > 2) src[3] = tb.zero;
+#endif
+#ifdef PF_ABL_SHARED_L1  // the parts siblings share (user, last node, last relation) from one row
+    src[0] = tb.zero;
+    if constexpr (NPARTS > 2) src[2] = tb.zero, src[3] = tb.zero;
+#endif
     // ---- weight chunk pipeline: global -> registers -> LDS stage (q & 1) ----
 #if PF_GLDS
     const int wave_u = wave_in_block();  // wave-uniform for the compiler too: the DMA's LDS base travels in M0
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         uint8_t* dst = lds + (q % PF_STAGES) * PF_CHUNK + wave_u * 1024;
 #pragma unroll
         for (int i = 0; i < 12; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t*)(src + 4096 * i), (lptr_t*)(dst + 4096 * i), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t*)(src + 4096 * i), (lptr_t*)(dst + 4096 * i), 16, 0, PF_DMA_AUX);
     };
     auto w_fetch = [&](int) {};
     auto w_put = [&](int) {};
@@ -277,7 +299,15 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
 #ifdef PF_ABL_NO_SYNC
         return;
 #endif
-#if PF_GLDS
+#if PF_GLDS && defined(PF_BWAIT)
+        // the wait as an instruction the compiler can see (hipcc's counter model reads pre-existing s_waitcnt): an LDS DMA it
+        // believes pending makes it force vmcnt(0) at the next use of ANY loaded register ("pending flat" rule)
+        constexpr int n = decltype(n_younger)::value;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (0 << 8) | ((n >> 4) << 14));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#elif PF_GLDS
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(decltype(n_younger)::value) : "memory");
 #else
         __syncthreads();
@@ -288,6 +318,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     // Two gather buffers and two operand sets: while the matrix pipe works on chunk c, the same wave turns the gathered rows
     // of chunk c + 1 into MFMA operands (ELU, dropout, split: ~600 vector instructions against 96 MFMAs of 32 cycles -- with
     // one wave per SIMD nothing else can fill the MFMA shadow) and the gathers of chunk c + 2 are in flight.
+#ifndef PF_HALFX
+#define PF_HALFX 0
+#endif
 #ifndef PF_SINGLE_X
 #define PF_SINGLE_X 0
 #endif
@@ -320,6 +353,24 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         if constexpr (MODE == 1)
 #pragma unroll
             for (int i = 0; i < 4; ++i) mq[i] = *reinterpret_cast<const f32x4*>(dr.mask1 + (size_t)rowc * H1 + k0 + 4 * i);
+    };
+    // PF_HALFX: the gather buffer refilled in halves -- the eight values k-step t of the next chunk reads are free as soon as
+    // piece t has been prepared, so the gathers of chunk c + 2's half t are issued right there, a WHOLE trip before their use
+    // (the one-piece form issues all sixteen loads after piece 1 and the compiler wants them back ~15 MFMAs into the next trip:
+    // ~50 MFMAs = 0.7 us of cover, less than a loaded L2 round trip)
+    auto x_fetch_half = [&](int c, int h, f32x4 (&xq)[NPARTS][4], f32x4 (&mq)[4]) {
+#ifdef PF_ABL_NO_X
+        return;
+#endif
+        const int k0 = PF_KC * c + 16 * g;
+#pragma unroll
+        for (int q = 0; q < NPARTS; ++q)
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i) xq[q][i] = *reinterpret_cast<const f32x4*>(src[q] + k0 + 4 * i);
+        if constexpr (MODE == 1)
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i)
+                mq[i] = *reinterpret_cast<const f32x4*>(dr.mask1 + (size_t)rowc * H1 + k0 + 4 * i);
     };
     uint32_t pw[4] = {0u, 0u, 0u, 0u};
     pf_bf16x8 xb[2][2][3];  // B operands: [set][k-step][plane]
@@ -525,6 +576,51 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
                 // The compiler's own order inside the region is kept: sched_group_barrier patterns measured slower (2.82 vs 2.51 ms).
                 const uint8_t* st = lds + (PF_STAGES == 3 ? c % 3 : (u & 1)) * PF_CHUNK;
                 const uint32_t keep = x_keep(c1, (u + 1) & 3);
+#if PF_HALFX
+                // The DMAs stay behind the last LDS read of the biases in the trip: hipcc makes every LDS load that carries a
+                // memory operand wait for ALL pending LDS DMAs (it cannot tell the stages from the bias rows), so a DMA issued
+                // at the top of the trip was waited for, vmcnt(0), at the first bias read.
+#if PF_HALFX == 2
+                // both halves of chunk c + 1 waited for HERE, by an instruction the compiler sees: no use of a gathered register
+                // is left behind the DMA below (a use behind a pending LDS DMA is forced to vmcnt(0)), so the DMA can go out a
+                // quarter of a trip in: it gets 72 MFMAs to land, each half 72 (second) or 96 (first)
+                mma_group(st, acc2, xb[u & 1], 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));  // vmcnt(0)
+                x_piece(c1, 0, keep, xs[0], xm[0], xb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                w_glds(c + 1);
+                x_fetch_half(c2, 0, xs[0], xm[0]);
+                mma_group(st, acc2, xb[u & 1], 0, 1);
+                x_piece(c1, 1, keep, xs[0], xm[0], xb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                x_fetch_half(c2, 1, xs[0], xm[0]);
+                mma_group(st, acc2, xb[u & 1], 1, 0);
+                mma_group(st, acc2, xb[u & 1], 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            trip_sync(std::integral_constant<int, NPARTS * 4 + (MODE == 1 ? 4 : 0)>{});
+#else
+                mma_group(st, acc2, xb[u & 1], 0, 0);
+                x_piece(c1, 0, keep, xs[0], xm[0], xb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);  // the gathers below overwrite what the piece above read
+                x_fetch_half(c2, 0, xs[0], xm[0]);
+                mma_group(st, acc2, xb[u & 1], 0, 1);
+                x_piece(c1, 1, keep, xs[0], xm[0], xb[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                w_glds(c + 1);
+                x_fetch_half(c2, 1, xs[0], xm[0]);
+                mma_group(st, acc2, xb[u & 1], 1, 0);
+                mma_group(st, acc2, xb[u & 1], 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            trip_sync(std::integral_constant<int, NPARTS * 2 + (MODE == 1 ? 2 : 0)>{});
+#endif
+            continue;
+            {
+                const uint8_t* st = lds;
+                const uint32_t keep = 0;
+#endif
                 mma_group(st, acc2, xb[u & 1], 0, 0);
                 w_fetch(c + 1);  // chunk n2 is the first actor chunk: always exists
 #if PF_SINGLE_X
