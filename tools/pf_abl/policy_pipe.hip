@@ -1,6 +1,9 @@
 // EXPERIMENT (round 5), not part of the product build: the forms of the policy kernel's main loop behind flags.  The default
-// (PF_GLDS: weight chunks by global_load_lds DMA with counted vmcnt + raw s_barrier, one gather buffer) IS the product kernel
-// (csrc/pgpr_policy.hip carries it with the switches resolved); -DPF_GLDS=0 is the round-4 form (weights staged through 48
+// (PF_GLDS: weight chunks by global_load_lds DMA with counted vmcnt + raw s_barrier, one gather buffer) was the product kernel
+// of the first half of round 5; -DPF_HALFX=1 -DPF_BWAIT (gather buffer refilled in halves, the closing wait as builtins the
+// compiler's counter model sees) IS the product kernel now (csrc/pgpr_policy.hip carries it with the switches resolved);
+// PF_HALFX=2, PF_DMA_AUX, PF_ASMDMA (+ PF_NSTAGE=3) are the forms tried on top of it without gain
+// (profiles/r5/policy_kernel_experiments_r5b.txt); -DPF_GLDS=0 is the round-4 form (weights staged through 48
 // registers, two gather buffers), PF_SINGLE_X its one-buffer variant, PF_NSTAGE=3 DMAs two chunks ahead, PF_PIPE sixteen
 // one-tile steps per trip with the fragments of the next step read a step ahead and the operand preparation in two-value
 // slices; the PF_ABL_* switches take parts of the work out for timing.  Every form computes the same bits.  On 1 M synthetic
@@ -118,6 +121,9 @@ __device__ __forceinline__ float pf_elu(float x) {
     return x > 0.f ? x : u;
 }
 
+#ifndef PF_HALFX
+#define PF_HALFX 0
+#endif
 #ifndef PF_DMA_AUX  // cache policy bits of the weight DMAs (gfx940 family: 1 = sc0, 2 = nt, 16 = sc1)
 #define PF_DMA_AUX 0
 #endif
@@ -175,6 +181,9 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     // a whole trip earlier -- nobody waits for memory there; 3 x 48 KB + biases = 149 KB of the CU's 160
     constexpr int PF_STAGES = PF_NSTAGE;
     static_assert(PF_STAGES == 2 || (PF_STAGES == 3 && PF_GLDS && !PF_PIPE), "three stages: the DMA form of the grouped trip");
+#if defined(PF_ASMDMA)
+    static_assert(PF_HALFX == 1 && PF_GLDS, "the invisible DMAs belong to the half-refill trip");
+#endif
     // ONE __shared__ object: a second one beside an array that direct-to-LDS loads write makes hipcc wait vmcnt(0) before the
     // first ds_read of every k-step (cdna_hip_programming.md, 'Projection GEMM at M = 256' item 4(a))
     __shared__ __attribute__((aligned(16))) uint8_t lds[PF_STAGES * PF_CHUNK + (1024 + PF_H2) * 4];
@@ -267,9 +276,23 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
         typedef __attribute__((address_space(3))) void lptr_t;
         const uint8_t* src = planes + (size_t)q * PF_CHUNK + (size_t)tid * 16;
         uint8_t* dst = lds + (q % PF_STAGES) * PF_CHUNK + wave_u * 1024;
+#ifdef PF_ASMDMA
+        // the DMAs as inline assembly: the compiler's counter model does not see them, so a use of a gathered register with a
+        // DMA in flight gets a counted wait instead of the forced vmcnt(0).  Safe: an operation the model does not know only
+        // ADDS to the outstanding count, so every wait the compiler computes waits for at least what it meant to; the DMAs'
+        // own completion is waited for by the explicit counted waits of the loop (and, in order, by the waits for younger
+        // gathers).
+        const uint32_t dst_u = (uint32_t)(uintptr_t)dst;
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst_u + 4096u * i),
+                         "v"(src + 4096 * i)
+                         : "memory", "m0");
+#else
 #pragma unroll
         for (int i = 0; i < 12; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t*)(src + 4096 * i), (lptr_t*)(dst + 4096 * i), 16, 0, PF_DMA_AUX);
+#endif
     };
     auto w_fetch = [&](int) {};
     auto w_put = [&](int) {};
@@ -318,9 +341,6 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
     // Two gather buffers and two operand sets: while the matrix pipe works on chunk c, the same wave turns the gathered rows
     // of chunk c + 1 into MFMA operands (ELU, dropout, split: ~600 vector instructions against 96 MFMAs of 32 cycles -- with
     // one wave per SIMD nothing else can fill the MFMA shadow) and the gathers of chunk c + 2 are in flight.
-#ifndef PF_HALFX
-#define PF_HALFX 0
-#endif
 #ifndef PF_SINGLE_X
 #define PF_SINGLE_X 0
 #endif
@@ -608,13 +628,20 @@ __global__ __launch_bounds__(256, 1) void pgpr_policy_fused_kernel(PfTables tb, 
                 mma_group(st, acc2, xb[u & 1], 0, 1);
                 x_piece(c1, 1, keep, xs[0], xm[0], xb[(u + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                w_glds(c + 1);
+                w_glds(c + PF_STAGES - 1);
                 x_fetch_half(c2, 1, xs[0], xm[0]);
                 mma_group(st, acc2, xb[u & 1], 1, 0);
                 mma_group(st, acc2, xb[u & 1], 1, 1);
             }
             __builtin_amdgcn_sched_barrier(0);
+#if defined(PF_ASMDMA) && PF_NSTAGE == 3
+            // three stages, DMAs two chunks ahead and invisible to the compiler: the DMA of chunk c + 1 (issued in trip c - 1)
+            // is older than the second half of chunk c + 1's gathers, whose use in THIS trip has already waited it out (vector
+            // memory returns in order) -- nothing to wait for here but the wave's own LDS reads
+            trip_sync(std::integral_constant<int, 63>{});
+#else
             trip_sync(std::integral_constant<int, NPARTS * 2 + (MODE == 1 ? 2 : 0)>{});
+#endif
 #endif
             continue;
             {
