@@ -84,7 +84,7 @@ def parse_args(argv=None):
     ap.add_argument("--pgpr-streams", type=int, default=3,
                     help="HIP streams the timed PGPR searches (independent user batches) are dealt over")
     ap.add_argument("--cafe-users", type=int, default=1024, help="users per CAFE run_program call")
-    ap.add_argument("--cafe-streams", type=int, default=3, help="HIP streams the timed CAFE calls are dealt over")
+    ap.add_argument("--cafe-streams", type=int, default=2, help="HIP streams the timed CAFE calls are dealt over")
     ap.add_argument("--sharded-steps", type=int, default=10)
     ap.add_argument("--sharded-batch", type=int, default=8192, help="rec positives and kg triples per rank per step")
     ap.add_argument("--sharded-deadline", type=float, default=300.0,

@@ -462,6 +462,17 @@ SIGNATURES = {
         [C.POINTER(PgprGraph), C.c_void_p, c_i32p, c_i64p, C.c_int64, C.c_int32, c_f32p, C.c_int64, C.c_void_p,
          C.c_int64, C.c_int32, c_i32p, c_f32p, c_i32p, c_i64p, C.c_void_p],
     ),
+    "hw_cafe_execute_logits": (
+        C.c_int,
+        [C.POINTER(PgprGraph), C.c_void_p, c_i32p, c_i64p, C.c_int64, C.c_int32, c_f32p, C.c_int64, c_f32p, C.c_void_p,
+         C.c_int64, C.c_int32, c_i32p, c_f32p, c_i32p, c_i64p, C.c_void_p],
+    ),
+    "hw_gemm_f32_lse": (
+        C.c_int,
+        [c_f32p, C.c_int64, c_f32p, C.c_int64, c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, c_f32p, c_f32p,
+         C.c_int64, C.c_void_p],
+    ),
+    "hw_lse_rows": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_void_p]),
     "hw_version": (C.c_char_p, []),
 }
 

@@ -8,6 +8,7 @@
 // One workgroup interprets one user's whole program; the sequential dependence (visited / excluded sets grow while
 // parent paths are consumed in order) stays inside the workgroup, users run in parallel.
 #include "hw_common.h"
+#include "rank_epilogue.h"
 
 namespace hw {
 
@@ -190,7 +191,7 @@ constexpr int CAFE_PCHUNK = 128;  // parent paths whose adjacency bounds are loo
 
 __global__ __launch_bounds__(256) void cafe_execute_kernel(
     hw_pgpr_graph g, const hw_cafe_node* __restrict__ nodes, const int32_t* __restrict__ node_ptr,
-    const int64_t* __restrict__ users, const float* __restrict__ logprobs, int64_t lp_ld,
+    const int64_t* __restrict__ users, const float* __restrict__ logprobs, int64_t lp_ld, const float* __restrict__ row_lse,
     const uint32_t* __restrict__ excluded_init, int64_t bit_words, int grow_excluded,
     int32_t* __restrict__ out_ids, float* __restrict__ out_vals, int32_t* __restrict__ out_count,
     const int64_t* __restrict__ slot_ptr) {
@@ -225,6 +226,10 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
         int32_t* c_ids = out_ids + (slot0 + nd.slot_off) * 3;
         float* c_vals = out_vals + (slot0 + nd.slot_off) * 3;
         const float* __restrict__ lp = logprobs + (size_t)nd.lp_row * lp_ld;
+        // row_lse: `logprobs` holds the LOGITS and row r's log-softmax is (x - row_lse[2 r]) - row_lse[2 r + 1] (its maximum and
+        // the log of its sum of exponentials, hw_lse_rows): the row pass that rewrote the matrix, taken at the few entries read
+        const float lp_max = row_lse ? row_lse[2 * (size_t)nd.lp_row] : 0.f;
+        const float lp_ls = row_lse ? row_lse[2 * (size_t)nd.lp_row + 1] : 0.f;
         int n_out = 0;
         int pfx_id[2] = {0, 0};  // this parent path's ids / values (depth - 1 <= 2 of them)
         float pfx_v[2] = {0.f, 0.f};
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
                 if (id < 0 || id >= nd.vocab) return 0ull;
                 if ((vis[id >> 5] >> (id & 31)) & 1u) return 0ull;
                 if (nd.is_leaf && ((excl[id >> 5] >> (id & 31)) & 1u)) return 0ull;
-                return lp_key(lp[id], (uint32_t)id);
+                return lp_key(row_lse ? (lp[id] - lp_max) - lp_ls : lp[id], (uint32_t)id);
             };
             // this thread's first four slots are gathered ONCE and kept for all rounds (segments of up to 1 024 edges: almost
             // all of them); the rounds used to gather every slot again, k times per parent path
@@ -346,9 +351,35 @@ __global__ __launch_bounds__(256) void cafe_execute_kernel(
     }
 }
 
+// Row r's (maximum, log sum exp(x - maximum)) from the per-stretch pairs hw_gemm_f32_lse left: one wave per row.
+__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ tile_max, const float* __restrict__ tile_sum,
+                                                       int64_t tile_ld, int64_t n_rows, int n_stretches,
+                                                       float* __restrict__ row_lse) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int lane = threadIdx.x & 63;
+    float m = -INFINITY, s = 0.f;
+    for (int t = lane; t < n_stretches; t += 64)
+        lse_merge(m, s, tile_max[(size_t)row * tile_ld + t], tile_sum[(size_t)row * tile_ld + t]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lse_merge(m, s, __shfl_xor(m, d, 64), __shfl_xor(s, d, 64));
+    if (lane == 0) row_lse[2 * row] = m, row_lse[2 * row + 1] = logf(s);
+}
+
 }  // namespace hw
 
 using namespace hw;
+
+extern "C" int hw_lse_rows(const float* tile_max, const float* tile_sum, int64_t tile_ld, int64_t n_rows, int64_t n_stretches,
+                           float* row_lse, void* stream) {
+    if (!tile_max || !tile_sum || !row_lse || n_rows < 0 || n_stretches < 1 || tile_ld < n_stretches || n_stretches > INT32_MAX)
+        return HW_ERR_INVALID_ARG;
+    if (n_rows == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    hipLaunchKernelGGL(lse_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, tile_max, tile_sum,
+                       tile_ld, n_rows, (int)n_stretches, row_lse);
+    return HW_LAUNCH_RC();
+}
 
 extern "C" int hw_log_softmax_rows(const float* x, int64_t ld, int64_t n_rows, int64_t n_cols, float* y, int64_t ldy,
                                    void* stream) {
@@ -579,11 +610,11 @@ extern "C" int hw_cafe_collect(const hw_cafe_node* nodes, const int32_t* node_pt
     return HW_LAUNCH_RC();
 }
 
-extern "C" int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
-                               const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task,
-                               const float* logprobs, int64_t logprob_ld, const uint32_t* excluded_init,
-                               int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
-                               int32_t* out_count, const int64_t* slot_ptr, void* stream) {
+static int cafe_execute_go(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
+                           const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task, const float* logprobs,
+                           int64_t logprob_ld, const float* row_lse, const uint32_t* excluded_init, int64_t bit_words,
+                           int32_t grow_excluded, int32_t* out_ids, float* out_vals, int32_t* out_count,
+                           const int64_t* slot_ptr, void* stream) {
     if (!graph || !graph->ptr || !graph->rel || !graph->dst || !nodes || !node_ptr || !users || !logprobs ||
         !excluded_init || !out_ids || !out_vals || !out_count || !slot_ptr)
         return HW_ERR_INVALID_ARG;
@@ -593,7 +624,28 @@ extern "C" int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* n
     HW_CLEAR_ERR();
     const size_t bits_bytes = 2 * (size_t)bit_words * sizeof(uint32_t);  // <= 64 KB (bit_words <= CAFE_BIT_WORDS)
     hipLaunchKernelGGL(cafe_execute_kernel, dim3((unsigned)n_tasks), dim3(256), bits_bytes, (hipStream_t)stream, *graph, nodes,
-                       node_ptr, users, logprobs, logprob_ld, excluded_init, bit_words, grow_excluded, out_ids, out_vals,
-                       out_count, slot_ptr);
+                       node_ptr, users, logprobs, logprob_ld, row_lse, excluded_init, bit_words, grow_excluded, out_ids,
+                       out_vals, out_count, slot_ptr);
     return HW_LAUNCH_RC();
+}
+
+extern "C" int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
+                               const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task,
+                               const float* logprobs, int64_t logprob_ld, const uint32_t* excluded_init,
+                               int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
+                               int32_t* out_count, const int64_t* slot_ptr, void* stream) {
+    return cafe_execute_go(graph, nodes, node_ptr, users, n_tasks, max_nodes_per_task, logprobs, logprob_ld, nullptr,
+                           excluded_init, bit_words, grow_excluded, out_ids, out_vals, out_count, slot_ptr, stream);
+}
+
+// hw_cafe_execute over LOGITS: `logits` is the product's output as it stands and row_lse [rows, 2] (hw_lse_rows) what turns an
+// entry into its log-probability where the interpreter reads one.
+extern "C" int hw_cafe_execute_logits(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
+                                      const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task, const float* logits,
+                                      int64_t logit_ld, const float* row_lse, const uint32_t* excluded_init,
+                                      int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
+                                      int32_t* out_count, const int64_t* slot_ptr, void* stream) {
+    if (!row_lse) return HW_ERR_INVALID_ARG;
+    return cafe_execute_go(graph, nodes, node_ptr, users, n_tasks, max_nodes_per_task, logits, logit_ld, row_lse,
+                           excluded_init, bit_words, grow_excluded, out_ids, out_vals, out_count, slot_ptr, stream);
 }

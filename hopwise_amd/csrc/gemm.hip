@@ -231,6 +231,9 @@ struct GemmBce {
     int64_t rank_mask_ld;
     float* rank_tile_max;
     int64_t rank_tile_ld;
+    //   rank_tile_sum  (with rank_tile_max) sum over the stretch of exp(x - that maximum): the pieces of the row's log-sum-exp
+    //                  (hw_gemm_f32_lse + hw_lse_rows: a vocabulary log-softmax without a pass over the logits)
+    float* rank_tile_sum;
 };
 
 // Epilogue: one wave's 32-row x 64-column slab (accumulator tiles [ti][0], [ti][1]) leaves through a wave-private 8 KB LDS
@@ -673,7 +676,24 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void gemm_f32_kernel(const floa
                     rmax[rg] = fmaxf(rmax[rg], gn < N ? x : -INFINITY);
                 }
             }
-            if (bce.rank_tile_max && n0 + wn < N) {  // a stretch that starts inside the row
+            if (bce.rank_tile_sum && n0 + wn < N) {  // (max, sum exp) of the stretch: the lane's two columns first
+                float rsum[16];
+                const bool in0 = n0 + wn + (lane & 31) < N, in1 = n0 + wn + 32 + (lane & 31) < N;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const float x0 = in0 ? v[0][rg] : -INFINITY, x1 = in1 ? v[1][rg] : -INFINITY;
+                    // exp(larger - max) = 1, exp(smaller - max) = exp(-|x0 - x1|); a lone column: exp(-inf) = 0; none: 0
+                    rsum[rg] = rmax[rg] == -INFINITY ? 0.f : 1.f + (x0 == x1 ? 1.f : __expf(-fabsf(x0 - x1)));
+                }
+                int rg;
+                float mx, sm;
+                half_wave_row_lse(rmax, rsum, lane, rg, mx, sm);  // rank_epilogue.h
+                const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
+                if ((lane & 1) == 0 && gm < M) {
+                    const size_t at = (size_t)gm * bce.rank_tile_ld + ((n0 + wn) >> 6);
+                    bce.rank_tile_max[at] = mx, bce.rank_tile_sum[at] = sm;
+                }
+            } else if (bce.rank_tile_max && n0 + wn < N) {  // a stretch that starts inside the row
                 int rg;
                 const float mx = half_wave_row_max(rmax, lane, rg);  // rank_epilogue.h
                 const int gm = gm0 + (rg & 3) + 8 * (rg >> 2) + 4 * g5;
@@ -1477,6 +1497,26 @@ extern "C" int hw_gemm_f32_masked(const float* q, int64_t ldq, const float* t, i
     HW_CLEAR_ERR();
     GemmBce rk{};
     rk.rank_mask = mask_bits, rk.rank_mask_ld = mask_ld, rk.rank_tile_max = tile_max, rk.rank_tile_ld = tile_ld;
+    const int rc = launch_gemm(q, ldq, true, t, ldt, true, c, ldc, nullptr, m, n, k, bias, 6, nullptr, 0, 0, 0, nullptr, 0,
+                               (hipStream_t)stream, rk);
+    if (rc != HW_OK) return rc;
+    return HW_LAUNCH_RC();
+}
+
+// c = q . t^T (+ bias) with fp32-level error, and per 64-column stretch of every row the pair (maximum, sum of exp(x - maximum))
+// in tile_max / tile_sum [m, tile_ld]: hw_lse_rows turns them into the row's (maximum, log sum exp) -- a log-softmax over the
+// whole row is then (x - maximum) - log sum exp wherever a consumer reads x, and the pass that rewrote the matrix is gone.
+extern "C" int hw_gemm_f32_lse(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c,
+                               int64_t ldc, int64_t m, int64_t n, int64_t k, float* tile_max, float* tile_sum, int64_t tile_ld,
+                               void* stream) {
+    if (!q || !t || !c || !tile_max || !tile_sum || m < 0 || n < 1 || k < 4 || ldc < n || ldq < k || ldt < k)
+        return HW_ERR_INVALID_ARG;
+    if (m > INT32_MAX || n > INT32_MAX || k > INT32_MAX || tile_ld < (n + 63) / 64) return HW_ERR_INVALID_ARG;
+    if (!aligned16(q, ldq) || !aligned16(t, ldt)) return HW_ERR_UNSUPPORTED;  // the split loop's operands
+    if (m == 0) return HW_OK;
+    HW_CLEAR_ERR();
+    GemmBce rk{};
+    rk.rank_tile_max = tile_max, rk.rank_tile_sum = tile_sum, rk.rank_tile_ld = tile_ld;
     const int rc = launch_gemm(q, ldq, true, t, ldt, true, c, ldc, nullptr, m, n, k, bias, 6, nullptr, 0, 0, 0, nullptr, 0,
                                (hipStream_t)stream, rk);
     if (rc != HW_OK) return rc;

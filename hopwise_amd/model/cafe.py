@@ -196,6 +196,9 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         self.topk_candidates = config["topk_candidates"]
         self.sample_size = config["sample_size"]
         self.topk_paths = config["topk_paths"]
+        # the vocabulary log-softmax of run_program from the logits product's epilogue (ops.gemm_lse) instead of a row pass over
+        # the [nodes, vocabulary] matrix; HW_CAFE_FUSED_LSE=0: product + hw_log_softmax_rows (equal to fp32 rounding)
+        self.fused_lse = os.environ.get("HW_CAFE_FUSED_LSE", "1") != "0"
         self.ui_relation = dataset.ui_relation
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         ue = np.asarray(dataset.get_preload_weight("user_embedding_id"))
@@ -475,21 +478,33 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
                 uv = user_vec.index_select(0, uv_all[o : o + n])
                 vec_all.index_copy_(0, row_all[o : o + n], mods[j]((eh, uv)).view(n, -1))
         # 2) log-probabilities of every node over its tail vocabulary: one GEMM per entity type + row log_softmax
+        # rows at a 16-byte pitch: a vocabulary of 13 805 entities makes every second row of a contiguous matrix start off a
+        # 16-byte boundary, and the product that writes it falls back to 4-byte stores (526 against 334 us for the 13 312 x
+        # 13 805 logits of a 1 024-user call, tools/bench_cafe_logits.py); the product writes into lp, the row pass runs in place
         width = max(self.n_users, self.n_entities)
-        lp = torch.empty((max(total, 1), width), dtype=torch.float32, device=dev)
+        lp = ops.padded_rows(max(total, 1), width, dev)
+        row_lse = None
         for et, rs in et_rows:
             rs_dev = take(len(rs))
-            whole = len(rs) == total
-            sc = ops.gemm(vec_all if whole else vec_all.index_select(0, rs_dev), self.embeddings[str(et)])  # [n, d] @ E^T
-            if whole:
-                P.log_softmax_rows(sc, out=lp[:, : self._vocab[str(et)]])
+            vocab = self._vocab[str(et)]
+            if len(rs) == total:
+                # one tail vocabulary for every node (the usual layout): the product leaves each row's (maximum, log sum exp)
+                # beside the logits and the interpreter takes (x - maximum) - log sum exp at the entries it reads -- the row
+                # pass rewrote 735 MB per 1 024 users (0.27 ms of a 1.4 ms call) for the few hundred entries per row read
+                done = ops.gemm_lse(vec_all, self.embeddings[str(et)], out=lp[:, :vocab]) if self.fused_lse else None
+                if done is not None:
+                    row_lse = done[1]
+                else:
+                    sc = ops.gemm(vec_all, self.embeddings[str(et)], out=lp[:, :vocab])  # [n, d] @ E^T
+                    P.log_softmax_rows(sc, out=sc)
             else:
-                lp[rs_dev, : self._vocab[str(et)]] = P.log_softmax_rows(sc)
+                sc = ops.gemm(vec_all.index_select(0, rs_dev), self.embeddings[str(et)], out=ops.padded_rows(len(rs), vocab, dev))
+                lp[rs_dev, :vocab] = P.log_softmax_rows(sc, out=sc)
         # 3) interpret
         excl = self._excluded_bits(users_np, exclude, users_dev)
         ids, vals, counts, nodes_dev, node_ptr_dev, slot_ptr_dev = P.cafe_execute(
             self.graph, nodes, node_ptr, users_dev, lp, excl, grow_excluded, slot_ptr, int(slot_ptr[-1]), keep_tables=True,
-            on_device=(on_dev["nodes"], on_dev["node_ptr"], on_dev["slot_ptr"]))
+            on_device=(on_dev["nodes"], on_dev["node_ptr"], on_dev["slot_ptr"]), row_lse=row_lse)
         if raw:
             return dict(ids=ids, vals=vals, counts=counts, nodes=nodes_dev, node_ptr=node_ptr_dev, slot_ptr=slot_ptr_dev,
                         cap=cap, node_ptr_np=node_ptr, leaf_nodes=on_dev.get("leaf_nodes"))

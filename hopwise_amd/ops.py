@@ -661,6 +661,31 @@ def gemm_rank(q, t, bias=None, out=None, mask=None, tile_max=None, exact=False):
     return out
 
 
+def gemm_lse(q, t, bias=None, out=None, row_lse=None):
+    """(out, row_lse): out[M, N] = q @ t^T + bias with ``gemm``'s values and row_lse[M, 2] = (row maximum, log of the row's sum
+    of exp(x - maximum)) -- ``F.log_softmax(out, 1)[r, j] == (out[r, j] - row_lse[r, 0]) - row_lse[r, 1]`` to fp32 rounding,
+    from the product's epilogue (``hw_gemm_f32_lse`` + ``hw_lse_rows``) instead of a pass over the matrix.  Returns None when the
+    split loop does not apply to the operands (the caller takes ``gemm`` + a row pass)."""
+    lib = _lib.load()
+    q = _unit_rows(_dev(q, torch.float32, "q"))
+    t = _unit_rows(_dev(t, torch.float32, "t"))
+    M, K = q.shape
+    N = t.shape[0]
+    if out is None:
+        out = padded_rows(M, N, q.device)
+    n_st = (N + 63) // 64
+    tiles = torch.empty((2, max(M, 1), n_st), dtype=torch.float32, device=q.device)
+    rc = lib.hw_gemm_f32_lse(_ptr(q), q.stride(0), _ptr(t), t.stride(0), _ptr(bias), _ptr(out), out.stride(0), M, N, K,
+                             _ptr(tiles[0]), _ptr(tiles[1]), n_st, _stream())
+    if rc == -2:  # HW_ERR_UNSUPPORTED: operands the split loop does not take, or HW_GEMM_SPLIT=0
+        return None
+    check(rc, "hw_gemm_f32_lse")
+    if row_lse is None:
+        row_lse = torch.empty((max(M, 1), 2), dtype=torch.float32, device=q.device)
+    check(lib.hw_lse_rows(_ptr(tiles[0]), _ptr(tiles[1]), n_st, M, n_st, _ptr(row_lse), _stream()), "hw_lse_rows")
+    return out, row_lse
+
+
 def rank_planes(x):
     """The (hi, mid) bf16 plane images of an fp32 matrix [rows, K] for ``gemm_rank_planes`` (``hw_rank_planes``): uint8 tensor."""
     lib = _lib.load()

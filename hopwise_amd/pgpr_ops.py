@@ -396,9 +396,10 @@ def _zeros_carved(dev, *specs):
 
 
 def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, grow_excluded, slot_ptr_np, n_slots,
-                 keep_tables=False, on_device=None):
+                 keep_tables=False, on_device=None, row_lse=None):
     """Run the program interpreter.  nodes_np: structured array of CafeNode fields; returns (ids [n_slots, 3] int32,
-    vals [n_slots, 3] float32, counts [n_nodes] int32) on the device."""
+    vals [n_slots, 3] float32, counts [n_nodes] int32) on the device.  ``row_lse`` [rows, 2] (``ops.gemm_lse``): ``logprobs``
+    holds the logits and an entry's log-probability is taken where it is read (``hw_cafe_execute_logits``)."""
     lib = _lib.load()
     dev = users.device
     if on_device is not None:  # (nodes [n, 10] int32, node_ptr int32, slot_ptr int64) already copied by the caller
@@ -410,12 +411,23 @@ def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, g
     ids, vals, counts = _zeros_carved(dev, ((max(n_slots, 1), 3), torch.int32), ((max(n_slots, 1), 3), torch.float32),
                                       ((max(len(nodes_np), 1),), torch.int32))
     max_nodes = int(np.diff(node_ptr_np).max()) if len(node_ptr_np) > 1 else 0
-    check(
-        lib.hw_cafe_execute(C.byref(graph.c), _ptr(nodes), _ptr(node_ptr), _ptr(users), users.numel(), max_nodes,
-                            _ptr(logprobs), logprobs.stride(0), _ptr(excluded_bits), excluded_bits.shape[1],
-                            int(bool(grow_excluded)), _ptr(ids), _ptr(vals), _ptr(counts), _ptr(slot_ptr), _stream()),
-        "hw_cafe_execute",
-    )
+    if row_lse is not None:
+        if row_lse.dim() != 2 or row_lse.shape[1] != 2 or not row_lse.is_contiguous() or row_lse.shape[0] < logprobs.shape[0]:
+            raise ValueError("row_lse: contiguous [rows, 2]")
+        check(
+            lib.hw_cafe_execute_logits(C.byref(graph.c), _ptr(nodes), _ptr(node_ptr), _ptr(users), users.numel(), max_nodes,
+                                       _ptr(logprobs), logprobs.stride(0), _ptr(row_lse), _ptr(excluded_bits),
+                                       excluded_bits.shape[1], int(bool(grow_excluded)), _ptr(ids), _ptr(vals), _ptr(counts),
+                                       _ptr(slot_ptr), _stream()),
+            "hw_cafe_execute_logits",
+        )
+    else:
+        check(
+            lib.hw_cafe_execute(C.byref(graph.c), _ptr(nodes), _ptr(node_ptr), _ptr(users), users.numel(), max_nodes,
+                                _ptr(logprobs), logprobs.stride(0), _ptr(excluded_bits), excluded_bits.shape[1],
+                                int(bool(grow_excluded)), _ptr(ids), _ptr(vals), _ptr(counts), _ptr(slot_ptr), _stream()),
+            "hw_cafe_execute",
+        )
     if keep_tables:
         return ids, vals, counts, nodes, node_ptr, slot_ptr
     return ids, vals, counts

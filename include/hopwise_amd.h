@@ -205,6 +205,17 @@ int hw_gemm_f32_masked(const float* q, int64_t ldq, const float* t, int64_t ldt,
                        int64_t m, int64_t n, int64_t k, const uint32_t* mask_bits, int64_t mask_ld, float* tile_max,
                        int64_t tile_ld, void* stream);
 
+/* hw_gemm_f32's product (q [m, k], t [n, k] row-major, 16-byte aligned rows) that also leaves, per 64-column stretch of every row,
+ * the pair (maximum, sum of exp(x - maximum)) in tile_max / tile_sum [m, tile_ld], tile_ld >= ceil(n / 64).  hw_lse_rows reduces a
+ * row's pairs to row_lse[2 r] = max_j x_rj, row_lse[2 r + 1] = log sum_j exp(x_rj - max): F.log_softmax(x, dim=1)[r, j] is then
+ * (x_rj - row_lse[2 r]) - row_lse[2 r + 1] -- the MetaProgramExecutor's `log_softmax(scores)` over the tail vocabulary
+ * (cafe.py:820-822) without the pass that rewrites the [rows, vocabulary] matrix; hw_cafe_execute_logits applies it at the
+ * entries it reads. */
+int hw_gemm_f32_lse(const float* q, int64_t ldq, const float* t, int64_t ldt, const float* bias, float* c, int64_t ldc, int64_t m,
+                    int64_t n, int64_t k, float* tile_max, float* tile_sum, int64_t tile_ld, void* stream);
+int hw_lse_rows(const float* tile_max, const float* tile_sum, int64_t tile_ld, int64_t n_rows, int64_t n_stretches,
+                float* row_lse, void* stream);
+
 /* hw_gemm_rank on operands split ONCE (csrc/gemm_rank.hip): hw_rank_planes turns an fp32 matrix [rows, k] (row pitch ld) into the
  * (hi, mid) bf16 plane images the product's DMA loads straight into LDS -- the item table once per weight version, a batch's query
  * rows once per call; hw_rank_planes_bytes sizes the buffer (16-byte aligned).  hw_gemm_rank_planes: the same c, mask and
@@ -791,6 +802,13 @@ int hw_cafe_execute(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const
                     const float* logprobs, int64_t logprob_ld, const uint32_t* excluded_init,
                     int64_t bit_words, int32_t grow_excluded, int32_t* out_ids, float* out_vals,
                     int32_t* out_count, const int64_t* slot_ptr, void* stream);
+/* The same over LOGITS: `logits` is the vocabulary product as hw_gemm_f32_lse wrote it and row_lse [rows, 2] (hw_lse_rows) turns
+ * an entry into its log-probability, (x - row_lse[2 r]) - row_lse[2 r + 1], where the interpreter reads one. */
+int hw_cafe_execute_logits(const hw_pgpr_graph* graph, const hw_cafe_node* nodes, const int32_t* node_ptr,
+                           const int64_t* users, int64_t n_tasks, int32_t max_nodes_per_task, const float* logits,
+                           int64_t logit_ld, const float* row_lse, const uint32_t* excluded_init, int64_t bit_words,
+                           int32_t grow_excluded, int32_t* out_ids, float* out_vals, int32_t* out_count,
+                           const int64_t* slot_ptr, void* stream);
 
 /* One relation module of SymbolicNetwork in evaluation mode (cafe.py:645-699): device pointers to the parameters of
  * RelationModule (deep = 0: fc1 [256, 2d], bn1, fc2 [d, 256], residual + eh_vec) or DeepRelationModule (deep = 1: fc1

@@ -396,3 +396,40 @@ def test_full_sort_predict_and_explain_keep_the_records_lazy():
     assert list(paths) == want and not paths.pending
     assert list(expl) == [list(r) for r in raw]
     assert torch.equal(scores, raw_scores) and torch.equal(s2, raw_scores)
+
+
+@pytest.mark.parametrize("m_rows,n_cols,k,with_bias", [(70, 333, 100, False), (300, 13805, 100, False), (129, 64, 36, True),
+                                                       (33, 130, 12, True)])
+def test_gemm_lse_is_the_product_plus_each_rows_log_sum_exp(m_rows, n_cols, k, with_bias):
+    """ops.gemm_lse (hw_gemm_f32_lse + hw_lse_rows): the logits are ops.gemm's bit for bit, and (x - max) - log sum exp from the
+    row pairs is torch's log_softmax to fp32 rounding -- stretches that end inside a tile, rows past the last tile row, one
+    stretch only, a bias."""
+    from hopwise_amd import ops
+
+    g = torch.Generator().manual_seed(m_rows + n_cols)
+    x = (torch.randn(m_rows, k, generator=g) * 0.6).to(dev())
+    e = (torch.randn(n_cols, k, generator=g) * 0.6).to(dev())
+    bias = (torch.randn(n_cols, generator=g)).to(dev()) if with_bias else None
+    want = ops.gemm(x, e, bias=bias, out=ops.padded_rows(m_rows, n_cols, dev()))
+    out, row_lse = ops.gemm_lse(x, e, bias=bias)
+    assert torch.equal(out, want)
+    ref = torch.log_softmax(want.double(), dim=1)
+    got = (out - row_lse[:, :1]) - row_lse[:, 1:]
+    assert torch.equal(row_lse[:, 0], want.max(dim=1).values)
+    torch.testing.assert_close(got.double(), ref, rtol=0, atol=2e-6 * float(ref.abs().max()))
+
+
+def test_run_program_with_the_log_softmax_taken_in_the_interpreter():
+    """run_program with the vocabulary log-softmax from the logits product's epilogue and applied where the interpreter reads an
+    entry (the default) against the row pass over the whole matrix: same items, same paths, scores to fp32 rounding."""
+    z, orc, m = build()
+    users = torch.from_numpy(z["users"])
+    out = {}
+    for fused in (True, False):
+        m.fused_lse = fused
+        scores, rec, leaves, _ = m.run_program_device(users)
+        out[fused] = (scores.cpu(), {k: v.cpu() for k, v in rec.items()})
+    for k in ("count", "item", "leaf", "ids"):
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+    assert int(out[True][1]["count"].sum()) > 0
+    torch.testing.assert_close(out[True][0].nan_to_num(-1e30), out[False][0].nan_to_num(-1e30), rtol=1e-5, atol=1e-6)
