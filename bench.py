@@ -83,7 +83,8 @@ def parse_args(argv=None):
                     help="users per beam search: 64 -> 5.8 G paths/s, 256 -> 6.7 G (the first hops' fixed cost amortised), ~8 GB of work buffers")
     ap.add_argument("--pgpr-streams", type=int, default=3,
                     help="HIP streams the timed PGPR searches (independent user batches) are dealt over")
-    ap.add_argument("--cafe-users", type=int, default=1024, help="users per CAFE run_program call")
+    ap.add_argument("--cafe-users", type=int, default=2048,
+                    help="users per CAFE run_program call (hopwise's eval_batch_size default is 4 096)")
     ap.add_argument("--cafe-streams", type=int, default=2, help="HIP streams the timed CAFE calls are dealt over")
     ap.add_argument("--sharded-steps", type=int, default=10)
     ap.add_argument("--sharded-batch", type=int, default=8192, help="rec positives and kg triples per rank per step")

@@ -104,7 +104,7 @@ def run(dev, n_users=256, n_metapaths=6, cpu_users=0, min_seconds=0.5, rank=0, s
         "ms_per_256_users": t_dev * 1e3 * 256 / n_users,
         "note": "latency-bound: one workgroup interprets one user's program (13 nodes, CSR segments per parent path), so a call "
                 "fills the chip only from ~4 users per CU on: 256 users per call 0.75 ms (72 M paths/s), 1 024 per call "
-                "1.06 ms (208 M) on one stream.  The vocabulary logits (13 rows per user x 13 805) run on the MFMA GEMM, "
+                "1.06 ms (208 M), 2 048 per call 1.83 ms (242 M) on one stream; 1.43 ms (310 M) over two.  The vocabulary logits (13 rows per user x 13 805) run on the MFMA GEMM, "
                 "whose epilogue leaves each row's log-sum-exp (no log-softmax pass over the matrix); the relation modules in one "
                 "launch per level -- no roofline is claimed for this leg",
     }
