@@ -1132,10 +1132,13 @@ def _unit_rows(t):
 
 
 def padded_rows(m, n, device, dtype=torch.float32):
-    """An [m, n] matrix whose rows start 16 bytes apart-aligned (pitch n rounded up to 4 elements): what the split GEMM and the
+    """An [m, n] matrix whose rows start on 128-byte boundaries (pitch n rounded up to 32 elements): what the split GEMM and the
     row kernels want of an operand whose width is whatever a vocabulary happens to be (13 805 entities: every second row of
-    the contiguous matrix starts off a 16-byte boundary, and the product that reads it falls back to the exact-FMA loop)."""
-    return torch.empty((m, (n + 3) & ~3), dtype=dtype, device=device)[:, :n]
+    the contiguous matrix starts off a 16-byte boundary, and the product that reads it falls back to the exact-FMA loop; a
+    product that WRITES such a matrix stores 4 bytes at a time).  16-byte rows are what the kernels require; whole cache lines
+    per 256-byte store segment are worth another 3-6 % to the products that write [rows, vocabulary] matrices
+    (tools/gemm_pitch_probe.py)."""
+    return torch.empty((m, (n + 31) & ~31), dtype=dtype, device=device)[:, :n]
 
 
 class MatMul(torch.autograd.Function):
