@@ -95,7 +95,7 @@ def run(dev, n_users=256, n_metapaths=6, cpu_users=0, min_seconds=0.5, rank=0, s
         "metric": "CAFE paths per second (run_program: neural program executor over the metapath layout tree, manual_topk 5)",
         "value": n_paths / t_dev, "unit": "paths/s", "users_per_step": n_users, "steps": reps,
         "ms_per_step": t_dev * 1e3, "users_per_s": n_users / t_dev, "paths_per_step": n_paths,
-        "streams": streams,  # the timed calls are dealt over this many HIP streams (1.06 -> 0.88 ms per 1 024-user call with one, two; 0.90 with three)
+        "streams": streams,  # the timed calls are dealt over this many HIP streams (1.00 -> 0.72 -> 0.70 ms per 1 024-user call with one, two, three)
         "metapaths": len(metapaths), "nodes_per_user": n_nodes,
         "recommended_items": int(torch.isfinite(scores).sum().item()),
         "with_python_lists": {"ms_per_step": t_all * 1e3, "steps": reps_all, "records": len(lists) if lists else 0,
@@ -104,7 +104,7 @@ def run(dev, n_users=256, n_metapaths=6, cpu_users=0, min_seconds=0.5, rank=0, s
         "ms_per_256_users": t_dev * 1e3 * 256 / n_users,
         "note": "latency-bound: one workgroup interprets one user's program (13 nodes, CSR segments per parent path), so a call "
                 "fills the chip only from ~4 users per CU on: 256 users per call 0.75 ms (72 M paths/s), 1 024 per call "
-                "1.06 ms (208 M), 2 048 per call 1.83 ms (242 M) on one stream; 1.43 ms (310 M) over two.  The vocabulary logits (13 rows per user x 13 805) run on the MFMA GEMM, "
+                "1.00 ms (220 M), 2 048 per call 1.80 ms (246 M) on one stream; 1.42 ms (312 M) over two.  The vocabulary logits (13 rows per user x 13 805) run on the MFMA GEMM, "
                 "whose epilogue leaves each row's log-sum-exp (no log-softmax pass over the matrix); the relation modules in one "
                 "launch per level -- no roofline is claimed for this leg",
     }

@@ -473,6 +473,12 @@ SIGNATURES = {
          C.c_int64, C.c_void_p],
     ),
     "hw_lse_rows": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int64, C.c_int64, c_f32p, C.c_void_p]),
+    "hw_cafe_plan": (
+        C.c_int,
+        [c_i64p, C.c_int64, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int64, c_i32p, c_i32p,
+         c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, c_i32p, c_i64p, c_i64p, c_i64p, c_i64p,
+         c_i32p, C.c_void_p],
+    ),
     "hw_version": (C.c_char_p, []),
 }
 

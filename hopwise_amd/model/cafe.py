@@ -199,6 +199,9 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         # the vocabulary log-softmax of run_program from the logits product's epilogue (ops.gemm_lse) instead of a row pass over
         # the [nodes, vocabulary] matrix; HW_CAFE_FUSED_LSE=0: product + hw_log_softmax_rows (equal to fp32 rounding)
         self.fused_lse = os.environ.get("HW_CAFE_FUSED_LSE", "1") != "0"
+        # run_program's node tables and index columns built on the device from each user's visiting order (hw_cafe_plan) instead
+        # of ~50 numpy passes and a 2 MB copy per call; HW_CAFE_DEVICE_PLAN=0: the host construction (equal element for element)
+        self.device_plan = os.environ.get("HW_CAFE_DEVICE_PLAN", "1") != "0"
         self.ui_relation = dataset.ui_relation
         self.ui_relation_id = dataset.field2token_id["relation_id"][dataset.ui_relation]
         ue = np.asarray(dataset.get_preload_weight("user_embedding_id"))
@@ -356,88 +359,111 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         dev = self.user_embedding.device
         users_np = users.cpu().numpy()
         B = len(users_np)
-        if flat is not None:  # run_program: the per-program columns come concatenated from the per-order cache
-            lens, par_i, rel_code, k_of, names = flat["lens"], flat["par_i"], flat["rel_code"], flat["k_of"], flat["names"]
+        dev_plan = flat.get("device_plan") if flat is not None else None
+        if dev_plan is not None:
+            # run_program on the usual layout: the node table, the pointers and the module stage's index columns are built on
+            # the device from each user's visiting order (hw_cafe_plan); the host sends 2 B integers and keeps what it needs
+            # as closed forms (every program has L nodes and the same number of output slots)
+            oid, TD, k_all = dev_plan
+            names, mods = TD["names"], TD["mods"]
+            Lp = TD["L"]
+            total = B * Lp
+            pk = _Packed()
+            pk.add("oid", np.asarray(oid, np.int64))
+            pk.add("users", np.asarray(users_np, np.int64))
+            sent = pk.to(dev)
+            on_dev = P.cafe_plan(sent["oid"], TD, B, k_all)
+            on_dev["users"] = sent["users"]
+            plan = [(dep, j, B * c) for dep, j, c in TD["plan1"]]
+            et_rows = [(TD["et"], range(total))]
+            nodes, cap, depth, slot_off = range(total), None, None, None  # (len() only; the raw form returns no host columns)
+            node_ptr = np.arange(B + 1, dtype=np.int64) * Lp
+            slot_ptr = np.arange(B + 1, dtype=np.int64) * TD["slots_per_task"]
+            d = self.user_embedding.shape[1]
+            vec_all = torch.empty((max(total, 1), d), dtype=torch.float32, device=dev)
         else:
-            lens = np.fromiter((len(p) for p in programs), np.int64, B)
-        node_ptr = np.zeros(B + 1, np.int64)
-        np.cumsum(lens, out=node_ptr[1:])
-        total = int(node_ptr[-1])
-        row_b = np.repeat(np.arange(B), lens)
-        row_i = np.arange(total) - node_ptr[row_b]
-        if flat is None:
-            par_i = np.fromiter((q[0] for p in programs for q in p), np.int64, total)
-            rel_names = [q[1] for p in programs for q in p]
-            k_of = np.fromiter((int(x) for kk in ks for x in kk), np.int64, total)
-            names = sorted(set(rel_names))
-            code = {n: j for j, n in enumerate(names)}
-            rel_code = np.fromiter((code[n] for n in rel_names), np.int64, total)
-        par_row = np.where(par_i < 0, -1, node_ptr[row_b] + par_i)
-        mods = [self._module(n) for n in names]
-        if flat is not None and "depth" in flat:  # run_program: per-order columns, gathered (see _order_tables)
-            depth, cap, is_leaf = flat["depth"], flat["cap"], flat["is_leaf"]
-        else:
-            # parents precede children inside a program: depth, capacity and leaf flags by program position
-            depth = np.ones(total, np.int64)
-            cap = k_of.copy()
-            for pos in range(int(lens.max()) if B else 0):
-                rows = np.nonzero((row_i == pos) & (par_i >= 0))[0]
-                depth[rows] = depth[par_row[rows]] + 1
-                cap[rows] = cap[par_row[rows]] * k_of[rows]
-            is_leaf = np.ones(total, np.int64)
-            is_leaf[par_row[par_row >= 0]] = 0
-        cum = np.cumsum(cap)
-        slot_ptr = np.concatenate([[0], cum[node_ptr[1:] - 1]]) if total else np.zeros(B + 1, np.int64)
-        slot_off = cum - cap - slot_ptr[row_b]
-        # 1) node vectors, level by level, one module call per (level, relation) over all users
-        d = self.user_embedding.shape[1]
-        # every node row is written by its (level, relation) group before anything reads it (the groups partition the nodes)
-        vec_all = torch.empty((max(total, 1), d), dtype=torch.float32, device=dev)
-        # every index column of stages 1 and 2 goes to the device in ONE copy (they were three pageable host-to-device copies
-        # per (level, relation) pair -- ~45 per call, each a stall of the launching thread in a leg that is host-bound)
-        # the (level, relation) groups in (level, relation) order, rows ascending inside a group: ONE stable sort by the
-        # group key instead of a mask + nonzero per pair (~50 passes over the node columns per call, most of the host time
-        # of a 1 024-user run_program)
-        plan, c_eh, c_uv, c_row = [], [], [], []
-        if total:
-            n_mods = len(mods)
-            key = depth * n_mods + rel_code
-            order = np.argsort(key, kind="stable")
-            sizes = np.bincount(key, minlength=(int(depth.max()) + 1) * n_mods)
-            plan = [(int(k // n_mods), int(k % n_mods), int(n)) for k, n in enumerate(sizes.tolist()) if n]
-            pr = par_row[order]
-            c_eh, c_uv, c_row = [np.where(pr < 0, row_b[order], B + pr)], [row_b[order]], [order]
-        # rows per tail-entity type, types in name order (integer codes: a string column per node and np.unique over it were
-        # a millisecond of a 1 024-user call)
-        et_rows = []
-        if total:
-            et_name_of_mod = [m.et_name for m in mods]
-            used_mods = np.nonzero(sizes.reshape(-1, n_mods).sum(0))[0].tolist()
-            ets = sorted({et_name_of_mod[j] for j in used_mods})
-            if len(ets) == 1:
-                et_rows = [(ets[0], np.arange(total))]
+            if flat is not None:  # run_program: the per-program columns come concatenated from the per-order cache
+                lens, par_i, rel_code, k_of, names = flat["lens"], flat["par_i"], flat["rel_code"], flat["k_of"], flat["names"]
             else:
-                et_code = np.array([ets.index(n) if n in ets else -1 for n in et_name_of_mod], np.int64)[rel_code]
-                et_rows = [(et, np.nonzero(et_code == e)[0]) for e, et in enumerate(ets)]
-        # the interpreter's node table (host-only inputs: built here so that it rides in the same copy)
-        nodes = np.zeros(total, P.CAFE_NODE_DTYPE)
-        nodes["parent"], nodes["k"], nodes["is_leaf"], nodes["depth"] = par_i, k_of, is_leaf, depth
-        nodes["rel"] = np.array([self.relation2rid[n] for n in names], np.int64)[rel_code] if total else 0
-        nodes["eh_is_entity"] = np.array([int(m.eh_name == "entity") for m in mods], np.int64)[rel_code] if total else 0
-        nodes["vocab"] = np.array([self._vocab[m.et_name] for m in mods], np.int64)[rel_code] if total else 0
-        nodes["lp_row"], nodes["cap"], nodes["slot_off"] = np.arange(total), cap, slot_off
-        # ONE host-to-device copy per call: the index columns of stages 1 and 2 (three columns over all groups, then the
-        # stage-2 row lists), the user ids, the node table and its pointers, the collector's leaf rows.  Each used to be its
-        # own pageable copy (~0.2 ms of the launching thread apiece, eight of them) in a leg that is bound by the host.
-        pk = _Packed()
-        pk.add("idx", np.concatenate(c_eh + c_uv + c_row + [rs for _, rs in et_rows]) if plan or et_rows else np.zeros(0, np.int64))
-        pk.add("users", np.asarray(users_np, np.int64))
-        pk.add("nodes", nodes.view(np.int32).reshape(-1, 10))
-        pk.add("node_ptr", np.asarray(node_ptr, np.int32))
-        pk.add("slot_ptr", np.asarray(slot_ptr, np.int64))
-        if flat is not None and "leaf_nodes" in flat:
-            pk.add("leaf_nodes", np.ascontiguousarray(flat["leaf_nodes"], np.int32))
-        on_dev = pk.to(dev)
+                lens = np.fromiter((len(p) for p in programs), np.int64, B)
+            node_ptr = np.zeros(B + 1, np.int64)
+            np.cumsum(lens, out=node_ptr[1:])
+            total = int(node_ptr[-1])
+            row_b = np.repeat(np.arange(B), lens)
+            row_i = np.arange(total) - node_ptr[row_b]
+            if flat is None:
+                par_i = np.fromiter((q[0] for p in programs for q in p), np.int64, total)
+                rel_names = [q[1] for p in programs for q in p]
+                k_of = np.fromiter((int(x) for kk in ks for x in kk), np.int64, total)
+                names = sorted(set(rel_names))
+                code = {n: j for j, n in enumerate(names)}
+                rel_code = np.fromiter((code[n] for n in rel_names), np.int64, total)
+            par_row = np.where(par_i < 0, -1, node_ptr[row_b] + par_i)
+            mods = [self._module(n) for n in names]
+            if flat is not None and "depth" in flat:  # run_program: per-order columns, gathered (see _order_tables)
+                depth, cap, is_leaf = flat["depth"], flat["cap"], flat["is_leaf"]
+            else:
+                # parents precede children inside a program: depth, capacity and leaf flags by program position
+                depth = np.ones(total, np.int64)
+                cap = k_of.copy()
+                for pos in range(int(lens.max()) if B else 0):
+                    rows = np.nonzero((row_i == pos) & (par_i >= 0))[0]
+                    depth[rows] = depth[par_row[rows]] + 1
+                    cap[rows] = cap[par_row[rows]] * k_of[rows]
+                is_leaf = np.ones(total, np.int64)
+                is_leaf[par_row[par_row >= 0]] = 0
+            cum = np.cumsum(cap)
+            slot_ptr = np.concatenate([[0], cum[node_ptr[1:] - 1]]) if total else np.zeros(B + 1, np.int64)
+            slot_off = cum - cap - slot_ptr[row_b]
+            # 1) node vectors, level by level, one module call per (level, relation) over all users
+            d = self.user_embedding.shape[1]
+            # every node row is written by its (level, relation) group before anything reads it (the groups partition the nodes)
+            vec_all = torch.empty((max(total, 1), d), dtype=torch.float32, device=dev)
+            # every index column of stages 1 and 2 goes to the device in ONE copy (they were three pageable host-to-device copies
+            # per (level, relation) pair -- ~45 per call, each a stall of the launching thread in a leg that is host-bound)
+            # the (level, relation) groups in (level, relation) order, rows ascending inside a group: ONE stable sort by the
+            # group key instead of a mask + nonzero per pair (~50 passes over the node columns per call, most of the host time
+            # of a 1 024-user run_program)
+            plan, c_eh, c_uv, c_row = [], [], [], []
+            if total:
+                n_mods = len(mods)
+                key = depth * n_mods + rel_code
+                order = np.argsort(key, kind="stable")
+                sizes = np.bincount(key, minlength=(int(depth.max()) + 1) * n_mods)
+                plan = [(int(k // n_mods), int(k % n_mods), int(n)) for k, n in enumerate(sizes.tolist()) if n]
+                pr = par_row[order]
+                c_eh, c_uv, c_row = [np.where(pr < 0, row_b[order], B + pr)], [row_b[order]], [order]
+            # rows per tail-entity type, types in name order (integer codes: a string column per node and np.unique over it were
+            # a millisecond of a 1 024-user call)
+            et_rows = []
+            if total:
+                et_name_of_mod = [m.et_name for m in mods]
+                used_mods = np.nonzero(sizes.reshape(-1, n_mods).sum(0))[0].tolist()
+                ets = sorted({et_name_of_mod[j] for j in used_mods})
+                if len(ets) == 1:
+                    et_rows = [(ets[0], np.arange(total))]
+                else:
+                    et_code = np.array([ets.index(n) if n in ets else -1 for n in et_name_of_mod], np.int64)[rel_code]
+                    et_rows = [(et, np.nonzero(et_code == e)[0]) for e, et in enumerate(ets)]
+            # the interpreter's node table (host-only inputs: built here so that it rides in the same copy)
+            nodes = np.zeros(total, P.CAFE_NODE_DTYPE)
+            nodes["parent"], nodes["k"], nodes["is_leaf"], nodes["depth"] = par_i, k_of, is_leaf, depth
+            nodes["rel"] = np.array([self.relation2rid[n] for n in names], np.int64)[rel_code] if total else 0
+            nodes["eh_is_entity"] = np.array([int(m.eh_name == "entity") for m in mods], np.int64)[rel_code] if total else 0
+            nodes["vocab"] = np.array([self._vocab[m.et_name] for m in mods], np.int64)[rel_code] if total else 0
+            nodes["lp_row"], nodes["cap"], nodes["slot_off"] = np.arange(total), cap, slot_off
+            # ONE host-to-device copy per call: the index columns of stages 1 and 2 (three columns over all groups, then the
+            # stage-2 row lists), the user ids, the node table and its pointers, the collector's leaf rows.  Each used to be its
+            # own pageable copy (~0.2 ms of the launching thread apiece, eight of them) in a leg that is bound by the host.
+            pk = _Packed()
+            pk.add("idx", np.concatenate(c_eh + c_uv + c_row + [rs for _, rs in et_rows]) if plan or et_rows else np.zeros(0, np.int64))
+            pk.add("users", np.asarray(users_np, np.int64))
+            pk.add("nodes", nodes.view(np.int32).reshape(-1, 10))
+            pk.add("node_ptr", np.asarray(node_ptr, np.int32))
+            pk.add("slot_ptr", np.asarray(slot_ptr, np.int64))
+            if flat is not None and "leaf_nodes" in flat:
+                pk.add("leaf_nodes", np.ascontiguousarray(flat["leaf_nodes"], np.int32))
+            on_dev = pk.to(dev)
         idx_all, users_dev = on_dev["idx"], on_dev["users"]
         user_vec = self.user_embedding[users_dev]
         offs = np.cumsum([0] + [n for _, _, n in plan])
@@ -661,6 +687,38 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
         perms = self.rng.permuted(np.tile(fast["base"], (B, 1)), axis=1)
         return np.searchsorted(T["codes"], perms @ fast["weights"]), T
 
+    def _order_tables_dev(self, T, names):
+        """Device copies of the per-order tables (:meth:`_order_tables`) and what hw_cafe_plan needs beside them: the modules'
+        relation id / head type / tail vocabulary by relation code, and the (depth, relation) groups of ONE program -- every
+        order visits the same nodes, so the groups' sizes per program, the output slots per program and the single tail
+        vocabulary hold for all of them (checked here once; None when they do not: the caller builds on the host)."""
+        dev = self.user_embedding.device
+        cache = T.setdefault("dev", {})
+        key = (dev.type, dev.index, id(names))
+        if key in cache:
+            return cache[key]
+        out = None
+        n_mods = len(names)
+        mods = [self._module(n) for n in names]
+        keys = T["depth"] * n_mods + T["rel"]
+        caps = T["cap"].sum(1)
+        same = (np.sort(keys, axis=1) == np.sort(keys[:1], axis=1)).all() and (caps == caps[0]).all()
+        n_keys = (int(T["depth"].max()) + 1) * n_mods
+        count = np.bincount(keys[0], minlength=n_keys)
+        ets = sorted({mods[j].et_name for j in np.nonzero(count.reshape(-1, n_mods).sum(0))[0].tolist()})
+        if same and len(ets) == 1 and int(caps[0]) * 1 < 2 ** 31 and T["par"].shape[1] <= 128:
+            i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.int32)).to(dev)
+            out = dict(
+                names=names, mods=mods, L=int(T["par"].shape[1]), n_leaves=int(T["leaf"].shape[1]), n_orders=int(T["par"].shape[0]),
+                n_mods=n_mods, n_keys=n_keys, slots_per_task=int(caps[0]), et=ets[0],
+                plan1=[(int(k // n_mods), int(k % n_mods), int(c)) for k, c in enumerate(count.tolist()) if c],
+                par=i32(T["par"]), rel=i32(T["rel"]), depth=i32(T["depth"]), cap=i32(T["cap"]), is_leaf=i32(T["is_leaf"]),
+                leaf=i32(T["leaf"]), mod_rid=i32([self.relation2rid[n] for n in names]),
+                mod_eh=i32([int(m.eh_name == "entity") for m in mods]), mod_vocab=i32([self._vocab[m.et_name] for m in mods]),
+                key_first=i32(np.cumsum(count) - count), key_count=i32(count))
+        cache[key] = out
+        return out
+
     def _bfs_order(self, perm=None):
         """One visiting order of the executor (children of a node in self.rng.permutation order, cafe.py:807-808; the
         draws happen per call, exactly as before) -> its cache entry: the order as (parent index, relation, node) triples
@@ -728,7 +786,15 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             self.__dict__["_rel_code_of"] = {n: j for j, n in enumerate(names)}
         code = self.__dict__["_rel_code_of"]
         got = self._order_tables(B, manual_topk, leaves, code)
-        if got is not None:  # the usual layout: columns gathered from the per-order tables
+        TD = None
+        if got is not None and self.device_plan:
+            TD = self._order_tables_dev(got[1], names)
+        if TD is not None:  # the usual layout, tables on the device: the host keeps the order indices only
+            oid, T = got
+            flat = dict(device_plan=(oid, TD, manual_topk), names=names)
+            leaf_nodes = T["leaf"][oid]
+            max_rec_all = int(T["max_rec"][oid].max())
+        elif got is not None:  # the usual layout: columns gathered from the per-order tables
             oid, T = got
             flat = dict(lens=np.full(B, T["par"].shape[1], np.int64), par_i=T["par"][oid].ravel(),
                         rel_code=T["rel"][oid].ravel(), names=names, depth=T["depth"][oid].ravel(),
@@ -744,8 +810,9 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
                         rel_code=np.concatenate([e["rel_code"] for e in ents]) if B else np.zeros(0, np.int64), names=names)
             leaf_nodes = np.stack([e["leaf_row"] for e in ents]) if B else np.full((0, max(len(leaves), 1)), -1, np.int32)
             max_rec_all = max([1] + [e["max_rec"] for e in ents])
-        flat["k_of"] = np.full(len(flat["par_i"]), manual_topk, np.int64)
-        flat["leaf_nodes"] = leaf_nodes  # rides in _run_programs' one host-to-device copy
+        if TD is None:
+            flat["k_of"] = np.full(len(flat["par_i"]), manual_topk, np.int64)
+            flat["leaf_nodes"] = leaf_nodes  # rides in _run_programs' one host-to-device copy
         raw = self._run_programs(users, None, None, grow_excluded=True, exclude=True, raw=True, flat=flat)
         max_rec = min(max(1, max_rec_all), self.n_items)
         scores, rec = P.cafe_collect(raw, leaf_nodes, self.n_items, max_rec, check_overflow=False,

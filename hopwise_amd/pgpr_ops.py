@@ -433,6 +433,27 @@ def cafe_execute(graph, nodes_np, node_ptr_np, users, logprobs, excluded_bits, g
     return ids, vals, counts
 
 
+def cafe_plan(order_of_task, tables, n_tasks, k):
+    """hw_cafe_plan: the node table, pointers, leaf rows and module-stage index columns of a run_program batch from each task's
+    visiting order.  ``tables``: the device dictionary CAFE._order_tables_dev builds.  Returns a dict of device tensors."""
+    lib = _lib.load()
+    dev = order_of_task.device
+    L, n_leaves = tables["L"], tables["n_leaves"]
+    total = n_tasks * L
+    nodes = torch.empty((max(total, 1), 10), dtype=torch.int32, device=dev)
+    ptrs = torch.empty(n_tasks + 2 + ((n_tasks + 1) & 1), dtype=torch.int32, device=dev)  # node_ptr [B + 1], padded to 8 bytes
+    i64 = torch.empty(n_tasks + 1 + 3 * max(total, 1), dtype=torch.int64, device=dev)
+    slot_ptr, idx = i64[: n_tasks + 1], i64[n_tasks + 1:]
+    leaf = torch.empty((max(n_tasks, 1), n_leaves), dtype=torch.int32, device=dev)
+    check(lib.hw_cafe_plan(_ptr(order_of_task), n_tasks, L, n_leaves, _ptr(tables["par"]), _ptr(tables["rel"]),
+                           _ptr(tables["depth"]), _ptr(tables["cap"]), _ptr(tables["is_leaf"]), _ptr(tables["leaf"]),
+                           tables["n_orders"], _ptr(tables["mod_rid"]), _ptr(tables["mod_eh"]), _ptr(tables["mod_vocab"]),
+                           tables["n_mods"], _ptr(tables["key_first"]), _ptr(tables["key_count"]), tables["n_keys"], int(k),
+                           tables["slots_per_task"], _ptr(nodes), _ptr(ptrs), _ptr(slot_ptr), _ptr(idx[:total]),
+                           _ptr(idx[total: 2 * total]), _ptr(idx[2 * total: 3 * total]), _ptr(leaf), _stream()), "hw_cafe_plan")
+    return dict(nodes=nodes, node_ptr=ptrs[: n_tasks + 1], slot_ptr=slot_ptr, idx=idx, leaf_nodes=leaf)
+
+
 def cafe_modules_forward(mod_structs, group_mod, group_ptr, user_vec, eh_idx, uv_idx, out_rows, vec_all):
     """hw_cafe_modules_forward: every (level, relation) module application of a run_program call from one host call.
     mod_structs: ctypes array of _lib.CafeModule; group_mod / group_ptr: host sequences; index columns and vectors on the device."""

@@ -810,6 +810,25 @@ int hw_cafe_execute_logits(const hw_pgpr_graph* graph, const hw_cafe_node* nodes
                            int32_t grow_excluded, int32_t* out_ids, float* out_vals, int32_t* out_count,
                            const int64_t* slot_ptr, void* stream);
 
+/* The inputs of hw_cafe_modules_forward(_fused) / hw_cafe_execute / hw_cafe_collect for a MetaProgramExecutor batch
+ * (cafe.py:790-857), built on the device from each task's VISITING ORDER of the layout tree (children of the branching node
+ * in a random order, cafe.py:807-808: the draw is the caller's).  Tables [n_orders, nodes_per_task] hold, per order, the
+ * program's columns (parent index, relation CODE = index into mod_*, 1-based depth, output capacity, leaf flag) and
+ * [n_orders, n_leaves] the program row of every leaf chain; mod_* [n_mods]: relation id, head type, tail vocabulary.
+ * key = depth * n_mods + relation code; key_count[key] = nodes of that key in ONE program (the same for every order),
+ * key_first[key] = sum of key_count below it.  Outputs: nodes / node_ptr / slot_ptr / leaf_nodes as the interpreter and the
+ * collector take them (slot_ptr[b] = b * slots_per_task), and the three index columns [n_tasks * nodes_per_task] of the
+ * module stage -- rows grouped by key, tasks ascending inside a group, a task's nodes in program order: eh_idx (the row of
+ * the parent's vector: task b's user row for parent < 0, else n_tasks + the parent's node row), uv_idx (b), row_idx (the
+ * node row).  Equal to the host construction element for element (tests/test_gpu_cafe.py). */
+int hw_cafe_plan(const int64_t* order_of_task, int64_t n_tasks, int32_t nodes_per_task, int32_t n_leaves,
+                 const int32_t* t_parent, const int32_t* t_rel_code, const int32_t* t_depth, const int32_t* t_cap,
+                 const int32_t* t_is_leaf, const int32_t* t_leaf_row, int64_t n_orders, const int32_t* mod_rid,
+                 const int32_t* mod_eh_is_entity, const int32_t* mod_vocab, int32_t n_mods, const int32_t* key_first,
+                 const int32_t* key_count, int32_t n_keys, int32_t k, int64_t slots_per_task, hw_cafe_node* nodes,
+                 int32_t* node_ptr, int64_t* slot_ptr, int64_t* eh_idx, int64_t* uv_idx, int64_t* row_idx,
+                 int32_t* leaf_nodes, void* stream);
+
 /* One relation module of SymbolicNetwork in evaluation mode (cafe.py:645-699): device pointers to the parameters of
  * RelationModule (deep = 0: fc1 [256, 2d], bn1, fc2 [d, 256], residual + eh_vec) or DeepRelationModule (deep = 1: fc1
  * [256, 2d], bn1, fc2 [2d, 256], residual + feature, bn2 [2d], fc3 [d, 2d]).  Weights are nn.Linear layouts [out, in]. */

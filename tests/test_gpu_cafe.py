@@ -433,3 +433,26 @@ def test_run_program_with_the_log_softmax_taken_in_the_interpreter():
         assert torch.equal(out[True][1][k], out[False][1][k]), k
     assert int(out[True][1]["count"].sum()) > 0
     torch.testing.assert_close(out[True][0].nan_to_num(-1e30), out[False][0].nan_to_num(-1e30), rtol=1e-5, atol=1e-6)
+
+
+def test_run_program_tables_built_on_the_device_equal_the_host_construction():
+    """run_program with its node table, pointers and index columns built by hw_cafe_plan from each user's visiting order (the
+    default) against the numpy construction: the same random draws, so scores and records are equal bit for bit -- on the
+    bench's layout (six metapaths under one branching node: the layout the device tables exist for), with more users than one
+    block of the plan kernel covers, users repeated."""
+    import bench_cafe
+
+    kg, ds, m, _ = bench_cafe.make_model(dev())
+    users = torch.from_numpy(np.concatenate([np.random.default_rng(5).integers(1, kg.n_users, 700), np.arange(1, 4), np.arange(1, 4)]))
+    out = {}
+    for on_device in (True, False):
+        m.device_plan = on_device
+        m.rng = np.random.default_rng(77)
+        scores, rec, leaves, _ = m.run_program_device(users)
+        out[on_device] = (scores.cpu(), {k: v.cpu() for k, v in rec.items()})
+    tabs = m._layout()["fast"]["tables"][5]
+    assert any(v is not None for v in tabs.get("dev", {}).values()), "the device tables were never built: wrong path tested"
+    assert torch.equal(out[True][0].nan_to_num(-1e30), out[False][0].nan_to_num(-1e30))
+    for k in ("count", "item", "score", "leaf", "ids"):
+        assert torch.equal(out[True][1][k], out[False][1][k]), k
+    assert int(out[True][1]["count"].sum()) > 1000
