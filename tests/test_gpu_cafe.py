@@ -411,7 +411,10 @@ def test_gemm_lse_is_the_product_plus_each_rows_log_sum_exp(m_rows, n_cols, k, w
     e = (torch.randn(n_cols, k, generator=g) * 0.6).to(dev())
     bias = (torch.randn(n_cols, generator=g)).to(dev()) if with_bias else None
     want = ops.gemm(x, e, bias=bias, out=ops.padded_rows(m_rows, n_cols, dev()))
-    out, row_lse = ops.gemm_lse(x, e, bias=bias)
+    res = ops.gemm_lse(x, e, bias=bias)
+    if res is None:
+        pytest.skip("HW_GEMM_SPLIT=0: the split loop (and its epilogues) are off; the caller takes gemm + a row pass")
+    out, row_lse = res
     assert torch.equal(out, want)
     ref = torch.log_softmax(want.double(), dim=1)
     got = (out - row_lse[:, :1]) - row_lse[:, 1:]
