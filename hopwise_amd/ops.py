@@ -43,6 +43,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_DESC_CACHE = {}
+
+
 def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0, tail_rows=None) -> KgeDesc:
     """Describe one scorer call.  ``head``/``rel``/``tail`` are tuples of [rows, dim] fp32 tables.
     ``tail_rows`` (optional) narrows the tail id space to [0, tail_rows) -- e.g. n_items on the rec side, where
@@ -51,6 +54,13 @@ def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0
     nh, nr, nt = _N_SLOT[model]
     if (len(head), len(rel), len(tail)) != (nh, nr, nt):
         raise ValueError(f"{model} takes {nh}/{nr}/{nt} head/rel/tail tables")
+    # the descriptor of the same tables is reused (nobody writes into one after this function): an evaluation step builds three
+    # of them, ~13 us of ctypes field stores each, on a path that is bound by its launching thread at ml-1m's item count
+    key = (model, tuple((t.data_ptr(), t.shape, t.dtype, t.is_contiguous()) for t in (*head, *rel, *tail)), float(margin),
+           float(eps), tail_rows)
+    hit = _DESC_CACHE.get(key)
+    if hit is not None:
+        return hit
     d = KgeDesc()
     d.model = MODEL_IDS[model]
     dim = head[0].shape[1]
@@ -73,6 +83,9 @@ def make_desc(model: str, head, rel, tail, margin: float = 0.0, eps: float = 0.0
         d.n_tail = int(tail_rows)
     d.margin = float(margin)
     d.eps = float(eps)
+    if len(_DESC_CACHE) >= 256:
+        _DESC_CACHE.clear()
+    _DESC_CACHE[key] = d
     return d
 
 
