@@ -364,6 +364,8 @@ class CAFE(ops.DropoutCounters, KnowledgeRecommender, ExplainableRecommender):
             # run_program on the usual layout: the node table, the pointers and the module stage's index columns are built on
             # the device from each user's visiting order (hw_cafe_plan); the host sends 2 B integers and keeps what it needs
             # as closed forms (every program has L nodes and the same number of output slots)
+            if not raw:
+                raise ValueError("the device-built plan serves the raw form only (run_program_device): no host columns exist")
             oid, TD, k_all = dev_plan
             names, mods = TD["names"], TD["mods"]
             Lp = TD["L"]
