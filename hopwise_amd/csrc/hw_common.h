@@ -330,6 +330,9 @@ __device__ __forceinline__ float bce_elem_unclamped(float x, float omt, float t_
 // VEC = true : dim % 4 == 0; lane gl owns float4 chunks gl, gl+G, ...  (NE/4 chunks)  -> 16-B loads
 // VEC = false: any dim;      lane gl owns elements   gl, gl+G, ...     (NE elements)  -> 4-B loads
 // Slots past the end of the row hold 0.
+#ifndef HW_ROW_LOAD_AUX  // cache policy bits of the whole-wave row loads (experiment switch, tools/scorer_ab.sh: 2 = nt)
+#define HW_ROW_LOAD_AUX 0
+#endif
 #ifndef HW_ROW_BUFFER_LOAD
 #define HW_ROW_BUFFER_LOAD 1
 #endif
@@ -355,7 +358,7 @@ struct Row {
             __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, dim * 4, 0x00020000);
 #pragma unroll
             for (int c = 0; c < NE / 4; ++c) {
-                const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (gl + c * G) * 16, 0, 0));
+                const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (gl + c * G) * 16, 0, HW_ROW_LOAD_AUX));
                 v[4 * c + 0] = x.x;
                 v[4 * c + 1] = x.y;
                 v[4 * c + 2] = x.z;

@@ -1,7 +1,8 @@
 #!/bin/bash
-# tools/scorer_ab.sh <macro>: bench.py's headline leg with the library as built (A), then with kge_score*.hip rebuilt on the
-# box with -D<macro>=0 (B), then A again -- same card, back to back.
+# tools/scorer_ab.sh <macro>[=value]: bench.py's headline leg with the library as built (A), then with kge_score*.hip rebuilt on
+# the box with -D<macro>=<value> (default 0) (B), then A again -- same card, back to back.
 MACRO=${1:-HW_ROW_BUFFER_LOAD}
+case "$MACRO" in *=*) ;; *) MACRO="$MACRO=0" ;; esac
 mkdir -p gpurun_out/scorer_ab
 ARGS="--no-pgpr --no-tucker --no-cafe --no-sharded --no-cpu-baseline"
 run() { timeout -k 10 300 python bench.py $ARGS > gpurun_out/scorer_ab/$1.json 2> gpurun_out/scorer_ab/$1.err; python - <<PY
@@ -13,7 +14,7 @@ PY
 }
 run A1
 cd hopwise_amd/csrc
-for f in kge_score kge_score_ext; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -D$MACRO=0 -c $f.hip -o /tmp/$f.o || exit 1; done
+for f in kge_score kge_score_ext; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I ../../include -D$MACRO -c $f.hip -o /tmp/$f.o || exit 1; done
 cp libhopwise_amd.so /tmp/lib_a.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libhopwise_amd.so $(ls *.o | grep -v "^kge_score.o$" | grep -v "^kge_score_ext.o$") /tmp/kge_score.o /tmp/kge_score_ext.o || exit 1
 cd ../..
