@@ -13,6 +13,14 @@ from tests.test_gpu_kge import build, dev
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _default_routes(monkeypatch):
+    """The tests of this module name the route they exercise by config key (or set the switch themselves): a caller's
+    HW_* route switches must not turn the default product routes off underneath them."""
+    for e in ("HW_FULLSORT_RANK_PLANES", "HW_FULLSORT_RANK_TERMS", "HW_GEMM_SPLIT"):
+        monkeypatch.delenv(e, raising=False)
+
 SHAPES = ((64, 1003, 700, 3, 10), (200, 777, 300, 17, 16), (24, 200, 130, 130, 20), (8, 90, 40, 1, 5), (30, 411, 97, 9, 10))
 
 

@@ -14,6 +14,14 @@ from tests.test_gpu_kge import build, dev
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _default_routes(monkeypatch):
+    """The tests of this module name the route they exercise by config key (or set the switch themselves): a caller's
+    HW_* route switches must not turn the default product routes off underneath them."""
+    for e in ("HW_FULLSORT_RANK_PLANES", "HW_FULLSORT_RANK_TERMS", "HW_GEMM_SPLIT"):
+        monkeypatch.delenv(e, raising=False)
+
+
 @pytest.mark.parametrize("model", ["DistMult", "ComplEx", "Analogy"])
 def test_gemm_full_sort_equals_the_gather_kernel_and_the_oracle(model):
     from hopwise_amd import ops
